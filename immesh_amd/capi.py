@@ -1,0 +1,240 @@
+"""ctypes binding of include/immesh_c_api.h.
+
+``HotPath(lib, prefix)`` wraps one context.  The same wrapper drives the product (``prefix='immesh_'``,
+libimmesh_hip.so) and -- from tests/bench only -- the CPU oracle (``prefix='orc_'``, oracle/liboracle.so), which
+exports the identical entry points.  Nothing here computes anything.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+STATE_DOUBLES = 348
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_double), ("max_layer", C.c_int32), ("layer_init", C.c_int32 * 5), ("max_points_size", C.c_int32),
+        ("planer_threshold", C.c_double), ("dept_err", C.c_double), ("beam_err", C.c_double), ("calib_laser", C.c_int32),
+        ("sigma_num", C.c_double), ("max_iter", C.c_int32), ("extR", C.c_double * 9), ("extT", C.c_double * 3),
+        ("mesh_min_spacing", C.c_double), ("mesh_voxel", C.c_double), ("mesh_region", C.c_double), ("mesh_append_budget", C.c_int32),
+        ("device", C.c_int32), ("cap_root_voxels", C.c_int64), ("cap_nodes", C.c_int64), ("cap_point_chunks", C.c_int64),
+        ("cap_vertices", C.c_int64), ("cap_triangles", C.c_int64), ("cap_scan_points", C.c_int64),
+    ]
+
+
+class MeshSizes(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vtx_base", "n_new_vtx", "n_add", "n_rem", "n_upd", "n_smooth", "n_voxels_meshed", "reserved")]
+
+
+class PlaneRec(C.Structure):
+    _fields_ = [("key", C.c_int64 * 3), ("layer", C.c_int32), ("path", C.c_int32), ("is_plane", C.c_int32), ("n_points", C.c_int32),
+                ("update_enable", C.c_int32), ("new_points", C.c_int32), ("radius", C.c_float), ("min_eig", C.c_float), ("d", C.c_float),
+                ("pad", C.c_float), ("center", C.c_double * 3), ("normal", C.c_double * 3), ("plane_var", C.c_double * 36)]
+
+
+PLANE_DTYPE = np.dtype([("key", "<i8", 3), ("layer", "<i4"), ("path", "<i4"), ("is_plane", "<i4"), ("n_points", "<i4"),
+                        ("update_enable", "<i4"), ("new_points", "<i4"), ("radius", "<f4"), ("min_eig", "<f4"), ("d", "<f4"),
+                        ("pad", "<f4"), ("center", "<f8", 3), ("normal", "<f8", 3), ("plane_var", "<f8", 36)])
+assert PLANE_DTYPE.itemsize == C.sizeof(PlaneRec)
+
+COUNTER_FIELDS = ("n_ds", "n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_app", "n_new", "v_act",
+                  "n_v", "n_u", "t_v", "t_add", "t_rem", "c1", "c20", "n_root_voxels", "n_nodes", "n_vertices", "n_triangles_live")
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in COUNTER_FIELDS]
+
+
+def avia_config(**over):
+    """config/avia.yaml + launch/mapping_avia.launch (SURVEY.md section 8 constants table)."""
+    c = Config()
+    c.voxel_size = 0.5; c.max_layer = 2
+    for i in range(5):
+        c.layer_init[i] = 5
+    c.max_points_size = 100; c.planer_threshold = 0.01; c.dept_err = 0.02; c.beam_err = 0.05; c.calib_laser = 0
+    c.sigma_num = 3.0; c.max_iter = 4
+    for i, v in enumerate([1, 0, 0, 0, 1, 0, 0, 0, 1]):
+        c.extR[i] = v
+    for i, v in enumerate([0.04165, 0.02326, -0.0284]):
+        c.extT[i] = v
+    c.mesh_min_spacing = 0.1; c.mesh_voxel = 0.4; c.mesh_region = 10.0; c.mesh_append_budget = 10000
+    c.device = 0
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def velodyne_config(**over):
+    """config/velodyne.yaml + launch/mapping_velody64.launch (KITTI)."""
+    c = avia_config()
+    c.voxel_size = 3.0; c.max_layer = 4; c.max_points_size = 1000; c.dept_err = 0.04; c.beam_err = 0.1; c.calib_laser = 1
+    c.max_iter = 3
+    for i in range(3):
+        c.extT[i] = 0.0
+    c.mesh_min_spacing = 0.1 * 1.5; c.mesh_voxel = 0.4 * 1.5; c.mesh_region = 10.0 * 1.5; c.mesh_append_budget = 10000
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def make_state(R=None, t=None, cov_diag=1e-7, vel=None, gravity=None):
+    """StatesGroup() defaults: identity pose, cov = I * INIT_COV (include/common_lib.h:201-210)."""
+    s = np.zeros(STATE_DOUBLES)
+    s[0:9] = (np.eye(3) if R is None else np.asarray(R, float)).reshape(-1)
+    if t is not None:
+        s[9:12] = t
+    if vel is not None:
+        s[12:15] = vel
+    if gravity is not None:
+        s[21:24] = gravity
+    s[24:] = (np.eye(18) * cov_diag).reshape(-1)
+    return s
+
+
+def hip_library_path():
+    return os.path.join(_HERE, "csrc", "libimmesh_hip.so")
+
+
+def load_hip_library():
+    """Load the product library.  Raises (never falls back) when it has not been built."""
+    p = hip_library_path()
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (or make -C immesh_amd/csrc). "
+                           "There is no CPU fallback for the hot path.")
+    return C.CDLL(p)
+
+
+def _ptr(a):
+    """host ndarray or raw device pointer (int) -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HotPath:
+    def __init__(self, lib, cfg, prefix="immesh_"):
+        self.lib, self.prefix, self.cfg = lib, prefix, cfg
+        self._f = lambda name: getattr(lib, prefix + name)
+        cr = self._f("create"); cr.restype = C.c_void_p; cr.argtypes = [C.POINTER(Config)]
+        self.ctx = cr(C.byref(cfg))
+        if not self.ctx:
+            msg = ""
+            if prefix == "immesh_":
+                lib.immesh_create_error.restype = C.c_char_p
+                msg = lib.immesh_create_error().decode()
+            raise RuntimeError(f"{prefix}create failed: {msg}")
+        self.ctx = C.c_void_p(self.ctx)
+
+    def close(self):
+        if self.ctx:
+            d = self._f("destroy"); d.argtypes = [C.c_void_p]; d.restype = None
+            d(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = ""
+            if self.prefix == "immesh_":
+                f = self.lib.immesh_last_error; f.restype = C.c_char_p; f.argtypes = [C.c_void_p]
+                msg = f(self.ctx).decode()
+            raise RuntimeError(f"{self.prefix}{what} failed rc={rc}: {msg}")
+
+    # -- registration ------------------------------------------------------------------------------------------
+    def map_build(self, pts_body_xyz, state, n=None):
+        f = self._f("map_build"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+        n = len(pts_body_xyz) if n is None else n
+        self._check(f(self.ctx, _ptr(pts_body_xyz), n, _ptr(state)), "map_build")
+
+    def register(self, pts_down, state_prior, state, n=None, want_eff=False):
+        f = self._f("register"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        n = len(pts_down) if n is None else n
+        out = np.array(state, dtype=np.float64, copy=True)
+        n_iter, n_match, res = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        eff_p = np.zeros((n, 3), np.float32) if want_eff else None
+        eff_n = np.zeros((n, 4), np.float32) if want_eff else None
+        self._check(f(self.ctx, _ptr(pts_down), n, _ptr(np.ascontiguousarray(state_prior, dtype=np.float64)), _ptr(out), C.byref(n_iter),
+                      C.byref(n_match), C.byref(res), _ptr(eff_p), _ptr(eff_n)), "register")
+        info = {"n_iter": n_iter.value, "n_match": n_match.value, "res_mean": res.value}
+        if want_eff:
+            info["eff_pts"] = eff_p[:n_match.value]; info["eff_norm_dis"] = eff_n[:n_match.value]
+        return out, info
+
+    def residuals(self, pts_down, state, n=None):
+        f = self._f("residuals"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p] + [C.c_void_p] * 7
+        n = len(pts_down) if n is None else n
+        HTH, HTz, nm = np.zeros(36), np.zeros(6), C.c_int32(0)
+        idx, nrm, dis, rinv = np.zeros(n, np.int32), np.zeros((n, 3)), np.zeros(n, np.float32), np.zeros(n)
+        self._check(f(self.ctx, _ptr(pts_down), n, _ptr(np.ascontiguousarray(state, dtype=np.float64)), _ptr(HTH), _ptr(HTz), C.byref(nm),
+                      _ptr(idx), _ptr(nrm), _ptr(dis), _ptr(rinv)), "residuals")
+        m = nm.value
+        return {"HTH": HTH.reshape(6, 6), "HTz": HTz, "n_match": m, "match_idx": idx[:m], "normals": nrm[:m], "dis": dis[:m], "r_inv": rinv[:m]}
+
+    def map_update(self, pts_down, state, n=None):
+        f = self._f("map_update"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]; f.restype = C.c_int
+        n = len(pts_down) if n is None else n
+        self._check(f(self.ctx, _ptr(pts_down), n, _ptr(np.ascontiguousarray(state, dtype=np.float64))), "map_update")
+
+    # -- meshing -----------------------------------------------------------------------------------------------
+    def mesh_scan(self, pts_world_xyzi, sensor_pos, frame_idx=0, n=None, fetch=True):
+        f = self._f("mesh_scan"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]; f.restype = C.c_int
+        n = len(pts_world_xyzi) if n is None else n
+        self._check(f(self.ctx, _ptr(pts_world_xyzi), n, _ptr(np.ascontiguousarray(sensor_pos, dtype=np.float64)), frame_idx), "mesh_scan")
+        return self.mesh_fetch() if fetch else None
+
+    def mesh_fetch(self):
+        fs = self._f("mesh_sizes"); fs.argtypes = [C.c_void_p, C.POINTER(MeshSizes)]; fs.restype = C.c_int
+        s = MeshSizes()
+        self._check(fs(self.ctx, C.byref(s)), "mesh_sizes")
+        r = {"vtx_base": s.vtx_base, "n_voxels_meshed": s.n_voxels_meshed,
+             "new_vtx": np.zeros((s.n_new_vtx, 3), np.float32), "tri_add": np.zeros((s.n_add, 3), np.int32), "flip_add": np.zeros(s.n_add, np.uint8),
+             "tri_rem": np.zeros((s.n_rem, 3), np.int32), "tri_upd": np.zeros((s.n_upd, 3), np.int32), "flip_upd": np.zeros(s.n_upd, np.uint8),
+             "smooth_ids": np.zeros(s.n_smooth, np.int32), "smooth_xyz": np.zeros((s.n_smooth, 3), np.float64)}
+        ff = self._f("mesh_fetch"); ff.argtypes = [C.c_void_p] + [C.c_void_p] * 8; ff.restype = C.c_int
+        self._check(ff(self.ctx, _ptr(r["new_vtx"]), _ptr(r["tri_add"]), _ptr(r["flip_add"]), _ptr(r["tri_rem"]), _ptr(r["tri_upd"]),
+                       _ptr(r["flip_upd"]), _ptr(r["smooth_ids"]), _ptr(r["smooth_xyz"])), "mesh_fetch")
+        return r
+
+    # -- whole scan -------------------------------------------------------------------------------------------
+    def process_scan(self, pts_down, pts_raw_xyzi, state_prior, state, frame_idx=0, do_mesh=True, n_ds=None, n_raw=None):
+        f = self._f("process_scan"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        n_ds = len(pts_down) if n_ds is None else n_ds
+        n_raw = len(pts_raw_xyzi) if n_raw is None else n_raw
+        out = np.array(state, dtype=np.float64, copy=True)
+        n_iter, n_match = C.c_int32(0), C.c_int32(0)
+        self._check(f(self.ctx, _ptr(pts_down), n_ds, _ptr(pts_raw_xyzi), n_raw, _ptr(np.ascontiguousarray(state_prior, dtype=np.float64)),
+                      _ptr(out), frame_idx, 1 if do_mesh else 0, C.byref(n_iter), C.byref(n_match)), "process_scan")
+        return out, {"n_iter": n_iter.value, "n_match": n_match.value}
+
+    def last_timing(self):
+        f = self._f("last_timing"); f.argtypes = [C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        ms = np.zeros(4, np.float32)
+        self._check(f(self.ctx, _ptr(ms)), "last_timing")
+        return {"total": float(ms[0]), "register": float(ms[1]), "map_update": float(ms[2]), "mesh": float(ms[3])}
+
+    # -- introspection ----------------------------------------------------------------------------------------
+    def dump_planes(self):
+        f = self._f("dump_planes"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+        n = C.c_int64(0)
+        self._check(f(self.ctx, None, 0, C.byref(n)), "dump_planes")
+        recs = np.zeros(n.value, PLANE_DTYPE)
+        if n.value:
+            self._check(f(self.ctx, _ptr(recs), n.value, C.byref(n)), "dump_planes")
+        return recs
+
+    def counters(self, reset=False):
+        f = self._f("counters"); f.argtypes = [C.c_void_p, C.POINTER(Counters), C.c_int32]; f.restype = C.c_int
+        c = Counters()
+        self._check(f(self.ctx, C.byref(c), 1 if reset else 0), "counters")
+        return {n: getattr(c, n) for n in COUNTER_FIELDS}

@@ -1,0 +1,158 @@
+/* immesh_c_api.h -- C ABI of the MI355X-native ImMesh per-scan hot path (libimmesh_hip.so).
+ *
+ * The reference (hku-mars/ImMesh) has no plugin/FFI boundary: its hot path is reached through C++ members of
+ * `class Voxel_mapping` and a few free functions.  Each entry point below replaces one of those call sites; the
+ * file:line cited is the reference symbol a drop-in shim forwards from (paths relative to the reference tree).
+ * INTEGRATION.md shows the shim.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - all matrices row-major; points are float xyz (3 floats) or xyzI (4 floats) exactly as the reference's
+ *     pcl::PointXYZINormal / pcl::PointXYZI clouds hold them.
+ *   - `state` = 348 doubles: R[9] t[3] vel[3] bias_g[3] bias_a[3] gravity[3] cov[18*18]   (StatesGroup,
+ *     include/common_lib.h:199-288; cov block order rot,pos,vel,bg,ba,g).
+ *   - input point pointers may be HOST or DEVICE (HIP) memory; the library detects which (hipPointerGetAttributes)
+ *     and uses device buffers in place.  Small in/out arrays (state, HTH, ...) are host memory.
+ *   - return 0 on success, negative IMMESH_E_* otherwise; immesh_last_error() gives text.  There is NO CPU
+ *     fallback: without a usable HIP device immesh_create() fails.
+ *   - one ctx per scan thread (reference thread A, service_LiDAR_update) ; calls on one ctx must be serialised.
+ */
+#ifndef IMMESH_C_API_H
+#define IMMESH_C_API_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMMESH_STATE_DOUBLES 348
+#define IMMESH_E_INVAL (-1)
+#define IMMESH_E_NODEV (-2)
+#define IMMESH_E_NOMEM (-3)
+#define IMMESH_E_CAPACITY (-4)
+#define IMMESH_E_HIP (-5)
+
+typedef struct immesh_ctx immesh_ctx;
+
+/* Parameters the reference reads once in Voxel_mapping::read_ros_parameters (src/voxel_mapping_common.cpp:625-707)
+ * and ImMesh_node.cpp:254-272. */
+typedef struct immesh_config {
+    double voxel_size;        /* voxel/max_voxel_size                          config/avia.yaml:53 */
+    int32_t max_layer;        /* voxel/max_layer                               :54 */
+    int32_t layer_init[5];    /* voxel/layer_init_size                         :55 */
+    int32_t max_points_size;  /* voxel/max_points_size                         :56 */
+    double planer_threshold;  /* voxel/min_eigen_value                         :50 */
+    double dept_err;          /* noise_model/ranging_cov                       :48 */
+    double beam_err;          /* noise_model/angle_cov                         :49 */
+    int32_t calib_laser;      /* preprocess/calib_laser (KITTI)                config/velodyne.yaml:26 */
+    double sigma_num;         /* 3.0, hard-coded at src/voxel_mapping.cpp:1365 */
+    int32_t max_iter;         /* mapping/max_iteration -> NUM_MAX_ITERATIONS   :3 */
+    double extR[9];           /* mapping/extrinsic_R                           :41 */
+    double extT[3];           /* mapping/extrinsic_T                           :40 */
+    double mesh_min_spacing;  /* meshing/points_minimum_scale * distance_scale (ImMesh_node.cpp:254-270) */
+    double mesh_voxel;        /* meshing/voxel_resolution * distance_scale */
+    double mesh_region;       /* meshing/region_size * distance_scale */
+    int32_t mesh_append_budget; /* meshing/number_of_pts_append_to_map */
+    int32_t device;           /* HIP device ordinal */
+    /* capacities of the HBM-resident pools (0 = library default) */
+    int64_t cap_root_voxels;  /* root voxels in the registration map hash */
+    int64_t cap_nodes;        /* octree nodes (roots + children) */
+    int64_t cap_point_chunks; /* 16-point chunks backing OctoTree::m_temp_points_ */
+    int64_t cap_vertices;     /* mesh vertices (Global_map::m_rgb_pts_vec) */
+    int64_t cap_triangles;    /* distinct triangles ever inserted (Triangle_manager::m_triangle_hash) */
+    int64_t cap_scan_points;  /* largest scan (raw points) */
+} immesh_config;
+
+void immesh_default_config(immesh_config* cfg); /* avia.yaml + mapping_avia.launch values */
+
+immesh_ctx* immesh_create(const immesh_config* cfg); /* NULL on failure (see immesh_create_error) */
+const char* immesh_create_error(void);
+void immesh_destroy(immesh_ctx* ctx);
+const char* immesh_last_error(immesh_ctx* ctx);
+
+/* ---- registration map ------------------------------------------------------------------------------------- */
+/* bool Voxel_mapping::voxel_map_init()              src/voxel_mapping.cpp:1243  (+ buildVoxelMap :110)
+ * pts_body_xyz = m_feats_undistort (ALL raw points of the first scan, lidar frame), n x 3 float. */
+int immesh_map_build(immesh_ctx* ctx, const float* pts_body_xyz, int64_t n, const double* state);
+
+/* void Voxel_mapping::lio_state_estimation(StatesGroup&)   src/voxel_mapping.cpp:1284
+ * One full iterated-EKF update.  pts_down_body_xyz = m_feats_down_body (n_ds x 3).  state_prior = state_propagat,
+ * state_inout = `state` (in: prior, out: posterior incl. covariance).  Optional outputs (may be NULL):
+ *   n_iter_out, n_match_out (m_effct_feat_num of the last iteration), res_mean_out (m_res_mean_last),
+ *   eff_pts_body  [n_ds*3]  m_laserCloudOri (matched body points, match order = ascending scan index),
+ *   eff_norm_dis  [n_ds*4]  m_corr_normvect  (float normal xyz + residual in .intensity). */
+int immesh_register(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state_prior, double* state_inout,
+                    int32_t* n_iter_out, int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis);
+
+/* One matcher + H-build pass at a fixed state: BuildResidualListOMP (src/voxel_mapping.cpp:153) + the residual /
+ * Jacobian loops (:1372-1392, :1487-1575) reduced to HTH = H^T R^-1 H (6x6) and HTz = H^T R^-1 z (6).
+ * Optional per-match outputs (capacity n_ds each, may be NULL): match_idx (scan index), normals (3 doubles),
+ * dis (float residual), r_inv. */
+int immesh_residuals(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state, double* HTH36, double* HTz6,
+                     int32_t* n_match, int32_t* match_idx, double* normals, float* dis, double* r_inv);
+
+/* void Voxel_mapping::map_incremental_grow()  (voxel-map half)   src/ImMesh_mesh_reconstruction.cpp:377-408
+ * + updateVoxelMap src/voxel_mapping.cpp:320.  Must follow immesh_register()/immesh_residuals() of the same scan
+ * only in the sense that it recomputes the per-point body covariances itself (no hidden dependency). */
+int immesh_map_update(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state);
+
+/* ---- meshing ---------------------------------------------------------------------------------------------- */
+/* void incremental_mesh_reconstruction(cloud, q, t, frame_idx)   src/ImMesh_mesh_reconstruction.cpp:92
+ * pts_world_xyzi = world_lidar_full (n_raw x 4 float).  Runs append + per-voxel retriangulation + diff + commit on
+ * the device; results stay in the ctx until the next call and are read with immesh_mesh_sizes / immesh_mesh_fetch. */
+int immesh_mesh_scan(immesh_ctx* ctx, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
+
+typedef struct immesh_mesh_sizes_t {
+    int32_t vtx_base;   /* id of the first vertex appended by this scan */
+    int32_t n_new_vtx;  /* vertices appended (ids vtx_base .. vtx_base+n_new_vtx-1) */
+    int32_t n_add;      /* triangles inserted   (Triangle_manager::insert_triangle, triangle.hpp:330) */
+    int32_t n_rem;      /* triangles erased     (remove_triangle_list, triangle.hpp:212) */
+    int32_t n_upd;      /* surviving triangles whose m_index_flip was rewritten (correct_triangle_index) */
+    int32_t n_smooth;   /* vertices whose smoothed position changed (RGB_pts::set_smooth_pos) */
+    int32_t n_voxels_meshed;
+    int32_t reserved;
+} immesh_mesh_sizes_t;
+int immesh_mesh_sizes(immesh_ctx* ctx, immesh_mesh_sizes_t* sizes);
+/* All lists are sorted (triplets: ids ascending inside a triplet, triplets lexicographic; smooth ids ascending).
+ * Any pointer may be NULL to skip that list. */
+int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd,
+                      uint8_t* flip_upd, int32_t* smooth_ids, double* smooth_xyz);
+
+/* ---- whole scan (what service_LiDAR_update does per scan, src/voxel_mapping.cpp:1959-1973) ---------------- */
+/* lio_state_estimation + map_incremental_grow (+ world transform of the full scan and incremental_mesh_reconstruction
+ * when do_mesh != 0).  pts_raw_body_xyzi = m_feats_undistort (n_raw x 4).  Everything stays on the device between
+ * stages; mesh results are read with immesh_mesh_sizes / immesh_mesh_fetch. */
+int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const float* pts_raw_body_xyzi, int32_t n_raw,
+                        const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
+                        int32_t* n_match_out);
+
+/* ---- introspection (parity tests, roofline denominators) -------------------------------------------------- */
+typedef struct immesh_plane_rec {  /* one initialised octree node */
+    int64_t key[3];      /* root voxel key (VOXEL_LOC) */
+    int32_t layer;       /* 0 = root */
+    int32_t path;        /* child indices from the root, 3 bits per level, first level in the low bits */
+    int32_t is_plane;    /* Plane::m_is_plane */
+    int32_t n_points;    /* retained m_temp_points_.size() */
+    int32_t update_enable;
+    int32_t new_points;
+    float radius, min_eig, d;
+    float pad;
+    double center[3], normal[3];
+    double plane_var[36];
+} immesh_plane_rec;
+/* writes up to cap records (unordered); *n_out = number of initialised nodes in the map */
+int immesh_dump_planes(immesh_ctx* ctx, immesh_plane_rec* out, int64_t cap, int64_t* n_out);
+
+typedef struct immesh_counters_t {  /* cumulative since create / last reset; SURVEY.md 8(d) symbols */
+    int64_t n_ds, n_iter, n_match, n_plane_tests, n_extra_probe, n_refits, n_refit_pts;
+    int64_t n_app, n_new, v_act, n_v, n_u, t_v, t_add, t_rem, c1, c20;
+    int64_t n_root_voxels, n_nodes, n_vertices, n_triangles_live;
+} immesh_counters_t;
+int immesh_counters(immesh_ctx* ctx, immesh_counters_t* out, int32_t reset);
+
+/* timing of the last immesh_process_scan, milliseconds from HIP events on the ctx stream:
+ * [0] total  [1] register  [2] map update  [3] mesh  */
+int immesh_last_timing(immesh_ctx* ctx, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,253 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (never linked into the product library).
+// C entry points mirroring include/immesh_c_api.h one-to-one (prefix orc_ instead of immesh_), so parity tests
+// drive the CPU restatement and the HIP library with the same calls.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load liboracle.so.
+#include "../include/immesh_c_api.h"
+#include "orc_mesher.hpp"
+#include <string>
+#include <chrono>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace orc;
+
+struct OrcCtx {
+    Config cfg;
+    VoxelMap vm;
+    Registration reg;
+    Mesher mesher;
+    MeshScanOut mout;
+    OrcCtx() : reg(&vm) {}
+};
+
+static void load_state(const double* s, State& st) {
+    std::memcpy(st.R, s, 9 * 8); std::memcpy(st.t, s + 9, 24); std::memcpy(st.vel, s + 12, 24); std::memcpy(st.bg, s + 15, 24);
+    std::memcpy(st.ba, s + 18, 24); std::memcpy(st.g, s + 21, 24); std::memcpy(st.cov, s + 24, 324 * 8);
+}
+static void store_state(const State& st, double* s) {
+    std::memcpy(s, st.R, 9 * 8); std::memcpy(s + 9, st.t, 24); std::memcpy(s + 12, st.vel, 24); std::memcpy(s + 15, st.bg, 24);
+    std::memcpy(s + 18, st.ba, 24); std::memcpy(s + 21, st.g, 24); std::memcpy(s + 24, st.cov, 324 * 8);
+}
+
+extern "C" {
+
+void* orc_create(const immesh_config* c) {
+    OrcCtx* o = new OrcCtx();
+    Config& g = o->cfg;
+    g.voxel_size = c->voxel_size; g.max_layer = c->max_layer;
+    for (int i = 0; i < 5; i++) g.layer_init[i] = c->layer_init[i];
+    g.max_points_size = c->max_points_size; g.planer_threshold = c->planer_threshold;
+    g.dept_err = c->dept_err; g.beam_err = c->beam_err; g.calib_laser = c->calib_laser; g.sigma_num = c->sigma_num; g.max_iter = c->max_iter;
+    std::memcpy(g.extR, c->extR, sizeof(g.extR)); std::memcpy(g.extT, c->extT, sizeof(g.extT));
+    g.mesh_min_spacing = c->mesh_min_spacing; g.mesh_voxel = c->mesh_voxel; g.mesh_region = c->mesh_region; g.mesh_append_budget = c->mesh_append_budget;
+    o->vm.cfg = g;
+    o->mesher.cfg = g;
+    o->mesher.cnt = &o->vm.cnt;
+    return o;
+}
+void orc_destroy(void* p) { delete (OrcCtx*)p; }
+
+int orc_map_build(void* p, const float* pts, int64_t n, const double* state) {
+    OrcCtx* o = (OrcCtx*)p;
+    State s; load_state(state, s);
+    o->reg.map_init(pts, (int)n, s);
+    return 0;
+}
+
+int orc_register(void* p, const float* pts, int32_t n_ds, const double* state_prior, double* state_inout, int32_t* n_iter_out,
+                 int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis) {
+    OrcCtx* o = (OrcCtx*)p;
+    State prior, st;
+    load_state(state_prior, prior); load_state(state_inout, st);
+    RegDebug dbg;
+    const int it = o->reg.run(pts, n_ds, prior, st, &dbg);
+    store_state(st, state_inout);
+    if (n_iter_out) *n_iter_out = it;
+    const int M = dbg.n_match.empty() ? 0 : dbg.n_match.back();
+    if (n_match_out) *n_match_out = M;
+    if (res_mean_out) *res_mean_out = dbg.res_mean_last;
+    for (int i = 0; i < M; i++) {
+        const int j = dbg.match_idx_last[i];
+        if (eff_pts_body) for (int k = 0; k < 3; k++) eff_pts_body[i * 3 + k] = pts[j * 3 + k];
+        if (eff_norm_dis) { for (int k = 0; k < 3; k++) eff_norm_dis[i * 4 + k] = (float)dbg.normals_last[i * 3 + k]; eff_norm_dis[i * 4 + 3] = dbg.dis_last[i]; }
+    }
+    return 0;
+}
+
+// one matcher + H-build pass at a fixed state: run() with max_iter forced to 1 on a scratch copy of the state
+int orc_residuals(void* p, const float* pts, int32_t n_ds, const double* state, double* HTH36, double* HTz6, int32_t* n_match,
+                  int32_t* match_idx, double* normals, float* dis, double* r_inv) {
+    OrcCtx* o = (OrcCtx*)p;
+    State st; load_state(state, st);
+    State prior = st;
+    const int keep = o->vm.cfg.max_iter;
+    o->vm.cfg.max_iter = 1;
+    RegDebug dbg;
+    o->reg.run(pts, n_ds, prior, st, &dbg);
+    o->vm.cfg.max_iter = keep;
+    std::memcpy(HTH36, dbg.HTH.data(), 36 * 8);
+    std::memcpy(HTz6, dbg.HTz.data(), 6 * 8);
+    const int M = dbg.n_match[0];
+    if (n_match) *n_match = M;
+    for (int i = 0; i < M; i++) {
+        if (match_idx) match_idx[i] = dbg.match_idx_last[i];
+        if (normals) for (int k = 0; k < 3; k++) normals[i * 3 + k] = dbg.normals_last[i * 3 + k];
+        if (dis) dis[i] = dbg.dis_last[i];
+        if (r_inv) r_inv[i] = dbg.rinv_last[i];
+    }
+    return 0;
+}
+
+int orc_map_update(void* p, const float* pts, int32_t n_ds, const double* state) {
+    OrcCtx* o = (OrcCtx*)p;
+    State s; load_state(state, s);
+    o->reg.prepare(pts, n_ds);
+    o->reg.map_grow(pts, n_ds, s);
+    return 0;
+}
+
+int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx) {
+    (void)frame_idx;
+    OrcCtx* o = (OrcCtx*)p;
+    o->mesher.mesh_scan(pts_world_xyzi, n_raw, sensor_pos, o->mout);
+    return 0;
+}
+int orc_mesh_sizes(void* p, immesh_mesh_sizes_t* s) {
+    OrcCtx* o = (OrcCtx*)p;
+    const MeshScanOut& m = o->mout;
+    s->vtx_base = m.vtx_base; s->n_new_vtx = (int)m.new_vtx.size() / 3; s->n_add = (int)m.tri_add.size() / 3; s->n_rem = (int)m.tri_rem.size() / 3;
+    s->n_upd = (int)m.tri_upd.size() / 3; s->n_smooth = (int)m.smooth_ids.size(); s->n_voxels_meshed = m.v_act; s->reserved = 0;
+    return 0;
+}
+int orc_mesh_fetch(void* p, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd, uint8_t* flip_upd,
+                   int32_t* smooth_ids, double* smooth_xyz) {
+    OrcCtx* o = (OrcCtx*)p;
+    const MeshScanOut& m = o->mout;
+    if (new_vtx_xyz) std::memcpy(new_vtx_xyz, m.new_vtx.data(), m.new_vtx.size() * 4);
+    if (tri_add) std::memcpy(tri_add, m.tri_add.data(), m.tri_add.size() * 4);
+    if (flip_add) std::memcpy(flip_add, m.flip_add.data(), m.flip_add.size());
+    if (tri_rem) std::memcpy(tri_rem, m.tri_rem.data(), m.tri_rem.size() * 4);
+    if (tri_upd) std::memcpy(tri_upd, m.tri_upd.data(), m.tri_upd.size() * 4);
+    if (flip_upd) std::memcpy(flip_upd, m.flip_upd.data(), m.flip_upd.size());
+    if (smooth_ids) std::memcpy(smooth_ids, m.smooth_ids.data(), m.smooth_ids.size() * 4);
+    if (smooth_xyz) std::memcpy(smooth_xyz, m.smooth_xyz.data(), m.smooth_xyz.size() * 8);
+    return 0;
+}
+
+// body->world of the full scan (transformLidar, voxel_mapping_common.cpp:709-726): f64 compute, f32 store, intensity kept
+static void transform_full(const Config& c, const State& s, const float* in_xyzi, int n, std::vector<float>& out) {
+    out.resize((size_t)n * 4);
+    for (int i = 0; i < n; i++) {
+        const double p[3] = {in_xyzi[i * 4 + 0], in_xyzi[i * 4 + 1], in_xyzi[i * 4 + 2]};
+        double pw[3];
+        body_to_world_d(c, s.R, s.t, p, pw);
+        out[i * 4 + 0] = (float)pw[0]; out[i * 4 + 1] = (float)pw[1]; out[i * 4 + 2] = (float)pw[2]; out[i * 4 + 3] = in_xyzi[i * 4 + 3];
+    }
+}
+
+static thread_local float g_timing[4] = {0, 0, 0, 0};
+int orc_process_scan(void* p, const float* pts_down, int32_t n_ds, const float* pts_raw_xyzi, int32_t n_raw, const double* state_prior,
+                     double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out) {
+    OrcCtx* o = (OrcCtx*)p;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = orc_register(p, pts_down, n_ds, state_prior, state_inout, n_iter_out, n_match_out, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    auto t1 = std::chrono::steady_clock::now();
+    State s; load_state(state_inout, s);
+    o->reg.map_grow(pts_down, n_ds, s);
+    auto t2 = std::chrono::steady_clock::now();
+    if (do_mesh) {
+        std::vector<float> world;
+        transform_full(o->cfg, s, pts_raw_xyzi, n_raw, world);
+        o->mesher.mesh_scan(world.data(), n_raw, s.t, o->mout);
+    }
+    auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return (float)std::chrono::duration<double, std::milli>(b - a).count(); };
+    g_timing[0] = ms(t0, t3); g_timing[1] = ms(t0, t1); g_timing[2] = ms(t1, t2); g_timing[3] = ms(t2, t3);
+    (void)frame_idx;
+    return 0;
+}
+int orc_last_timing(void* p, float ms[4]) { (void)p; for (int i = 0; i < 4; i++) ms[i] = g_timing[i]; return 0; }
+
+static void dump_node(const Key& k, const OctoTree* n, int path, int depth, immesh_plane_rec* out, int64_t cap, int64_t& cnt) {
+    if (n->init_octo) {
+        if (cnt < cap && out) {
+            immesh_plane_rec& r = out[cnt];
+            r.key[0] = k.x; r.key[1] = k.y; r.key[2] = k.z;
+            r.layer = n->layer; r.path = path; r.is_plane = n->plane.is_plane ? 1 : 0; r.n_points = (int)n->temp_points.size();
+            r.update_enable = n->update_enable ? 1 : 0; r.new_points = n->new_points;
+            r.radius = n->plane.radius; r.min_eig = n->plane.min_eig; r.d = n->plane.d; r.pad = 0;
+            for (int i = 0; i < 3; i++) { r.center[i] = n->plane.center[i]; r.normal[i] = n->plane.normal[i]; }
+            std::memcpy(r.plane_var, n->plane.plane_var, sizeof(r.plane_var));
+        }
+        cnt++;
+    }
+    for (int l = 0; l < 8; l++)
+        if (n->leaves[l]) dump_node(k, n->leaves[l], path | (l << (3 * depth)), depth + 1, out, cap, cnt);
+}
+int orc_dump_planes(void* p, immesh_plane_rec* out, int64_t cap, int64_t* n_out) {
+    OrcCtx* o = (OrcCtx*)p;
+    int64_t cnt = 0;
+    for (const auto& kv : o->vm.map) dump_node(kv.first, kv.second, 0, 0, out, cap, cnt);
+    *n_out = cnt;
+    return 0;
+}
+
+int orc_counters(void* p, immesh_counters_t* c, int32_t reset) {
+    OrcCtx* o = (OrcCtx*)p;
+    const Counters& k = o->vm.cnt;
+    c->n_ds = k.n_ds; c->n_iter = k.n_iter; c->n_match = k.n_match; c->n_plane_tests = k.n_plane_tests; c->n_extra_probe = k.n_extra_probe;
+    c->n_refits = k.n_refits; c->n_refit_pts = k.n_refit_pts; c->n_app = k.n_app; c->n_new = k.n_new; c->v_act = k.v_act; c->n_v = k.n_v;
+    c->n_u = k.n_u; c->t_v = k.t_v; c->t_add = k.t_add; c->t_rem = k.t_rem; c->c1 = k.c1; c->c20 = k.c20;
+    c->n_root_voxels = (int64_t)o->vm.map.size(); c->n_nodes = 0; c->n_vertices = (int64_t)o->mesher.verts.size();
+    c->n_triangles_live = (int64_t)o->mesher.live_triangle_count();
+    if (reset) o->vm.cnt = Counters();
+    return 0;
+}
+
+// ---- fine-grained hooks used only by the oracle's own unit tests ------------------------------------------------
+void orc_calc_body_var(const double* pb, float range_inc, float degree_inc, double* var9) {
+    double p[3] = {pb[0], pb[1], pb[2]};
+    calc_body_var(p, range_inc, degree_inc, var9);
+}
+void orc_sym3_eigen(const double* A9, double* evals3, double* V9) { sym3_eigen_jacobi(A9, evals3, V9); }
+int orc_inv(const double* A, double* Ainv, int n) { return inv_gauss_jordan(A, Ainv, n) ? 0 : -1; }
+void orc_key(const double* p3, double voxel_size, int64_t* key3) {
+    const double q[3] = {p3[0] / voxel_size, p3[1] / voxel_size, p3[2] / voxel_size};
+    Key k = key_from_quotient(q);
+    key3[0] = k.x; key3[1] = k.y; key3[2] = k.z;
+}
+// 2-D Delaunay of n points -> triangles (local indices); returns triangle count, writes up to cap triangles
+int orc_delaunay2d(const double* xy, int n, int32_t* tris, int cap) {
+    Delaunay2D dt;
+    std::vector<int> f;
+    dt.run(xy, n, f);
+    const int nt = (int)f.size() / 3;
+    for (int i = 0; i < nt && i < cap; i++) { tris[i * 3] = f[i * 3]; tris[i * 3 + 1] = f[i * 3 + 1]; tris[i * 3 + 2] = f[i * 3 + 2]; }
+    return nt;
+}
+// exact kNN over the mesher's current vertex set (for validation against oracle/_ref's real ikd-Tree)
+int orc_mesh_knn(void* p, const float* q, int k, double r_max, int32_t* ids, float* d2) {
+    OrcCtx* o = (OrcCtx*)p;
+    std::vector<Mesher::NN> nn;
+    o->mesher.knn(q, k, r_max, nn);
+    for (size_t i = 0; i < nn.size(); i++) { ids[i] = nn[i].id; d2[i] = nn[i].d2; }
+    return (int)nn.size();
+}
+int orc_mesh_live_triangles(void* p, int32_t* out, int64_t cap) {
+    OrcCtx* o = (OrcCtx*)p;
+    std::vector<int> t;
+    o->mesher.live_triangles(t);
+    const int64_t n = (int64_t)t.size() / 3;
+    for (int64_t i = 0; i < n && i < cap; i++) for (int k = 0; k < 3; k++) out[i * 3 + k] = t[i * 3 + k];
+    return (int)n;
+}
+int orc_mesh_vertices(void* p, double* pos, double* smooth, int64_t cap) {
+    OrcCtx* o = (OrcCtx*)p;
+    const int64_t n = (int64_t)o->mesher.verts.size();
+    for (int64_t i = 0; i < n && i < cap; i++) for (int k = 0; k < 3; k++) { if (pos) pos[i * 3 + k] = o->mesher.verts[i].pos[k]; if (smooth) smooth[i * 3 + k] = o->mesher.verts[i].smooth[k]; }
+    return (int)n;
+}
+
+}  // extern "C"

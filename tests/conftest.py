@@ -1,0 +1,73 @@
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from immesh_amd import capi  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """CPU oracle (test infrastructure).  Built on demand; g++ only."""
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".hpp", ".cpp"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def ref_ikd_lib():
+    """The reference's own ikd-Tree compiled from /root/reference (oracle/_ref).  Absent on the GPU box unless prebuilt."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_ikdtree.so")
+    if not os.path.exists(so):
+        if os.path.exists("/root/reference/include/ikd-Tree/ikd_Tree.cpp"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        else:
+            pytest.skip("oracle/_ref not built and /root/reference absent")
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    return capi.load_hip_library()
+
+
+@pytest.fixture()
+def avia():
+    return capi.avia_config()
+
+
+def make_oracle(oracle_lib, cfg):
+    return capi.HotPath(oracle_lib, cfg, prefix="orc_")
+
+
+def make_hip(hip_lib, cfg):
+    return capi.HotPath(hip_lib, cfg, prefix="immesh_")
