@@ -1,0 +1,154 @@
+"""Pins the oracle's mesher restatement: 2-D Delaunay vs scipy/Qhull, exact kNN and vertex admission vs the REFERENCE'S
+OWN ikd-Tree (oracle/_ref, compiled from /root/reference/include/ikd-Tree), and structural invariants of the mesh."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy.spatial import Delaunay, cKDTree
+
+from immesh_amd import capi, synth
+from conftest import make_oracle
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _tri_set(t):
+    return set(map(tuple, np.sort(np.asarray(t).reshape(-1, 3), axis=1)))
+
+
+@pytest.mark.parametrize("n,seed", [(3, 0), (4, 1), (7, 2), (30, 3), (200, 4), (1000, 5)])
+def test_delaunay_vs_qhull(oracle_lib, n, seed):
+    rng = np.random.default_rng(seed)
+    xy = np.ascontiguousarray(rng.normal(size=(n, 2)) * [1.0, 0.4])
+    tris = np.zeros((4 * n + 8, 3), np.int32)
+    nt = oracle_lib.orc_delaunay2d(_dp(xy), n, _dp(tris), len(tris))
+    mine = _tri_set(tris[:nt])
+    ref = _tri_set(Delaunay(xy).simplices)
+    assert mine == ref
+    # orientation ccw + Euler count T = 2n - 2 - h
+    for a, b, c in tris[:nt]:
+        assert (xy[b, 0] - xy[a, 0]) * (xy[c, 1] - xy[a, 1]) - (xy[c, 0] - xy[a, 0]) * (xy[b, 1] - xy[a, 1]) > 0
+    from scipy.spatial import ConvexHull
+    assert nt == 2 * n - 2 - len(ConvexHull(xy).vertices)
+
+
+def test_delaunay_degenerate_inputs(oracle_lib):
+    tris = np.zeros((64, 3), np.int32)
+    # all collinear -> no faces; duplicates -> ignored, still a valid triangulation of the distinct points
+    xy = np.ascontiguousarray(np.stack([np.arange(6.0), 2 * np.arange(6.0)], axis=1))
+    assert oracle_lib.orc_delaunay2d(_dp(xy), 6, _dp(tris), 64) == 0
+    xy = np.array([[0, 0], [1, 0], [0, 1], [1, 0], [0.3, 0.3], [0, 0]], float)
+    nt = oracle_lib.orc_delaunay2d(_dp(xy), 6, _dp(tris), 64)
+    assert nt == 3 and set(np.unique(tris[:nt])) <= {0, 1, 2, 3, 4, 5}
+    assert oracle_lib.orc_delaunay2d(_dp(xy), 2, _dp(tris), 64) == 0
+
+
+def _mesh_cfg():
+    return capi.avia_config()
+
+
+def _scan_world(k, n=20000):
+    R, t = synth.trajectory_pose(k)
+    raw = synth.livox_scan(k, R, t, n_pts=n)
+    w = raw.copy()
+    w[:, :3] = (raw[:, :3].astype(np.float64) @ R.T + t).astype(np.float32)
+    return np.ascontiguousarray(w), t
+
+
+def test_append_and_knn_vs_reference_ikdtree(oracle_lib, ref_ikd_lib):
+    """Vertex admission (a17) re-run in Python on top of the REAL ikd-Tree must accept exactly the oracle's vertices, and the
+    oracle's exact kNN (a18) must return the real tree's neighbours."""
+    L = ref_ikd_lib
+    L.ref_ikd_create.restype = C.c_void_p
+    tree = C.c_void_p(L.ref_ikd_create())
+    cfg = _mesh_cfg()
+    hp = make_oracle(oracle_lib, cfg)
+    grid = {}
+    verts = []
+    idx1, d1 = np.zeros(1, np.int64), np.zeros(1, np.float32)
+    for k in range(3):
+        w, t = _scan_world(k, n=12000)
+        out = hp.mesh_scan(w, t, frame_idx=k)
+        step = max(1, int(round(len(w) // cfg.mesh_append_budget)))
+        base = len(verts)
+        for p in w[::step]:
+            g = tuple(int(np.round(float(p[a]) / cfg.mesh_min_spacing)) for a in range(3))
+            if g in grid:
+                continue
+            if L.ref_ikd_has_root(tree):
+                n = L.ref_ikd_knn(tree, _dp(p[:3].copy()), 1, _dp(idx1), _dp(d1))
+                if n and float(np.sqrt(d1[0])) < cfg.mesh_min_spacing:
+                    continue
+            grid[g] = len(verts)
+            L.ref_ikd_add(tree, _dp(p[:3].copy()), C.c_long(len(verts)))
+            verts.append(p[:3].copy())
+        assert out["vtx_base"] == base
+        np.testing.assert_array_equal(out["new_vtx"], np.array(verts[base:], np.float32).reshape(-1, 3))
+    V = np.array(verts, np.float32)
+    assert len(V) > 3000
+    # min spacing invariant (float distances as the tree computes them)
+    dd, _ = cKDTree(V.astype(np.float64)).query(V.astype(np.float64), k=2)
+    assert dd[:, 1].min() >= cfg.mesh_min_spacing * (1 - 1e-6)
+    # 20-NN parity with the real ikd-Tree on 300 vertex queries (skip queries with an exact distance tie at rank 20)
+    ids_o, d_o = np.zeros(20, np.int32), np.zeros(20, np.float32)
+    ids_r, d_r = np.zeros(20, np.int64), np.zeros(20, np.float32)
+    rng = np.random.default_rng(0)
+    checked = 0
+    for q in V[rng.choice(len(V), 300, replace=False)]:
+        no = oracle_lib.orc_mesh_knn(hp.ctx, _dp(q.copy()), 20, C.c_double(1.0), _dp(ids_o), _dp(d_o))
+        nr = L.ref_ikd_knn(tree, _dp(q.copy()), 20, _dp(ids_r), _dp(d_r))
+        keep_r = np.sqrt(d_r[:nr]) < 1.0
+        m = int(keep_r.sum())
+        assert no >= m
+        if len(np.unique(d_r[:nr])) < nr:
+            continue
+        np.testing.assert_array_equal(ids_o[:m], ids_r[:nr][keep_r])
+        np.testing.assert_array_equal(d_o[:m], d_r[:nr][keep_r])
+        checked += 1
+    assert checked > 250
+    L.ref_ikd_destroy(tree)
+
+
+def test_mesh_invariants(oracle_lib):
+    cfg = _mesh_cfg()
+    hp = make_oracle(oracle_lib, cfg)
+    live = set()
+    nv = 0
+    for k in range(4):
+        w, t = _scan_world(k, n=20000)
+        out = hp.mesh_scan(w, t, frame_idx=k)
+        add, rem, upd = _tri_set(out["tri_add"]), _tri_set(out["tri_rem"]), _tri_set(out["tri_upd"])
+        nv += len(out["new_vtx"])
+        # triplets sorted, unique, in range; removed ones were live; added ones were not; updated ones stay live
+        for arr in (out["tri_add"], out["tri_rem"], out["tri_upd"]):
+            assert np.all(arr[:, 0] < arr[:, 1]) and np.all(arr[:, 1] < arr[:, 2])
+            assert arr.size == 0 or (arr.min() >= 0 and arr.max() < nv)
+            assert len(_tri_set(arr)) == len(arr)
+        assert rem <= live and not (add & live) and (upd - rem) <= live
+        live = (live - rem) | add
+        assert set(np.unique(out["flip_add"])) <= {0, 1}
+    got = np.zeros((len(live) + 8, 3), np.int32)
+    n = oracle_lib.orc_mesh_live_triangles(hp.ctx, _dp(got), C.c_int64(len(got)))
+    assert _tri_set(got[:n]) == live and n > 5000
+    # every live triangle obeys the 150-degree rule in 3-D up to projection slack, and has no edge longer than the kNN pull radius*2
+    pos = np.zeros((nv, 3)); sm = np.zeros((nv, 3))
+    assert oracle_lib.orc_mesh_vertices(hp.ctx, _dp(pos), _dp(sm), C.c_int64(nv)) == nv
+    T = got[:n]
+    e = np.linalg.norm(pos[T[:, 0]] - pos[T[:, 1]], axis=1)
+    assert e.max() < (np.sqrt(3) + 2 * 1.25) * cfg.mesh_voxel   # voxel diagonal + two pull radii
+    assert np.abs(sm - pos).max() < 2.5 * cfg.mesh_voxel
+
+
+def test_append_step_rule(oracle_lib):
+    """A.11: step = max(1, round(N / budget)) with integer division first -> 24 000 pts => every 2nd point."""
+    cfg = _mesh_cfg()
+    hp = make_oracle(oracle_lib, cfg)
+    rng = np.random.default_rng(1)
+    pts = np.zeros((24000, 4), np.float32)
+    pts[:, 0] = np.arange(24000) * 0.25        # one candidate per 0.25 m along x: all accepted
+    pts[:, 1:3] = rng.normal(0, 1e-3, (24000, 2))
+    out = hp.mesh_scan(pts, np.zeros(3))
+    assert len(out["new_vtx"]) == 12000
+    np.testing.assert_array_equal(out["new_vtx"][:, 0], pts[::2, 0])
