@@ -1,0 +1,388 @@
+// C ABI of libimmesh_hip.so (include/immesh_c_api.h): host orchestration of the HIP kernels.
+// There is NO CPU compute path here: every per-point / per-voxel operation is a kernel in reg_kernels.hip / mesh_kernels.hip;
+// the host keeps only the 18x18 EKF algebra (as the reference does) and stream plumbing.
+#include "host_ctx.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+static thread_local std::string g_create_error;
+
+static int64_t next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" {
+
+void immesh_default_config(immesh_config* c) {
+    std::memset(c, 0, sizeof(*c));
+    c->voxel_size = 0.5; c->max_layer = 2;
+    for (int i = 0; i < 5; i++) c->layer_init[i] = 5;
+    c->max_points_size = 100; c->planer_threshold = 0.01; c->dept_err = 0.02; c->beam_err = 0.05; c->calib_laser = 0;
+    c->sigma_num = 3.0; c->max_iter = 4;
+    c->extR[0] = c->extR[4] = c->extR[8] = 1.0;
+    c->extT[0] = 0.04165; c->extT[1] = 0.02326; c->extT[2] = -0.0284;
+    c->mesh_min_spacing = 0.1; c->mesh_voxel = 0.4; c->mesh_region = 10.0; c->mesh_append_budget = 10000;
+}
+
+const char* immesh_create_error(void) { return g_create_error.c_str(); }
+const char* immesh_last_error(immesh_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+static int alloc_all(immesh_ctx* c) {
+    const immesh_config& g = c->cfg;
+    RegMapDev& m = c->map;
+    const int64_t cap_roots = g.cap_root_voxels > 0 ? g.cap_root_voxels : (1 << 20);
+    const int64_t cap_nodes = g.cap_nodes > 0 ? g.cap_nodes : cap_roots + cap_roots / 2;
+    const int64_t cap_chunks = g.cap_point_chunks > 0 ? g.cap_point_chunks : cap_nodes * 2;
+    const int64_t cap_ext = std::max<int64_t>(1024, cap_nodes / 64);
+    const int64_t hcap = next_pow2(cap_roots * 2);
+    if (cap_nodes > 0x7fffffff || cap_chunks > 0x7fffffff || hcap > 0xffffffffLL) { c->err = "capacity too large for 32-bit indices"; return IMMESH_E_INVAL; }
+    int rc;
+#define A(ptr, n) if ((rc = c->dalloc(&(ptr), (size_t)(n)))) return rc
+    A(m.hkeys, hcap); A(m.hvals, hcap);
+    m.hmask = (uint64_t)hcap - 1;
+    A(m.n_child, cap_nodes * 8); A(m.n_center, cap_nodes * 3); A(m.n_quarter, cap_nodes); A(m.n_flags, cap_nodes); A(m.n_layer, cap_nodes);
+    A(m.n_npts, cap_nodes); A(m.n_newpts, cap_nodes); A(m.n_chunks, cap_nodes * IM_INLINE_CHUNKS); A(m.n_ext, cap_nodes); A(m.n_key, cap_nodes);
+    A(m.n_path, cap_nodes);
+    A(m.p_center, cap_nodes * 3); A(m.p_normal, cap_nodes * 3); A(m.p_d, cap_nodes); A(m.p_radius, cap_nodes); A(m.p_min_eig, cap_nodes);
+    A(m.p_var, cap_nodes * 21);
+    A(m.chunk_data, cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES); A(m.ext_tables, cap_ext * IM_EXT_CHUNKS);
+    A(m.counters, 16); A(m.free_ready, cap_chunks); A(m.free_pending, cap_chunks);
+    m.cap_nodes = (int32_t)cap_nodes; m.cap_chunks = (int32_t)cap_chunks; m.cap_ext = (int32_t)cap_ext;
+    m.max_layer = g.max_layer; m.max_points_size = g.max_points_size;
+    for (int i = 0; i < 5; i++) m.init_size[i] = g.layer_init[i];
+    m.planer_threshold = (float)g.planer_threshold;
+    m.voxel_size_f = (float)g.voxel_size;
+    m.voxel_size_d = g.voxel_size;
+    HIPCHK(c, hipMemsetAsync(m.counters, 0, 16 * sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(m.hvals, 0xFF, hcap * sizeof(int32_t), c->stream));
+    launch_fill_u64(c->stream, m.hkeys, IM_KEY_EMPTY, (size_t)hcap);
+    A(c->d_stats, 8);
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
+
+    const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
+    c->cap_scan = ns;
+    A(c->d_pts_down, ns * 3); A(c->d_pts_raw, ns * 4); A(c->d_pts_world, ns * 4);
+    A(c->d_partials, ((ns + 255) / 256) * RES_NV_HOST); A(c->d_out48, RES_NV_HOST);
+    A(c->d_match, ns); A(c->d_mnode, ns); A(c->d_dis, ns); A(c->d_rinv, ns); A(c->d_normal, ns * 3);
+    A(c->d_ptdata, ns * IM_PT_DOUBLES);
+    A(c->d_key_a, ns); A(c->d_key_b, ns); A(c->d_idx_a, ns); A(c->d_idx_b, ns); A(c->d_idx_c, ns);
+    A(c->d_slot, ns); A(c->d_slot_g, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 4);
+    c->sort_temp_bytes = std::max(sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns)) + 256;
+    { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
+    A(c->d_dump_count, 2);
+#undef A
+    HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t)));
+    return 0;
+}
+
+int mesh_alloc(immesh_ctx* c);   // mesh_host.cpp
+void mesh_free(immesh_ctx* c);
+
+immesh_ctx* immesh_create(const immesh_config* cfg) {
+    g_create_error.clear();
+    if (!cfg) { g_create_error = "null config"; return nullptr; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") + "); the hot path has no CPU fallback";
+        return nullptr;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return nullptr; }
+    if (cfg->max_layer < 0 || cfg->max_layer > 4 || cfg->voxel_size <= 0 || cfg->max_iter < 1) { g_create_error = "invalid config"; return nullptr; }
+    immesh_ctx* c = new (std::nothrow) immesh_ctx();
+    if (!c) { g_create_error = "out of host memory"; return nullptr; }
+    c->cfg = *cfg;
+    std::memset(&c->cnt, 0, sizeof(c->cnt));
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
+    }
+    for (auto& ev : c->ev) hipEventCreate(&ev);
+    // per-config constants of calcBodyVar: pow(sin(DEG2RAD(deg)),2) with PCL's DEG2RAD(x) = x*0.017453293 and float `degree_inc`
+    { const double s = std::sin((double)(float)cfg->beam_err * 0.017453293); c->dvar_beam = s * s; }
+    { const double s = std::sin((double)(float)0.01 * 0.017453293); c->dvar_calib = s * s; }
+    int rc = alloc_all(c);
+    if (!rc) rc = mesh_alloc(c);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { rc = IMMESH_E_HIP; c->err = "initialisation kernels failed"; }
+    if (rc) { g_create_error = c->err; immesh_destroy(c); return nullptr; }
+    return c;
+}
+
+void immesh_destroy(immesh_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    mesh_free(c);
+    for (void* p : c->allocs) hipFree(p);
+    if (c->h_out48) hipHostFree(c->h_out48);
+    if (c->h_counters) hipHostFree(c->h_counters);
+    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+static void make_scan_params(const immesh_ctx* c, const imh::State& st, const double* prior_cov, ScanParams& sp) {
+    const immesh_config& g = c->cfg;
+    std::memcpy(sp.R, st.R, 72); std::memcpy(sp.t, st.t, 24);
+    std::memcpy(sp.extR, g.extR, 72); std::memcpy(sp.extT, g.extT, 24);
+    imh::mat3_mul(st.R, g.extR, sp.RextR);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { sp.rot_var[i * 3 + j] = prior_cov[i * 18 + j]; sp.t_var[i * 3 + j] = prior_cov[(3 + i) * 18 + (3 + j)]; }
+    sp.dvar_beam = c->dvar_beam; sp.dvar_calib = c->dvar_calib; sp.sigma_num = g.sigma_num;
+    sp.dept_err = (float)g.dept_err; sp.calib_laser = g.calib_laser;
+}
+
+static int check_overflow(immesh_ctx* c) {  // after a stream sync
+    const int f = c->h_counters[5];
+    if (f) {
+        static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 1152 retained points", "extension-table pool exhausted",
+                                    "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)"};
+        c->err = std::string("registration map capacity: ") + why[f < 6 ? f : 0];
+        return IMMESH_E_CAPACITY;
+    }
+    return 0;
+}
+
+static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh::State& st, const double* prior_cov) {
+    ScanParams sp;
+    make_scan_params(c, st, prior_cov, sp);
+    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_out48, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
+    HIPCHK(c, hipMemcpyAsync(c->h_out48, c->d_out48, RES_NV_HOST * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cnt.n_match += (int64_t)c->h_out48[42];
+    c->cnt.n_plane_tests += (int64_t)c->h_out48[44];
+    c->cnt.n_extra_probe += (int64_t)c->h_out48[45];
+    return 0;
+}
+
+// compact per-point match outputs (ascending scan index == the reference's ptpl_list order)
+static int fetch_matches(immesh_ctx* c, int n, std::vector<int8_t>& mt) {
+    mt.resize(n);
+    HIPCHK(c, hipMemcpyAsync(mt.data(), c->d_match, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
+static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
+    imh::EkfLoop ekf;
+    const int max_iter = c->cfg.max_iter;
+    int iters = 0;
+    for (int it = 0; it < max_iter; it++) {
+        iters++;
+        int rc = run_residual_pass(c, d_pts, n_ds, st, st.cov);
+        if (rc) return rc;
+        const double* o = c->h_out48;
+        if (n_match) *n_match = (int)o[42];
+        if (res_mean) *res_mean = o[42] > 0 ? o[43] / o[42] : 0.0;
+        if (ekf.step(o, o + 36, prior, st, it, max_iter)) break;
+    }
+    c->cnt.n_iter += iters;
+    c->cnt.n_ds = n_ds;
+    c->last_n_ds = n_ds;
+    if (n_iter) *n_iter = iters;
+    return 0;
+}
+
+int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state_prior, double* state_inout, int32_t* n_iter_out,
+                    int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis) {
+    if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    const void* d_pts;
+    int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
+    if (rc) return rc;
+    imh::State prior, st;
+    imh::load_state(state_prior, prior); imh::load_state(state_inout, st);
+    int n_iter = 0, n_match = 0; double res = 0;
+    rc = register_device(c, (const float*)d_pts, n_ds, prior, st, &n_iter, &n_match, &res);
+    if (rc) return rc;
+    imh::store_state(st, state_inout);
+    if (n_iter_out) *n_iter_out = n_iter;
+    if (n_match_out) *n_match_out = n_match;
+    if (res_mean_out) *res_mean_out = res;
+    if (eff_pts_body || eff_norm_dis) {
+        std::vector<int8_t> mt;
+        if ((rc = fetch_matches(c, n_ds, mt))) return rc;
+        std::vector<float> hp((size_t)n_ds * 3), hd(n_ds);
+        std::vector<double> hn((size_t)n_ds * 3);
+        HIPCHK(c, hipMemcpy(hp.data(), d_pts, (size_t)n_ds * 12, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hd.data(), c->d_dis, (size_t)n_ds * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hn.data(), c->d_normal, (size_t)n_ds * 24, hipMemcpyDeviceToHost));
+        int k = 0;
+        for (int i = 0; i < n_ds; i++)
+            if (mt[i]) {
+                if (eff_pts_body) for (int a = 0; a < 3; a++) eff_pts_body[k * 3 + a] = hp[(size_t)i * 3 + a];
+                if (eff_norm_dis) { for (int a = 0; a < 3; a++) eff_norm_dis[k * 4 + a] = (float)hn[(size_t)i * 3 + a]; eff_norm_dis[k * 4 + 3] = hd[i]; }
+                k++;
+            }
+    }
+    return 0;
+}
+
+int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state, double* HTH36, double* HTz6, int32_t* n_match,
+                     int32_t* match_idx, double* normals, float* dis, double* r_inv) {
+    if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state || !HTH36 || !HTz6) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    const void* d_pts;
+    int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
+    if (rc) return rc;
+    imh::State st;
+    imh::load_state(state, st);
+    if ((rc = run_residual_pass(c, (const float*)d_pts, n_ds, st, st.cov))) return rc;
+    std::memcpy(HTH36, c->h_out48, 36 * 8);
+    std::memcpy(HTz6, c->h_out48 + 36, 6 * 8);
+    if (n_match) *n_match = (int)c->h_out48[42];
+    if (match_idx || normals || dis || r_inv) {
+        std::vector<int8_t> mt;
+        if ((rc = fetch_matches(c, n_ds, mt))) return rc;
+        std::vector<float> hd(n_ds);
+        std::vector<double> hn((size_t)n_ds * 3), hr(n_ds);
+        HIPCHK(c, hipMemcpy(hd.data(), c->d_dis, (size_t)n_ds * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hn.data(), c->d_normal, (size_t)n_ds * 24, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hr.data(), c->d_rinv, (size_t)n_ds * 8, hipMemcpyDeviceToHost));
+        int k = 0;
+        for (int i = 0; i < n_ds; i++)
+            if (mt[i]) {
+                if (match_idx) match_idx[k] = i;
+                if (normals) for (int a = 0; a < 3; a++) normals[k * 3 + a] = hn[(size_t)i * 3 + a];
+                if (dis) dis[k] = hd[i];
+                if (r_inv) r_inv[k] = hr[i];
+                k++;
+            }
+    }
+    return 0;
+}
+
+// shared by map_build / map_update: per-point var + root slots, sort, per-voxel replay
+static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode) {
+    ScanParams sp;
+    make_scan_params(c, st, st.cov, sp);
+    hipStream_t s = c->stream;
+    launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot);
+    launch_iota(s, c->d_idx_a, (int)n);
+    int hbits = 1;
+    while (((uint64_t)1 << hbits) <= c->map.hmask) hbits++;
+    const int32_t* idx_in = c->d_idx_a;
+    const uint32_t* slot_in = c->d_slot;
+    if (mode == 0) {  // std::sort(pv_list, var_contrast): ascending covariance norm, ties by scan index (stable)
+        sort_pairs_u64(s, c->d_sort_temp, c->sort_temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, (int)n);
+        launch_gather_u32(s, c->d_slot, c->d_idx_b, c->d_slot_g, (int)n);
+        idx_in = c->d_idx_b; slot_in = c->d_slot_g;
+    }
+    // group by root voxel, stable (keeps the replay order inside each voxel).  32 bits so the 0xFFFFFFFF "no slot" marker sorts last.
+    sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, slot_in, c->d_slot_s, idx_in, c->d_idx_c, (int)n, 32);
+    (void)hbits;
+    launch_segment_heads(s, c->d_slot_s, (int)n, c->d_seg_start, c->d_nseg);
+    launch_replay(s, c->map, c->d_slot_s, c->d_idx_c, c->d_ptdata, (int)n, c->d_seg_start, c->d_nseg, (int)n, mode, c->d_stats);
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* state) {
+    if (!c || !pts || n <= 0 || n > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    const void* d_pts;
+    int rc = resolve_input(c, pts, (size_t)n * 12, c->d_pts_down, &d_pts);
+    if (rc) return rc;
+    imh::State st;
+    imh::load_state(state, st);
+    if ((rc = map_ingest_device(c, (const float*)d_pts, n, 3, st, 1))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_overflow(c);
+}
+
+int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state) {
+    if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    const void* d_pts;
+    int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
+    if (rc) return rc;
+    imh::State st;
+    imh::load_state(state, st);
+    if ((rc = map_ingest_device(c, (const float*)d_pts, n_ds, 3, st, 0))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return check_overflow(c);
+}
+
+int mesh_scan_device(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);  // mesh_host.cpp
+int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, int n_raw, const imh::State& st);                      // mesh_host.cpp
+
+int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, const float* pts_raw, int32_t n_raw, const double* state_prior,
+                        double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out) {
+    if (!c || !pts_down || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout || (do_mesh && (!pts_raw || n_raw <= 0 || n_raw > c->cap_scan))) {
+        if (c) c->err = "bad arguments";
+        return IMMESH_E_INVAL;
+    }
+    hipSetDevice(c->cfg.device);
+    const void *d_down, *d_raw = nullptr;
+    int rc = resolve_input(c, pts_down, (size_t)n_ds * 12, c->d_pts_down, &d_down);
+    if (rc) return rc;
+    if (do_mesh && (rc = resolve_input(c, pts_raw, (size_t)n_raw * 16, c->d_pts_raw, &d_raw))) return rc;
+    imh::State prior, st;
+    imh::load_state(state_prior, prior); imh::load_state(state_inout, st);
+    hipEventRecord(c->ev[0], c->stream);
+    int n_iter = 0, n_match = 0;
+    if ((rc = register_device(c, (const float*)d_down, n_ds, prior, st, &n_iter, &n_match, nullptr))) return rc;
+    hipEventRecord(c->ev[1], c->stream);
+    if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0))) return rc;
+    hipEventRecord(c->ev[2], c->stream);
+    if (do_mesh) {
+        if ((rc = mesh_transform_full(c, (const float*)d_raw, n_raw, st))) return rc;
+        if ((rc = mesh_scan_device(c, c->d_pts_world, n_raw, st.t, frame_idx))) return rc;
+    }
+    hipEventRecord(c->ev[3], c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipEventElapsedTime(&c->timing[0], c->ev[0], c->ev[3]);
+    hipEventElapsedTime(&c->timing[1], c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&c->timing[2], c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&c->timing[3], c->ev[2], c->ev[3]);
+    imh::store_state(st, state_inout);
+    if (n_iter_out) *n_iter_out = n_iter;
+    if (n_match_out) *n_match_out = n_match;
+    return check_overflow(c);
+}
+
+int immesh_last_timing(immesh_ctx* c, float ms[4]) {
+    if (!c || !ms) return IMMESH_E_INVAL;
+    for (int i = 0; i < 4; i++) ms[i] = c->timing[i];
+    return 0;
+}
+
+int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_t* n_out) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    hipSetDevice(c->cfg.device);
+    static_assert(sizeof(PlaneRecDev) == sizeof(immesh_plane_rec), "plane record layout");
+    PlaneRecDev* d_out = nullptr;
+    if (out && cap > 0) HIPCHK(c, hipMalloc((void**)&d_out, (size_t)cap * sizeof(PlaneRecDev)));
+    launch_dump_planes(c->stream, c->map, d_out, d_out ? cap : 0, c->d_dump_count);
+    unsigned long long cnt = 0;
+    hipError_t e = hipMemcpyAsync(&cnt, c->d_dump_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && d_out) e = hipMemcpy(out, d_out, (size_t)std::min<int64_t>(cap, (int64_t)cnt) * sizeof(PlaneRecDev), hipMemcpyDeviceToHost);
+    if (d_out) hipFree(d_out);
+    if (e != hipSuccess) { c->err = std::string("dump_planes: ") + hipGetErrorString(e); return IMMESH_E_HIP; }
+    *n_out = (int64_t)cnt;
+    return 0;
+}
+
+void mesh_counters(immesh_ctx* c, immesh_counters_t* out);  // mesh_host.cpp
+
+int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
+    if (!c || !out) return IMMESH_E_INVAL;
+    hipSetDevice(c->cfg.device);
+    int64_t stats[8];
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *out = c->cnt;
+    out->n_refits = stats[0]; out->n_refit_pts = stats[1];
+    out->n_root_voxels = c->h_counters[6]; out->n_nodes = c->h_counters[0];
+    mesh_counters(c, out);
+    if (reset) {
+        std::memset(&c->cnt, 0, sizeof(c->cnt));
+        HIPCHK(c, hipMemset(c->d_stats, 0, sizeof(stats)));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// Host-side context of libimmesh_hip.so: owns the HIP stream, every HBM-resident pool and the scratch buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include "../../include/immesh_c_api.h"
+#include "regmap.hpp"
+#include "kernels.hpp"
+#include "mesh_kernels.hpp"
+#include "ekf_host.hpp"
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                                 \
+            return IMMESH_E_HIP;                                                                            \
+        }                                                                                                   \
+    } while (0)
+
+struct DevBuf {  // grow-only device buffer
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct immesh_ctx {
+    immesh_config cfg;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float timing[4] = {0, 0, 0, 0};
+    std::vector<void*> allocs;
+    size_t bytes_allocated = 0;
+
+    // ---- registration map
+    RegMapDev map;
+    int64_t* d_stats = nullptr;      // [8] refits, refit pts, ...
+    double dvar_beam = 0, dvar_calib = 0;
+
+    // ---- per-scan scratch (sized for cap_scan_points)
+    int64_t cap_scan = 0;
+    float* d_pts_down = nullptr;     // staging for host inputs (n x 3)
+    float* d_pts_raw = nullptr;      // staging (n x 4)
+    float* d_pts_world = nullptr;    // world_lidar_full (n x 4)
+    double* d_partials = nullptr;    // residual block partials
+    double* d_out48 = nullptr;
+    double* h_out48 = nullptr;       // pinned
+    int8_t* d_match = nullptr;
+    int32_t* d_mnode = nullptr;
+    float* d_dis = nullptr;
+    double* d_rinv = nullptr;
+    double* d_normal = nullptr;
+    double* d_ptdata = nullptr;      // n x 9
+    unsigned long long *d_key_a = nullptr, *d_key_b = nullptr;
+    int32_t *d_idx_a = nullptr, *d_idx_b = nullptr, *d_idx_c = nullptr;
+    uint32_t *d_slot = nullptr, *d_slot_g = nullptr, *d_slot_s = nullptr;
+    int32_t* d_seg_start = nullptr;
+    int32_t* d_nseg = nullptr;
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    int32_t* h_counters = nullptr;   // pinned copy of map.counters (8 ints)
+    unsigned long long* d_dump_count = nullptr;
+
+    // cumulative counters (host side)
+    immesh_counters_t cnt;
+    int last_n_ds = 0;
+
+    // ---- mesher
+    MeshDev mesh;
+    MeshHost mesh_host;
+
+    template <typename T>
+    int dalloc(T** out, size_t count) {
+        void* p = nullptr;
+        const size_t bytes = count * sizeof(T);
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) { err = "hipMalloc(" + std::to_string(bytes) + " B): " + hipGetErrorString(e); return IMMESH_E_NOMEM; }
+        allocs.push_back(p);
+        bytes_allocated += bytes;
+        *out = (T*)p;
+        return 0;
+    }
+};
+
+// resolve an input pointer that may be host or device memory; host data is staged into `staging` on the ctx stream
+inline int resolve_input(immesh_ctx* c, const void* p, size_t bytes, void* staging, const void** dev_out) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    bool is_dev = false;
+    if (e == hipSuccess) is_dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+    else (void)hipGetLastError();  // plain host pointer: clear the sticky error
+    if (is_dev) { *dev_out = p; return 0; }
+    HIPCHK(c, hipMemcpyAsync(staging, p, bytes, hipMemcpyHostToDevice, c->stream));
+    *dev_out = staging;
+    return 0;
+}

@@ -1,0 +1,47 @@
+// Host <-> kernel interface structs and launcher prototypes (shared by the .hip translation units and the C++ host layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct RegMapDev;
+
+struct ScanParams {          // everything a per-point kernel needs about the current state estimate
+    double R[9], t[3];       // state.rot_end / pos_end
+    double extR[9], extT[3]; // m_extR / m_extT
+    double RextR[9];         // R * extR
+    double rot_var[9], t_var[9];  // state.cov blocks (0:3,0:3) and (3:6,3:6)
+    double dvar_beam;        // sin(DEG2RAD(beam_err))^2, host-computed
+    double dvar_calib;       // same for CALIB_ANGLE_COV (include/common_lib.h:41)
+    double sigma_num;
+    float dept_err;
+    int calib_laser;
+};
+
+struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
+    long long key[3];
+    int layer, path, is_plane, n_points, update_enable, new_points;
+    float radius, min_eig, d, pad;
+    double center[3], normal[3], plane_var[36];
+};
+
+#define RES_NV_HOST 48
+
+void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, double* out48,
+                     int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
+                      unsigned long long* sort_key, uint32_t* slot);
+void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);
+void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
+                   const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats);
+void launch_dump_planes(hipStream_t s, const RegMapDev& m, PlaneRecDev* out, long long cap, unsigned long long* count);
+void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v, size_t n);
+void launch_iota(hipStream_t s, int32_t* p, int n);
+void launch_gather_u32(hipStream_t s, const uint32_t* src, const int32_t* idx, uint32_t* dst, int n);
+
+// stable LSD radix sort of (key,value) pairs, device-resident (sort.hip)
+size_t sort_pairs_u64_temp_bytes(int n);
+size_t sort_pairs_u32_temp_bytes(int n);
+void sort_pairs_u64(hipStream_t s, void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
+                    const int32_t* vals_in, int32_t* vals_out, int n);
+void sort_pairs_u32(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in,
+                    int32_t* vals_out, int n, int end_bit);

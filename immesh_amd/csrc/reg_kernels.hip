@@ -1,0 +1,667 @@
+// HIP kernels of the registration half of the hot path, gfx950.
+//   residual_kernel      BuildResidualListOMP + build_single_residual (src/voxel_mapping.cpp:153-318) fused with the
+//                        residual / Jacobian loops (:1372-1392, :1487-1575) and a deterministic block reduction of
+//                        H^T R^-1 H (36) and H^T R^-1 z (6): one thread per scan point, map read-only.
+//   point_var_kernel     world transform + covariance propagation of map_incremental_grow / voxel_map_init and
+//                        find-or-insert of the root voxel (ImMesh_mesh_reconstruction.cpp:393-404, voxel_mapping.cpp:1243-1281, :320-354)
+//   replay_kernel        updateVoxelMap / buildVoxelMap semantics: ONE WAVEFRONT PER ROOT VOXEL replays that voxel's points in
+//                        the reference's order (OctoTree::UpdateOctoTree state machine, src/voxel_loc.cpp:219-308);
+//                        plane fits (OctoTree::init_plane, :47-139) are wave-parallel: lanes stride the retained points,
+//                        64-lane butterfly reductions for the moment sums and the 21-entry plane covariance.
+// Bound: HBM/latency (dependent gathers through hash -> node -> plane); no GEMM-shaped work, MFMA is not used.
+#include "regmap.hpp"
+#include "kernels.hpp"
+
+using namespace imd;
+
+// =====================================================================================================================
+// matcher + H build
+// =====================================================================================================================
+struct BestMatch { int node; int layer; double prob; bool ok; };
+
+IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigma_out) {  // J * plane_var * J^T, plane_var symmetric (21)
+    const double* pv = m.p_var + (size_t)node * 21;
+    double tmp[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double s = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) s += J[r] * pv[(r <= c) ? sym21_index(r, c) : sym21_index(c, r)];
+        tmp[c] = s;
+    }
+    double sig = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) sig += tmp[c] * J[c];
+    *sigma_out = sig;
+}
+
+// build_single_residual on one plane node (voxel_mapping.cpp:252-290)
+IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
+    n_tests++;
+    const double nx = m.p_normal[(size_t)node * 3 + 0], ny = m.p_normal[(size_t)node * 3 + 1], nz = m.p_normal[(size_t)node * 3 + 2];
+    const double cx = m.p_center[(size_t)node * 3 + 0], cy = m.p_center[(size_t)node * 3 + 1], cz = m.p_center[(size_t)node * 3 + 2];
+    const float pd = m.p_d[node], radius = m.p_radius[node];
+    const float dis_to_plane = (float)fabs(nx * pw[0] + ny * pw[1] + nz * pw[2] + (double)pd);
+    const float dis_to_center = (float)((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2]));
+    const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);  // NaN compares false below
+    if ((double)range_dis <= 3.0 * (double)radius) {
+        const double J[6] = {pw[0] - cx, pw[1] - cy, pw[2] - cz, -nx, -ny, -nz};
+        double sigma_l;
+        plane_sigma(m, node, J, &sigma_l);
+        const double nrm[3] = {nx, ny, nz};
+        double vn[3];
+        m3t_vec(var, nrm, vn);
+        sigma_l += vn[0] * nx + vn[1] * ny + vn[2] * nz;
+        if ((double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
+            best.ok = true;
+            const double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
+            if (this_prob > best.prob) { best.prob = this_prob; best.node = node; best.layer = layer; }
+        }
+    }
+}
+
+// recursive descent over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312), explicit stack
+IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
+    if (m.n_flags[root] & NF_PLANE) { test_plane(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
+    if (m.max_layer <= 0) return;
+    int st_node[5], st_k[5];
+    int sp = 0;
+    st_node[0] = root; st_k[0] = 0;
+    while (sp >= 0) {
+        if (st_k[sp] >= 8) { sp--; continue; }
+        const int k = st_k[sp]++;
+        const int child = m.n_child[(size_t)st_node[sp] * 8 + k];
+        if (child < 0) continue;
+        const int layer = sp + 1;
+        if (m.n_flags[child] & NF_PLANE) test_plane(m, child, layer, pw, var, sigma_num, best, n_tests);
+        else if (layer < m.max_layer) { sp++; st_node[sp] = child; st_k[sp] = 0; }
+    }
+}
+
+#define RES_NV 48  // 36 HTH + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe + 2 spare
+
+__global__ __launch_bounds__(256) void residual_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n,
+                                                        double* __restrict__ partials, int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
+                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[RES_NV];
+#pragma unroll
+    for (int k = 0; k < RES_NV; k++) acc[k] = 0;
+    if (i < n) {
+        const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
+        // --- per-scan part of lio_state_estimation (:1302-1316): body covariance + cross matrix of the IMU-frame point
+        double pz[3] = {p[0], p[1], p[2]};
+        if (pz[2] == 0) pz[2] = 0.001;
+        double bcov[9];
+        calc_body_var(pz, sp.dept_err, sp.dvar_beam, bcov);
+        double pimu_z[3];
+        m3_vec(sp.extR, pz, pimu_z);
+        pimu_z[0] += sp.extT[0]; pimu_z[1] += sp.extT[1]; pimu_z[2] += sp.extT[2];
+        // --- transformLidar (:1344): f64 compute, f32 store
+        double pimu[3], pwd[3];
+        m3_vec(sp.extR, p, pimu);
+        pimu[0] += sp.extT[0]; pimu[1] += sp.extT[1]; pimu[2] += sp.extT[2];
+        m3_vec(sp.R, pimu, pwd);
+        pwd[0] += sp.t[0]; pwd[1] += sp.t[1]; pwd[2] += sp.t[2];
+        const double pw[3] = {(double)(float)pwd[0], (double)(float)pwd[1], (double)(float)pwd[2]};
+        // --- covariance propagation (:1346-1359)
+        double var[9];
+        {
+            double a[9], cm[9], nc[9], nct[9], tmp[9], b[9];
+            m3_sandwich(sp.R, bcov, a);
+            skew(pimu_z, cm);
+#pragma unroll
+            for (int k = 0; k < 9; k++) nc[k] = -cm[k];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) nct[r * 3 + c] = -cm[c * 3 + r];
+            m3_mul(nc, sp.rot_var, tmp);
+            m3_mul(tmp, nct, b);
+#pragma unroll
+            for (int k = 0; k < 9; k++) var[k] = (a[k] + b[k]) + sp.t_var[k];
+        }
+        // --- BuildResidualListOMP (:171-222)
+        float loc[3];
+        int64_t kx[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { loc[j] = loc_axis(pw[j] / m.voxel_size_d); kx[j] = (int64_t)loc[j]; }
+        const int64_t slot = hash_find(m, pack_key(kx[0], kx[1], kx[2]));
+        BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
+        int n_tests = 0, n_extra = 0;
+        if (slot >= 0) {
+            const int root = m.hvals[slot];
+            if (root >= 0) match_tree(m, root, pw, var, sp.sigma_num, best, n_tests);
+            if (root >= 0 && !best.ok) {  // near-voxel retry with the literal unit mismatch
+                int64_t nk[3] = {kx[0], kx[1], kx[2]};
+                const float ql = m.n_quarter[root];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const double c = m.n_center[(size_t)root * 3 + j];
+                    if ((double)loc[j] > (c + (double)ql)) nk[j] = nk[j] + 1;
+                    else if ((double)loc[j] < (c - (double)ql)) nk[j] = nk[j] - 1;
+                }
+                n_extra = 1;
+                const int64_t s2 = hash_find(m, pack_key(nk[0], nk[1], nk[2]));
+                if (s2 >= 0 && m.hvals[s2] >= 0) match_tree(m, m.hvals[s2], pw, var, sp.sigma_num, best, n_tests);
+            }
+        }
+        acc[44] = (double)n_tests; acc[45] = (double)n_extra;
+        o_match[i] = best.ok ? 1 : 0;
+        o_node[i] = best.node;
+        if (best.ok) {
+            const int nd = best.node;
+            const double nrm_d[3] = {m.p_normal[(size_t)nd * 3 + 0], m.p_normal[(size_t)nd * 3 + 1], m.p_normal[(size_t)nd * 3 + 2]};
+            const double cen[3] = {m.p_center[(size_t)nd * 3 + 0], m.p_center[(size_t)nd * 3 + 1], m.p_center[(size_t)nd * 3 + 2]};
+            // residual (:1372-1392): float normals, unrounded world point
+            const float nxf = (float)nrm_d[0], nyf = (float)nrm_d[1], nzf = (float)nrm_d[2];
+            const float dis = (float)(pwd[0] * (double)nxf + pwd[1] * (double)nyf + pwd[2] * (double)nzf + (double)m.p_d[nd]);
+            o_dis[i] = dis;
+            o_normal[(size_t)i * 3 + 0] = nrm_d[0]; o_normal[(size_t)i * 3 + 1] = nrm_d[1]; o_normal[(size_t)i * 3 + 2] = nrm_d[2];
+            // H / R^-1 (:1493-1575)
+            const double nv[3] = {(double)nxf, (double)nyf, (double)nzf};
+            double cm[9];
+            skew(pimu, cm);
+            double pthis[3] = {pimu[0], pimu[1], pimu[2]};
+            double bv[9], varw[9];
+            calc_body_var(pthis, sp.dept_err, sp.calib_laser ? sp.dvar_calib : sp.dvar_beam, bv);
+            m3_sandwich(sp.RextR, bv, varw);
+            const double J[6] = {pwd[0] - cen[0], pwd[1] - cen[1], pwd[2] - cen[2], -nrm_d[0], -nrm_d[1], -nrm_d[2]};
+            double sigma_l;
+            plane_sigma(m, nd, J, &sigma_l);
+            double vn[3];
+            m3t_vec(varw, nv, vn);
+            const double nvn = vn[0] * nv[0] + vn[1] * nv[1] + vn[2] * nv[2];
+            const double ri = 1.0 / (sigma_l + nvn);
+            o_rinv[i] = ri;
+            double T1[9], A[3];
+            m3_mul_bt(cm, sp.R, T1);  // crossmat * R^T
+            m3_vec(T1, nv, A);
+            const double H[6] = {A[0], A[1], A[2], nv[0], nv[1], nv[2]};
+            const double meas = -(double)dis;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const double hr = H[r] * ri;
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[r * 6 + c] = hr * H[c];
+                acc[36 + r] = hr * meas;
+            }
+            acc[42] = 1.0;
+            acc[43] = fabs((double)dis);
+        }
+    }
+    // deterministic block reduction: wave butterflies, then the 4 waves in fixed order
+    __shared__ double red[4][RES_NV];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < RES_NV; k++) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < RES_NV) partials[(size_t)blockIdx.x * RES_NV + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void residual_reduce_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= RES_NV) return;
+    double s = 0;
+    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * RES_NV + k];
+    out[k] = s;
+}
+
+// =====================================================================================================================
+// map update / build: per-point preparation
+// =====================================================================================================================
+// mode 0: map_incremental_grow  (var = (R extR) bcov (R extR)^T + (-[p_imu]x) Srot (-[p_imu]x)^T + St, p_imu with the z==0 -> 1e-3 quirk)
+// mode 1: voxel_map_init        (var = R bcov R^T + (-[p_lidar]x) Srot (..)^T + St, p_lidar after calcBodyVar's z==0 -> 1e-4 quirk)
+__global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n, int stride, int mode,
+                                                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double p[3] = {(double)pts[(size_t)i * stride + 0], (double)pts[(size_t)i * stride + 1], (double)pts[(size_t)i * stride + 2]};
+    double pimu[3], pwd[3];
+    m3_vec(sp.extR, p, pimu);
+    pimu[0] += sp.extT[0]; pimu[1] += sp.extT[1]; pimu[2] += sp.extT[2];
+    m3_vec(sp.R, pimu, pwd);
+    pwd[0] += sp.t[0]; pwd[1] += sp.t[1]; pwd[2] += sp.t[2];
+    const double pw[3] = {(double)(float)pwd[0], (double)(float)pwd[1], (double)(float)pwd[2]};
+    double bcov[9], cm[9], a[9];
+    if (mode == 0) {
+        double pz[3] = {p[0], p[1], p[2]};
+        if (pz[2] == 0) pz[2] = 0.001;
+        calc_body_var(pz, sp.dept_err, sp.dvar_beam, bcov);
+        double pimu_z[3];
+        m3_vec(sp.extR, pz, pimu_z);
+        pimu_z[0] += sp.extT[0]; pimu_z[1] += sp.extT[1]; pimu_z[2] += sp.extT[2];
+        skew(pimu_z, cm);
+        m3_sandwich(sp.RextR, bcov, a);
+    } else {
+        double pl[3] = {p[0], p[1], p[2]};
+        calc_body_var(pl, sp.dept_err, sp.dvar_beam, bcov);
+        skew(pl, cm);
+        m3_sandwich(sp.R, bcov, a);
+    }
+    double nc[9], tmp[9], b[9], var[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) nc[k] = -cm[k];
+    m3_mul(nc, sp.rot_var, tmp);
+    m3_mul_bt(tmp, nc, b);
+#pragma unroll
+    for (int k = 0; k < 9; k++) var[k] = (a[k] + b[k]) + sp.t_var[k];
+    double* o = pt_data + (size_t)i * IM_PT_DOUBLES;
+    o[0] = pw[0]; o[1] = pw[1]; o[2] = pw[2];
+    o[3] = var[0]; o[4] = var[1]; o[5] = var[2]; o[6] = var[4]; o[7] = var[5]; o[8] = var[8];
+    // var_contrast key (voxel_mapping.cpp:49): ||diag(var)||, non-negative double -> order-preserving as uint64
+    const double key = sqrt(var[0] * var[0] + var[4] * var[4] + var[8] * var[8]);
+    sort_key[i] = (unsigned long long)__double_as_longlong(key);
+    // root voxel (voxel_mapping.cpp:328-351): key from the float-rounded world point / float voxel size
+    int64_t kx[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) kx[j] = key_axis(pw[j] / (double)m.voxel_size_f);
+    const uint64_t pk = pack_key(kx[0], kx[1], kx[2]);
+    bool created;
+    const int64_t slot = hash_find_or_insert(m, pk, &created);
+    if (slot < 0) { m.counters[5] = 5; slot_out[i] = 0xFFFFFFFFu; return; }
+    if (created) {
+        const float vs = m.voxel_size_f;
+        const double c[3] = {(0.5 + (double)kx[0]) * (double)vs, (0.5 + (double)kx[1]) * (double)vs, (0.5 + (double)kx[2]) * (double)vs};
+        const int node = node_alloc(m, 0, c, vs / 4, pk, 0);
+        m.hvals[slot] = node;
+        atomicAdd(&m.counters[6], 1);
+    }
+    slot_out[i] = (uint32_t)slot;
+}
+
+// segment heads of the slot-sorted point list
+__global__ void segment_heads_kernel(const uint32_t* __restrict__ sorted_slot, int n, int32_t* __restrict__ seg_start, int32_t* __restrict__ nseg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (sorted_slot[i] == 0xFFFFFFFFu) return;
+    if (i == 0 || sorted_slot[i - 1] != sorted_slot[i]) seg_start[atomicAdd(nseg, 1)] = i;
+}
+
+// =====================================================================================================================
+// wave-cooperative octree maintenance
+// =====================================================================================================================
+struct WaveCtx { int lane; int64_t* stats; };  // stats[0] refits, stats[1] refit points
+
+// OctoTree::init_plane (src/voxel_loc.cpp:47-139) for node `nd` holding `n` points; returns planar?  All lanes get the result.
+__device__ bool wave_init_plane(const RegMapDev& m, int nd, int n, const WaveCtx& w) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) s[k] = 0;
+    for (int i = w.lane; i < n; i += 64) {
+        const double* q = node_point_ptr(m, nd, i);
+        const double x = q[0], y = q[1], z = q[2];
+        s[0] += x; s[1] += y; s[2] += z;
+        s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) s[k] = wave_sum(s[k]);
+    const double dn = (double)n;
+    const double c[3] = {s[0] / dn, s[1] / dn, s[2] / dn};
+    double cov[9];
+    cov[0] = s[3] / dn - c[0] * c[0]; cov[1] = s[4] / dn - c[0] * c[1]; cov[2] = s[5] / dn - c[0] * c[2];
+    cov[3] = cov[1];                  cov[4] = s[6] / dn - c[1] * c[1]; cov[5] = s[7] / dn - c[1] * c[2];
+    cov[6] = cov[2];                  cov[7] = cov[5];                  cov[8] = s[8] / dn - c[2] * c[2];
+    double ev[3], U[9];
+    sym3_eigen_jacobi(cov, ev, U);
+    int imin = 0, imax = 0;
+    if (ev[1] < ev[imin]) imin = 1;
+    if (ev[2] < ev[imin]) imin = 2;
+    if (ev[1] > ev[imax]) imax = 1;
+    if (ev[2] > ev[imax]) imax = 2;
+    const bool planar = ev[imin] < (double)m.planer_threshold;
+    if (w.lane == 0 && w.stats) { atomicAdd((unsigned long long*)&w.stats[0], 1ull); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n); }
+    if (planar) {
+        const double Umin[3] = {U[0 * 3 + imin], U[1 * 3 + imin], U[2 * 3 + imin]};
+        double pv[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) pv[k] = 0;
+        for (int i = w.lane; i < n; i += 64) {
+            const double* q = node_point_ptr(m, nd, i);
+            const double dp[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
+            const double V[9] = {q[3], q[4], q[5], q[4], q[6], q[7], q[5], q[7], q[8]};
+            double F[9];
+#pragma unroll
+            for (int mm = 0; mm < 3; mm++) {
+                if (mm != imin) {
+                    const double denom = dn * (ev[imin] - ev[mm]);
+                    const double row[3] = {dp[0] / denom, dp[1] / denom, dp[2] / denom};
+                    const double Um[3] = {U[0 * 3 + mm], U[1 * 3 + mm], U[2 * 3 + mm]};
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++) {
+                        const double S0 = Um[0] * Umin[cc] + Umin[0] * Um[cc];
+                        const double S1 = Um[1] * Umin[cc] + Umin[1] * Um[cc];
+                        const double S2 = Um[2] * Umin[cc] + Umin[2] * Um[cc];
+                        F[mm * 3 + cc] = row[0] * S0 + row[1] * S1 + row[2] * S2;
+                    }
+                } else { F[mm * 3 + 0] = 0; F[mm * 3 + 1] = 0; F[mm * 3 + 2] = 0; }
+            }
+            double J[18];
+            m3_mul(U, F, J);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) J[(3 + r) * 3 + cc] = (r == cc) ? 1.0 / dn : 0.0;
+            double JV[18];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) JV[r * 3 + cc] = J[r * 3 + 0] * V[0 * 3 + cc] + J[r * 3 + 1] * V[1 * 3 + cc] + J[r * 3 + 2] * V[2 * 3 + cc];
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int cc = r; cc < 6; cc++) { pv[k] += JV[r * 3 + 0] * J[cc * 3 + 0] + JV[r * 3 + 1] * J[cc * 3 + 1] + JV[r * 3 + 2] * J[cc * 3 + 2]; k++; }
+        }
+#pragma unroll
+        for (int k = 0; k < 21; k++) pv[k] = wave_sum(pv[k]);
+        if (w.lane < 21) {
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < 21; k++) if (w.lane == k) v = pv[k];
+            m.p_var[(size_t)nd * 21 + w.lane] = v;
+        }
+        if (w.lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { m.p_center[(size_t)nd * 3 + k] = c[k]; m.p_normal[(size_t)nd * 3 + k] = Umin[k]; }
+            m.p_min_eig[nd] = (float)ev[imin];
+            m.p_radius[nd] = (float)sqrt(ev[imax]);
+            m.p_d[nd] = (float)(-(Umin[0] * c[0] + Umin[1] * c[1] + Umin[2] * c[2]));
+        }
+    } else if (w.lane == 0) {
+        // reference zeroes centre/normal/plane_var before the test and leaves them zero when not planar; only the centre is observable (dump)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { m.p_center[(size_t)nd * 3 + k] = c[k]; m.p_normal[(size_t)nd * 3 + k] = 0.0; }
+        m.p_radius[nd] = 0.f;
+    }
+    return planar;
+}
+
+// append one point (9 doubles at src) to node `nd` currently holding `n` points; lanes 0..8 copy.  Returns false on pool exhaustion.
+__device__ bool wave_push_point(const RegMapDev& m, int nd, int n, const double* src, const WaveCtx& w) {
+    int ok = 1;
+    if (w.lane == 0 && (n % IM_CHUNK_PTS) == 0) ok = node_ensure_chunk(m, nd, n / IM_CHUNK_PTS) ? 1 : 0;
+    ok = __shfl(ok, 0, 64);
+    if (!ok) return false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (w.lane < IM_PT_DOUBLES) {
+        double* dst = node_point_ptr(m, nd, n);
+        dst[w.lane] = src[w.lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    return true;
+}
+
+IMD int octant_of(const double* q, const double* center) {  // strict > against the centre (voxel_loc.cpp:169-181)
+    return 4 * (q[0] > center[0] ? 1 : 0) + 2 * (q[1] > center[1] ? 1 : 0) + (q[2] > center[2] ? 1 : 0);
+}
+// create child `oct` of `nd` (one lane) -- voxel_loc.cpp:184-190
+IMD int make_child(const RegMapDev& m, int nd, int oct) {
+    const float ql = m.n_quarter[nd];
+    const int xyz[3] = {(oct >> 2) & 1, (oct >> 1) & 1, oct & 1};
+    double c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = m.n_center[(size_t)nd * 3 + k] + (double)((float)(2 * xyz[k] - 1) * ql);
+    const int layer = m.n_layer[nd] + 1;
+    const int child = node_alloc(m, layer, c, ql / 2, m.n_key[nd], m.n_path[nd] | (oct << (3 * (layer - 1))));
+    m.n_child[(size_t)nd * 8 + oct] = child;
+    return child;
+}
+
+// OctoTree::init_octo_tree + recursive cut_octo_tree (voxel_loc.cpp:141-217) for a node that just exceeded its init size.
+// stack: per-wave LDS scratch (>= 40 ints).
+__device__ void wave_init_octo_tree(const RegMapDev& m, int node, int* stack, const WaveCtx& w) {
+    int sp = 0;
+    if (w.lane == 0) stack[0] = node;
+    sp = 1;
+    while (sp > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int nd = __shfl(stack[sp - 1], 0, 64);  // LDS read by every lane is fine too; shfl keeps it uniform
+        sp--;
+        const int n = m.n_npts[nd];
+        const bool planar = wave_init_plane(m, nd, n, w);
+        const int layer = m.n_layer[nd];
+        if (w.lane == 0) {
+            int f = m.n_flags[nd] | NF_INIT;
+            f = planar ? (f | NF_PLANE) : (f & ~NF_PLANE);
+            m.n_flags[nd] = f;
+            m.n_newpts[nd] = 0;
+        }
+        if (planar || layer >= m.max_layer) continue;
+        // ---- cut_octo_tree: distribute the retained points to the 8 octants, order-preserving
+        const double ctr[3] = {m.n_center[(size_t)nd * 3 + 0], m.n_center[(size_t)nd * 3 + 1], m.n_center[(size_t)nd * 3 + 2]};
+        int child_id[8], child_n[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { child_id[k] = m.n_child[(size_t)nd * 8 + k]; child_n[k] = child_id[k] >= 0 ? m.n_npts[child_id[k]] : 0; }
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + w.lane;
+            const double* q = (i < n) ? node_point_ptr(m, nd, i) : nullptr;
+            const int oct = (i < n) ? octant_of(q, ctr) : -1;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned long long mask = __ballot(oct == k);
+                if (mask == 0) continue;
+                const int cnt = __popcll(mask);
+                int cid = child_id[k];
+                int ok = 1;
+                if (w.lane == 0) {
+                    if (cid < 0) cid = make_child(m, nd, k);
+                    if (cid < 0) ok = 0;
+                    else for (int pos = child_n[k]; pos < child_n[k] + cnt; pos++)
+                        if ((pos % IM_CHUNK_PTS) == 0 || pos == child_n[k]) { if (!node_ensure_chunk(m, cid, pos / IM_CHUNK_PTS)) ok = 0; }
+                }
+                cid = __shfl(cid, 0, 64); ok = __shfl(ok, 0, 64);
+                child_id[k] = cid;
+                if (!ok) return;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (oct == k) {
+                    const int pos = child_n[k] + __popcll(mask & ((1ull << w.lane) - 1ull));
+                    double* dst = node_point_ptr(m, cid, pos);
+#pragma unroll
+                    for (int e = 0; e < IM_PT_DOUBLES; e++) dst[e] = q[e];
+                }
+                child_n[k] += cnt;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (w.lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (child_id[k] >= 0) { m.n_npts[child_id[k]] = child_n[k]; m.n_newpts[child_id[k]] = child_n[k]; }
+            node_free_points(m, nd);  // the parent's buffer is never read again (UpdateOctoTree drops it on the next visit, voxel_loc.cpp:263-266)
+        }
+        // children that exceed their init size are fitted next (depth-first like the reference; order does not affect results)
+#pragma unroll
+        for (int k = 7; k >= 0; k--)
+            if (child_id[k] >= 0 && child_n[k] > m.init_size[min(layer + 1, 4)]) {
+                if (w.lane == 0) stack[sp] = child_id[k];
+                sp++;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+}
+
+// OctoTree::UpdateOctoTree (voxel_loc.cpp:219-308) for one point; wave-uniform control flow
+__device__ void wave_update_point(const RegMapDev& m, int root, const double* src, int* stack, const WaveCtx& w) {
+    int nd = root;
+    for (int depth = 0; depth < 8; depth++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int flags = m.n_flags[nd];
+        const int layer = m.n_layer[nd];
+        const int n = m.n_npts[nd];
+        if (!(flags & NF_INIT)) {
+            if (!wave_push_point(m, nd, n, src, w)) return;
+            if (w.lane == 0) { m.n_npts[nd] = n + 1; m.n_newpts[nd] = m.n_newpts[nd] + 1; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (n + 1 > m.init_size[min(layer, 4)]) wave_init_octo_tree(m, nd, stack, w);
+            return;
+        }
+        if (flags & NF_PLANE) {
+            if (!(flags & NF_UPDATE_EN)) return;
+            if (!wave_push_point(m, nd, n, src, w)) return;
+            int newp = m.n_newpts[nd] + 1;
+            if (w.lane == 0) m.n_npts[nd] = n + 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (newp > 5) {  // m_update_size_threshold_
+                const bool planar = wave_init_plane(m, nd, n + 1, w);
+                if (w.lane == 0) m.n_flags[nd] = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+                newp = 0;
+            }
+            if (w.lane == 0) {
+                m.n_newpts[nd] = newp;
+                if (n + 1 >= m.max_points_size) {
+                    m.n_flags[nd] = m.n_flags[nd] & ~NF_UPDATE_EN;
+                    node_free_points(m, nd);
+                    m.n_newpts[nd] = 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            return;
+        }
+        if (layer < m.max_layer) {
+            int child;
+            if (w.lane == 0) {
+                if (n != 0) node_free_points(m, nd);
+                const double ctr[3] = {m.n_center[(size_t)nd * 3 + 0], m.n_center[(size_t)nd * 3 + 1], m.n_center[(size_t)nd * 3 + 2]};
+                const int oct = octant_of(src, ctr);
+                child = m.n_child[(size_t)nd * 8 + oct];
+                if (child < 0) child = make_child(m, nd, oct);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            child = __shfl(child, 0, 64);
+            if (child < 0) return;
+            nd = child;
+            continue;
+        }
+        // non-planar node at the last layer (voxel_loc.cpp:289-305)
+        if (!(flags & NF_UPDATE_EN)) return;
+        if (!wave_push_point(m, nd, n, src, w)) return;
+        int newp = m.n_newpts[nd] + 1;
+        if (w.lane == 0) m.n_npts[nd] = n + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (newp > 5) {
+            const bool planar = wave_init_plane(m, nd, n + 1, w);
+            if (w.lane == 0) m.n_flags[nd] = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+            newp = 0;
+        }
+        if (w.lane == 0) {
+            m.n_newpts[nd] = newp;
+            if (n + 1 > IM_G_MAX_POINTS) { m.n_flags[nd] = m.n_flags[nd] & ~NF_UPDATE_EN; node_free_points(m, nd); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        return;
+    }
+}
+
+// one wavefront per touched root voxel.  mode 0 = updateVoxelMap (sequential replay), mode 1 = buildVoxelMap (bucket all, then init)
+__global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t* __restrict__ sorted_slot, const int32_t* __restrict__ sorted_idx,
+                                                      const double* __restrict__ pt_data, int n, const int32_t* __restrict__ seg_start,
+                                                      const int32_t* __restrict__ nseg, int mode, int64_t* stats) {
+    __shared__ int stacks[4][48];
+    const int wv = threadIdx.x >> 6;
+    const int seg = blockIdx.x * 4 + wv;
+    if (seg >= *nseg) return;
+    WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
+    const int start = seg_start[seg];
+    const uint32_t slot = sorted_slot[start];
+    const int root = m.hvals[slot];
+    if (root < 0) return;
+    if (mode == 0) {
+        for (int j = start; j < n && sorted_slot[j] == slot; j++)
+            wave_update_point(m, root, pt_data + (size_t)sorted_idx[j] * IM_PT_DOUBLES, stacks[wv], w);
+    } else {
+        int cnt = m.n_npts[root];
+        for (int j = start; j < n && sorted_slot[j] == slot; j++) {
+            if (!wave_push_point(m, root, cnt, pt_data + (size_t)sorted_idx[j] * IM_PT_DOUBLES, w)) return;
+            cnt++;
+        }
+        if (w.lane == 0) { m.n_npts[root] = cnt; m.n_newpts[root] = cnt; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (cnt > m.init_size[0]) wave_init_octo_tree(m, root, stacks[wv], w);
+    }
+}
+
+// merge chunk ids freed by the previous kernel into the ready stack
+__global__ void merge_free_kernel(RegMapDev m) {
+    const int np = m.counters[3];
+    const int base = m.counters[2];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) m.free_ready[base + i] = m.free_pending[i];
+}
+__global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; }
+
+// =====================================================================================================================
+// introspection
+// =====================================================================================================================
+__global__ void dump_planes_kernel(RegMapDev m, PlaneRecDev* out, long long cap, unsigned long long* count) {
+    const int nn = m.counters[0];
+    for (int nd = blockIdx.x * blockDim.x + threadIdx.x; nd < nn; nd += gridDim.x * blockDim.x) {
+        const int f = m.n_flags[nd];
+        if (!(f & NF_INIT)) continue;
+        const unsigned long long idx = atomicAdd(count, 1ull);
+        if ((long long)idx >= cap || out == nullptr) continue;
+        PlaneRecDev& r = out[idx];
+        const unsigned long long pk = m.n_key[nd];
+        r.key[0] = (long long)(pk & IM_KEY_MASK) - IM_KEY_BIAS;
+        r.key[1] = (long long)((pk >> 21) & IM_KEY_MASK) - IM_KEY_BIAS;
+        r.key[2] = (long long)((pk >> 42) & IM_KEY_MASK) - IM_KEY_BIAS;
+        r.layer = m.n_layer[nd]; r.path = m.n_path[nd]; r.is_plane = (f & NF_PLANE) ? 1 : 0; r.n_points = m.n_npts[nd];
+        r.update_enable = (f & NF_UPDATE_EN) ? 1 : 0; r.new_points = m.n_newpts[nd];
+        r.radius = m.p_radius[nd]; r.min_eig = m.p_min_eig[nd]; r.d = m.p_d[nd]; r.pad = 0;
+        for (int k = 0; k < 3; k++) { r.center[k] = m.p_center[(size_t)nd * 3 + k]; r.normal[k] = m.p_normal[(size_t)nd * 3 + k]; }
+        for (int a = 0; a < 6; a++)
+            for (int b = 0; b < 6; b++) r.plane_var[a * 6 + b] = (f & NF_PLANE) ? m.p_var[(size_t)nd * 21 + (a <= b ? sym21_index(a, b) : sym21_index(b, a))] : 0.0;
+    }
+}
+
+// fill helpers
+__global__ void fill_u64_kernel(unsigned long long* p, unsigned long long v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void iota_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, uint32_t* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// compact the matched points in ascending scan order is done on the host from o_match (tiny); see reg_host.cpp
+
+// ---- launchers (called from the host layer) -------------------------------------------------------------------------
+void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, double* out48,
+                     int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+    const int nb = (n + 255) / 256;
+    hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(256), 0, s, m, sp, pts, n, partials, o_match, o_node, o_dis, o_rinv, o_normal);
+    hipLaunchKernelGGL(residual_reduce_kernel, dim3(1), dim3(64), 0, s, partials, nb, out48);
+}
+void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
+                      unsigned long long* sort_key, uint32_t* slot) {
+    hipLaunchKernelGGL(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot);
+}
+void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
+    hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
+    hipLaunchKernelGGL(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, nseg);
+}
+void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
+                   const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats) {
+    hipLaunchKernelGGL(replay_kernel, dim3((max_segments + 3) / 4), dim3(256), 0, s, m, sorted_slot, sorted_idx, pt_data, n, seg_start, nseg, mode, stats);
+    hipLaunchKernelGGL(merge_free_kernel, dim3(64), dim3(256), 0, s, m);
+    hipLaunchKernelGGL(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
+}
+void launch_dump_planes(hipStream_t s, const RegMapDev& m, PlaneRecDev* out, long long cap, unsigned long long* count) {
+    hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(dump_planes_kernel, dim3(1024), dim3(256), 0, s, m, out, cap, count);
+}
+void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v, size_t n) {
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(2048), dim3(256), 0, s, p, v, n);
+}
+void launch_iota(hipStream_t s, int32_t* p, int n) { hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n); }
+void launch_gather_u32(hipStream_t s, const uint32_t* src, const int32_t* idx, uint32_t* dst, int n) {
+    hipLaunchKernelGGL(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, dst, n);
+}

@@ -1,0 +1,170 @@
+// HBM-resident registration map: what the reference keeps as std::unordered_map<VOXEL_LOC, OctoTree*> + heap OctoTree /
+// Plane objects (src/voxel_loc.hpp:89-177) laid out for the GPU:
+//   * open-addressing hash  packed 3x21-bit key -> slot ; slot -> root node id      (one 8-byte probe per lookup)
+//   * flat octree node pool, SoA                                                     (children[8], centre, flags, counts)
+//   * plane table, SoA, indexed by node id                                           (centre, normal, d/radius, 21-entry symmetric plane_var)
+//   * retained points (OctoTree::m_temp_points_) in 16-point chunks of a shared pool (xyz + symmetric 3x3 covariance = 9 doubles/pt)
+// All of it lives in one context and never leaves the device between scans.
+#pragma once
+#include "dev_math.hpp"
+
+#define IM_CHUNK_PTS 16
+#define IM_PT_DOUBLES 9           /* x y z + var(00 01 02 11 12 22) */
+#define IM_INLINE_CHUNKS 8        /* 128 points inline per node; beyond that an extension table */
+#define IM_EXT_CHUNKS 64          /* + 1024 points (KITTI: max_points_size 1000 / g_max_points 1000) */
+#define IM_G_MAX_POINTS 1000      /* g_max_points, src/voxel_loc.cpp:45 */
+
+// node flag bits
+#define NF_INIT 1          /* m_init_octo_ */
+#define NF_PLANE 2         /* m_plane_ptr_->m_is_plane */
+#define NF_UPDATE_EN 4     /* m_update_enable_ */
+
+struct RegMapDev {
+    // hash
+    unsigned long long* hkeys;  // [hcap]
+    int32_t* hvals;             // [hcap] root node id
+    uint64_t hmask;
+    // node pool
+    int32_t* n_child;           // [cap_nodes*8]
+    double* n_center;           // [cap_nodes*3]  m_voxel_center_
+    float* n_quarter;           // m_quater_length_
+    int32_t* n_flags;
+    int32_t* n_layer;
+    int32_t* n_npts;            // m_temp_points_.size()
+    int32_t* n_newpts;          // m_new_points_
+    int32_t* n_chunks;          // [cap_nodes*IM_INLINE_CHUNKS] chunk ids (-1 = none)
+    int32_t* n_ext;             // extension table id or -1
+    unsigned long long* n_key;  // packed root key (for dumps)
+    int32_t* n_path;            // child path from the root, 3 bits per level
+    // plane table
+    double* p_center;           // [cap_nodes*3]
+    double* p_normal;           // [cap_nodes*3]
+    float* p_d;                 // Plane::m_d
+    float* p_radius;            // Plane::m_radius
+    float* p_min_eig;
+    double* p_var;              // [cap_nodes*21] upper triangle of the 6x6 plane covariance, row-major
+    // pools
+    double* chunk_data;         // [cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES]
+    int32_t* ext_tables;        // [cap_ext * IM_EXT_CHUNKS]
+    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels
+    int32_t* counters;
+    int32_t* free_ready;        // chunk ids available for allocation
+    int32_t* free_pending;      // chunk ids freed by the running kernel (merged into ready afterwards)
+    int32_t cap_nodes, cap_chunks, cap_ext;
+    // parameters
+    int32_t max_layer, max_points_size, init_size[5];
+    float planer_threshold;
+    float voxel_size_f;         // the float voxel_size of build/update (voxel_mapping.cpp:110,320)
+    double voxel_size_d;        // the double of the matcher (:153)
+};
+
+namespace imd {
+
+IMD int sym21_index(int r, int c) {  // r <= c, 6x6 upper triangle row-major
+    return r * 6 - (r * (r - 1)) / 2 + (c - r);
+}
+
+// ---- hash ---------------------------------------------------------------------------------------------------
+IMD int64_t hash_find(const RegMapDev& m, uint64_t key) {  // returns slot or -1
+    uint64_t h = hash64(key) & m.hmask;
+    for (int probe = 0; probe < 4096; probe++) {
+        const unsigned long long k = m.hkeys[h];
+        if (k == key) return (int64_t)h;
+        if (k == IM_KEY_EMPTY) return -1;
+        h = (h + 1) & m.hmask;
+    }
+    return -1;
+}
+// find or claim a slot for `key`; *created = true if this call inserted it.  Values are filled by the caller.
+IMD int64_t hash_find_or_insert(const RegMapDev& m, uint64_t key, bool* created) {
+    uint64_t h = hash64(key) & m.hmask;
+    *created = false;
+    for (int probe = 0; probe < 4096; probe++) {
+        unsigned long long k = m.hkeys[h];
+        if (k == key) return (int64_t)h;
+        if (k == IM_KEY_EMPTY) {
+            const unsigned long long prev = atomicCAS(&m.hkeys[h], (unsigned long long)IM_KEY_EMPTY, (unsigned long long)key);
+            if (prev == IM_KEY_EMPTY) { *created = true; return (int64_t)h; }
+            if (prev == key) return (int64_t)h;
+        }
+        h = (h + 1) & m.hmask;
+    }
+    return -1;
+}
+
+// ---- chunk pool --------------------------------------------------------------------------------------------------
+IMD int alloc_chunk(const RegMapDev& m) {
+    int i = atomicSub(&m.counters[2], 1) - 1;
+    if (i >= 0) return m.free_ready[i];
+    atomicAdd(&m.counters[2], 1);  // undo
+    const int c = atomicAdd(&m.counters[1], 1);
+    if (c >= m.cap_chunks) { m.counters[5] = 1; return -1; }
+    return c;
+}
+IMD void free_chunk(const RegMapDev& m, int c) {
+    if (c < 0) return;
+    const int i = atomicAdd(&m.counters[3], 1);
+    m.free_pending[i] = c;
+}
+IMD int node_chunk_id(const RegMapDev& m, int node, int ci) {
+    if (ci < IM_INLINE_CHUNKS) return m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
+    const int e = m.n_ext[node];
+    return m.ext_tables[(size_t)e * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
+}
+IMD double* node_point_ptr(const RegMapDev& m, int node, int i) {
+    const int c = node_chunk_id(m, node, i / IM_CHUNK_PTS);
+    return m.chunk_data + ((size_t)c * IM_CHUNK_PTS + (i % IM_CHUNK_PTS)) * IM_PT_DOUBLES;
+}
+// make sure chunk slot `ci` of `node` exists (called by one lane)
+IMD bool node_ensure_chunk(const RegMapDev& m, int node, int ci) {
+    if (ci < IM_INLINE_CHUNKS) {
+        int* slot = &m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
+        if (*slot < 0) { const int c = alloc_chunk(m); if (c < 0) return false; *slot = c; }
+        return true;
+    }
+    if (ci - IM_INLINE_CHUNKS >= IM_EXT_CHUNKS) { m.counters[5] = 2; return false; }
+    if (m.n_ext[node] < 0) {
+        const int e = atomicAdd(&m.counters[4], 1);
+        if (e >= m.cap_ext) { m.counters[5] = 3; return false; }
+        for (int k = 0; k < IM_EXT_CHUNKS; k++) m.ext_tables[(size_t)e * IM_EXT_CHUNKS + k] = -1;
+        m.n_ext[node] = e;
+    }
+    int* slot = &m.ext_tables[(size_t)m.n_ext[node] * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
+    if (*slot < 0) { const int c = alloc_chunk(m); if (c < 0) return false; *slot = c; }
+    return true;
+}
+// release all retained points of a node (std::vector<Point_with_var>().swap(m_temp_points_)); one lane
+IMD void node_free_points(const RegMapDev& m, int node) {
+    const int n = m.n_npts[node];
+    const int nch = (n + IM_CHUNK_PTS - 1) / IM_CHUNK_PTS;
+    for (int ci = 0; ci < nch; ci++) {
+        if (ci < IM_INLINE_CHUNKS) {
+            int* slot = &m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
+            free_chunk(m, *slot); *slot = -1;
+        } else {
+            int* slot = &m.ext_tables[(size_t)m.n_ext[node] * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
+            free_chunk(m, *slot); *slot = -1;
+        }
+    }
+    m.n_npts[node] = 0;
+}
+
+// allocate + initialise a node (one lane).  centre/quarter/layer as OctoTree ctor + caller-provided geometry.
+IMD int node_alloc(const RegMapDev& m, int layer, const double* center, float quarter, unsigned long long key, int path) {
+    const int id = atomicAdd(&m.counters[0], 1);
+    if (id >= m.cap_nodes) { m.counters[5] = 4; return -1; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) m.n_child[(size_t)id * 8 + k] = -1;
+#pragma unroll
+    for (int k = 0; k < IM_INLINE_CHUNKS; k++) m.n_chunks[(size_t)id * IM_INLINE_CHUNKS + k] = -1;
+    m.n_center[(size_t)id * 3 + 0] = center[0]; m.n_center[(size_t)id * 3 + 1] = center[1]; m.n_center[(size_t)id * 3 + 2] = center[2];
+    m.n_quarter[id] = quarter;
+    m.n_flags[id] = NF_UPDATE_EN;
+    m.n_layer[id] = layer;
+    m.n_npts[id] = 0; m.n_newpts[id] = 0; m.n_ext[id] = -1;
+    m.n_key[id] = key; m.n_path[id] = path;
+    m.p_d[id] = 0.f; m.p_radius[id] = 0.f; m.p_min_eig[id] = 1.f;
+    return id;
+}
+
+}  // namespace imd

@@ -1,0 +1,142 @@
+"""GPU parity tests proper (rows a1-a16): the HIP path through the C ABI vs the CPU oracle on identical seeded inputs.
+Bars (BASELINE.json north_star): match index sets identical; plane normals / pose within 1e-5."""
+import numpy as np
+import pytest
+
+from immesh_amd import capi, synth
+from conftest import make_oracle, make_hip
+from parity_utils import compare_plane_tables
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _scan(k, n, cfg, kind="livox"):
+    R, t = synth.trajectory_pose(k)
+    extT = np.array(list(cfg.extT))
+    raw = synth.livox_scan(k, R, t, n_pts=n, extT=extT) if kind == "livox" else synth.hdl64_scan(k, R, t, n_az=n)
+    return R, t, raw
+
+
+def _both(oracle_lib, hip_lib, cfg):
+    return make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+
+
+@pytest.mark.parametrize("n", [6, 300, 30000])
+def test_map_build_parity(oracle_lib, hip_lib, n):
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R, t, raw = _scan(0, max(n, 100), cfg)
+    pts = np.ascontiguousarray(raw[:n, :3])
+    st = capi.make_state(R=R, t=t)
+    o.map_build(pts, st); h.map_build(pts, st)
+    a, b = o.dump_planes(), h.dump_planes()
+    npl = compare_plane_tables(a, b, TOL)
+    if n >= 30000:
+        assert npl > 500
+    assert h.counters()["n_root_voxels"] == o.counters()["n_root_voxels"]
+
+
+def test_map_build_kitti_deep_octree(oracle_lib, hip_lib):
+    cfg = capi.velodyne_config(cap_root_voxels=1 << 14, cap_scan_points=200000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R, t, raw = _scan(0, 1024, cfg, kind="hdl64")
+    pts = np.ascontiguousarray(raw[:, :3])
+    st = capi.make_state(R=R, t=t)
+    o.map_build(pts, st); h.map_build(pts, st)
+    a, b = o.dump_planes(), h.dump_planes()
+    assert a["layer"].max() >= 2           # the 3 m roots really split
+    assert compare_plane_tables(a, b, TOL) > 100
+
+
+def test_residuals_parity(oracle_lib, hip_lib):
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R0, t0, raw0 = _scan(0, 40000, cfg)
+    st0 = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st0); h.map_build(p0, st0)
+    R1, t1, raw1 = _scan(1, 40000, cfg)
+    down = synth.voxel_grid_downsample(raw1, 0.4)
+    st = capi.make_state(R=R1 @ synth.so3_exp(np.array([1e-3, -2e-3, 1.5e-3])), t=t1 + np.array([0.02, -0.01, 0.01]), cov_diag=1e-4)
+    st[24:].reshape(18, 18)[0:3, 0:3] = np.eye(3) * 1e-5
+    ro, rh = o.residuals(down, st), h.residuals(down, st)
+    assert ro["n_match"] > 1000
+    np.testing.assert_array_equal(rh["match_idx"], ro["match_idx"])           # identical match sets
+    s = np.sign(np.sum(rh["normals"] * ro["normals"], axis=1))
+    np.testing.assert_allclose(rh["normals"] * s[:, None], ro["normals"], atol=TOL)
+    np.testing.assert_allclose(rh["dis"] * s, ro["dis"], atol=TOL)
+    np.testing.assert_allclose(rh["r_inv"], ro["r_inv"], rtol=1e-6)
+    np.testing.assert_allclose(rh["HTH"], ro["HTH"], rtol=1e-7, atol=1e-7 * np.abs(ro["HTH"]).max())
+    np.testing.assert_allclose(rh["HTz"], ro["HTz"], rtol=1e-7, atol=1e-7 * np.abs(ro["HTz"]).max())
+    co, ch = o.counters(), h.counters()
+    assert ch["n_plane_tests"] == co["n_plane_tests"] and ch["n_extra_probe"] == co["n_extra_probe"]
+
+
+def test_register_and_update_stream_parity(oracle_lib, hip_lib):
+    """A 6-scan stream: iterated EKF update + map growth each scan; pose and the whole plane table must agree."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 17, cap_scan_points=200000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R0, t0, raw0 = _scan(0, 30000, cfg)
+    st0 = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st0); h.map_build(p0, st0)
+    so = st0.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    for k in range(1, 7):
+        _, tk, raw = _scan(k, 30000, cfg)
+        down = synth.voxel_grid_downsample(raw, 0.4)
+        po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
+        so, io = o.register(down, po, po)
+        sh, ih = h.register(down, ph, ph, want_eff=(k == 1))
+        assert ih["n_iter"] == io["n_iter"] and ih["n_match"] == io["n_match"]
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)        # pose / velocity / biases
+        np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=TOL * np.abs(so[24:]).max())
+        assert np.linalg.norm(sh[9:12] - tk) < 0.05
+        if k == 1:
+            assert len(ih["eff_pts"]) == ih["n_match"] and np.all(np.isfinite(ih["eff_norm_dis"]))
+        o.map_update(down, so); h.map_update(down, sh)
+    a, b = o.dump_planes(), h.dump_planes()
+    assert compare_plane_tables(a, b, TOL) > 1000
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+    assert ch["n_root_voxels"] == co["n_root_voxels"]
+
+
+def test_update_state_machine_freeze(oracle_lib, hip_lib):
+    """Many scans of the same wall patch: voxels reach max_points_size (100) and freeze (update_enable=0, points freed)."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000)
+    for i in range(3):
+        cfg.extT[i] = 0.0
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    rng = np.random.default_rng(11)
+    st = capi.make_state()
+    for it in range(12):
+        n = 400
+        P = np.stack([rng.uniform(5.0, 6.0, n), rng.uniform(-0.5, 0.5, n), -1.3 + rng.normal(0, 0.004, n)], axis=1).astype(np.float32)
+        if it == 0:
+            o.map_build(P, st); h.map_build(P, st)
+        else:
+            o.map_update(P, st); h.map_update(P, st)
+    a, b = o.dump_planes(), h.dump_planes()
+    assert (a["update_enable"] == 0).sum() > 0
+    compare_plane_tables(a, b, TOL)
+
+
+def test_edge_cases(oracle_lib, hip_lib):
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    # negative coordinates, exact voxel-boundary values, z == 0 exactly, a single point
+    P = np.array([[-1.0, -0.5, 0.0], [-1.0, -0.5, 0.0], [2.0, 3.0, 0.0], [-2.25, 4.5, -0.75], [1e-3, -1e-3, 0.0], [7.5, -7.5, 0.0]], np.float32)
+    P = np.concatenate([P, P + np.float32(0.01), P - np.float32(0.02)] * 4)
+    st = capi.make_state(t=np.array([0.0, 0.0, 0.5]))
+    o.map_build(P, st); h.map_build(P, st)
+    compare_plane_tables(o.dump_planes(), h.dump_planes(), TOL)
+    one = np.array([[3.0, 1.0, 0.0]], np.float32)
+    ro, rh = o.residuals(one, st), h.residuals(one, st)
+    assert rh["n_match"] == ro["n_match"]
+    o.map_update(one, st); h.map_update(one, st)
+    compare_plane_tables(o.dump_planes(), h.dump_planes(), TOL)
+    # bad arguments are errors, not crashes
+    with pytest.raises(RuntimeError):
+        h.map_update(one, st, n=0)
