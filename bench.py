@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- scans/s of the MI355X-native ImMesh hot path (BASELINE.json metric).
+
+One "step" = one LiDAR scan through the whole per-scan hot path behind the C ABI (immesh_process_scan):
+iterated-EKF point-to-plane registration against the HBM-resident voxel/plane map, map growth, and (``--mesh 1``)
+incremental voxel-wise meshing.  Workload at N=1: the synthetic Livox-Avia-shaped 100k-pt/scan stream of SURVEY.md
+8(d) C2/C3 into a pre-built ~10 M-root-voxel map; scans and the down-sampled clouds are resident in HBM before the
+timed region starts.  N>1 (torchrun, one rank per GPU): every rank runs the same stream against its own map shard
+replica-free -- see DESIGN.md "Multi-GPU" -- weak scaling, max-over-ranks timing.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from immesh_amd import capi, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924):
+    """Pre-build the registration map by streaming a dense survey of the procedural world (synth.py geometry) through
+    immesh_map_update, strip by strip, generated on the GPU (harness only; the product never sees torch)."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    extT = torch.tensor(list(cfg.extT), device=dev, dtype=torch.float32)
+    st = capi.make_state()  # identity pose: p_world = extR p + extT  ->  p_body = p_world - extT
+    L = synth.LATTICE
+    x0 = -side_m / 2 + 50.0
+    nstrip = int(np.ceil(side_m / L))
+    gs, ws = 1.0 / 6.0, 1.0 / 8.0   # survey lattice spacing: ground 36 pts/m^2, walls 64 pts/m^2
+    t0 = time.time()
+    nv = 0
+    for si in range(nstrip):
+        xs0 = (np.floor(x0 / L) + si) * L
+        # ground
+        nx, ny = int(L / gs), int(side_m / gs)
+        ix = torch.arange(nx, device=dev, dtype=torch.float32)
+        iy = torch.arange(ny, device=dev, dtype=torch.float32)
+        X = (xs0 + (ix[:, None] + 0.5) * gs).expand(nx, ny).reshape(-1)
+        Y = (-side_m / 2 + (iy[None, :] + 0.5) * gs).expand(nx, ny).reshape(-1)
+        X = X + (torch.rand(X.shape, device=dev, generator=g) - 0.5) * 0.8 * gs
+        Y = Y + (torch.rand(Y.shape, device=dev, generator=g) - 0.5) * 0.8 * gs
+        fx = torch.remainder(X, L); fy = torch.remainder(Y, L)
+        keep = ~((fx > synth.BOX_LO) & (fx < synth.BOX_HI) & (fy > synth.BOX_LO) & (fy < synth.BOX_HI))
+        X, Y = X[keep], Y[keep]
+        Z = synth.GROUND_Z + torch.randn(X.shape, device=dev, generator=g) * 0.02
+        parts = [torch.stack([X, Y, Z], dim=1)]
+        # walls of the boxes in this strip
+        nb = int(np.ceil(side_m / L))
+        jy = torch.arange(nb, device=dev, dtype=torch.float32) + np.floor(-side_m / 2 / L)
+        nu = int((synth.BOX_HI - synth.BOX_LO) / ws); nz = int((synth.BOX_TOP - synth.GROUND_Z) / ws)
+        iu = torch.arange(nu, device=dev, dtype=torch.float32); iz = torch.arange(nz, device=dev, dtype=torch.float32)
+        U = (synth.BOX_LO + (iu[:, None] + 0.5) * ws).expand(nu, nz).reshape(-1)
+        Zw = (synth.GROUND_Z + (iz[None, :] + 0.5) * ws).expand(nu, nz).reshape(-1)
+        for axis, val in ((0, synth.BOX_LO), (0, synth.BOX_HI), (1, synth.BOX_LO), (1, synth.BOX_HI)):
+            m = len(U) * nb
+            u = U[None, :].expand(nb, -1).reshape(-1) + (torch.rand(m, device=dev, generator=g) - 0.5) * 0.8 * ws
+            z = Zw[None, :].expand(nb, -1).reshape(-1) + (torch.rand(m, device=dev, generator=g) - 0.5) * 0.8 * ws
+            w = val + torch.randn(m, device=dev, generator=g) * 0.02
+            by = (jy[:, None] * L).expand(nb, len(U)).reshape(-1)
+            if axis == 0:
+                parts.append(torch.stack([xs0 + w, by + u, z], dim=1))
+            else:
+                parts.append(torch.stack([xs0 + u, by + w, z], dim=1))
+        P = (torch.cat(parts, dim=0) - extT[None, :]).contiguous()
+        torch.cuda.synchronize()
+        cap = int(cfg.cap_scan_points)
+        for a in range(0, P.shape[0], cap):
+            chunk = P[a:a + cap]
+            h.map_update(chunk.data_ptr(), st, n=chunk.shape[0])
+        nv = h.counters()["n_root_voxels"]
+        if nv >= target_voxels:
+            break
+    log(f"[bench] map pre-build: {nv} root voxels, {si + 1} strips, {time.time() - t0:.1f} s")
+    return nv
+
+
+def make_scans(n_scans, n_pts, cfg, cache_dir):
+    """Synthetic Livox-shaped stream: raw scans (lidar frame, xyzI) + the VoxelGrid-downsampled clouds."""
+    os.makedirs(cache_dir, exist_ok=True)
+    extT = np.array(list(cfg.extT))
+    raws, downs = [], []
+    for k in range(n_scans):
+        f = os.path.join(cache_dir, f"livox_{n_pts}_{k}.npy")
+        if os.path.exists(f):
+            raw = np.load(f)
+        else:
+            R, t = synth.trajectory_pose(k)
+            raw = synth.livox_scan(k, R, t, n_pts=n_pts, extT=extT)
+            np.save(f, raw)
+        raws.append(raw)
+        downs.append(synth.voxel_grid_downsample(raw, 0.4))
+    return raws, downs
+
+
+# algorithmic bytes of one launch of each kernel (SURVEY.md 8(d) record sizes; DESIGN.md "Kernels")
+def algorithmic_bytes(kname, c, n_scans, n_raw):
+    n_ds = c["_n_ds_mean"]; iters = max(1, c["n_iter"]) / n_scans
+    if kname == "residual_kernel":      # per EKF iteration: point 12 B + key/slot 12 B per point, 12 B per extra probe, 229 B per plane test
+        launches = c["n_iter"]
+        return (n_ds * 24 * launches + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / launches
+    if kname == "point_var_kernel":     # point 12 B in, Point_with_var 96 B + sort key 8 + slot 12 out
+        return n_ds * (12 + 96 + 8 + 12)
+    if kname == "replay_kernel":        # per scan: every point record once (96 B) + every refit re-reads its retained points (96 B each) and writes a plane (229 B)
+        return n_ds * 96 + (c["n_refit_pts"] * 96 + c["n_refits"] * 229) / n_scans
+    if kname == "mesh_knn_kernel":      # per scan: C20 inspected vertices x 12 B + query 12 B + 20 ids out
+        return (c["c20"] * 12 + c["n_v"] * (12 + 80 + 24)) / n_scans
+    if kname == "mesh_delaunay_kernel":  # per scan: n_u x (12 B pos + 6 x 12 B incident triangles) + T_v x 12 B
+        return (c["n_u"] * 84 + c["t_v"] * 12) / n_scans
+    if kname == "mesh_transform_kernel":
+        return n_raw * 32
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pts", type=int, default=100000, help="raw points per scan")
+    ap.add_argument("--map-voxels", type=float, default=10e6, help="root voxels of the pre-built registration map")
+    ap.add_argument("--mesh", type=int, default=1, help="1 = full pipeline (configs[2]); 0 = registration + map update only (configs[1])")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the oracle baseline leg (0 = skip)")
+    ap.add_argument("--profile-scans", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    hip = capi.load_hip_library()
+    side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0     # ~8.8 root voxels per m^2 of this world (ground + walls)
+    cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3) + (1 << 16), cap_scan_points=2_500_000,
+                           cap_vertices=1 << 24, cap_triangles=1 << 25)
+    h = capi.HotPath(hip, cfg, "immesh_")
+    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
+
+    n_total = args.warmup + args.steps + args.profile_scans
+    raws, downs = make_scans(n_total + 1, args.pts, cfg, os.path.join(ROOT, "gpurun_out", "scan_cache"))
+    d_raw = [torch.from_numpy(r).to(dev) for r in raws]
+    d_down = [torch.from_numpy(d).to(dev) for d in downs]
+    n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))
+
+    # scan 0 seeds the stream state; constant-velocity prior (Forward_without_imu) between scans
+    R0, t0 = synth.trajectory_pose(0)
+    st = capi.make_state(R=R0, t=t0)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    if args.mesh:
+        # mesh map is seeded by scan 0 (the registration map is the pre-built survey)
+        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=True, n_ds=len(downs[0]), n_raw=len(raws[0]))
+
+    def run(k, state):
+        prior = synth.forward_without_imu(state)
+        out, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=bool(args.mesh),
+                                   n_ds=len(downs[k]), n_raw=len(raws[k]))
+        return out, info
+
+    k = 1
+    for _ in range(args.warmup):
+        st, _ = run(k, st); k += 1
+    h.counters(reset=True)
+    stage = np.zeros(4)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_begin = time.perf_counter()
+    for _ in range(args.steps):
+        st, info = run(k, st); k += 1
+        tm = h.last_timing()
+        stage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    cnt = h.counters()
+    cnt["_n_ds_mean"] = n_ds_mean
+    pose_err = float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))
+
+    # ---- roofline leg: per-kernel HIP-event timing (events recorded on the library's own stream) over extra scans
+    roofline = None
+    kstats = {}
+    if rank == 0 and args.profile_scans > 0:
+        h.counters(reset=True)
+        h.profile_enable(True)
+        for _ in range(args.profile_scans):
+            st, _ = run(k, st); k += 1
+        kstats = h.profile_read()
+        h.profile_enable(False)
+        pc = h.counters(); pc["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k - args.profile_scans:k]]))
+        best = None
+        for name, s in kstats.items():
+            if s["launches"] and algorithmic_bytes(name, pc, args.profile_scans, args.pts) is not None:
+                if best is None or s["total_ms"] > kstats[best]["total_ms"]:
+                    best = name
+        if best:
+            per_scan_launches = kstats[best]["launches"] / args.profile_scans
+            by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
+            if best not in ("residual_kernel",):
+                by = by / max(1.0, per_scan_launches)
+            avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]
+            ach = by / (avg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": best, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                        "algorithmic_bytes_per_launch": int(by)}
+            tr = os.path.join(ROOT, "profiles", "traffic_r01.json")   # PMC-derived HBM bytes/launch from the committed rocprofv3 --pmc passes
+            if os.path.exists(tr):
+                try:
+                    roofline["traffic"] = json.load(open(tr)).get(best)
+                except Exception:
+                    pass
+
+    # ---- CPU baseline leg: the oracle (CPU restatement, "port") on the host cores, bounded sample of the same stream
+    cpu = None
+    if rank == 0 and args.cpu_seconds > 0:
+        orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(orc_so):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+        o = capi.HotPath(ctypes.CDLL(orc_so), cfg, "orc_")
+        so = capi.make_state(R=R0, t=t0)
+        o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)
+        so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+        if args.mesh:
+            o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
+        tc, nc, kk = 0.0, 0, 1
+        while tc < args.cpu_seconds and kk < len(raws):
+            prior = synth.forward_without_imu(so)
+            a = time.perf_counter()
+            so, _ = o.process_scan(downs[kk], raws[kk], prior, prior, frame_idx=kk, do_mesh=bool(args.mesh))
+            tc += time.perf_counter() - a
+            nc += 1; kk += 1
+        cpu = {"value": round(nc / tc, 4), "unit": "scans/s", "cores": 1, "kind": "port",
+               "sample": f"{nc} scans of the same stream through oracle/liboracle.so (single thread), map = scan 0 + growth (not the 10M-voxel map)",
+               "ms_per_scan": round(1e3 * tc / nc, 3)}
+
+    if rank == 0:
+        total_scans = args.steps * world
+        out = {
+            "metric": "scans/sec (reg+mesh), 100k-pt scan into 10M-voxel map" if args.mesh else "scans/sec (registration + map update, meshing off), 100k-pt scan into 10M-voxel map",
+            "value": round(total_scans / elapsed, 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": ("synthetic Livox-Avia 100k-pt/scan stream, full pipeline (registration + map update + voxel meshing)" if args.mesh else
+                                    "synthetic Livox-Avia 100k-pt/scan stream, registration + map update, meshing off"),
+                       "n_raw": args.pts, "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/avia.yaml",
+                       "parallelism": f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"},
+            "stages_ms": {"gpu_total": round(stage[0] / args.steps, 4), "register": round(stage[1] / args.steps, 4),
+                          "map_update": round(stage[2] / args.steps, 4), "mesh": round(stage[3] / args.steps, 4)},
+            "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_new", "v_act", "n_u", "t_add", "t_rem")},
+            "pose_err_m": round(pose_err, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+            "kernels_ms_per_scan": {n: round(s["total_ms"] / max(1, args.profile_scans), 4) for n, s in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,10 @@ COUNTER_FIELDS = ("n_ds", "n_iter", "n_match", "n_plane_tests", "n_extra_probe",
                   "n_v", "n_u", "t_v", "t_add", "t_rem", "c1", "c20", "n_root_voxels", "n_nodes", "n_vertices", "n_triangles_live")
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 56), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
 class Counters(C.Structure):
     _fields_ = [(n, C.c_int64) for n in COUNTER_FIELDS]
 
@@ -222,6 +226,18 @@ class HotPath:
         ms = np.zeros(4, np.float32)
         self._check(f(self.ctx, _ptr(ms)), "last_timing")
         return {"total": float(ms[0]), "register": float(ms[1]), "map_update": float(ms[2]), "mesh": float(ms[3])}
+
+    # -- per-kernel timing (product library only) --------------------------------------------------------------
+    def profile_enable(self, on=True):
+        f = self._f("profile_enable"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int
+        self._check(f(self.ctx, 1 if on else 0), "profile_enable")
+
+    def profile_read(self, reset=False):
+        f = self._f("profile_read"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]; f.restype = C.c_int
+        buf = (KernelStat * 128)()
+        n = C.c_int32(0)
+        self._check(f(self.ctx, C.byref(buf), 128, C.byref(n), 1 if reset else 0), "profile_read")
+        return {buf[i].name.decode(): {"launches": buf[i].launches, "total_ms": buf[i].total_ms} for i in range(min(n.value, 128))}
 
     # -- introspection ----------------------------------------------------------------------------------------
     def dump_planes(self):

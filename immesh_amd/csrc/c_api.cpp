@@ -7,6 +7,12 @@
 #include <new>
 
 static thread_local std::string g_create_error;
+thread_local KProf* g_kprof = nullptr;
+struct ProfBind {  // binds the ctx profiler to the calling thread for the duration of one C-ABI call
+    immesh_ctx* c;
+    explicit ProfBind(immesh_ctx* ctx) : c(ctx) { g_kprof = &ctx->prof; }
+    ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); c->prof.flush(); } g_kprof = nullptr; }
+};
 
 static int64_t next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -32,7 +38,7 @@ static int alloc_all(immesh_ctx* c) {
     const int64_t cap_roots = g.cap_root_voxels > 0 ? g.cap_root_voxels : (1 << 20);
     const int64_t cap_nodes = g.cap_nodes > 0 ? g.cap_nodes : cap_roots + cap_roots / 2;
     const int64_t cap_chunks = g.cap_point_chunks > 0 ? g.cap_point_chunks : cap_nodes * 2;
-    const int64_t cap_ext = std::max<int64_t>(1024, cap_nodes / 64);
+    const int64_t cap_ext = g.max_points_size > IM_INLINE_CHUNKS * IM_CHUNK_PTS ? std::max<int64_t>(1024, cap_nodes / 4) : std::max<int64_t>(1024, cap_nodes / 64);
     const int64_t hcap = next_pow2(cap_roots * 2);
     if (cap_nodes > 0x7fffffff || cap_chunks > 0x7fffffff || hcap > 0xffffffffLL) { c->err = "capacity too large for 32-bit indices"; return IMMESH_E_INVAL; }
     int rc;
@@ -75,8 +81,6 @@ static int alloc_all(immesh_ctx* c) {
     return 0;
 }
 
-int mesh_alloc(immesh_ctx* c);   // mesh_host.cpp
-void mesh_free(immesh_ctx* c);
 
 immesh_ctx* immesh_create(const immesh_config* cfg) {
     g_create_error.clear();
@@ -135,7 +139,7 @@ static void make_scan_params(const immesh_ctx* c, const imh::State& st, const do
 static int check_overflow(immesh_ctx* c) {  // after a stream sync
     const int f = c->h_counters[5];
     if (f) {
-        static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 1152 retained points", "extension-table pool exhausted",
+        static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 32896 retained points", "extension-table pool exhausted",
                                     "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)"};
         c->err = std::string("registration map capacity: ") + why[f < 6 ? f : 0];
         return IMMESH_E_CAPACITY;
@@ -188,6 +192,7 @@ int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double*
                     int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -223,6 +228,7 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
                      int32_t* match_idx, double* normals, float* dis, double* r_inv) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state || !HTH36 || !HTz6) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -281,6 +287,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
 int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* state) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -294,6 +301,7 @@ int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* s
 int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -304,8 +312,6 @@ int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const doubl
     return check_overflow(c);
 }
 
-int mesh_scan_device(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);  // mesh_host.cpp
-int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, int n_raw, const imh::State& st);                      // mesh_host.cpp
 
 int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, const float* pts_raw, int32_t n_raw, const double* state_prior,
                         double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out) {
@@ -314,6 +320,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         return IMMESH_E_INVAL;
     }
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     const void *d_down, *d_raw = nullptr;
     int rc = resolve_input(c, pts_down, (size_t)n_ds * 12, c->d_pts_down, &d_down);
     if (rc) return rc;
@@ -351,6 +358,7 @@ int immesh_last_timing(immesh_ctx* c, float ms[4]) {
 int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_t* n_out) {
     if (!c || !n_out) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     static_assert(sizeof(PlaneRecDev) == sizeof(immesh_plane_rec), "plane record layout");
     PlaneRecDev* d_out = nullptr;
     if (out && cap > 0) HIPCHK(c, hipMalloc((void**)&d_out, (size_t)cap * sizeof(PlaneRecDev)));
@@ -365,11 +373,11 @@ int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_
     return 0;
 }
 
-void mesh_counters(immesh_ctx* c, immesh_counters_t* out);  // mesh_host.cpp
 
 int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     if (!c || !out) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
     int64_t stats[8];
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost));
@@ -382,6 +390,28 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
         std::memset(&c->cnt, 0, sizeof(c->cnt));
         HIPCHK(c, hipMemset(c->d_stats, 0, sizeof(stats)));
     }
+    return 0;
+}
+
+int immesh_profile_enable(immesh_ctx* c, int32_t on) {
+    if (!c) return IMMESH_E_INVAL;
+    c->prof.on = on != 0;
+    return 0;
+}
+
+int immesh_profile_read(immesh_ctx* c, immesh_kernel_stat* out, int32_t cap, int32_t* n_out, int32_t reset) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->prof.flush(); }
+    const int n = (int)c->prof.names.size();
+    for (int i = 0; i < n && i < cap && out; i++) {
+        std::memset(&out[i], 0, sizeof(out[i]));
+        std::strncpy(out[i].name, c->prof.names[i].c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = c->prof.cnt[i];
+        out[i].total_ms = c->prof.ms[i];
+    }
+    *n_out = n;
+    if (reset) c->prof.reset();
     return 0;
 }
 

@@ -9,6 +9,7 @@
 #include "kernels.hpp"
 #include "mesh_kernels.hpp"
 #include "ekf_host.hpp"
+#include "prof.hpp"
 
 #define HIPCHK(ctx, expr)                                                                                   \
     do {                                                                                                    \
@@ -62,6 +63,8 @@ struct immesh_ctx {
     int32_t* h_counters = nullptr;   // pinned copy of map.counters (8 ints)
     unsigned long long* d_dump_count = nullptr;
 
+    KProf prof;
+
     // cumulative counters (host side)
     immesh_counters_t cnt;
     int last_n_ds = 0;
@@ -95,3 +98,10 @@ inline int resolve_input(immesh_ctx* c, const void* p, size_t bytes, void* stagi
     *dev_out = staging;
     return 0;
 }
+
+// mesher host orchestration (mesh_host.cpp)
+int mesh_alloc(immesh_ctx* c);
+void mesh_free(immesh_ctx* c);
+int mesh_scan_device(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);
+int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, int n_raw, const imh::State& st);
+void mesh_counters(immesh_ctx* c, immesh_counters_t* out);

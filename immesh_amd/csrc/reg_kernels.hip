@@ -11,6 +11,7 @@
 // Bound: HBM/latency (dependent gathers through hash -> node -> plane); no GEMM-shaped work, MFMA is not used.
 #include "regmap.hpp"
 #include "kernels.hpp"
+#include "prof.hpp"
 
 using namespace imd;
 
@@ -637,31 +638,31 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_
 void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, double* out48,
                      int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = (n + 255) / 256;
-    hipLaunchKernelGGL(residual_kernel, dim3(nb), dim3(256), 0, s, m, sp, pts, n, partials, o_match, o_node, o_dis, o_rinv, o_normal);
-    hipLaunchKernelGGL(residual_reduce_kernel, dim3(1), dim3(64), 0, s, partials, nb, out48);
+    KLAUNCH(residual_kernel, dim3(nb), dim3(256), 0, s, m, sp, pts, n, partials, o_match, o_node, o_dis, o_rinv, o_normal);
+    KLAUNCH(residual_reduce_kernel, dim3(1), dim3(64), 0, s, partials, nb, out48);
 }
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
                       unsigned long long* sort_key, uint32_t* slot) {
-    hipLaunchKernelGGL(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot);
+    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
     hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
-    hipLaunchKernelGGL(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, nseg);
+    KLAUNCH(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, nseg);
 }
 void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
                    const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats) {
-    hipLaunchKernelGGL(replay_kernel, dim3((max_segments + 3) / 4), dim3(256), 0, s, m, sorted_slot, sorted_idx, pt_data, n, seg_start, nseg, mode, stats);
-    hipLaunchKernelGGL(merge_free_kernel, dim3(64), dim3(256), 0, s, m);
-    hipLaunchKernelGGL(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
+    KLAUNCH(replay_kernel, dim3((max_segments + 3) / 4), dim3(256), 0, s, m, sorted_slot, sorted_idx, pt_data, n, seg_start, nseg, mode, stats);
+    KLAUNCH(merge_free_kernel, dim3(64), dim3(256), 0, s, m);
+    KLAUNCH(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
 }
 void launch_dump_planes(hipStream_t s, const RegMapDev& m, PlaneRecDev* out, long long cap, unsigned long long* count) {
     hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
-    hipLaunchKernelGGL(dump_planes_kernel, dim3(1024), dim3(256), 0, s, m, out, cap, count);
+    KLAUNCH(dump_planes_kernel, dim3(1024), dim3(256), 0, s, m, out, cap, count);
 }
 void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v, size_t n) {
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(2048), dim3(256), 0, s, p, v, n);
+    KLAUNCH(fill_u64_kernel, dim3(2048), dim3(256), 0, s, p, v, n);
 }
-void launch_iota(hipStream_t s, int32_t* p, int n) { hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n); }
+void launch_iota(hipStream_t s, int32_t* p, int n) { KLAUNCH(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n); }
 void launch_gather_u32(hipStream_t s, const uint32_t* src, const int32_t* idx, uint32_t* dst, int n) {
-    hipLaunchKernelGGL(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, dst, n);
+    KLAUNCH(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, dst, n);
 }

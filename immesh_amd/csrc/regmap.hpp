@@ -11,7 +11,7 @@
 #define IM_CHUNK_PTS 16
 #define IM_PT_DOUBLES 9           /* x y z + var(00 01 02 11 12 22) */
 #define IM_INLINE_CHUNKS 8        /* 128 points inline per node; beyond that an extension table */
-#define IM_EXT_CHUNKS 64          /* + 1024 points (KITTI: max_points_size 1000 / g_max_points 1000) */
+#define IM_EXT_CHUNKS 2048        /* + 32768 points: KITTI max_points_size / g_max_points 1000, and buildVoxelMap roots that hold a whole 3 m voxel of the first scan */
 #define IM_G_MAX_POINTS 1000      /* g_max_points, src/voxel_loc.cpp:45 */
 
 // node flag bits

@@ -3,6 +3,7 @@
 // needs: ties keep ascending scan index, the tie-break the CPU checker uses for std::sort's unspecified order.
 #include <hipcub/hipcub.hpp>
 #include "kernels.hpp"
+#include "prof.hpp"
 
 size_t sort_pairs_u64_temp_bytes(int n) {
     size_t bytes = 0;
@@ -18,9 +19,9 @@ size_t sort_pairs_u32_temp_bytes(int n) {
 }
 void sort_pairs_u64(hipStream_t s, void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
                     const int32_t* vals_in, int32_t* vals_out, int n) {
-    hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, s);
+    KTIMED("radix_sort_pairs_u64", s, (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, s));
 }
 void sort_pairs_u32(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in,
                     int32_t* vals_out, int n, int end_bit) {
-    hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, s);
+    KTIMED("radix_sort_pairs_u32", s, (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, s));
 }

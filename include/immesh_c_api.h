@@ -152,6 +152,15 @@ int immesh_counters(immesh_ctx* ctx, immesh_counters_t* out, int32_t reset);
  * [0] total  [1] register  [2] map update  [3] mesh  */
 int immesh_last_timing(immesh_ctx* ctx, float ms[4]);
 
+/* per-kernel timing (HIP events on the ctx stream around every launch); off by default.  bench.py's roofline leg. */
+typedef struct immesh_kernel_stat {
+    char name[56];
+    int64_t launches;
+    double total_ms;
+} immesh_kernel_stat;
+int immesh_profile_enable(immesh_ctx* ctx, int32_t on);
+int immesh_profile_read(immesh_ctx* ctx, immesh_kernel_stat* out, int32_t cap, int32_t* n_out, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif
