@@ -156,7 +156,7 @@ def main():
     n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
 
     n_total = args.warmup + args.steps + args.profile_scans
-    raws, downs = make_scans(n_total + 1, args.pts, cfg, os.path.join(ROOT, "gpurun_out", "scan_cache"))
+    raws, downs = make_scans(n_total + 1, args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"))
     d_raw = [torch.from_numpy(r).to(dev) for r in raws]
     d_down = [torch.from_numpy(d).to(dev) for d in downs]
     n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))

@@ -1,8 +1,101 @@
-// Mesher device structures + launchers (filled in by mesh_kernels.hip).
+// HBM-resident mesh map + launcher prototypes of the mesher half of the hot path.
+// What the reference keeps as Global_map (vector<shared_ptr<RGB_pts>>, two Hash_map_3d, ikd-Tree of vertices;
+// src/meshing/r3live/pointcloud_rgbd.hpp:234-298) and Triangle_manager (triangle hash + vertex->triangle adjacency;
+// src/meshing/r3live/triangle.hpp:115-395) becomes:
+//   * vertex store, SoA                      v_pos f32 xyz (the reference's f64 m_pos holds exactly these float values),
+//                                            v_smooth f64 xyz (m_pos_aft_smooth), v_voxel (owner mesh voxel)
+//   * dedupe grid hash (m_hashmap_3d_pts)    packed 3x21-bit cell key -> vertex id         (<= 1 vertex per min-spacing cell)
+//   * mesh-voxel hash (m_hashmap_voxels)     packed key -> voxel index; voxel SoA with a fixed-stride point list
+//     -- the grid doubles as the spatial index that replaces the ikd-Tree: the 1-NN insert test probes the 27 cells around
+//        a candidate, the 20-NN neighbourhood pull stages the voxel block around a mesh voxel through LDS.
+//   * triangle pool + triangle hash           sorted-triplet -> triangle index (m_triangle_hash; entries persist after erase),
+//     live flag, flip word, and "triangles by smallest vertex" chunk lists (the role of m_map_pt_triangle).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
 
-struct MeshDev { int placeholder; };
-struct MeshHost { int placeholder; };
+#define MV_VOX_CAP 128      /* vertices per mesh voxel: ((int)(voxel/min_spacing)+1)^3 = 125 for every shipped config */
+#define MV_KNN 20           /* neighbours pulled per vertex, mesh_rec_geometry.cpp:350 */
+#define MV_REL_CAP 1024     /* vertices in one voxel's neighbourhood union (n_u) */
+#define MV_ADJ_SLOTS 7      /* triangle ids per adjacency chunk (+1 next pointer) */
+
+// per-scan device counters (MeshDev::sc)
+enum {
+    SC_UNDECIDED = 0, SC_ACCEPTED, SC_RECENT, SC_ACTIVE, SC_ADD, SC_REM, SC_UPD, SC_SMOOTH, SC_OVERFLOW, SC_C1, SC_C20, SC_NV, SC_NU, SC_TV,
+    SC_COUNT = 16
+};
+// persistent device counters (MeshDev::pc)
+enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
+
+struct MeshDev {
+    // vertices
+    float* v_pos; double* v_smooth; double* v_smooth_new; int32_t* v_voxel;
+    // dedupe grid hash
+    unsigned long long* g_keys; int32_t* g_vals; uint64_t g_mask;
+    // mesh voxels
+    unsigned long long* x_keys; int32_t* x_vals; uint64_t x_mask;
+    unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
+    int32_t* vx_rank; int32_t* vx_rank_seq; double* vx_short_axis;
+    // triangles
+    int32_t* t_v; unsigned long long* t_word; int32_t* t_live; int32_t* t_rem_seq; int8_t* t_flip;
+    int32_t* th_slots; uint64_t th_mask;
+    int32_t* a_head; int32_t* a_chunks;
+    // counters
+    int32_t* sc; int32_t* pc;
+    // per-scan scratch
+    int32_t* cand_status; int32_t* cand_vox; unsigned long long* cand_cell; int32_t* cand_next; int32_t* cand_rank;
+    unsigned long long* ch_keys; int32_t* ch_head; uint64_t ch_mask;       // candidate-cell chains
+    int32_t* recent;                                                       // voxel indices visited this scan
+    unsigned long long* act_key; int32_t* act_vox; unsigned long long* act_key_s; int32_t* act_vox_s;
+    int32_t* rel_ids; int32_t* rel_n;                                      // [n_active][MV_REL_CAP], [n_active]
+    int32_t* vox_tris; int32_t* vox_ntris;                                 // [n_active][2*MV_REL_CAP] triangle ids touched (bit 31 = add)
+    int32_t* list_add; int32_t* list_rem; int32_t* list_upd; int32_t* list_smooth;   // unsorted unique lists
+    // sorted outputs
+    int32_t* out_tri_add; uint8_t* out_flip_add; int32_t* out_tri_rem; int32_t* out_tri_upd; uint8_t* out_flip_upd; int32_t* out_smooth_ids;
+    double* out_smooth_xyz;
+    // capacities
+    int32_t cap_verts, cap_voxels, cap_tris, cap_adj_chunks, cap_cand, cap_active, cap_list;
+    // parameters
+    double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
+    int32_t seq;                         // scan sequence number (>= 1)
+};
+
+struct MeshScanParams {
+    double cam[3];
+    int32_t n_raw, step, n_cand, vtx_base;
+};
+
+struct MeshHost {
+    int32_t seq = 0;
+    immesh_mesh_sizes_t sizes;
+    int64_t cum[SC_COUNT];
+    // sort scratch
+    uint32_t *k32_a = nullptr, *k32_b = nullptr;
+    unsigned long long *k64_a = nullptr, *k64_b = nullptr;
+    int32_t *p_a = nullptr, *p_b = nullptr, *p_c = nullptr;
+    int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters
+    int32_t* h_pc = nullptr;
+    bool ready = false;
+};
+
+void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
+                           const double* extT);
+void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
+void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
+void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
+void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active);
+void launch_mesh_knn(hipStream_t s, const MeshDev& m, int n_active);
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, int n_active);
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m, int n_active);
+void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
+void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip);
+void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris, int n);
+void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n);
+void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n);
+void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n);
+
+// device prefix sum (sort.hip)
+size_t exclusive_sum_temp_bytes(int n);
+void exclusive_sum_i32(hipStream_t s, void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n);

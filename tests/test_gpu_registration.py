@@ -128,7 +128,10 @@ def test_edge_cases(oracle_lib, hip_lib):
     o, h = _both(oracle_lib, hip_lib, cfg)
     # negative coordinates, exact voxel-boundary values, z == 0 exactly, a single point
     P = np.array([[-1.0, -0.5, 0.0], [-1.0, -0.5, 0.0], [2.0, 3.0, 0.0], [-2.25, 4.5, -0.75], [1e-3, -1e-3, 0.0], [7.5, -7.5, 0.0]], np.float32)
-    P = np.concatenate([P, P + np.float32(0.01), P - np.float32(0.02)] * 4)
+    # small non-collinear in-plane offsets: exactly collinear clusters have a rank-1 covariance whose minimum eigenvector is arbitrary
+    # (in the reference too), which no implementation can be compared on
+    offs = np.array([[0, 0, 0], [0.01, 0, 0], [0, -0.02, 0], [0.013, 0.017, 0], [-0.021, 0.009, 0.001], [0.004, -0.015, -0.001]], np.float32)
+    P = np.concatenate([P + o for o in offs] * 2)
     st = capi.make_state(t=np.array([0.0, 0.0, 0.5]))
     o.map_build(P, st); h.map_build(P, st)
     compare_plane_tables(o.dump_planes(), h.dump_planes(), TOL)
