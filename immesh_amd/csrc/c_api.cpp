@@ -8,11 +8,7 @@
 
 static thread_local std::string g_create_error;
 thread_local KProf* g_kprof = nullptr;
-struct ProfBind {  // binds the ctx profiler to the calling thread for the duration of one C-ABI call
-    immesh_ctx* c;
-    explicit ProfBind(immesh_ctx* ctx) : c(ctx) { g_kprof = &ctx->prof; }
-    ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); c->prof.flush(); } g_kprof = nullptr; }
-};
+
 
 static int64_t next_pow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -387,6 +383,7 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     out->n_root_voxels = c->h_counters[6]; out->n_nodes = c->h_counters[0];
     mesh_counters(c, out);
     if (reset) {
+        mesh_counters_reset(c);
         std::memset(&c->cnt, 0, sizeof(c->cnt));
         HIPCHK(c, hipMemset(c->d_stats, 0, sizeof(stats)));
     }

@@ -99,9 +99,16 @@ inline int resolve_input(immesh_ctx* c, const void* p, size_t bytes, void* stagi
     return 0;
 }
 
+struct ProfBind {  // binds the ctx profiler to the calling thread for the duration of one C-ABI call
+    immesh_ctx* c;
+    explicit ProfBind(immesh_ctx* ctx) : c(ctx) { g_kprof = &ctx->prof; }
+    ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); c->prof.flush(); } g_kprof = nullptr; }
+};
+
 // mesher host orchestration (mesh_host.cpp)
 int mesh_alloc(immesh_ctx* c);
 void mesh_free(immesh_ctx* c);
 int mesh_scan_device(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);
 int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, int n_raw, const imh::State& st);
 void mesh_counters(immesh_ctx* c, immesh_counters_t* out);
+void mesh_counters_reset(immesh_ctx* c);

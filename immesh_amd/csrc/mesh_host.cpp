@@ -1,12 +1,237 @@
-// Host orchestration of the mesher kernels (temporary stub until mesh_kernels.hip lands).
+// Host orchestration of the mesher kernels (mesh_kernels.hip): incremental_mesh_reconstruction (ImMesh_mesh_reconstruction.cpp:92-267)
+// as a sequence of launches on the context stream.  No per-point / per-voxel / per-triangle work happens on the host: it only
+// sizes launches from a handful of device counters and moves the result lists on immesh_mesh_fetch.
 #include "host_ctx.hpp"
-int mesh_alloc(immesh_ctx* c) { (void)c; return 0; }
-void mesh_free(immesh_ctx* c) { (void)c; }
-int mesh_scan_device(immesh_ctx* c, const float*, int, const double*, int) { c->err = "mesher not built yet"; return IMMESH_E_INVAL; }
-int mesh_transform_full(immesh_ctx* c, const float*, int, const imh::State&) { c->err = "mesher not built yet"; return IMMESH_E_INVAL; }
-void mesh_counters(immesh_ctx*, immesh_counters_t*) {}
-extern "C" {
-int immesh_mesh_scan(immesh_ctx* c, const float*, int32_t, const double*, int32_t) { if (c) c->err = "mesher not built yet"; return IMMESH_E_INVAL; }
-int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t*) { if (c) c->err = "mesher not built yet"; return IMMESH_E_INVAL; }
-int immesh_mesh_fetch(immesh_ctx* c, float*, int32_t*, uint8_t*, int32_t*, int32_t*, uint8_t*, int32_t*, double*) { if (c) c->err = "mesher not built yet"; return IMMESH_E_INVAL; }
+#include <algorithm>
+#include <cmath>
+
+static int64_t np2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+
+int mesh_alloc(immesh_ctx* c) {
+    const immesh_config& g = c->cfg;
+    MeshDev& m = c->mesh;
+    MeshHost& h = c->mesh_host;
+    std::memset(&m, 0, sizeof(m));
+    std::memset(h.cum, 0, sizeof(h.cum));
+    std::memset(&h.sizes, 0, sizeof(h.sizes));
+    if (g.mesh_min_spacing <= 0 || g.mesh_voxel <= 0 || g.mesh_append_budget <= 0) { c->err = "invalid meshing parameters"; return IMMESH_E_INVAL; }
+    {   // every dedupe cell holds at most one vertex, so a mesh voxel holds at most (cells per axis)^3
+        const int per_axis = (int)(g.mesh_voxel / g.mesh_min_spacing) + 1;
+        if ((int64_t)per_axis * per_axis * per_axis > MV_VOX_CAP) { c->err = "mesh_voxel / mesh_min_spacing ratio above 4 is not supported (voxel point list stride)"; return IMMESH_E_INVAL; }
+    }
+    const int64_t cap_verts = g.cap_vertices > 0 ? g.cap_vertices : (1 << 22);
+    const int64_t cap_voxels = cap_verts;
+    const int64_t cap_tris = g.cap_triangles > 0 ? g.cap_triangles : cap_verts * 4;
+    const int64_t cap_adj = cap_verts + cap_tris / 4;
+    const int64_t cap_cand = c->cap_scan;
+    const int64_t cap_active = std::min<int64_t>(cap_cand, 1 << 17);
+    const int64_t cap_list = 1 << 22;
+    if (cap_verts > 0x3fffffff || cap_tris > 0x3fffffff) { c->err = "mesh capacity too large for 31-bit indices"; return IMMESH_E_INVAL; }
+    int rc;
+#define A(ptr, n) if ((rc = c->dalloc(&(ptr), (size_t)(n)))) return rc
+    A(m.v_pos, cap_verts * 3); A(m.v_smooth, cap_verts * 3); A(m.v_smooth_new, cap_verts * 3); A(m.v_voxel, cap_verts);
+    const int64_t gcap = np2(cap_verts * 2), xcap = np2(cap_voxels * 2), tcap = np2(cap_tris * 2), ccap = np2(cap_cand * 4);
+    A(m.g_keys, gcap); A(m.g_vals, gcap); m.g_mask = (uint64_t)gcap - 1;
+    A(m.x_keys, xcap); A(m.x_vals, xcap); m.x_mask = (uint64_t)xcap - 1;
+    A(m.vx_key, cap_voxels); A(m.vx_npts, cap_voxels); A(m.vx_pts, cap_voxels * MV_VOX_CAP); A(m.vx_meshing_times, cap_voxels);
+    A(m.vx_new_added, cap_voxels); A(m.vx_stamp, cap_voxels); A(m.vx_rank, cap_voxels); A(m.vx_rank_seq, cap_voxels); A(m.vx_short_axis, cap_voxels * 3);
+    A(m.t_v, cap_tris * 3); A(m.t_word, cap_tris); A(m.t_live, cap_tris); A(m.t_rem_seq, cap_tris); A(m.t_flip, cap_tris);
+    A(m.th_slots, tcap); m.th_mask = (uint64_t)tcap - 1;
+    A(m.a_head, cap_verts); A(m.a_chunks, cap_adj * 8);
+    A(m.sc, SC_COUNT); A(m.pc, PC_COUNT);
+    A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand);
+    A(m.ch_keys, ccap); A(m.ch_head, ccap);
+    A(m.recent, cap_cand);
+    A(m.act_key, cap_active); A(m.act_vox, cap_active); A(m.act_key_s, cap_active); A(m.act_vox_s, cap_active);
+    A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active);
+    A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
+    A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
+    A(m.out_tri_add, cap_list * 3); A(m.out_flip_add, cap_list); A(m.out_tri_rem, cap_list * 3); A(m.out_tri_upd, cap_list * 3); A(m.out_flip_upd, cap_list);
+    A(m.out_smooth_ids, cap_list); A(m.out_smooth_xyz, cap_list * 3);
+    A(h.k32_a, cap_list); A(h.k32_b, cap_list); A(h.k64_a, cap_list); A(h.k64_b, cap_list); A(h.p_a, cap_list); A(h.p_b, cap_list); A(h.p_c, cap_list);
+    h.sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)cap_list), sort_pairs_u32_temp_bytes((int)cap_list), exclusive_sum_temp_bytes((int)cap_cand)}) + 256;
+    { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
+#undef A
+    m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
+    m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
+    m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
+    hipStream_t s = c->stream;
+    launch_fill_u64(s, m.g_keys, ~0ull, (size_t)gcap);
+    launch_fill_u64(s, m.x_keys, ~0ull, (size_t)xcap);
+    HIPCHK(c, hipMemsetAsync(m.x_vals, 0xFF, (size_t)xcap * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.th_slots, 0xFF, (size_t)tcap * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
+    HIPCHK(c, hipHostMalloc((void**)&h.h_sc, SC_COUNT * 4));
+    HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
+    std::memset(h.h_sc, 0, SC_COUNT * 4); std::memset(h.h_pc, 0, PC_COUNT * 4);
+    h.ready = true;
+    return 0;
 }
+
+void mesh_free(immesh_ctx* c) {
+    MeshHost& h = c->mesh_host;
+    if (h.h_sc) (void)hipHostFree(h.h_sc);
+    if (h.h_pc) (void)hipHostFree(h.h_pc);
+    h.h_sc = h.h_pc = nullptr;
+}
+
+static int mesh_overflow(immesh_ctx* c) {
+    const int f = c->mesh_host.h_sc[SC_OVERFLOW];
+    if (!f) return 0;
+    static const char* why[] = {"", "mesh-voxel hash full", "mesh-voxel pool exhausted (cap_vertices)", "candidate-cell table full", "vertex pool exhausted (cap_vertices)",
+                                "mesh voxel lookup failed", "dedupe grid hash full", "mesh voxel holds more than 128 vertices", "more active voxels than cap (131072 per scan)",
+                                "voxel neighbourhood above 1024 vertices", "triangle pool exhausted (cap_triangles)", "triangle hash full", "Delaunay cavity / triangle buffer overflow",
+                                "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries"};
+    c->err = std::string("mesh map capacity: ") + why[(f > 0 && f < 15) ? f : 0];
+    return IMMESH_E_CAPACITY;
+}
+
+// sort a list of triangle indices lexicographically by (v0, v1, v2): LSD with two stable radix passes; result in h.p_c
+static void sort_tris(immesh_ctx* c, const int32_t* list, int n) {
+    MeshHost& h = c->mesh_host;
+    hipStream_t s = c->stream;
+    launch_mesh_tri_keys(s, c->mesh, list, n, 0, h.k32_a, nullptr);
+    sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, h.k32_a, h.k32_b, list, h.p_b, n, 32);
+    launch_mesh_tri_keys(s, c->mesh, h.p_b, n, 1, nullptr, h.k64_a);
+    sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, h.k64_a, h.k64_b, h.p_b, h.p_c, n);
+}
+
+int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx) {
+    (void)frame_idx;
+    MeshDev& m = c->mesh;
+    MeshHost& h = c->mesh_host;
+    hipStream_t s = c->stream;
+    if (!h.ready) { c->err = "mesher not initialised"; return IMMESH_E_INVAL; }
+    h.seq++;
+    m.seq = h.seq;
+    MeshScanParams sp;
+    sp.cam[0] = sensor_pos[0]; sp.cam[1] = sensor_pos[1]; sp.cam[2] = sensor_pos[2];
+    sp.n_raw = n_raw;
+    sp.step = std::max(1, (int)std::round((double)(n_raw / c->cfg.mesh_append_budget)));  // integer division first (ImMesh_mesh_reconstruction.cpp:111)
+    sp.n_cand = (n_raw + sp.step - 1) / sp.step;
+    sp.vtx_base = h.n_vertices;
+    if (sp.n_cand > m.cap_cand) { c->err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
+    const int64_t ccap = np2((int64_t)sp.n_cand * 4);
+    m.ch_mask = (uint64_t)ccap - 1;
+    HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
+    HIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
+    // ---- a17 append
+    launch_mesh_append_prepare(s, m, sp, d_pts);
+    for (int round = 0; round < 1000; round++) {
+        if (round > 0) HIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
+        launch_mesh_append_resolve(s, m, sp, d_pts);
+        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (h.h_sc[SC_UNDECIDED] == 0) break;
+    }
+    launch_mesh_append_flags(s, m, sp.n_cand);
+    exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
+    launch_mesh_append_commit(s, m, sp, d_pts);
+    launch_mesh_select_active(s, m, sp.n_cand);
+    HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(h.h_pc, m.pc, PC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int rc = mesh_overflow(c);
+    if (rc) return rc;
+    const int n_new = h.h_sc[SC_ACCEPTED], n_active = h.h_sc[SC_ACTIVE];
+    h.sizes.vtx_base = sp.vtx_base; h.sizes.n_new_vtx = n_new; h.sizes.n_voxels_meshed = n_active;
+    h.sizes.n_add = h.sizes.n_rem = h.sizes.n_upd = h.sizes.n_smooth = 0; h.sizes.reserved = 0;
+    h.n_vertices = sp.vtx_base + n_new;
+    h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
+    h.cum[SC_RECENT] += sp.n_cand;  // n_app: candidates offered
+    if (n_active > 0) {
+        // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
+        // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
+        sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, m.act_key, m.act_key_s, m.act_vox, m.act_vox_s, n_active);
+        launch_mesh_rank(s, m, n_active);
+        launch_mesh_knn(s, m, n_active);                // a18-a19
+        launch_mesh_delaunay(s, m, sp, n_active);       // a20-a23
+        launch_mesh_finalize(s, m, n_active);
+        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if ((rc = mesh_overflow(c))) return rc;
+        const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
+        // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
+        if (n_rem > 0) {
+            launch_mesh_commit_rem(s, m, m.list_rem, n_rem);
+            sort_tris(c, m.list_rem, n_rem);
+            launch_mesh_emit(s, m, h.p_c, n_rem, m.out_tri_rem, nullptr);
+        }
+        if (n_add > 0) {
+            sort_tris(c, m.list_add, n_add);
+            launch_mesh_emit(s, m, h.p_c, n_add, m.out_tri_add, m.out_flip_add);
+            launch_mesh_commit_add(s, m, h.p_c, n_add);
+        }
+        if (n_upd > 0) {
+            sort_tris(c, m.list_upd, n_upd);
+            launch_mesh_emit(s, m, h.p_c, n_upd, m.out_tri_upd, m.out_flip_upd);
+        }
+        if (n_smooth > 0) {
+            sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, (const uint32_t*)m.list_smooth, h.k32_b, m.list_smooth, h.p_b, n_smooth, 32);
+            launch_mesh_emit_smooth(s, m, h.p_b, n_smooth);
+        }
+        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if ((rc = mesh_overflow(c))) return rc;
+        h.sizes.n_add = n_add; h.sizes.n_rem = n_rem; h.sizes.n_upd = n_upd; h.sizes.n_smooth = n_smooth;
+        h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
+        h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
+        h.n_live += n_add - n_rem;
+    }
+    return 0;
+}
+
+int mesh_transform_full(immesh_ctx* c, const float* d_raw, int n_raw, const imh::State& st) {
+    launch_mesh_transform(c->stream, d_raw, c->d_pts_world, n_raw, st.R, st.t, c->cfg.extR, c->cfg.extT);
+    return 0;
+}
+
+void mesh_counters(immesh_ctx* c, immesh_counters_t* out) {
+    const MeshHost& h = c->mesh_host;
+    out->n_app = h.cum[SC_RECENT]; out->n_new = h.cum[SC_ACCEPTED]; out->v_act = h.cum[SC_ACTIVE]; out->n_v = h.cum[SC_NV]; out->n_u = h.cum[SC_NU];
+    out->t_v = h.cum[SC_TV]; out->t_add = h.cum[SC_ADD]; out->t_rem = h.cum[SC_REM]; out->c1 = h.cum[SC_C1]; out->c20 = h.cum[SC_C20];
+    out->n_vertices = h.n_vertices; out->n_triangles_live = h.n_live;
+}
+void mesh_counters_reset(immesh_ctx* c) { std::memset(c->mesh_host.cum, 0, sizeof(c->mesh_host.cum)); }
+
+extern "C" {
+
+int immesh_mesh_scan(immesh_ctx* c, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx) {
+    if (!c || !pts_world_xyzi || n_raw <= 0 || n_raw > c->cap_scan || !sensor_pos) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    const void* d_pts;
+    int rc = resolve_input(c, pts_world_xyzi, (size_t)n_raw * 16, c->d_pts_world, &d_pts);
+    if (!rc) rc = mesh_scan_device(c, (const float*)d_pts, n_raw, sensor_pos, frame_idx);
+    return rc;
+}
+
+int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
+    if (!c || !sizes) return IMMESH_E_INVAL;
+    *sizes = c->mesh_host.sizes;
+    return 0;
+}
+
+int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd, uint8_t* flip_upd,
+                      int32_t* smooth_ids, double* smooth_xyz) {
+    if (!c) return IMMESH_E_INVAL;
+    hipSetDevice(c->cfg.device);
+    const MeshDev& m = c->mesh;
+    const immesh_mesh_sizes_t& z = c->mesh_host.sizes;
+    hipStream_t s = c->stream;
+    if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
+    if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, m.out_tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
+    if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, m.out_flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));
+    if (tri_rem && z.n_rem) HIPCHK(c, hipMemcpyAsync(tri_rem, m.out_tri_rem, (size_t)z.n_rem * 12, hipMemcpyDeviceToHost, s));
+    if (tri_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(tri_upd, m.out_tri_upd, (size_t)z.n_upd * 12, hipMemcpyDeviceToHost, s));
+    if (flip_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(flip_upd, m.out_flip_upd, (size_t)z.n_upd, hipMemcpyDeviceToHost, s));
+    if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, m.out_smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
+    if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, m.out_smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,1 +1,949 @@
-// mesher kernels (placeholder TU until implemented)
+// HIP kernels of the mesher half of the hot path, gfx950.
+//   mesh_transform_kernel        transformLidar of the full scan (voxel_mapping_common.cpp:709-726)
+//   mesh_append_*_kernel         Global_map::append_points_to_global_map (pointcloud_rgbd.cpp:411-552): the sequential
+//                                "accept a point iff no earlier accepted vertex within min_spacing" rule as a parallel fixed
+//                                point over the 27-cell neighbourhood of the dedupe grid (lowest scan index wins)
+//   mesh_knn_kernel              retrieve_neighbor_pts_kdtree (mesh_rec_geometry.cpp:336-377): one workgroup per active mesh
+//                                voxel, the surrounding voxel block staged through LDS, exact 20-NN per vertex (float
+//                                distances as KD_TREE::calc_dist, ikd_Tree.cpp:1722), smoothing, neighbourhood union
+//   mesh_delaunay_kernel         delaunay_triangulation + triangle_compare + correct_triangle_index
+//                                (mesh_rec_geometry.cpp:174-295, 137-172, 399-433): one wavefront per voxel; PCA, 2-D
+//                                projection, wave-parallel Bowyer-Watson with the plain-double Simple_cartesian predicates,
+//                                skinny-face filter, diff against the live triangles found through the min-vertex lists
+//   mesh_finalize/commit/emit    cross-voxel resolution ("all removes, then all adds", later voxel wins a flip) and the
+//                                Triangle_manager update (triangle.hpp:164-246, 330-395)
+// Bound: latency / LDS (integer, pointer and predicate work); nothing here is GEMM-shaped, MFMA is not used.
+#include "../../include/immesh_c_api.h"
+#include "mesh_kernels.hpp"
+#include "dev_math.hpp"
+#include "prof.hpp"
+
+using namespace imd;
+
+#define MKEY_BIAS (1 << 20)
+#define MKEY_MASK ((1ull << 21) - 1)
+#define MKEY_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define ST_UNDECIDED 0
+#define ST_ACCEPT 1
+#define ST_REJECT 2
+#define TRI_ADD_BIT 0x80000000u
+
+// x-major packing: ascending packed key == ascending (x,y,z), the order in which the CPU checker visits active voxels
+IMD unsigned long long mkey(long x, long y, long z) {
+    return (((unsigned long long)(x + MKEY_BIAS) & MKEY_MASK) << 42) | (((unsigned long long)(y + MKEY_BIAS) & MKEY_MASK) << 21) |
+           ((unsigned long long)(z + MKEY_BIAS) & MKEY_MASK);
+}
+IMD long rnd_cell(float p, double cell) { return (long)(int)round((double)p / cell); }  // std::round of the f64 quotient, pointcloud_rgbd.cpp:467-472
+IMD int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+IMD void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+IMD long long h_find(const unsigned long long* keys, unsigned long long mask, unsigned long long key) {
+    unsigned long long h = hash64(key) & mask;
+    for (int probe = 0; probe < 8192; probe++) {
+        const unsigned long long k = keys[h];
+        if (k == key) return (long long)h;
+        if (k == MKEY_EMPTY) return -1;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+IMD long long h_find_or_insert(unsigned long long* keys, unsigned long long mask, unsigned long long key, bool* created) {
+    unsigned long long h = hash64(key) & mask;
+    *created = false;
+    for (int probe = 0; probe < 8192; probe++) {
+        const unsigned long long k = keys[h];
+        if (k == key) return (long long)h;
+        if (k == MKEY_EMPTY) {
+            const unsigned long long prev = atomicCAS(&keys[h], (unsigned long long)MKEY_EMPTY, key);
+            if (prev == MKEY_EMPTY) { *created = true; return (long long)h; }
+            if (prev == key) return (long long)h;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// float squared distance exactly as KD_TREE::calc_dist (include/ikd-Tree/ikd_Tree.cpp:1722-1728)
+IMD float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+}
+
+IMD void list_push(const MeshDev& m, int32_t* list, int counter, int v) {
+    const int pos = atomicAdd(&m.sc[counter], 1);
+    if (pos < m.cap_list) list[pos] = v; else m.sc[SC_OVERFLOW] = 14;
+}
+
+// =====================================================================================================================
+// transformLidar of the full scan
+// =====================================================================================================================
+struct XformParams { double R[9], t[3], extR[9], extT[3]; };
+__global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __restrict__ in, float4* __restrict__ out, int n, XformParams xp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = in[i];
+    const double p[3] = {(double)v.x, (double)v.y, (double)v.z};
+    double pi[3], pw[3];
+    m3_vec(xp.extR, p, pi);
+    pi[0] += xp.extT[0]; pi[1] += xp.extT[1]; pi[2] += xp.extT[2];
+    m3_vec(xp.R, pi, pw);
+    out[i] = make_float4((float)(pw[0] + xp.t[0]), (float)(pw[1] + xp.t[1]), (float)(pw[2] + xp.t[2]), v.w);
+}
+
+// =====================================================================================================================
+// append_points_to_global_map
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.n_cand) return;
+    const float* p = pts + 4 * (size_t)i * sp.step;
+    const float px = p[0], py = p[1], pz = p[2];
+    const long gx = rnd_cell(px, m.min_spacing), gy = rnd_cell(py, m.min_spacing), gz = rnd_cell(pz, m.min_spacing);
+    const long bx = rnd_cell(px, m.voxel), by = rnd_cell(py, m.voxel), bz = rnd_cell(pz, m.voxel);
+    // mesh voxel: find or create, mark visited (m_voxels_recent_visited, pointcloud_rgbd.cpp:480-500)
+    const unsigned long long vkey = mkey(bx, by, bz);
+    bool created;
+    const long long vs = h_find_or_insert(m.x_keys, m.x_mask, vkey, &created);
+    int vi = -1;
+    if (vs < 0) { m.sc[SC_OVERFLOW] = 1; }
+    else if (created) {
+        vi = atomicAdd(&m.pc[PC_VOXELS], 1);
+        if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
+        else {
+            m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_stamp[vi] = m.seq;
+            m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
+            m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
+            __threadfence();
+            st_agent(&m.x_vals[vs], vi);
+        }
+    } else {
+        vi = ld_agent(&m.x_vals[vs]);  // -1 while the creating lane of this launch has not published it: the creator marks it visited
+        if (vi >= 0 && atomicExch(&m.vx_stamp[vi], m.seq) != m.seq) m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
+    }
+    m.cand_vox[i] = vi;
+    const unsigned long long gkey = mkey(gx, gy, gz);
+    m.cand_cell[i] = gkey;
+    // existing vertices: occupied dedupe cell, or any vertex closer than min_spacing (1-NN test, pointcloud_rgbd.cpp:503-516).
+    // A vertex within min_spacing lies in one of the 27 cells around the candidate's cell and every cell holds at most one vertex.
+    int status = ST_UNDECIDED;
+    int probes = 0;
+    if (h_find(m.g_keys, m.g_mask, gkey) >= 0) status = ST_REJECT;
+    else {
+        for (int dx = -1; dx <= 1 && status == ST_UNDECIDED; dx++)
+            for (int dy = -1; dy <= 1 && status == ST_UNDECIDED; dy++)
+                for (int dz = -1; dz <= 1; dz++) {
+                    if (dx == 0 && dy == 0 && dz == 0) continue;
+                    const long long s = h_find(m.g_keys, m.g_mask, mkey(gx + dx, gy + dy, gz + dz));
+                    if (s < 0) continue;
+                    probes++;
+                    const int id = m.g_vals[s];
+                    const float d2 = dist2f(px, py, pz, m.v_pos[(size_t)id * 3 + 0], m.v_pos[(size_t)id * 3 + 1], m.v_pos[(size_t)id * 3 + 2]);
+                    if ((double)sqrtf(d2) < m.min_spacing) { status = ST_REJECT; break; }
+                }
+    }
+    if (probes) atomicAdd(&m.sc[SC_C1], probes);
+    m.cand_next[i] = -1;
+    if (status == ST_UNDECIDED) {  // chain the survivor under its cell for the in-scan conflict resolution
+        bool c2;
+        const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
+        if (cs < 0) m.sc[SC_OVERFLOW] = 3;
+        else m.cand_next[i] = atomicExch(&m.ch_head[cs], i);
+    }
+    m.cand_status[i] = status;
+}
+
+// Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
+// loop's outcome.  Each lane re-evaluates until every lower-index conflicting candidate is decided (bounded; relaunched by the host).
+__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.n_cand) return;
+    if (ld_agent(&m.cand_status[i]) != ST_UNDECIDED) return;
+    const float* p = pts + 4 * (size_t)i * sp.step;
+    const float px = p[0], py = p[1], pz = p[2];
+    const long gx = rnd_cell(px, m.min_spacing), gy = rnd_cell(py, m.min_spacing), gz = rnd_cell(pz, m.min_spacing);
+    const unsigned long long own = m.cand_cell[i];
+    for (int iter = 0; iter < 48; iter++) {
+        bool rej = false, blocked = false;
+        for (int dx = -1; dx <= 1 && !rej; dx++)
+            for (int dy = -1; dy <= 1 && !rej; dy++)
+                for (int dz = -1; dz <= 1 && !rej; dz++) {
+                    const unsigned long long ck = mkey(gx + dx, gy + dy, gz + dz);
+                    const long long s = h_find(m.ch_keys, m.ch_mask, ck);
+                    if (s < 0) continue;
+                    for (int j = m.ch_head[s]; j >= 0; j = m.cand_next[j]) {
+                        if (j >= i) continue;
+                        const int sj = ld_agent(&m.cand_status[j]);
+                        if (sj == ST_REJECT) continue;
+                        bool conflict = (ck == own);
+                        if (!conflict) {
+                            const float* q = pts + 4 * (size_t)j * sp.step;
+                            conflict = (double)sqrtf(dist2f(px, py, pz, q[0], q[1], q[2])) < m.min_spacing;
+                        }
+                        if (!conflict) continue;
+                        if (sj == ST_ACCEPT) { rej = true; break; }
+                        blocked = true;
+                    }
+                }
+        if (rej) { st_agent(&m.cand_status[i], ST_REJECT); return; }
+        if (!blocked) { st_agent(&m.cand_status[i], ST_ACCEPT); return; }
+    }
+    atomicAdd(&m.sc[SC_UNDECIDED], 1);
+}
+
+__global__ void mesh_append_flags_kernel(MeshDev m, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m.cand_rank[i] = (m.cand_status[i] == ST_ACCEPT) ? 1 : 0;
+}
+
+// new vertex id = vtx_base + (number of accepted candidates with a lower scan index): ids grow in scan order as in the reference
+__global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.n_cand) return;
+    const bool acc = m.cand_status[i] == ST_ACCEPT;
+    if (i == sp.n_cand - 1) {
+        const int total = m.cand_rank[i] + (acc ? 1 : 0);
+        m.sc[SC_ACCEPTED] = total;
+        m.pc[PC_VERTS] = sp.vtx_base + total;
+    }
+    if (!acc) return;
+    const int id = sp.vtx_base + m.cand_rank[i];
+    if (id >= m.cap_verts) { m.sc[SC_OVERFLOW] = 4; return; }
+    const float* p = pts + 4 * (size_t)i * sp.step;
+    const float px = p[0], py = p[1], pz = p[2];
+    m.v_pos[(size_t)id * 3 + 0] = px; m.v_pos[(size_t)id * 3 + 1] = py; m.v_pos[(size_t)id * 3 + 2] = pz;
+    m.v_smooth[(size_t)id * 3 + 0] = (double)px; m.v_smooth[(size_t)id * 3 + 1] = (double)py; m.v_smooth[(size_t)id * 3 + 2] = (double)pz;
+    int vi = m.cand_vox[i];
+    if (vi < 0) {
+        const long long vs = h_find(m.x_keys, m.x_mask, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
+        vi = vs >= 0 ? m.x_vals[vs] : -1;
+    }
+    if (vi < 0) { m.sc[SC_OVERFLOW] = 5; return; }
+    m.v_voxel[id] = vi;
+    bool created;
+    const long long gs = h_find_or_insert(m.g_keys, m.g_mask, m.cand_cell[i], &created);
+    if (gs < 0) { m.sc[SC_OVERFLOW] = 6; return; }
+    m.g_vals[gs] = id;
+    const int pos = atomicAdd(&m.vx_npts[vi], 1);
+    if (pos >= MV_VOX_CAP) { m.sc[SC_OVERFLOW] = 7; atomicSub(&m.vx_npts[vi], 1); return; }
+    m.vx_pts[(size_t)vi * MV_VOX_CAP + pos] = id;
+    atomicAdd(&m.vx_new_added[vi], 1);
+    m.vx_meshing_times[vi] = 0;
+}
+
+// voxels to (re)mesh this scan: visited, m_meshing_times < 1, m_new_added_pts_count >= 0, >= 3 vertices
+// (ImMesh_mesh_reconstruction.cpp:132-151)
+__global__ void mesh_select_active_kernel(MeshDev m) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m.sc[SC_RECENT]) return;
+    const int vi = m.recent[r];
+    if (m.vx_meshing_times[vi] >= 1 || m.vx_new_added[vi] < 0) return;
+    m.vx_meshing_times[vi] = m.vx_meshing_times[vi] + 1;
+    m.vx_new_added[vi] = 0;
+    if (m.vx_npts[vi] < 3) return;
+    const int a = atomicAdd(&m.sc[SC_ACTIVE], 1);
+    if (a >= m.cap_active) { m.sc[SC_OVERFLOW] = 8; return; }
+    m.act_key[a] = m.vx_key[vi];
+    m.act_vox[a] = vi;
+}
+__global__ void mesh_rank_kernel(MeshDev m, int n_active) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_active) return;
+    const int vi = m.act_vox_s[r];
+    m.vx_rank[vi] = r;
+    m.vx_rank_seq[vi] = m.seq;
+}
+
+// =====================================================================================================================
+// LDS helpers
+// =====================================================================================================================
+template <typename T, int NT>
+IMD void lds_bitonic_sort(T* a, int N, int tid) {  // N power of two; ascending; every thread of the workgroup participates
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < N; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const bool up = ((i & k) == 0);
+                    const T x = a[i], y = a[ixj];
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+}
+IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+IMD int lds_bsearch_i32(const int* a, int n, int key) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = a[mid]; if (v == key) return mid; if (v < key) lo = mid + 1; else hi = mid - 1; }
+    return -1;
+}
+IMD int lds_bsearch_u32(const unsigned int* a, int n, unsigned int key) {
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) { const int mid = (lo + hi) >> 1; const unsigned int v = a[mid]; if (v == key) return mid; if (v < key) lo = mid + 1; else hi = mid - 1; }
+    return -1;
+}
+IMD unsigned long long wave_min_u64(unsigned long long x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_xor(x, off, 64); x = y < x ? y : x; }
+    return x;
+}
+IMD float wave_min_f(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fminf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+IMD float wave_max_f(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+IMD double wave_min_d(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmin(x, __shfl_xor(x, off, 64));
+    return x;
+}
+IMD double wave_max_d(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
+// =====================================================================================================================
+// 20-NN neighbourhood pull + smoothing: one workgroup (4 wavefronts) per active voxel
+// =====================================================================================================================
+#define KC 1000                 /* candidates staged per batch */
+#define WL (KC + MV_KNN + 4)    /* per-wave work list */
+#define HSET 4096
+
+__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
+    __shared__ float cx[KC], cy[KC], cz[KC];
+    __shared__ int cid[KC];
+    __shared__ unsigned long long best[MV_VOX_CAP][MV_KNN];
+    __shared__ unsigned long long wl[4][WL];
+    __shared__ int nbest[MV_VOX_CAP];
+    __shared__ float qx[MV_VOX_CAP], qy[MV_VOX_CAP], qz[MV_VOX_CAP];
+    __shared__ int qid[MV_VOX_CAP];
+    __shared__ int rel_l[MV_REL_CAP];
+    __shared__ int wsum[4];
+    __shared__ int s_misc[8];   // 0 ncand, 1 vend, 2 nrel, 3 any-needs-pass-2
+    __shared__ long s_box[6];
+
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int vi = m.act_vox_s[r];
+    const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
+    if (tid < nq) {
+        const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + tid];
+        qid[tid] = id;
+        qx[tid] = m.v_pos[(size_t)id * 3 + 0]; qy[tid] = m.v_pos[(size_t)id * 3 + 1]; qz[tid] = m.v_pos[(size_t)id * 3 + 2];
+        nbest[tid] = 0;
+    }
+    if (tid == 0) s_misc[3] = 0;
+    __syncthreads();
+    long long inspected = 0;
+    const double r_max = m.accept * 2.0;  // retrieve_neighbor_pts_kdtree only uses neighbours closer than 2 x accept
+    for (int pass = 0; pass < 2; pass++) {
+        // pass 0: radius r_max/2; when it already holds >= 20 neighbours they are the global 20 nearest.  pass 1 (rare): radius r_max.
+        const double rr = (pass == 0 ? r_max * 0.5 : r_max) * 1.001 + 1e-6;
+        if (pass == 1) {
+            if (tid < nq) { const bool need = nbest[tid] < MV_KNN; if (need) { nbest[tid] = 0; s_misc[3] = 1; } else nbest[tid] = nbest[tid] | 0x10000; }
+            __syncthreads();
+            if (!s_misc[3]) break;
+        }
+        if (wv == 0) {  // voxel-index box covering every query's ball (index of x is round(x/voxel): monotone)
+            float mnx = 3e38f, mny = 3e38f, mnz = 3e38f, mxx = -3e38f, mxy = -3e38f, mxz = -3e38f;
+            for (int q = lane; q < nq; q += 64) {
+                mnx = fminf(mnx, qx[q]); mny = fminf(mny, qy[q]); mnz = fminf(mnz, qz[q]);
+                mxx = fmaxf(mxx, qx[q]); mxy = fmaxf(mxy, qy[q]); mxz = fmaxf(mxz, qz[q]);
+            }
+            mnx = wave_min_f(mnx); mny = wave_min_f(mny); mnz = wave_min_f(mnz);
+            mxx = wave_max_f(mxx); mxy = wave_max_f(mxy); mxz = wave_max_f(mxz);
+            if (lane == 0) {
+                s_box[0] = (long)round(((double)mnx - rr) / m.voxel); s_box[1] = (long)round(((double)mxx + rr) / m.voxel);
+                s_box[2] = (long)round(((double)mny - rr) / m.voxel); s_box[3] = (long)round(((double)mxy + rr) / m.voxel);
+                s_box[4] = (long)round(((double)mnz - rr) / m.voxel); s_box[5] = (long)round(((double)mxz + rr) / m.voxel);
+            }
+        }
+        __syncthreads();
+        const long bx0 = s_box[0], by0 = s_box[2], bz0 = s_box[4];
+        const int ex = (int)(s_box[1] - bx0 + 1), ey = (int)(s_box[3] - by0 + 1), ez = (int)(s_box[5] - bz0 + 1);
+        const int nvox = ex * ey * ez;
+        int vstart = 0;
+        while (vstart < nvox) {
+            // ---- stage the next batch of voxels (<= 256 voxels, <= KC vertices) into LDS
+            int v2 = -1, n2 = 0;
+            const int vidx = vstart + tid;
+            if (vidx < nvox) {
+                const int iz = vidx % ez, iy = (vidx / ez) % ey, ix = vidx / (ez * ey);
+                const long long s = h_find(m.x_keys, m.x_mask, mkey(bx0 + ix, by0 + iy, bz0 + iz));
+                if (s >= 0) { v2 = m.x_vals[s]; if (v2 >= 0) n2 = min(m.vx_npts[v2], MV_VOX_CAP); }
+            }
+            int incl = n2;  // inclusive scan over the 256 threads
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+            if (lane == 63) wsum[wv] = incl;
+            if (tid == 0) { s_misc[0] = 0; s_misc[1] = min(vstart + 256, nvox); }
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wv; w++) woff += wsum[w];
+            incl += woff;
+            const int excl = incl - n2;
+            const bool fits = incl <= KC;
+            if (!fits && excl <= KC && vidx < nvox) s_misc[1] = vidx;  // first voxel that does not fit starts the next batch (unique writer)
+            if (fits && n2 > 0) {
+                for (int k = 0; k < n2; k++) {
+                    const int id = m.vx_pts[(size_t)v2 * MV_VOX_CAP + k];
+                    cx[excl + k] = m.v_pos[(size_t)id * 3 + 0]; cy[excl + k] = m.v_pos[(size_t)id * 3 + 1]; cz[excl + k] = m.v_pos[(size_t)id * 3 + 2];
+                    cid[excl + k] = id;
+                }
+                atomicMax(&s_misc[0], incl);
+            }
+            __syncthreads();
+            const int ncand = s_misc[0];
+            vstart = s_misc[1];
+            // ---- every query against the staged candidates: one wavefront per query
+            for (int q = wv; q < nq; q += 4) {
+                if (nbest[q] & 0x10000) continue;  // finished in pass 0
+                const float ax = qx[q], ay = qy[q], az = qz[q];
+                int nl = nbest[q];
+                for (int k = lane; k < nl; k += 64) wl[wv][k] = best[q][k];
+                for (int base = 0; base < ncand; base += 64) {
+                    const int c = base + lane;
+                    bool ok = false;
+                    unsigned long long key = 0;
+                    if (c < ncand) {
+                        const float d2 = dist2f(ax, ay, az, cx[c], cy[c], cz[c]);
+                        ok = (double)sqrtf(d2) < rr;
+                        key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)cid[c];
+                    }
+                    const unsigned long long mask = __ballot(ok);
+                    if (ok) wl[wv][nl + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                    nl += __popcll(mask);
+                }
+                inspected += (lane == 0) ? ncand : 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                // the MV_KNN smallest (d2, id) keys, ascending: repeated "smallest key above the previous one"
+                const int cnt = min(MV_KNN, nl);
+                unsigned long long prev = 0;
+                for (int k = 0; k < cnt; k++) {
+                    unsigned long long mine = ~0ull;
+                    for (int e = lane; e < nl; e += 64) {
+                        const unsigned long long v = wl[wv][e];
+                        if ((k == 0 || v > prev) && v < mine) mine = v;
+                    }
+                    prev = wave_min_u64(mine);
+                    if (lane == 0) best[q][k] = prev;
+                }
+                if (lane == 0) nbest[q] = cnt;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- smoothing (mean of the neighbours closer than 2 x accept, smooth_factor 1.0) and the neighbourhood union (closer than accept)
+    int* hset = (int*)&wl[0][0];
+    for (int k = tid; k < HSET; k += 256) hset[k] = -1;
+    if (tid == 0) s_misc[2] = 0;
+    __syncthreads();
+    for (int q = wv; q < nq; q += 4) {
+        const int nb = nbest[q] & 0xFFFF;
+        unsigned long long key = 0;
+        float nxp = 0, nyp = 0, nzp = 0;
+        bool in_acc = false, in_sm = false;
+        if (lane < nb) {
+            key = best[q][lane];
+            const int id = (int)(unsigned int)(key & 0xFFFFFFFFull);
+            const float d = sqrtf(__uint_as_float((unsigned int)(key >> 32)));
+            in_acc = (double)d < m.accept;
+            in_sm = (double)d < m.accept * 2.0;
+            nxp = m.v_pos[(size_t)id * 3 + 0]; nyp = m.v_pos[(size_t)id * 3 + 1]; nzp = m.v_pos[(size_t)id * 3 + 2];
+            if (in_acc) {
+                unsigned int h = ((unsigned int)id * 2654435761u) & (HSET - 1);
+                for (int probe = 0; probe < HSET; probe++) {
+                    const int old = atomicCAS(&hset[h], -1, id);
+                    if (old == -1 || old == id) break;
+                    h = (h + 1) & (HSET - 1);
+                }
+            }
+        }
+        double sx = 0, sy = 0, sz = 0;
+        int sc = 0;
+        for (int k = 0; k < nb; k++) {  // neighbour order = ascending (d2, id), as returned by the tree search
+            const int use = __shfl((int)in_sm, k, 64);
+            const float x = __shfl(nxp, k, 64), y = __shfl(nyp, k, 64), z = __shfl(nzp, k, 64);
+            if (use) { sc++; sx += (double)x; sy += (double)y; sz += (double)z; }
+        }
+        if (lane == 0 && sc > 0) {
+            const int id = qid[q];
+            m.v_smooth_new[(size_t)id * 3 + 0] = sx / (double)sc;
+            m.v_smooth_new[(size_t)id * 3 + 1] = sy / (double)sc;
+            m.v_smooth_new[(size_t)id * 3 + 2] = sz / (double)sc;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < HSET; k += 256) {
+        const int v = hset[k];
+        if (v >= 0) { const int pos = atomicAdd(&s_misc[2], 1); if (pos < MV_REL_CAP) rel_l[pos] = v; }
+    }
+    __syncthreads();
+    int nrel = s_misc[2];
+    if (nrel > MV_REL_CAP) { if (tid == 0) m.sc[SC_OVERFLOW] = 9; nrel = 0; }
+    const int np2 = next_pow2_i(max(nrel, 1));
+    for (int k = nrel + tid; k < np2; k += 256) rel_l[k] = 0x7FFFFFFF;
+    __syncthreads();
+    lds_bitonic_sort<int, 256>(rel_l, np2, tid);
+    for (int k = tid; k < nrel; k += 256) m.rel_ids[(size_t)r * MV_REL_CAP + k] = rel_l[k];
+    if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); }
+    if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
+}
+
+// =====================================================================================================================
+// per-voxel PCA -> 2-D Delaunay -> filter -> diff: one wavefront per active voxel
+// =====================================================================================================================
+#define DT_INF 0xFFFFu
+#define DT_CAV_CAP 256
+
+// CGAL Simple_cartesian<double> predicates as plain double expressions
+IMD double orient2d(const double* p, const double* q, const double* r) { return (q[0] - p[0]) * (r[1] - p[1]) - (r[0] - p[0]) * (q[1] - p[1]); }
+IMD double incircle2d(const double* p, const double* q, const double* r, const double* t) {
+    const double qpx = q[0] - p[0], qpy = q[1] - p[1], rpx = r[0] - p[0], rpy = r[1] - p[1], tpx = t[0] - p[0], tpy = t[1] - p[1];
+    return (qpx * tpy - qpy * tpx) * (rpx * (r[0] - q[0]) + rpy * (r[1] - q[1])) - (tpx * (t[0] - q[0]) + tpy * (t[1] - q[1])) * (qpx * rpy - qpy * rpx);
+}
+// does the circumdisk of the (possibly infinite) triangle contain p ?
+IMD bool dt_in_disk(const double* xy, unsigned v0, unsigned v1, unsigned v2, const double* p) {
+    int gi = -1;
+    if (v0 == DT_INF) gi = 0; else if (v1 == DT_INF) gi = 1; else if (v2 == DT_INF) gi = 2;
+    if (gi >= 0) {  // ghost: hull edge a->b seen from outside -> half-plane test; collinear: strictly between a and b
+        const unsigned a = gi == 0 ? v1 : (gi == 1 ? v2 : v0), b = gi == 0 ? v2 : (gi == 1 ? v0 : v1);
+        const double* A = xy + 2 * a; const double* B = xy + 2 * b;
+        const double o = orient2d(A, B, p);
+        if (o > 0) return true;
+        if (o < 0) return false;
+        const double d = (p[0] - A[0]) * (B[0] - A[0]) + (p[1] - A[1]) * (B[1] - A[1]);
+        const double l = (B[0] - A[0]) * (B[0] - A[0]) + (B[1] - A[1]) * (B[1] - A[1]);
+        return d > 0 && d < l;
+    }
+    return incircle2d(xy + 2 * v0, xy + 2 * v1, xy + 2 * v2, p) > 0;
+}
+
+// vertex position "after smoothing" as the sequential per-voxel loop would see it while meshing the voxel of rank my_rank:
+// vertices of voxels already meshed this scan (rank <= my_rank) carry this scan's value, the rest last scan's
+IMD void smooth_seen(const MeshDev& m, int vtx, int my_rank, double* out) {
+    const int w = m.v_voxel[vtx];
+    const bool fresh = (m.vx_rank_seq[w] == m.seq) && (m.vx_rank[w] <= my_rank);
+    const double* src = (fresh ? m.v_smooth_new : m.v_smooth) + (size_t)vtx * 3;
+    out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
+}
+// correct_triangle_index (mesh_rec_geometry.cpp:399-433): m_index_flip
+IMD int flip_of(const MeshDev& m, int a, int b, int c, int my_rank, const double* cam, const double* short_axis) {
+    double A[3], B[3], C[3];
+    smooth_seen(m, a, my_rank, A); smooth_seen(m, b, my_rank, B); smooth_seen(m, c, my_rank, C);
+    const double ab[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, ac[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    const double tc[3] = {cam[0] - A[0], cam[1] - A[1], cam[2] - A[2]};
+    double nrm[3];
+    cross3(ab, ac, nrm);
+    const double nn = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+    if (nn != 0) { nrm[0] /= nn; nrm[1] /= nn; nrm[2] /= nn; }
+    else { nrm[0] = 0; nrm[1] = 0; nrm[2] = 1; }
+    double sa[3] = {short_axis[0], short_axis[1], short_axis[2]};
+    if (sa[0] * tc[0] + sa[1] * tc[1] + sa[2] * tc[2] < 0) { sa[0] *= -1; sa[1] *= -1; sa[2] *= -1; }
+    return (sa[0] * nrm[0] + sa[1] * nrm[1] + sa[2] * nrm[2] < 0) ? 0 : 1;
+}
+
+IMD unsigned long long tri_hash3(int a, int b, int c) {
+    return hash64(((unsigned long long)(unsigned int)a * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(unsigned int)b << 21) ^ ((unsigned long long)(unsigned int)c << 42) ^ (unsigned long long)(unsigned int)c);
+}
+// m_triangle_hash: sorted triplet -> triangle index (created on first use; entries persist after erase)
+IMD int tri_find_or_insert(const MeshDev& m, int a, int b, int c, int* spare) {
+    unsigned long long h = tri_hash3(a, b, c) & m.th_mask;
+    for (int probe = 0; probe < 16384; probe++) {
+        int s = ld_agent(&m.th_slots[h]);
+        if (s < 0) {
+            if (*spare < 0) {
+                const int t = atomicAdd(&m.pc[PC_TRIS], 1);
+                if (t >= m.cap_tris) { m.sc[SC_OVERFLOW] = 10; return -1; }
+                *spare = t;
+            }
+            const int t = *spare;
+            st_agent(&m.t_v[(size_t)t * 3 + 0], a); st_agent(&m.t_v[(size_t)t * 3 + 1], b); st_agent(&m.t_v[(size_t)t * 3 + 2], c);
+            m.t_word[t] = 0; m.t_live[t] = 0; m.t_rem_seq[t] = 0; m.t_flip[t] = 0;
+            __threadfence();
+            const int prev = atomicCAS(&m.th_slots[h], -1, t);
+            if (prev == -1) { *spare = -1; return t; }
+            s = prev;
+        }
+        if (ld_agent(&m.t_v[(size_t)s * 3 + 0]) == a && ld_agent(&m.t_v[(size_t)s * 3 + 1]) == b && ld_agent(&m.t_v[(size_t)s * 3 + 2]) == c) return s;
+        h = (h + 1) & m.th_mask;
+    }
+    m.sc[SC_OVERFLOW] = 11;
+    return -1;
+}
+
+template <int CAP>
+__global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanParams sp, int n_lo, int n_hi) {
+    constexpr int TCAP = 2 * CAP + 8;
+    __shared__ int ids[CAP];
+    __shared__ float pf[CAP * 3];
+    __shared__ double xy[CAP * 2];
+    __shared__ unsigned long long keys[CAP];
+    __shared__ unsigned short tri[TCAP * 4];
+    __shared__ unsigned short cav[DT_CAV_CAP];
+    __shared__ unsigned short ea[DT_CAV_CAP * 3], eb[DT_CAV_CAP * 3];
+    __shared__ unsigned int fresh[TCAP];
+    __shared__ unsigned char fhit[TCAP];
+    __shared__ int s_cnt[2];
+
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int n = m.rel_n[r];
+    if (n < n_lo || n > n_hi) return;  // size class of the other instantiation
+    const int vi = m.act_vox_s[r];
+    for (int i = lane; i < n; i += 64) {
+        const int id = m.rel_ids[(size_t)r * MV_REL_CAP + i];
+        ids[i] = id;
+        pf[i * 3 + 0] = m.v_pos[(size_t)id * 3 + 0]; pf[i * 3 + 1] = m.v_pos[(size_t)id * 3 + 1]; pf[i * 3 + 2] = m.v_pos[(size_t)id * 3 + 2];
+    }
+    if (lane == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
+    __syncthreads();
+    int nf = 0;
+    if (n >= 3) {
+        // ---- centre and covariance: sequential sums in vertex order (bit-identical to the CPU path), one lane per component
+        double acc = 0;
+        if (lane < 3) { for (int i = 0; i < n; i++) acc += (double)pf[i * 3 + lane]; acc /= (double)n; }
+        const double c[3] = {__shfl(acc, 0, 64), __shfl(acc, 1, 64), __shfl(acc, 2, 64)};
+        double cv = 0;
+        if (lane < 6) {
+            const int a = lane < 3 ? 0 : (lane < 5 ? 1 : 2), b = lane < 3 ? lane : (lane < 5 ? lane - 2 : 2);
+            for (int i = 0; i < n; i++) cv += ((double)pf[i * 3 + a] - c[a]) * ((double)pf[i * 3 + b] - c[b]);
+            cv /= (double)n;
+        }
+        const double c00 = __shfl(cv, 0, 64), c01 = __shfl(cv, 1, 64), c02 = __shfl(cv, 2, 64), c11 = __shfl(cv, 3, 64), c12 = __shfl(cv, 4, 64), c22 = __shfl(cv, 5, 64);
+        const double cov[9] = {c00, c01, c02, c01, c11, c12, c02, c12, c22};
+        double ev[3], U[9];
+        sym3_eigen_jacobi(cov, ev, U);  // SelfAdjointEigenSolver::compute, mesh_rec_geometry.cpp:199-200 (eigenvalues ascending)
+        int o0 = 0, o1 = 1, o2 = 2;     // stable ascending order of three
+        if (ev[o1] < ev[o0]) { const int t = o0; o0 = o1; o1 = t; }
+        if (ev[o2] < ev[o1]) { const int t = o1; o1 = o2; o2 = t; if (ev[o1] < ev[o0]) { const int t2 = o0; o0 = o1; o1 = t2; } }
+        double sh[3] = {U[0 * 3 + o0], U[1 * 3 + o0], U[2 * 3 + o0]};
+        double mid[3] = {U[0 * 3 + o1], U[1 * 3 + o1], U[2 * 3 + o1]};
+        {
+            const double X0[3] = {(double)pf[0] - c[0], (double)pf[1] - c[1], (double)pf[2] - c[2]};
+            const double X1[3] = {(double)pf[3] - c[0], (double)pf[4] - c[1], (double)pf[5] - c[2]};
+            if (X0[0] * sh[0] + X0[1] * sh[1] + X0[2] * sh[2] < 0) { sh[0] *= -1; sh[1] *= -1; sh[2] *= -1; }          // :204-207
+            if (X1[0] * mid[0] + X1[1] * mid[1] + X1[2] * mid[2] < 0) { mid[0] *= -1; mid[1] *= -1; mid[2] *= -1; }    // :208-211
+        }
+        double lg[3];
+        cross3(sh, mid, lg);
+        if (lane == 0) { m.vx_short_axis[(size_t)vi * 3 + 0] = sh[0]; m.vx_short_axis[(size_t)vi * 3 + 1] = sh[1]; m.vx_short_axis[(size_t)vi * 3 + 2] = sh[2]; }
+        // ---- 2-D projection
+        double mn0 = 1e300, mn1 = 1e300, mx0 = -1e300, mx1 = -1e300;
+        for (int i = lane; i < n; i += 64) {
+            const double X[3] = {(double)pf[i * 3 + 0] - c[0], (double)pf[i * 3 + 1] - c[1], (double)pf[i * 3 + 2] - c[2]};
+            const double u = X[0] * lg[0] + X[1] * lg[1] + X[2] * lg[2];
+            const double v = X[0] * mid[0] + X[1] * mid[1] + X[2] * mid[2];
+            xy[2 * i] = u; xy[2 * i + 1] = v;
+            mn0 = fmin(mn0, u); mx0 = fmax(mx0, u); mn1 = fmin(mn1, v); mx1 = fmax(mx1, v);
+        }
+        mn0 = wave_min_d(mn0); mn1 = wave_min_d(mn1); mx0 = wave_max_d(mx0); mx1 = wave_max_d(mx1);
+        const double ext = fmax(mx0 - mn0, mx1 - mn1);
+        // ---- insertion order: Morton code over the bounding box, ties by index
+        const int np2 = next_pow2_i(n);
+        for (int i = lane; i < np2; i += 64) {
+            unsigned long long key = ~0ull;
+            if (i < n) {
+                const double f0 = ext > 0 ? (xy[2 * i] - mn0) / ext : 0, f1 = ext > 0 ? (xy[2 * i + 1] - mn1) / ext : 0;
+                const unsigned int q0 = (unsigned int)fmin(65535.0, fmax(0.0, f0 * 65535.0)), q1 = (unsigned int)fmin(65535.0, fmax(0.0, f1 * 65535.0));
+                unsigned int code = 0;
+#pragma unroll
+                for (int b = 0; b < 16; b++) code |= (((q0 >> b) & 1u) << (2 * b)) | (((q1 >> b) & 1u) << (2 * b + 1));
+                key = ((unsigned long long)code << 16) | (unsigned long long)i;
+            }
+            keys[i] = key;
+        }
+        __syncthreads();
+        lds_bitonic_sort<unsigned long long, 64>(keys, np2, lane);
+        // ---- first non-degenerate triangle
+        const int i0 = (int)(keys[0] & 0xFFFF);
+        int i1 = -1, i2 = -1;
+        for (int k = 1; k < n && i1 < 0; k++) { const int cc = (int)(keys[k] & 0xFFFF); if (xy[2 * cc] != xy[2 * i0] || xy[2 * cc + 1] != xy[2 * i0 + 1]) i1 = cc; }
+        if (i1 >= 0)
+            for (int k = 1; k < n && i2 < 0; k++) { const int cc = (int)(keys[k] & 0xFFFF); if (cc != i1 && orient2d(xy + 2 * i0, xy + 2 * i1, xy + 2 * cc) != 0) i2 = cc; }
+        int nt = 0;
+        if (i2 >= 0) {
+            if (orient2d(xy + 2 * i0, xy + 2 * i1, xy + 2 * i2) < 0) { const int t = i1; i1 = i2; i2 = t; }
+            if (lane == 0) {
+                const unsigned short init[16] = {(unsigned short)i0, (unsigned short)i1, (unsigned short)i2, 0, (unsigned short)i2, (unsigned short)i1, DT_INF, 0,
+                                                 (unsigned short)i0, (unsigned short)i2, DT_INF, 0, (unsigned short)i1, (unsigned short)i0, DT_INF, 0};
+                for (int k = 0; k < 16; k++) tri[k] = init[k];
+            }
+            nt = 4;
+            __syncthreads();
+            bool fail = false;
+            for (int oi = 0; oi < n && !fail; oi++) {
+                const int pi = (int)(keys[oi] & 0xFFFF);
+                if (pi == i0 || pi == i1 || pi == i2) continue;
+                const double p[2] = {xy[2 * pi], xy[2 * pi + 1]};
+                // cavity: every triangle whose circumdisk contains p
+                int ncav = 0;
+                for (int base = 0; base < nt; base += 64) {
+                    const int t = base + lane;
+                    bool in = false;
+                    if (t < nt) in = dt_in_disk(xy, tri[t * 4 + 0], tri[t * 4 + 1], tri[t * 4 + 2], p);
+                    const unsigned long long mask = __ballot(in);
+                    if (in) { const int pos = ncav + __popcll(mask & ((1ull << lane) - 1ull)); if (pos < DT_CAV_CAP) cav[pos] = (unsigned short)t; }
+                    ncav += __popcll(mask);
+                }
+                if (ncav == 0) continue;  // duplicate / on every circle: not inserted
+                if (ncav > DT_CAV_CAP) { fail = true; break; }
+                __syncthreads();
+                const int ne = 3 * ncav;
+                for (int e = lane; e < ne; e += 64) {
+                    const int cc = cav[e / 3], k = e % 3;
+                    ea[e] = tri[cc * 4 + (k + 1) % 3]; eb[e] = tri[cc * 4 + (k + 2) % 3];
+                }
+                __syncthreads();
+                // boundary edges (twin not in the cavity) -> fan of new triangles (a, b, p), reusing the cavity slots first
+                int nb = 0;
+                for (int base = 0; base < ne; base += 64) {
+                    const int e = base + lane;
+                    bool bd = false;
+                    unsigned short a = 0, b = 0;
+                    if (e < ne) {
+                        a = ea[e]; b = eb[e]; bd = true;
+                        for (int f = 0; f < ne; f++) if (ea[f] == b && eb[f] == a) { bd = false; break; }
+                    }
+                    const unsigned long long mask = __ballot(bd);
+                    if (bd) {
+                        const int j = nb + __popcll(mask & ((1ull << lane) - 1ull));
+                        const int slot = j < ncav ? (int)cav[j] : nt + (j - ncav);
+                        if (slot < TCAP) { tri[slot * 4 + 0] = a; tri[slot * 4 + 1] = b; tri[slot * 4 + 2] = (unsigned short)pi; }
+                    }
+                    nb += __popcll(mask);
+                }
+                if (nb >= ncav) { nt += nb - ncav; if (nt > TCAP) { fail = true; break; } }
+                else {  // inconsistent predicates left fewer new triangles than holes: close the holes from the back
+                    __syncthreads();
+                    if (lane == 0)
+                        for (int j = ncav - 1; j >= nb; j--) {
+                            const int slot = cav[j], last = nt - 1;
+                            if (slot != last) { tri[slot * 4 + 0] = tri[last * 4 + 0]; tri[slot * 4 + 1] = tri[last * 4 + 1]; tri[slot * 4 + 2] = tri[last * 4 + 2]; }
+                            nt--;
+                        }
+                    nt = __shfl(nt, 0, 64);
+                }
+                __syncthreads();
+            }
+            if (fail) { if (lane == 0) m.sc[SC_OVERFLOW] = 12; nt = 0; }
+        }
+        // ---- finite faces that pass the skinny-face filter (is_face_is_ok: every interior angle * 57.3 <= 150) as sorted local triplets
+        for (int base = 0; base < nt; base += 64) {
+            const int t = base + lane;
+            bool ok = false;
+            unsigned int packed = 0;
+            if (t < nt) {
+                const unsigned a = tri[t * 4 + 0], b = tri[t * 4 + 1], cc = tri[t * 4 + 2];
+                if (a != DT_INF && b != DT_INF && cc != DT_INF) {
+                    const double* A = xy + 2 * a; const double* B = xy + 2 * b; const double* C = xy + 2 * cc;
+                    auto angle = [](const double* P, const double* Q, const double* R) {  // compute_angle at P
+                        const double abx = Q[0] - P[0], aby = Q[1] - P[1], acx = R[0] - P[0], acy = R[1] - P[1];
+                        return acos((abx * acx + aby * acy) / (sqrt(abx * abx + aby * aby) * sqrt(acx * acx + acy * acy))) * 57.3;
+                    };
+                    ok = !(angle(A, B, C) > 150) && !(angle(B, A, C) > 150) && !(angle(C, A, B) > 150);
+                    unsigned l0 = a, l1 = b, l2 = cc;  // local index order == vertex id order (ids ascending)
+                    if (l0 > l1) { const unsigned x = l0; l0 = l1; l1 = x; }
+                    if (l1 > l2) { const unsigned x = l1; l1 = l2; l2 = x; }
+                    if (l0 > l1) { const unsigned x = l0; l0 = l1; l1 = x; }
+                    packed = (l0 << 20) | (l1 << 10) | l2;
+                }
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (ok) fresh[nf + __popcll(mask & ((1ull << lane) - 1ull))] = packed;
+            nf += __popcll(mask);
+        }
+        const int nfp = next_pow2_i(max(nf, 1));
+        for (int k = nf + lane; k < nfp; k += 64) fresh[k] = 0xFFFFFFFFu;
+        for (int k = lane; k < nf; k += 64) fhit[k] = 0;
+        __syncthreads();
+        lds_bitonic_sort<unsigned int, 64>(fresh, nfp, lane);
+    }
+    __syncthreads();
+    // ---- old = live triangles with all three vertices in the neighbourhood (find_relative_triangulation_combination), via the
+    //      min-vertex lists; old \ fresh -> remove, old & fresh -> existing (flip rewritten), fresh \ old -> add
+    const double* sa = m.vx_short_axis + (size_t)vi * 3;
+    const double short_axis[3] = {sa[0], sa[1], sa[2]};
+    int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
+    const unsigned long long wbase = ((unsigned long long)(unsigned int)m.seq << 32) | ((unsigned long long)(unsigned int)r << 1);
+    for (int i = lane; i < n; i += 64) {
+        const int id = ids[i];
+        for (int ch = m.a_head[id]; ch >= 0; ch = m.a_chunks[(size_t)ch * 8 + 7])
+            for (int s = 0; s < MV_ADJ_SLOTS; s++) {
+                const int t = m.a_chunks[(size_t)ch * 8 + s];
+                if (t < 0) continue;
+                const int v1 = m.t_v[(size_t)t * 3 + 1], v2 = m.t_v[(size_t)t * 3 + 2];
+                const int l1 = lds_bsearch_i32(ids, n, v1), l2 = lds_bsearch_i32(ids, n, v2);
+                if (l1 < 0 || l2 < 0) continue;
+                const int pos = lds_bsearch_u32(fresh, nf, ((unsigned int)i << 20) | ((unsigned int)l1 << 10) | (unsigned int)l2);
+                if (pos >= 0) {
+                    fhit[pos] = 1;
+                    const int fl = flip_of(m, id, v1, v2, r, sp.cam, short_axis);
+                    atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
+                    touched[atomicAdd(&s_cnt[0], 1)] = t;
+                } else if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) {
+                    list_push(m, m.list_rem, SC_REM, t);
+                }
+            }
+    }
+    __syncthreads();
+    int spare = -1;
+    for (int k = lane; k < nf; k += 64) {
+        if (fhit[k]) continue;
+        const unsigned int pk = fresh[k];
+        const int a = ids[pk >> 20], b = ids[(pk >> 10) & 1023], c = ids[pk & 1023];
+        const int t = tri_find_or_insert(m, a, b, c, &spare);
+        if (t < 0) continue;
+        const int fl = flip_of(m, a, b, c, r, sp.cam, short_axis);
+        atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
+        touched[atomicAdd(&s_cnt[0], 1)] = (int)((unsigned int)t | TRI_ADD_BIT);
+    }
+    __syncthreads();
+    if (lane == 0) { m.vox_ntris[r] = s_cnt[0]; atomicAdd(&m.sc[SC_TV], nf); }
+}
+
+// cross-voxel resolution: the voxel with the highest rank that touched a triangle owns its flip (later voxel wins, as the
+// sequential loop); it also queues the triangle for insertion / reports a changed flip.  Then this scan's smoothed positions commit.
+__global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const int vi = m.act_vox_s[r];
+    const int nt = m.vox_ntris[r];
+    const int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
+    for (int k = lane; k < nt; k += 64) {
+        const unsigned int e = (unsigned int)touched[k];
+        const int t = (int)(e & 0x7FFFFFFFu);
+        const unsigned long long w = m.t_word[t];
+        if ((unsigned int)(w >> 32) != (unsigned int)m.seq || (int)((w >> 1) & 0x7FFFFFFFull) != r) continue;
+        const int8_t fl = (int8_t)(w & 1ull);
+        if (e & TRI_ADD_BIT) { m.t_flip[t] = fl; list_push(m, m.list_add, SC_ADD, t); }
+        else if (m.t_flip[t] != fl) { m.t_flip[t] = fl; list_push(m, m.list_upd, SC_UPD, t); }
+    }
+    const int np = min(m.vx_npts[vi], MV_VOX_CAP);
+    for (int k = lane; k < np; k += 64) {
+        const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + k];
+        m.v_smooth[(size_t)id * 3 + 0] = m.v_smooth_new[(size_t)id * 3 + 0];
+        m.v_smooth[(size_t)id * 3 + 1] = m.v_smooth_new[(size_t)id * 3 + 1];
+        m.v_smooth[(size_t)id * 3 + 2] = m.v_smooth_new[(size_t)id * 3 + 2];
+        list_push(m, m.list_smooth, SC_SMOOTH, id);
+    }
+}
+
+// sort keys of a triangle list: which 0 -> third vertex (32-bit), 1 -> (first, second) vertex (64-bit)
+__global__ void mesh_tri_keys_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int which, uint32_t* __restrict__ k32, unsigned long long* __restrict__ k64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tris[i];
+    if (which == 0) k32[i] = (uint32_t)m.t_v[(size_t)t * 3 + 2];
+    else k64[i] = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
+}
+__global__ void mesh_emit_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int32_t* __restrict__ out_tri, uint8_t* __restrict__ out_flip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tris[i];
+    out_tri[(size_t)i * 3 + 0] = m.t_v[(size_t)t * 3 + 0]; out_tri[(size_t)i * 3 + 1] = m.t_v[(size_t)t * 3 + 1]; out_tri[(size_t)i * 3 + 2] = m.t_v[(size_t)t * 3 + 2];
+    if (out_flip) out_flip[i] = (uint8_t)m.t_flip[t];
+}
+// Triangle_manager::remove_triangle_list (triangle.hpp:212-221): drop from the live set and from its smallest vertex's list
+__global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tris, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tris[i];
+    m.t_live[t] = 0;
+    const int v0 = m.t_v[(size_t)t * 3 + 0];
+    for (int ch = m.a_head[v0]; ch >= 0; ch = m.a_chunks[(size_t)ch * 8 + 7])
+        for (int s = 0; s < MV_ADJ_SLOTS; s++)
+            if (m.a_chunks[(size_t)ch * 8 + s] == t) { m.a_chunks[(size_t)ch * 8 + s] = -1; return; }
+}
+// Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
+// vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
+__global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tris, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v0 = m.t_v[(size_t)tris[i] * 3 + 0];
+    if (i > 0 && m.t_v[(size_t)tris[i - 1] * 3 + 0] == v0) return;
+    int ch = m.a_head[v0], s = 0;
+    for (int j = i; j < n; j++) {
+        const int t = tris[j];
+        if (m.t_v[(size_t)t * 3 + 0] != v0) break;
+        m.t_live[t] = 1;
+        bool placed = false;
+        while (ch >= 0 && !placed) {
+            for (; s < MV_ADJ_SLOTS; s++)
+                if (m.a_chunks[(size_t)ch * 8 + s] < 0) { m.a_chunks[(size_t)ch * 8 + s] = t; placed = true; s++; break; }
+            if (!placed) { ch = m.a_chunks[(size_t)ch * 8 + 7]; s = 0; }
+        }
+        if (!placed) {  // every chunk of the chain is full: push a new chunk at the front
+            const int nc = atomicAdd(&m.pc[PC_ADJ_CHUNKS], 1);
+            if (nc >= m.cap_adj_chunks) { m.sc[SC_OVERFLOW] = 13; return; }
+            m.a_chunks[(size_t)nc * 8 + 0] = t;
+            for (int k = 1; k < MV_ADJ_SLOTS; k++) m.a_chunks[(size_t)nc * 8 + k] = -1;
+            m.a_chunks[(size_t)nc * 8 + 7] = m.a_head[v0];
+            m.a_head[v0] = nc;
+            ch = nc; s = 1;
+        }
+    }
+}
+__global__ void mesh_emit_smooth_kernel(MeshDev m, const int32_t* __restrict__ ids, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int id = ids[i];
+    m.out_smooth_ids[i] = id;
+    m.out_smooth_xyz[(size_t)i * 3 + 0] = m.v_smooth[(size_t)id * 3 + 0];
+    m.out_smooth_xyz[(size_t)i * 3 + 1] = m.v_smooth[(size_t)id * 3 + 1];
+    m.out_smooth_xyz[(size_t)i * 3 + 2] = m.v_smooth[(size_t)id * 3 + 2];
+}
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+static inline dim3 g1(int n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
+                           const double* extT) {
+    XformParams xp;
+    for (int i = 0; i < 9; i++) { xp.R[i] = R[i]; xp.extR[i] = extR[i]; }
+    for (int i = 0; i < 3; i++) { xp.t[i] = t[i]; xp.extT[i] = extT[i]; }
+    KLAUNCH(mesh_transform_kernel, g1(n), dim3(256), 0, s, (const float4*)raw_xyzi, (float4*)world_xyzi, n, xp);
+}
+void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
+    KLAUNCH(mesh_append_prepare_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+}
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
+    KLAUNCH(mesh_append_resolve_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+}
+void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
+    KLAUNCH(mesh_append_commit_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+}
+void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n) { KLAUNCH(mesh_append_flags_kernel, g1(n), dim3(256), 0, s, m, n); }
+void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
+void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_rank_kernel, g1(n_active), dim3(256), 0, s, m, n_active); }
+void launch_mesh_knn(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_knn_kernel, dim3(n_active), dim3(256), 0, s, m); }
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, int n_active) {
+    KLAUNCH(mesh_delaunay_kernel<256>, dim3(n_active), dim3(64), 0, s, m, sp, 0, 256);
+    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(n_active), dim3(64), 0, s, m, sp, 257, MV_REL_CAP);
+}
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_finalize_kernel, dim3(n_active), dim3(64), 0, s, m); }
+void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64) {
+    KLAUNCH(mesh_tri_keys_kernel, g1(n), dim3(256), 0, s, m, tris, n, which, k32, k64);
+}
+void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip) {
+    KLAUNCH(mesh_emit_kernel, g1(n), dim3(256), 0, s, m, tris, n, out_tri, out_flip);
+}
+void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris, int n) { KLAUNCH(mesh_commit_rem_kernel, g1(n), dim3(256), 0, s, m, tris, n); }
+void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n) {
+    KLAUNCH(mesh_commit_add_kernel, g1(n), dim3(256), 0, s, m, tris_sorted, n);
+}
+void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n) {
+    KLAUNCH(mesh_emit_smooth_kernel, g1(n), dim3(256), 0, s, m, ids_sorted, n);
+}
+void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n) { KLAUNCH(fill_i32_kernel, dim3(1024), dim3(256), 0, s, p, v, n); }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include "../../include/immesh_c_api.h"
 
 #define MV_VOX_CAP 128      /* vertices per mesh voxel: ((int)(voxel/min_spacing)+1)^3 = 125 for every shipped config */
 #define MV_KNN 20           /* neighbours pulled per vertex, mesh_rec_geometry.cpp:350 */
@@ -76,6 +77,10 @@ struct MeshHost {
     int32_t *p_a = nullptr, *p_b = nullptr, *p_c = nullptr;
     int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters
     int32_t* h_pc = nullptr;
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    int32_t n_vertices = 0;
+    int64_t n_live = 0;
     bool ready = false;
 };
 
@@ -84,6 +89,7 @@ void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xy
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
+void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active);
 void launch_mesh_knn(hipStream_t s, const MeshDev& m, int n_active);

@@ -105,7 +105,7 @@ typedef struct immesh_mesh_sizes_t {
     int32_t n_new_vtx;  /* vertices appended (ids vtx_base .. vtx_base+n_new_vtx-1) */
     int32_t n_add;      /* triangles inserted   (Triangle_manager::insert_triangle, triangle.hpp:330) */
     int32_t n_rem;      /* triangles erased     (remove_triangle_list, triangle.hpp:212) */
-    int32_t n_upd;      /* surviving triangles whose m_index_flip was rewritten (correct_triangle_index) */
+    int32_t n_upd;      /* existing triangles whose m_index_flip was rewritten to a different value (correct_triangle_index) */
     int32_t n_smooth;   /* vertices whose smoothed position changed (RGB_pts::set_smooth_pos) */
     int32_t n_voxels_meshed;
     int32_t reserved;

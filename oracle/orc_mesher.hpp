@@ -37,7 +37,7 @@ struct MeshVoxel {                                       // RGB_Voxel, pointclou
 struct MeshScanOut {
     int vtx_base = 0;
     std::vector<float> new_vtx;         // xyz per new vertex (ids vtx_base, vtx_base+1, ...)
-    std::vector<int> tri_add, tri_rem, tri_upd;  // sorted triplets, lexicographically sorted, deduped
+    std::vector<int> tri_add, tri_rem, tri_upd;  // sorted triplets, lexicographically sorted, deduped; tri_upd = surviving triangles whose flip CHANGED
     std::vector<uint8_t> flip_add, flip_upd;
     std::vector<int> smooth_ids;        // vertices whose smoothed position was (re)set this scan (ascending)
     std::vector<double> smooth_xyz;
@@ -206,7 +206,7 @@ struct Mesher {
         });
         const double accept = cfg.mesh_voxel * 1.25;  // g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343
         std::set<Tri> all_rem;
-        std::map<Tri, int> all_add, all_upd;
+        std::map<Tri, int> all_add, all_upd, upd_orig;
         std::map<int, std::array<double, 3>> smoothed;
         std::vector<NN> nn;
         for (int vi : recent) {
@@ -256,7 +256,10 @@ struct Mesher {
             for (const Tri& t : old) if (!fresh.count(t)) all_rem.insert(t);
             for (const Tri& t : fresh) {
                 const int fl = flip_of(t, sensor_pos, vox.short_axis);
-                if (old.count(t)) { all_upd[t] = fl; tri_flip[t] = fl; }  // existing: flip rewritten in place (:203-205)
+                if (old.count(t)) {  // existing: flip rewritten in place (:203-205); reported only when the scan changes it
+                    if (!upd_orig.count(t)) upd_orig[t] = tri_flip[t];
+                    all_upd[t] = fl; tri_flip[t] = fl;
+                }
                 else all_add[t] = fl;                                     // later voxel (ascending key order) wins on duplicates
             }
         }
@@ -273,6 +276,7 @@ struct Mesher {
             out.flip_add.push_back((uint8_t)kv.second);
         }
         for (const auto& kv : all_upd) {
+            if (kv.second == upd_orig[kv.first]) continue;
             out.tri_upd.insert(out.tri_upd.end(), kv.first.begin(), kv.first.end());
             out.flip_upd.push_back((uint8_t)kv.second);
         }

@@ -1,0 +1,140 @@
+"""GPU parity tests proper (rows a17-a26): the HIP mesher through the C ABI vs the CPU oracle on identical seeded inputs.
+Bar (BASELINE.json north_star): vertex ids / triangle triplets bit-exact; smoothed positions within 1e-9 (f64 means of
+exactly representable values; the sum order is the same on both sides)."""
+import numpy as np
+import pytest
+
+from immesh_amd import capi, synth
+from conftest import make_oracle, make_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _world_scan(k, n, cfg):
+    """scan k transformed to the world frame with the true pose (what map_incremental_grow hands to the mesher)."""
+    R, t = synth.trajectory_pose(k)
+    extT = np.array(list(cfg.extT))
+    raw = synth.livox_scan(k, R, t, n_pts=n, extT=extT)
+    pw = (raw[:, :3].astype(np.float64) + extT) @ R.T + t
+    out = raw.copy()
+    out[:, :3] = pw.astype(np.float32)
+    return np.ascontiguousarray(out), t
+
+
+def _compare_scan(mo, mh, tag=""):
+    assert mh["vtx_base"] == mo["vtx_base"], tag
+    np.testing.assert_array_equal(mh["new_vtx"], mo["new_vtx"], err_msg=f"{tag} new vertices")
+    assert mh["n_voxels_meshed"] == mo["n_voxels_meshed"], tag
+    np.testing.assert_array_equal(mh["tri_rem"], mo["tri_rem"], err_msg=f"{tag} tri_rem")
+    np.testing.assert_array_equal(mh["tri_add"], mo["tri_add"], err_msg=f"{tag} tri_add")
+    np.testing.assert_array_equal(mh["flip_add"], mo["flip_add"], err_msg=f"{tag} flip_add")
+    np.testing.assert_array_equal(mh["tri_upd"], mo["tri_upd"], err_msg=f"{tag} tri_upd")
+    np.testing.assert_array_equal(mh["flip_upd"], mo["flip_upd"], err_msg=f"{tag} flip_upd")
+    np.testing.assert_array_equal(mh["smooth_ids"], mo["smooth_ids"], err_msg=f"{tag} smooth ids")
+    np.testing.assert_allclose(mh["smooth_xyz"], mo["smooth_xyz"], rtol=0, atol=1e-9, err_msg=f"{tag} smooth xyz")
+
+
+def test_mesh_stream_parity(oracle_lib, hip_lib):
+    """8 overlapping scans: append (ids), 20-NN union, Delaunay, diff, flips -- every result list must be identical."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    tot_add = tot_rem = 0
+    for k in range(8):
+        pts, cam = _world_scan(k, 40000, cfg)
+        mo = o.mesh_scan(pts, cam, frame_idx=k)
+        mh = h.mesh_scan(pts, cam, frame_idx=k)
+        _compare_scan(mo, mh, f"scan {k}")
+        tot_add += len(mo["tri_add"]); tot_rem += len(mo["tri_rem"])
+    assert tot_add > 10000 and tot_rem > 1000
+    co, ch = o.counters(), h.counters()
+    for key in ("n_app", "n_new", "v_act", "n_v", "n_u", "t_v", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
+        assert ch[key] == co[key], key
+
+
+def test_mesh_dense_repeat(oracle_lib, hip_lib):
+    """The same area scanned repeatedly until the min-spacing grid saturates: voxels with many vertices, large
+    neighbourhoods, heavy remove/re-add traffic; budget 5000 -> step 4."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20, mesh_append_budget=5000)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    rng = np.random.default_rng(5)
+    cam = np.array([0.0, 0.0, 1.5])
+    for k in range(10):
+        n = 20000
+        # a 6 m x 6 m floor patch with a 1.5 m step and a wall: edges where the PCA plane is ambiguous
+        x = rng.uniform(2, 8, n); y = rng.uniform(-3, 3, n)
+        z = np.where(x > 5, 0.0, 0.0) + rng.normal(0, 0.01, n)
+        wall = rng.random(n) < 0.3
+        x[wall] = 8.0 + rng.normal(0, 0.01, wall.sum()); z[wall] = rng.uniform(0, 2.5, wall.sum())
+        pts = np.stack([x, y, z, np.ones(n)], axis=1).astype(np.float32)
+        mo = o.mesh_scan(pts, cam, frame_idx=k)
+        mh = h.mesh_scan(pts, cam, frame_idx=k)
+        _compare_scan(mo, mh, f"scan {k}")
+    assert o.counters()["n_u"] / max(1, o.counters()["v_act"]) > 40     # neighbourhoods really are large
+
+
+def test_mesh_kitti_scale(oracle_lib, hip_lib):
+    """velodyne.yaml meshing constants (distance_scale 1.5: 0.15 m spacing, 0.6 m voxels), HDL-64-shaped scans."""
+    cfg = capi.velodyne_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    for k in range(3):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.hdl64_scan(k, R, t, n_az=512)
+        pw = raw[:, :3].astype(np.float64) @ R.T + t
+        pts = raw.copy(); pts[:, :3] = pw.astype(np.float32)
+        pts = np.ascontiguousarray(pts)
+        mo = o.mesh_scan(pts, t, frame_idx=k)
+        mh = h.mesh_scan(pts, t, frame_idx=k)
+        _compare_scan(mo, mh, f"scan {k}")
+
+
+def test_mesh_edge_cases(oracle_lib, hip_lib):
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000, cap_vertices=1 << 16, cap_triangles=1 << 18)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    cam = np.zeros(3)
+    # fewer than 3 points, duplicates, negative coordinates / exact cell boundaries (std::round half away from zero)
+    tiny = np.array([[0.05, 0.05, 0.0, 1], [-0.05, -0.05, 0.0, 1], [0.05, 0.05, 0.0, 1]], np.float32)
+    _compare_scan(o.mesh_scan(tiny, cam), h.mesh_scan(tiny, cam), "tiny")
+    rng = np.random.default_rng(9)
+    g = np.stack(np.meshgrid(np.arange(-10, 10) * 0.15, np.arange(-10, 10) * 0.15, indexing="ij"), axis=-1).reshape(-1, 2)
+    pts = np.concatenate([g + rng.normal(0, 0.003, g.shape), rng.normal(0, 0.002, (len(g), 1)), np.ones((len(g), 1))], axis=1).astype(np.float32)
+    _compare_scan(o.mesh_scan(pts, cam), h.mesh_scan(pts, cam), "grid")
+    # a scan that adds nothing: voxels are visited but nothing is re-meshed
+    _compare_scan(o.mesh_scan(pts, cam), h.mesh_scan(pts, cam), "repeat")
+    with pytest.raises(RuntimeError):
+        h.mesh_scan(pts, cam, n=0)
+
+
+def test_process_scan_full_pipeline(oracle_lib, hip_lib):
+    """immesh_process_scan = lio_state_estimation + map_incremental_grow + incremental_mesh_reconstruction on device-resident inputs."""
+    torch = pytest.importorskip("torch")
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    R0, t0 = synth.trajectory_pose(0)
+    raw0 = synth.livox_scan(0, R0, t0, n_pts=30000, extT=extT)
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st); h.map_build(p0, st)
+    so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    exact = True
+    for k in range(1, 5):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, Rk, tk, n_pts=30000, extT=extT)
+        down = synth.voxel_grid_downsample(raw, 0.4)
+        po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
+        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=True)
+        d_down = torch.from_numpy(down).cuda(); d_raw = torch.from_numpy(raw).cuda()     # device-resident inputs are used in place
+        sh, ih = h.process_scan(d_down.data_ptr(), d_raw.data_ptr(), ph, ph, frame_idx=k, do_mesh=True, n_ds=len(down), n_raw=len(raw))
+        assert ih == io
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=1e-5)
+        mo, mh = o.mesh_fetch(), h.mesh_fetch()
+        # the world-frame full scan is f32-rounded from an f64 transform with a pose that agrees to ~1e-12: identical floats except at
+        # rounding boundaries, so compare structure exactly only when the vertex sets agree
+        exact = exact and np.array_equal(mh["new_vtx"], mo["new_vtx"])
+        if exact:
+            _compare_scan(mo, mh, f"scan {k}")
+        else:
+            assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50
+        tm = h.last_timing()
+        assert tm["total"] > 0 and tm["mesh"] > 0
