@@ -23,6 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from immesh_amd import capi, synth  # noqa: E402
+from immesh_amd import dist as D  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -100,7 +101,9 @@ def make_scans(n_scans, n_pts, cfg, cache_dir):
         else:
             R, t = synth.trajectory_pose(k)
             raw = synth.livox_scan(k, R, t, n_pts=n_pts, extT=extT)
-            np.save(f, raw)
+            tmp = f + f".{os.getpid()}.tmp.npy"     # ranks generate the same scans concurrently: publish atomically
+            np.save(tmp, raw)
+            os.replace(tmp, f)
         raws.append(raw)
         downs.append(synth.voxel_grid_downsample(raw, 0.4))
     return raws, downs
@@ -138,15 +141,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dist = D.init("nccl", dev) if world > 1 else None
 
     hip = capi.load_hip_library()
     side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0     # ~8.8 root voxels per m^2 of this world (ground + walls)
@@ -156,13 +156,15 @@ def main():
     n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
 
     n_total = args.warmup + args.steps + args.profile_scans
-    raws, downs = make_scans(n_total + 1, args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"))
+    raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"))
+    idx = D.stream_of_rank(rank, n_total)       # replicas-only multi-GPU: rank r replays the stream phase-shifted by r scans
+    raws, downs = [raws[i] for i in idx], [downs[i] for i in idx]
     d_raw = [torch.from_numpy(r).to(dev) for r in raws]
     d_down = [torch.from_numpy(d).to(dev) for d in downs]
     n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))
 
     # scan 0 seeds the stream state; constant-velocity prior (Forward_without_imu) between scans
-    R0, t0 = synth.trajectory_pose(0)
+    R0, t0 = synth.trajectory_pose(idx[0])
     st = capi.make_state(R=R0, t=t0)
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
     if args.mesh:
@@ -181,24 +183,18 @@ def main():
     h.counters(reset=True)
     stage = np.zeros(4)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         st, info = run(k, st); k += 1
         tm = h.last_timing()
         stage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_begin
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()
     cnt["_n_ds_mean"] = n_ds_mean
-    pose_err = float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))
+    pose_err = float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1]))
 
     # ---- roofline leg: per-kernel HIP-event timing (events recorded on the library's own stream) over extra scans
     roofline = None
@@ -257,10 +253,9 @@ def main():
                "ms_per_scan": round(1e3 * tc / nc, 3)}
 
     if rank == 0:
-        total_scans = args.steps * world
         out = {
             "metric": "scans/sec (reg+mesh), 100k-pt scan into 10M-voxel map" if args.mesh else "scans/sec (registration + map update, meshing off), 100k-pt scan into 10M-voxel map",
-            "value": round(total_scans / elapsed, 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(D.aggregate_throughput(args.steps, world, elapsed), 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("synthetic Livox-Avia 100k-pt/scan stream, full pipeline (registration + map update + voxel meshing)" if args.mesh else

@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the product library loads and exports every symbol include/immesh_c_api.h declares,
+struct layouts of the ctypes binding match the header, and a context cannot be created without a HIP device (no CPU fallback).
+No compute calls are made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from immesh_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "immesh_c_api.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(immesh_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    fns = _declared_functions()
+    for must in ("immesh_create", "immesh_destroy", "immesh_map_build", "immesh_register", "immesh_residuals", "immesh_map_update",
+                 "immesh_mesh_scan", "immesh_mesh_sizes", "immesh_mesh_fetch", "immesh_process_scan", "immesh_dump_planes", "immesh_counters"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(capi.hip_library_path()):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "immesh_amd", "csrc"), "-j8"])
+    lib = capi.load_hip_library()
+    missing = [f for f in _declared_functions() if not hasattr(lib, f)]
+    assert not missing, missing
+
+
+def test_oracle_mirrors_the_boundary(oracle_lib):
+    """The checker exports the same entry points under the orc_ prefix (so parity tests drive both with identical calls)."""
+    for f in _declared_functions():
+        if f in ("immesh_default_config", "immesh_create_error", "immesh_last_error", "immesh_profile_enable", "immesh_profile_read"):
+            continue
+        assert hasattr(oracle_lib, f.replace("immesh_", "orc_", 1)), f
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(capi.PlaneRec) == 8 * 3 + 4 * 6 + 4 * 4 + 8 * 3 + 8 * 3 + 8 * 36
+    assert C.sizeof(capi.MeshSizes) == 32
+    assert C.sizeof(capi.Counters) == 8 * len(capi.COUNTER_FIELDS)
+    assert C.sizeof(capi.KernelStat) == 72
+    # immesh_config: field order / padding as the C compiler lays it out
+    src = open(HEADER).read()
+    body = src[src.index("typedef struct immesh_config {"):src.index("} immesh_config;")]
+    names = re.findall(r"\b(?:double|int32_t|int64_t)\s+([A-Za-z_]+)(?:\[\d+\])?;", body)
+    assert names == [n for n, _ in capi.Config._fields_]
+
+
+def test_no_cpu_fallback_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    lib = capi.load_hip_library()
+    with pytest.raises(RuntimeError, match="no usable HIP device|fallback"):
+        capi.HotPath(lib, capi.avia_config(), "immesh_")

@@ -1,0 +1,42 @@
+"""The N>1 path of bench.py on CPU: world_size-2 gloo process group, barrier, max-over-ranks timing, per-rank stream assignment,
+whole-job aggregation.  (Round-1 multi-GPU mode is replicas-only: no data-path collective to test beyond this.)"""
+import os
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from immesh_amd import dist as D
+    assert D.env_rank() == (rank, world, rank)
+    dist = D.init("gloo")
+    D.barrier()
+    elapsed = 0.5 + 0.25 * rank            # rank 1 is the slow one
+    mx = D.max_over_ranks(elapsed)
+    stream = D.stream_of_rank(rank, 4)
+    out[rank] = (mx, stream, D.aggregate_throughput(20, world, mx))
+    D.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_timing_and_streams():
+    world = 2
+    port = 29500 + (os.getpid() % 400)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert set(out.keys()) == {0, 1}
+    assert out[0][0] == out[1][0] == 0.75                       # both ranks agree on the max
+    assert out[0][1] == [0, 1, 2, 3, 4] and out[1][1] == [1, 2, 3, 4, 5]
+    assert abs(out[0][2] - 40 / 0.75) < 1e-9                    # whole-job scans/s = all ranks' scans / slowest rank
+
+
+def test_single_process_is_identity():
+    sys.path.insert(0, ROOT)
+    from immesh_amd import dist as D
+    assert D.max_over_ranks(1.25) == 1.25
+    assert D.aggregate_throughput(10, 1, 2.0) == 5.0
