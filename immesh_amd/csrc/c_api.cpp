@@ -39,13 +39,9 @@ static int alloc_all(immesh_ctx* c) {
     if (cap_nodes > 0x7fffffff || cap_chunks > 0x7fffffff || hcap > 0xffffffffLL) { c->err = "capacity too large for 32-bit indices"; return IMMESH_E_INVAL; }
     int rc;
 #define A(ptr, n) if ((rc = c->dalloc(&(ptr), (size_t)(n)))) return rc
-    A(m.hkeys, hcap); A(m.hvals, hcap);
+    A(m.htab, hcap); A(m.slot_head, hcap);
     m.hmask = (uint64_t)hcap - 1;
-    A(m.n_child, cap_nodes * 8); A(m.n_center, cap_nodes * 3); A(m.n_quarter, cap_nodes); A(m.n_flags, cap_nodes); A(m.n_layer, cap_nodes);
-    A(m.n_npts, cap_nodes); A(m.n_newpts, cap_nodes); A(m.n_chunks, cap_nodes * IM_INLINE_CHUNKS); A(m.n_ext, cap_nodes); A(m.n_key, cap_nodes);
-    A(m.n_path, cap_nodes);
-    A(m.p_center, cap_nodes * 3); A(m.p_normal, cap_nodes * 3); A(m.p_d, cap_nodes); A(m.p_radius, cap_nodes); A(m.p_min_eig, cap_nodes);
-    A(m.p_var, cap_nodes * 21);
+    A(m.nodes, cap_nodes);
     A(m.chunk_data, cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES); A(m.ext_tables, cap_ext * IM_EXT_CHUNKS);
     A(m.counters, 16); A(m.free_ready, cap_chunks); A(m.free_pending, cap_chunks);
     m.cap_nodes = (int32_t)cap_nodes; m.cap_chunks = (int32_t)cap_chunks; m.cap_ext = (int32_t)cap_ext;
@@ -55,15 +51,17 @@ static int alloc_all(immesh_ctx* c) {
     m.voxel_size_f = (float)g.voxel_size;
     m.voxel_size_d = g.voxel_size;
     HIPCHK(c, hipMemsetAsync(m.counters, 0, 16 * sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(m.hvals, 0xFF, hcap * sizeof(int32_t), c->stream));
-    launch_fill_u64(c->stream, m.hkeys, IM_KEY_EMPTY, (size_t)hcap);
+    HIPCHK(c, hipMemsetAsync(m.htab, 0xFF, hcap * sizeof(HashEnt), c->stream));   // key = IM_KEY_EMPTY, root = -1
+    HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
+    m.upd_seq = 0;
     A(c->d_stats, 8);
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
     c->cap_scan = ns;
     A(c->d_pts_down, ns * 3); A(c->d_pts_raw, ns * 4); A(c->d_pts_world, ns * 4);
-    A(c->d_partials, ((ns + 255) / 256) * RES_NV_HOST); A(c->d_out48, RES_NV_HOST);
+    A(c->d_partials, ((ns + 63) / 64) * RES_NR_HOST); A(c->d_out48, RES_NV_HOST); A(c->d_done, 4);
+    HIPCHK(c, hipMemsetAsync(c->d_done, 0, 16, c->stream));
     A(c->d_match, ns); A(c->d_mnode, ns); A(c->d_dis, ns); A(c->d_rinv, ns); A(c->d_normal, ns * 3);
     A(c->d_ptdata, ns * IM_PT_DOUBLES);
     A(c->d_key_a, ns); A(c->d_key_b, ns); A(c->d_idx_a, ns); A(c->d_idx_b, ns); A(c->d_idx_c, ns);
@@ -72,7 +70,8 @@ static int alloc_all(immesh_ctx* c) {
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
     A(c->d_dump_count, 2);
 #undef A
-    HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_out48_host, c->h_out48, 0));
     HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t)));
     return 0;
 }
@@ -136,8 +135,9 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
     const int f = c->h_counters[5];
     if (f) {
         static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 32896 retained points", "extension-table pool exhausted",
-                                    "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)"};
-        c->err = std::string("registration map capacity: ") + why[f < 6 ? f : 0];
+                                    "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)",
+                                    "more than 512 points of one scan fall into one root voxel (down-sample the scan, or use immesh_map_build)"};
+        c->err = std::string("registration map capacity: ") + why[f < 7 ? f : 0];
         return IMMESH_E_CAPACITY;
     }
     return 0;
@@ -146,8 +146,8 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
 static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh::State& st, const double* prior_cov) {
     ScanParams sp;
     make_scan_params(c, st, prior_cov, sp);
-    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_out48, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
-    HIPCHK(c, hipMemcpyAsync(c->h_out48, c->d_out48, RES_NV_HOST * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // the last block of the launch writes the 48 sums straight into pinned host memory: one launch + one stream sync per EKF iteration
+    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_done, c->d_out48_host, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cnt.n_match += (int64_t)c->h_out48[42];
     c->cnt.n_plane_tests += (int64_t)c->h_out48[44];
@@ -260,22 +260,21 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
-    launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot);
-    launch_iota(s, c->d_idx_a, (int)n);
-    int hbits = 1;
-    while (((uint64_t)1 << hbits) <= c->map.hmask) hbits++;
-    const int32_t* idx_in = c->d_idx_a;
-    const uint32_t* slot_in = c->d_slot;
-    if (mode == 0) {  // std::sort(pv_list, var_contrast): ascending covariance norm, ties by scan index (stable)
-        sort_pairs_u64(s, c->d_sort_temp, c->sort_temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, (int)n);
-        launch_gather_u32(s, c->d_slot, c->d_idx_b, c->d_slot_g, (int)n);
-        idx_in = c->d_idx_b; slot_in = c->d_slot_g;
+    if (mode == 0) {
+        // map_incremental_grow: no global sort -- points are chained per root voxel and each voxel's wavefront orders its own points
+        // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
+        c->map.upd_seq++;
+        c->map.touched = (uint32_t*)c->d_seg_start;
+        launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats);
+    } else {
+        // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
+        launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, nullptr);
+        launch_iota(s, c->d_idx_a, (int)n);
+        sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_slot, c->d_slot_s, c->d_idx_a, c->d_idx_c, (int)n, 32);  // 0xFFFFFFFF "no slot" sorts last
+        launch_segment_heads(s, c->d_slot_s, (int)n, c->d_seg_start, c->d_nseg);
+        launch_replay(s, c->map, c->d_slot_s, c->d_idx_c, c->d_ptdata, (int)n, c->d_seg_start, c->d_nseg, (int)n, mode, c->d_stats);
     }
-    // group by root voxel, stable (keeps the replay order inside each voxel).  32 bits so the 0xFFFFFFFF "no slot" marker sorts last.
-    sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, slot_in, c->d_slot_s, idx_in, c->d_idx_c, (int)n, 32);
-    (void)hbits;
-    launch_segment_heads(s, c->d_slot_s, (int)n, c->d_seg_start, c->d_nseg);
-    launch_replay(s, c->map, c->d_slot_s, c->d_idx_c, c->d_ptdata, (int)n, c->d_seg_start, c->d_nseg, (int)n, mode, c->d_stats);
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     return 0;
 }

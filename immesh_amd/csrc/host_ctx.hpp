@@ -46,7 +46,9 @@ struct immesh_ctx {
     float* d_pts_world = nullptr;    // world_lidar_full (n x 4)
     double* d_partials = nullptr;    // residual block partials
     double* d_out48 = nullptr;
-    double* h_out48 = nullptr;       // pinned
+    double* h_out48 = nullptr;       // pinned, device-mapped
+    double* d_out48_host = nullptr;  // device view of h_out48
+    unsigned int* d_done = nullptr;  // residual_kernel's "blocks finished" counter
     int8_t* d_match = nullptr;
     int32_t* d_mnode = nullptr;
     float* d_dis = nullptr;

@@ -25,11 +25,14 @@ struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
 };
 
 #define RES_NV_HOST 48
+#define RES_NR_HOST 32
 
-void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, double* out48,
-                     int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
+                     double* out48, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
-                      unsigned long long* sort_key, uint32_t* slot);
+                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next);
+void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
+                         int64_t* stats);
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);
 void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
                    const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats);

@@ -22,7 +22,7 @@ int mesh_alloc(immesh_ctx* c) {
     const int64_t cap_verts = g.cap_vertices > 0 ? g.cap_vertices : (1 << 22);
     const int64_t cap_voxels = cap_verts;
     const int64_t cap_tris = g.cap_triangles > 0 ? g.cap_triangles : cap_verts * 4;
-    const int64_t cap_adj = cap_verts + cap_tris / 4;
+    const int64_t cap_adj = cap_verts + cap_tris / 3;
     const int64_t cap_cand = c->cap_scan;
     const int64_t cap_active = std::min<int64_t>(cap_cand, 1 << 17);
     const int64_t cap_list = 1 << 22;
@@ -31,13 +31,13 @@ int mesh_alloc(immesh_ctx* c) {
 #define A(ptr, n) if ((rc = c->dalloc(&(ptr), (size_t)(n)))) return rc
     A(m.v_pos, cap_verts * 3); A(m.v_smooth, cap_verts * 3); A(m.v_smooth_new, cap_verts * 3); A(m.v_voxel, cap_verts);
     const int64_t gcap = np2(cap_verts * 2), xcap = np2(cap_voxels * 2), tcap = np2(cap_tris * 2), ccap = np2(cap_cand * 4);
-    A(m.g_keys, gcap); A(m.g_vals, gcap); m.g_mask = (uint64_t)gcap - 1;
+    A(m.g_keys, gcap); A(m.g_rec, gcap * 4); m.g_mask = (uint64_t)gcap - 1;
     A(m.x_keys, xcap); A(m.x_vals, xcap); m.x_mask = (uint64_t)xcap - 1;
     A(m.vx_key, cap_voxels); A(m.vx_npts, cap_voxels); A(m.vx_pts, cap_voxels * MV_VOX_CAP); A(m.vx_meshing_times, cap_voxels);
     A(m.vx_new_added, cap_voxels); A(m.vx_stamp, cap_voxels); A(m.vx_rank, cap_voxels); A(m.vx_rank_seq, cap_voxels); A(m.vx_short_axis, cap_voxels * 3);
     A(m.t_v, cap_tris * 3); A(m.t_word, cap_tris); A(m.t_live, cap_tris); A(m.t_rem_seq, cap_tris); A(m.t_flip, cap_tris);
     A(m.th_slots, tcap); m.th_mask = (uint64_t)tcap - 1;
-    A(m.a_head, cap_verts); A(m.a_chunks, cap_adj * 8);
+    A(m.a_head, cap_verts); A(m.a_chunks, cap_adj * MV_ADJ_STRIDE);
     A(m.sc, SC_COUNT); A(m.pc, PC_COUNT);
     A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand);
     A(m.ch_keys, ccap); A(m.ch_head, ccap);
@@ -145,8 +145,12 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
     if (n_active > 0) {
         // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
         // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-        sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, m.act_key, m.act_key_s, m.act_vox, m.act_vox_s, n_active);
-        launch_mesh_rank(s, m, n_active);
+        const int lcap = mesh_lsort_cap();
+        if (n_active <= lcap) launch_mesh_sort_active(s, m, n_active);   // one-workgroup LDS sort + rank assignment
+        else {
+            sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, m.act_key, m.act_key_s, m.act_vox, m.act_vox_s, n_active);
+            launch_mesh_rank(s, m, n_active);
+        }
         launch_mesh_knn(s, m, n_active);                // a18-a19
         launch_mesh_delaunay(s, m, sp, n_active);       // a20-a23
         launch_mesh_finalize(s, m, n_active);
@@ -155,21 +159,21 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
         if ((rc = mesh_overflow(c))) return rc;
         const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
         // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
+        // the four result lists are sorted and emitted by one launch (4 workgroups, LDS); longer lists take the radix-sort path
+        launch_mesh_sort_lists(s, m, n_rem, n_add, n_upd, n_smooth, h.p_a);
         if (n_rem > 0) {
             launch_mesh_commit_rem(s, m, m.list_rem, n_rem);
-            sort_tris(c, m.list_rem, n_rem);
-            launch_mesh_emit(s, m, h.p_c, n_rem, m.out_tri_rem, nullptr);
+            if (n_rem > lcap) { sort_tris(c, m.list_rem, n_rem); launch_mesh_emit(s, m, h.p_c, n_rem, m.out_tri_rem, nullptr); }
         }
         if (n_add > 0) {
-            sort_tris(c, m.list_add, n_add);
-            launch_mesh_emit(s, m, h.p_c, n_add, m.out_tri_add, m.out_flip_add);
-            launch_mesh_commit_add(s, m, h.p_c, n_add);
+            if (n_add > lcap) {
+                sort_tris(c, m.list_add, n_add);
+                launch_mesh_emit(s, m, h.p_c, n_add, m.out_tri_add, m.out_flip_add);
+                launch_mesh_commit_add(s, m, h.p_c, n_add);
+            } else launch_mesh_commit_add(s, m, h.p_a, n_add);
         }
-        if (n_upd > 0) {
-            sort_tris(c, m.list_upd, n_upd);
-            launch_mesh_emit(s, m, h.p_c, n_upd, m.out_tri_upd, m.out_flip_upd);
-        }
-        if (n_smooth > 0) {
+        if (n_upd > lcap) { sort_tris(c, m.list_upd, n_upd); launch_mesh_emit(s, m, h.p_c, n_upd, m.out_tri_upd, m.out_flip_upd); }
+        if (n_smooth > lcap) {
             sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, (const uint32_t*)m.list_smooth, h.k32_b, m.list_smooth, h.p_b, n_smooth, 32);
             launch_mesh_emit_smooth(s, m, h.p_b, n_smooth);
         }

@@ -123,22 +123,34 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m, Mes
     const unsigned long long gkey = mkey(gx, gy, gz);
     m.cand_cell[i] = gkey;
     // existing vertices: occupied dedupe cell, or any vertex closer than min_spacing (1-NN test, pointcloud_rgbd.cpp:503-516).
-    // A vertex within min_spacing lies in one of the 27 cells around the candidate's cell and every cell holds at most one vertex.
+    // A vertex within min_spacing lies in one of the 27 cells around the candidate's cell and every cell holds at most one vertex
+    // (stored with its position in the hash entry), so the test is 27 independent probes: issued 9 at a time, one latency per batch.
     int status = ST_UNDECIDED;
     int probes = 0;
-    if (h_find(m.g_keys, m.g_mask, gkey) >= 0) status = ST_REJECT;
-    else {
-        for (int dx = -1; dx <= 1 && status == ST_UNDECIDED; dx++)
-            for (int dy = -1; dy <= 1 && status == ST_UNDECIDED; dy++)
-                for (int dz = -1; dz <= 1; dz++) {
-                    if (dx == 0 && dy == 0 && dz == 0) continue;
-                    const long long s = h_find(m.g_keys, m.g_mask, mkey(gx + dx, gy + dy, gz + dz));
-                    if (s < 0) continue;
-                    probes++;
-                    const int id = m.g_vals[s];
-                    const float d2 = dist2f(px, py, pz, m.v_pos[(size_t)id * 3 + 0], m.v_pos[(size_t)id * 3 + 1], m.v_pos[(size_t)id * 3 + 2]);
-                    if ((double)sqrtf(d2) < m.min_spacing) { status = ST_REJECT; break; }
-                }
+    const float4* grec = (const float4*)m.g_rec;
+    for (int dx = -1; dx <= 1 && status == ST_UNDECIDED; dx++) {
+        unsigned long long key9[9], k9[9], h9[9];
+        float4 r9[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
+            h9[q] = hash64(key9[q]) & m.g_mask;
+            k9[q] = m.g_keys[h9[q]];
+            r9[q] = grec[h9[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            float4 r = r9[q];
+            bool hit = (k9[q] == key9[q]);
+            if (!hit && k9[q] != MKEY_EMPTY) {  // displaced entry: continue the linear probe
+                const long long s2 = h_find(m.g_keys, m.g_mask, key9[q]);
+                if (s2 >= 0) { r = grec[s2]; hit = true; }
+            }
+            if (!hit) continue;
+            if (dx == 0 && q == 4) { status = ST_REJECT; continue; }  // the candidate's own cell is occupied
+            probes++;
+            if ((double)sqrtf(dist2f(px, py, pz, r.x, r.y, r.z)) < m.min_spacing) status = ST_REJECT;
+        }
     }
     if (probes) atomicAdd(&m.sc[SC_C1], probes);
     m.cand_next[i] = -1;
@@ -163,26 +175,33 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, Mes
     const unsigned long long own = m.cand_cell[i];
     for (int iter = 0; iter < 48; iter++) {
         bool rej = false, blocked = false;
-        for (int dx = -1; dx <= 1 && !rej; dx++)
-            for (int dy = -1; dy <= 1 && !rej; dy++)
-                for (int dz = -1; dz <= 1 && !rej; dz++) {
-                    const unsigned long long ck = mkey(gx + dx, gy + dy, gz + dz);
-                    const long long s = h_find(m.ch_keys, m.ch_mask, ck);
-                    if (s < 0) continue;
-                    for (int j = m.ch_head[s]; j >= 0; j = m.cand_next[j]) {
-                        if (j >= i) continue;
-                        const int sj = ld_agent(&m.cand_status[j]);
-                        if (sj == ST_REJECT) continue;
-                        bool conflict = (ck == own);
-                        if (!conflict) {
-                            const float* q = pts + 4 * (size_t)j * sp.step;
-                            conflict = (double)sqrtf(dist2f(px, py, pz, q[0], q[1], q[2])) < m.min_spacing;
-                        }
-                        if (!conflict) continue;
-                        if (sj == ST_ACCEPT) { rej = true; break; }
-                        blocked = true;
+        for (int dx = -1; dx <= 1 && !rej; dx++) {
+            unsigned long long key9[9], k9[9], h9[9];
+            int hd9[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {  // 9 independent cell lookups in flight
+                key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
+                h9[q] = hash64(key9[q]) & m.ch_mask;
+                k9[q] = m.ch_keys[h9[q]];
+                hd9[q] = m.ch_head[h9[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                int head = -1;
+                if (k9[q] == key9[q]) head = hd9[q];
+                else if (k9[q] != MKEY_EMPTY) { const long long s2 = h_find(m.ch_keys, m.ch_mask, key9[q]); if (s2 >= 0) head = m.ch_head[s2]; }
+                for (int j = head; j >= 0 && !rej;) {
+                    const int nxt = m.cand_next[j];
+                    const int sj = ld_agent(&m.cand_status[j]);
+                    const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
+                    if (j < i && sj != ST_REJECT) {
+                        const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
+                        if (conflict) { if (sj == ST_ACCEPT) rej = true; else blocked = true; }
                     }
+                    j = nxt;
                 }
+            }
+        }
         if (rej) { st_agent(&m.cand_status[i], ST_REJECT); return; }
         if (!blocked) { st_agent(&m.cand_status[i], ST_ACCEPT); return; }
     }
@@ -221,7 +240,7 @@ __global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m, Mesh
     bool created;
     const long long gs = h_find_or_insert(m.g_keys, m.g_mask, m.cand_cell[i], &created);
     if (gs < 0) { m.sc[SC_OVERFLOW] = 6; return; }
-    m.g_vals[gs] = id;
+    ((float4*)m.g_rec)[gs] = make_float4(px, py, pz, __int_as_float(id));
     const int pos = atomicAdd(&m.vx_npts[vi], 1);
     if (pos >= MV_VOX_CAP) { m.sc[SC_OVERFLOW] = 7; atomicSub(&m.vx_npts[vi], 1); return; }
     m.vx_pts[(size_t)vi * MV_VOX_CAP + pos] = id;
@@ -324,6 +343,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     __shared__ int qid[MV_VOX_CAP];
     __shared__ int rel_l[MV_REL_CAP];
     __shared__ int wsum[4];
+    __shared__ int s_incl[256], s_v2[256];
     __shared__ int s_misc[8];   // 0 ncand, 1 vend, 2 nrel, 3 any-needs-pass-2
     __shared__ long s_box[6];
 
@@ -388,13 +408,22 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
             const int excl = incl - n2;
             const bool fits = incl <= KC;
             if (!fits && excl <= KC && vidx < nvox) s_misc[1] = vidx;  // first voxel that does not fit starts the next batch (unique writer)
-            if (fits && n2 > 0) {
-                for (int k = 0; k < n2; k++) {
-                    const int id = m.vx_pts[(size_t)v2 * MV_VOX_CAP + k];
-                    cx[excl + k] = m.v_pos[(size_t)id * 3 + 0]; cy[excl + k] = m.v_pos[(size_t)id * 3 + 1]; cz[excl + k] = m.v_pos[(size_t)id * 3 + 2];
-                    cid[excl + k] = id;
+            s_incl[tid] = fits ? incl : 0x7FFFFFFF;
+            s_v2[tid] = v2;
+            if (fits && n2 > 0) atomicMax(&s_misc[0], incl);
+            __syncthreads();
+            {   // copy at vertex granularity: thread c stages candidate c (voxel found by binary search in the prefix sums),
+                // so the two dependent gathers (vertex id, position) happen once per thread instead of once per vertex of a voxel
+                const int ntot = s_misc[0];
+                for (int cpos = tid; cpos < ntot; cpos += 256) {
+                    int lo = 0, hi = 255;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_incl[mid] > cpos) hi = mid; else lo = mid + 1; }
+                    const int vv = s_v2[lo];
+                    const int first = lo > 0 ? s_incl[lo - 1] : 0;  // == exclusive prefix of voxel lo (empty voxels repeat the previous value)
+                    const int id = m.vx_pts[(size_t)vv * MV_VOX_CAP + (cpos - first)];
+                    cx[cpos] = m.v_pos[(size_t)id * 3 + 0]; cy[cpos] = m.v_pos[(size_t)id * 3 + 1]; cz[cpos] = m.v_pos[(size_t)id * 3 + 2];
+                    cid[cpos] = id;
                 }
-                atomicMax(&s_misc[0], incl);
             }
             __syncthreads();
             const int ncand = s_misc[0];
@@ -537,10 +566,8 @@ IMD void smooth_seen(const MeshDev& m, int vtx, int my_rank, double* out) {
     const double* src = (fresh ? m.v_smooth_new : m.v_smooth) + (size_t)vtx * 3;
     out[0] = src[0]; out[1] = src[1]; out[2] = src[2];
 }
-// correct_triangle_index (mesh_rec_geometry.cpp:399-433): m_index_flip
-IMD int flip_of(const MeshDev& m, int a, int b, int c, int my_rank, const double* cam, const double* short_axis) {
-    double A[3], B[3], C[3];
-    smooth_seen(m, a, my_rank, A); smooth_seen(m, b, my_rank, B); smooth_seen(m, c, my_rank, C);
+// correct_triangle_index (mesh_rec_geometry.cpp:399-433): m_index_flip.  A, B, C = smoothed positions of the (id-sorted) vertices
+IMD int flip_of(const double* A, const double* B, const double* C, const double* cam, const double* short_axis) {
     const double ab[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, ac[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
     const double tc[3] = {cam[0] - A[0], cam[1] - A[1], cam[2] - A[2]};
     double nrm[3];
@@ -594,6 +621,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     __shared__ unsigned short ea[DT_CAV_CAP * 3], eb[DT_CAV_CAP * 3];
     __shared__ unsigned int fresh[TCAP];
     __shared__ unsigned char fhit[TCAP];
+    __shared__ double sm[CAP * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
     __shared__ int s_cnt[2];
 
     const int r = blockIdx.x, lane = threadIdx.x;
@@ -604,6 +632,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
         const int id = m.rel_ids[(size_t)r * MV_REL_CAP + i];
         ids[i] = id;
         pf[i * 3 + 0] = m.v_pos[(size_t)id * 3 + 0]; pf[i * 3 + 1] = m.v_pos[(size_t)id * 3 + 1]; pf[i * 3 + 2] = m.v_pos[(size_t)id * 3 + 2];
+        smooth_seen(m, id, r, &sm[i * 3]);
     }
     if (lane == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
     __syncthreads();
@@ -710,8 +739,11 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
                     const int e = base + lane;
                     bool bd = false;
                     unsigned short a = 0, b = 0;
-                    if (e < ne) {
-                        a = ea[e]; b = eb[e]; bd = true;
+                    if (e < ne) { a = ea[e]; b = eb[e]; bd = true; }
+                    if (ne <= 64) {  // one edge per lane: the twin search runs on registers (v_readlane), no LDS round trips
+                        const unsigned int key = ((unsigned int)a << 16) | (unsigned int)b, twin = ((unsigned int)b << 16) | (unsigned int)a;
+                        for (int f = 0; f < ne; f++) if ((unsigned int)__builtin_amdgcn_readlane((int)key, f) == twin) bd = false;
+                    } else if (e < ne) {
                         for (int f = 0; f < ne; f++) if (ea[f] == b && eb[f] == a) { bd = false; break; }
                     }
                     const unsigned long long mask = __ballot(bd);
@@ -777,33 +809,41 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     const unsigned long long wbase = ((unsigned long long)(unsigned int)m.seq << 32) | ((unsigned long long)(unsigned int)r << 1);
     for (int i = lane; i < n; i += 64) {
         const int id = ids[i];
-        for (int ch = m.a_head[id]; ch >= 0; ch = m.a_chunks[(size_t)ch * 8 + 7])
-            for (int s = 0; s < MV_ADJ_SLOTS; s++) {
-                const int t = m.a_chunks[(size_t)ch * 8 + s];
+        for (int ch = m.a_head[id]; ch >= 0;) {
+            const int* cp = m.a_chunks + (size_t)ch * MV_ADJ_STRIDE;
+            int e[MV_ADJ_STRIDE];
+#pragma unroll
+            for (int k = 0; k < MV_ADJ_STRIDE; k++) e[k] = cp[k];   // one 64-byte chunk: 5 x (triangle, v1, v2) + next
+#pragma unroll
+            for (int sl = 0; sl < MV_ADJ_SLOTS; sl++) {
+                const int t = e[sl * 3];
                 if (t < 0) continue;
-                const int v1 = m.t_v[(size_t)t * 3 + 1], v2 = m.t_v[(size_t)t * 3 + 2];
+                const int v1 = e[sl * 3 + 1], v2 = e[sl * 3 + 2];
                 const int l1 = lds_bsearch_i32(ids, n, v1), l2 = lds_bsearch_i32(ids, n, v2);
                 if (l1 < 0 || l2 < 0) continue;
                 const int pos = lds_bsearch_u32(fresh, nf, ((unsigned int)i << 20) | ((unsigned int)l1 << 10) | (unsigned int)l2);
                 if (pos >= 0) {
                     fhit[pos] = 1;
-                    const int fl = flip_of(m, id, v1, v2, r, sp.cam, short_axis);
+                    const int fl = flip_of(&sm[i * 3], &sm[l1 * 3], &sm[l2 * 3], sp.cam, short_axis);
                     atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
                     touched[atomicAdd(&s_cnt[0], 1)] = t;
                 } else if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) {
                     list_push(m, m.list_rem, SC_REM, t);
                 }
             }
+            ch = e[MV_ADJ_STRIDE - 1];
+        }
     }
     __syncthreads();
     int spare = -1;
     for (int k = lane; k < nf; k += 64) {
         if (fhit[k]) continue;
         const unsigned int pk = fresh[k];
-        const int a = ids[pk >> 20], b = ids[(pk >> 10) & 1023], c = ids[pk & 1023];
+        const int la = (int)(pk >> 20), lb = (int)((pk >> 10) & 1023), lc = (int)(pk & 1023);
+        const int a = ids[la], b = ids[lb], c = ids[lc];
         const int t = tri_find_or_insert(m, a, b, c, &spare);
         if (t < 0) continue;
-        const int fl = flip_of(m, a, b, c, r, sp.cam, short_axis);
+        const int fl = flip_of(&sm[la * 3], &sm[lb * 3], &sm[lc * 3], sp.cam, short_axis);
         atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
         touched[atomicAdd(&s_cnt[0], 1)] = (int)((unsigned int)t | TRI_ADD_BIT);
     }
@@ -837,6 +877,89 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
     }
 }
 
+// =====================================================================================================================
+// small sorts: one workgroup, 16-byte records in LDS (<= 8192 records = 128 KB), bitonic network with a lexicographic (k0, k1)
+// comparator.  Replaces ~10 multi-kernel device-wide radix sorts per scan whose cost at these sizes is pure launch latency.
+// =====================================================================================================================
+#define LSORT_CAP 8192
+struct SortRec { unsigned long long k0, k1; };
+IMD bool rec_gt(const SortRec& a, const SortRec& b) { return a.k0 > b.k0 || (a.k0 == b.k0 && a.k1 > b.k1); }
+template <int NT>
+IMD void lds_sort_recs(SortRec* a, int np2, int tid) {
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (np2 >> 1); p += NT) {
+                const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
+                const bool up = ((i & k) == 0);
+                const SortRec x = a[i], y = a[ixj];
+                if (rec_gt(x, y) == up) { a[i] = y; a[ixj] = x; }
+            }
+            __syncthreads();
+        }
+}
+// block 0/1/2: the remove / add / flip-update triangle lists -> sorted by (v0, v1, v2) triplets (+ flips; the add list also as sorted
+// triangle indices for the commit); block 3: smoothed vertex ids ascending + their positions.  Lists above LSORT_CAP are left to the host's
+// radix-sort path.
+__global__ __launch_bounds__(1024) void mesh_sort_lists_kernel(MeshDev m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* __restrict__ add_sorted) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsort_smem[];
+    SortRec* recs = (SortRec*)lsort_smem;
+    const int job = blockIdx.x, tid = threadIdx.x;
+    const int n = job == 0 ? n_rem : (job == 1 ? n_add : (job == 2 ? n_upd : n_smooth));
+    if (n <= 0 || n > LSORT_CAP) return;
+    const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : m.list_smooth));
+    const int np2 = next_pow2_i(n);
+    for (int i = tid; i < np2; i += 1024) {
+        SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
+        if (i < n) {
+            const int t = list[i];
+            if (job < 3) {
+                r.k0 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
+                r.k1 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 2] << 32) | (unsigned long long)(unsigned int)t;
+            } else { r.k0 = (unsigned long long)(unsigned int)t; r.k1 = 0; }
+        }
+        recs[i] = r;
+    }
+    __syncthreads();
+    lds_sort_recs<1024>(recs, np2, tid);
+    for (int i = tid; i < n; i += 1024) {
+        const SortRec r = recs[i];
+        if (job < 3) {
+            int32_t* out_tri = job == 0 ? m.out_tri_rem : (job == 1 ? m.out_tri_add : m.out_tri_upd);
+            uint8_t* out_flip = job == 0 ? nullptr : (job == 1 ? m.out_flip_add : m.out_flip_upd);
+            const int t = (int)(unsigned int)(r.k1 & 0xFFFFFFFFull);
+            out_tri[(size_t)i * 3 + 0] = (int)(r.k0 >> 32); out_tri[(size_t)i * 3 + 1] = (int)(unsigned int)(r.k0 & 0xFFFFFFFFull); out_tri[(size_t)i * 3 + 2] = (int)(r.k1 >> 32);
+            if (out_flip) out_flip[i] = (uint8_t)m.t_flip[t];
+            if (job == 1) add_sorted[i] = t;
+        } else {
+            const int id = (int)(unsigned int)r.k0;
+            m.out_smooth_ids[i] = id;
+            m.out_smooth_xyz[(size_t)i * 3 + 0] = m.v_smooth[(size_t)id * 3 + 0];
+            m.out_smooth_xyz[(size_t)i * 3 + 1] = m.v_smooth[(size_t)id * 3 + 1];
+            m.out_smooth_xyz[(size_t)i * 3 + 2] = m.v_smooth[(size_t)id * 3 + 2];
+        }
+    }
+}
+// active voxels in ascending (x,y,z) key order + their ranks, one workgroup (n_active <= LSORT_CAP)
+__global__ __launch_bounds__(1024) void mesh_sort_active_kernel(MeshDev m, int n_active) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsort_smem[];
+    SortRec* recs = (SortRec*)lsort_smem;
+    const int tid = threadIdx.x;
+    const int np2 = next_pow2_i(n_active);
+    for (int i = tid; i < np2; i += 1024) {
+        SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
+        if (i < n_active) { r.k0 = m.act_key[i]; r.k1 = (unsigned long long)(unsigned int)m.act_vox[i]; }
+        recs[i] = r;
+    }
+    __syncthreads();
+    lds_sort_recs<1024>(recs, np2, tid);
+    for (int i = tid; i < n_active; i += 1024) {
+        const int vi = (int)(unsigned int)recs[i].k1;
+        m.act_vox_s[i] = vi;
+        m.vx_rank[vi] = i;
+        m.vx_rank_seq[vi] = m.seq;
+    }
+}
+
 // sort keys of a triangle list: which 0 -> third vertex (32-bit), 1 -> (first, second) vertex (64-bit)
 __global__ void mesh_tri_keys_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int which, uint32_t* __restrict__ k32, unsigned long long* __restrict__ k64) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -859,9 +982,9 @@ __global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tr
     const int t = tris[i];
     m.t_live[t] = 0;
     const int v0 = m.t_v[(size_t)t * 3 + 0];
-    for (int ch = m.a_head[v0]; ch >= 0; ch = m.a_chunks[(size_t)ch * 8 + 7])
+    for (int ch = m.a_head[v0]; ch >= 0; ch = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + MV_ADJ_STRIDE - 1])
         for (int s = 0; s < MV_ADJ_SLOTS; s++)
-            if (m.a_chunks[(size_t)ch * 8 + s] == t) { m.a_chunks[(size_t)ch * 8 + s] = -1; return; }
+            if (m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] == t) { m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] = -1; return; }
 }
 // Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
@@ -874,19 +997,22 @@ __global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tr
     for (int j = i; j < n; j++) {
         const int t = tris[j];
         if (m.t_v[(size_t)t * 3 + 0] != v0) break;
+        const int v1 = m.t_v[(size_t)t * 3 + 1], v2 = m.t_v[(size_t)t * 3 + 2];
         m.t_live[t] = 1;
         bool placed = false;
         while (ch >= 0 && !placed) {
+            int* cp = m.a_chunks + (size_t)ch * MV_ADJ_STRIDE;
             for (; s < MV_ADJ_SLOTS; s++)
-                if (m.a_chunks[(size_t)ch * 8 + s] < 0) { m.a_chunks[(size_t)ch * 8 + s] = t; placed = true; s++; break; }
-            if (!placed) { ch = m.a_chunks[(size_t)ch * 8 + 7]; s = 0; }
+                if (cp[s * 3] < 0) { cp[s * 3 + 1] = v1; cp[s * 3 + 2] = v2; cp[s * 3] = t; placed = true; s++; break; }
+            if (!placed) { ch = cp[MV_ADJ_STRIDE - 1]; s = 0; }
         }
         if (!placed) {  // every chunk of the chain is full: push a new chunk at the front
             const int nc = atomicAdd(&m.pc[PC_ADJ_CHUNKS], 1);
             if (nc >= m.cap_adj_chunks) { m.sc[SC_OVERFLOW] = 13; return; }
-            m.a_chunks[(size_t)nc * 8 + 0] = t;
-            for (int k = 1; k < MV_ADJ_SLOTS; k++) m.a_chunks[(size_t)nc * 8 + k] = -1;
-            m.a_chunks[(size_t)nc * 8 + 7] = m.a_head[v0];
+            int* cp = m.a_chunks + (size_t)nc * MV_ADJ_STRIDE;
+            cp[0] = t; cp[1] = v1; cp[2] = v2;
+            for (int k = 1; k < MV_ADJ_SLOTS; k++) cp[k * 3] = -1;
+            cp[MV_ADJ_STRIDE - 1] = m.a_head[v0];
             m.a_head[v0] = nc;
             ch = nc; s = 1;
         }
@@ -945,5 +1071,25 @@ void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris
 }
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n) {
     KLAUNCH(mesh_emit_smooth_kernel, g1(n), dim3(256), 0, s, m, ids_sorted, n);
+}
+static void lsort_attr_once() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)mesh_sort_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSORT_CAP * 16);
+    (void)hipFuncSetAttribute((const void*)mesh_sort_active_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSORT_CAP * 16);
+    done = true;
+}
+static int lsort_np2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+int mesh_lsort_cap() { return LSORT_CAP; }
+void launch_mesh_sort_lists(hipStream_t s, const MeshDev& m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* add_sorted) {
+    lsort_attr_once();
+    int mx = 1;
+    const int ns[4] = {n_rem, n_add, n_upd, n_smooth};
+    for (int k = 0; k < 4; k++) if (ns[k] <= LSORT_CAP && ns[k] > mx) mx = ns[k];
+    KLAUNCH(mesh_sort_lists_kernel, dim3(4), dim3(1024), (size_t)lsort_np2(mx) * 16, s, m, n_rem, n_add, n_upd, n_smooth, add_sorted);
+}
+void launch_mesh_sort_active(hipStream_t s, const MeshDev& m, int n_active) {
+    lsort_attr_once();
+    KLAUNCH(mesh_sort_active_kernel, dim3(1), dim3(1024), (size_t)lsort_np2(n_active) * 16, s, m, n_active);
 }
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n) { KLAUNCH(fill_i32_kernel, dim3(1024), dim3(256), 0, s, p, v, n); }

@@ -19,7 +19,8 @@
 #define MV_VOX_CAP 128      /* vertices per mesh voxel: ((int)(voxel/min_spacing)+1)^3 = 125 for every shipped config */
 #define MV_KNN 20           /* neighbours pulled per vertex, mesh_rec_geometry.cpp:350 */
 #define MV_REL_CAP 1024     /* vertices in one voxel's neighbourhood union (n_u) */
-#define MV_ADJ_SLOTS 7      /* triangle ids per adjacency chunk (+1 next pointer) */
+#define MV_ADJ_SLOTS 5      /* (triangle, v1, v2) entries per adjacency chunk */
+#define MV_ADJ_STRIDE 16     /* ints per chunk: 5 x 3 + next pointer in the last int = one 64-byte line */
 
 // per-scan device counters (MeshDev::sc)
 enum {
@@ -33,7 +34,7 @@ struct MeshDev {
     // vertices
     float* v_pos; double* v_smooth; double* v_smooth_new; int32_t* v_voxel;
     // dedupe grid hash
-    unsigned long long* g_keys; int32_t* g_vals; uint64_t g_mask;
+    unsigned long long* g_keys; float* g_rec; uint64_t g_mask;   // g_rec: 16 B per slot = vertex xyz + id (one probe yields the position)
     // mesh voxels
     unsigned long long* x_keys; int32_t* x_vals; uint64_t x_mask;
     unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
@@ -101,6 +102,9 @@ void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n);
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n);
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n);
+int mesh_lsort_cap();
+void launch_mesh_sort_lists(hipStream_t s, const MeshDev& m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* add_sorted);
+void launch_mesh_sort_active(hipStream_t s, const MeshDev& m, int n_active);
 
 // device prefix sum (sort.hip)
 size_t exclusive_sum_temp_bytes(int n);

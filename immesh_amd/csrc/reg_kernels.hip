@@ -21,7 +21,7 @@ using namespace imd;
 struct BestMatch { int node; int layer; double prob; bool ok; };
 
 IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigma_out) {  // J * plane_var * J^T, plane_var symmetric (21)
-    const double* pv = m.p_var + (size_t)node * 21;
+    const double* pv = m.nodes[node].p_var;
     double tmp[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -36,34 +36,47 @@ IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigm
     *sigma_out = sig;
 }
 
-// build_single_residual on one plane node (voxel_mapping.cpp:252-290)
+// build_single_residual on one plane node (voxel_mapping.cpp:252-290).  The whole plane record (normal, centre, d, radius, 21-entry
+// covariance) is fetched up front -- one gather latency -- and both gates are evaluated from registers; computing sigma_l before
+// knowing that the range gate passed has no side effect, so the accept set is the reference's.
 IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
     n_tests++;
-    const double nx = m.p_normal[(size_t)node * 3 + 0], ny = m.p_normal[(size_t)node * 3 + 1], nz = m.p_normal[(size_t)node * 3 + 2];
-    const double cx = m.p_center[(size_t)node * 3 + 0], cy = m.p_center[(size_t)node * 3 + 1], cz = m.p_center[(size_t)node * 3 + 2];
-    const float pd = m.p_d[node], radius = m.p_radius[node];
+    const NodeRec& nr = m.nodes[node];
+    double pv[21];
+#pragma unroll
+    for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
+    const double nx = nr.p_normal[0], ny = nr.p_normal[1], nz = nr.p_normal[2];
+    const double cx = nr.p_center[0], cy = nr.p_center[1], cz = nr.p_center[2];
+    const float pd = nr.d, radius = nr.radius;
     const float dis_to_plane = (float)fabs(nx * pw[0] + ny * pw[1] + nz * pw[2] + (double)pd);
     const float dis_to_center = (float)((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2]));
     const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);  // NaN compares false below
-    if ((double)range_dis <= 3.0 * (double)radius) {
-        const double J[6] = {pw[0] - cx, pw[1] - cy, pw[2] - cz, -nx, -ny, -nz};
-        double sigma_l;
-        plane_sigma(m, node, J, &sigma_l);
-        const double nrm[3] = {nx, ny, nz};
-        double vn[3];
-        m3t_vec(var, nrm, vn);
-        sigma_l += vn[0] * nx + vn[1] * ny + vn[2] * nz;
-        if ((double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
-            best.ok = true;
-            const double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
-            if (this_prob > best.prob) { best.prob = this_prob; best.node = node; best.layer = layer; }
-        }
+    const double J[6] = {pw[0] - cx, pw[1] - cy, pw[2] - cz, -nx, -ny, -nz};
+    double tmp[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        double sacc = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) sacc += J[r] * pv[(r <= c) ? sym21_index(r, c) : sym21_index(c, r)];
+        tmp[c] = sacc;
+    }
+    double sigma_l = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) sigma_l += tmp[c] * J[c];
+    const double nrm[3] = {nx, ny, nz};
+    double vn[3];
+    m3t_vec(var, nrm, vn);
+    sigma_l += vn[0] * nx + vn[1] * ny + vn[2] * nz;
+    if ((double)range_dis <= 3.0 * (double)radius && (double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
+        best.ok = true;
+        const double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
+        if (this_prob > best.prob) { best.prob = this_prob; best.node = node; best.layer = layer; }
     }
 }
 
 // recursive descent over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312), explicit stack
 IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
-    if (m.n_flags[root] & NF_PLANE) { test_plane(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
+    if (m.nodes[root].flags & NF_PLANE) { test_plane(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
     if (m.max_layer <= 0) return;
     int st_node[5], st_k[5];
     int sp = 0;
@@ -71,23 +84,29 @@ IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double
     while (sp >= 0) {
         if (st_k[sp] >= 8) { sp--; continue; }
         const int k = st_k[sp]++;
-        const int child = m.n_child[(size_t)st_node[sp] * 8 + k];
+        const int child = m.nodes[st_node[sp]].child[k];
         if (child < 0) continue;
         const int layer = sp + 1;
-        if (m.n_flags[child] & NF_PLANE) test_plane(m, child, layer, pw, var, sigma_num, best, n_tests);
+        if (m.nodes[child].flags & NF_PLANE) test_plane(m, child, layer, pw, var, sigma_num, best, n_tests);
         else if (layer < m.max_layer) { sp++; st_node[sp] = child; st_k[sp] = 0; }
     }
 }
 
-#define RES_NV 48  // 36 HTH + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe + 2 spare
+#define RES_NV 48   // host layout: 36 HTH + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe + 2 spare
+#define RES_NR 32   // reduced per block: 21 (upper triangle of HTH) + 6 HTz + 4 counters + 1 spare
 
-__global__ __launch_bounds__(256) void residual_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n,
-                                                        double* __restrict__ partials, int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
-                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+
+// One wavefront per block (n/64 blocks: a down-sampled scan is only ~8k points, so small blocks are what spreads it over the CUs).
+// Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
+// finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
+__global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n,
+                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
+                                                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
+                                                       float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double acc[RES_NV];
+    double acc[RES_NR];
 #pragma unroll
-    for (int k = 0; k < RES_NV; k++) acc[k] = 0;
+    for (int k = 0; k < RES_NR; k++) acc[k] = 0;
     if (i < n) {
         const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
         // --- per-scan part of lio_state_estimation (:1302-1316): body covariance + cross matrix of the IMU-frame point
@@ -131,32 +150,32 @@ __global__ __launch_bounds__(256) void residual_kernel(RegMapDev m, ScanParams s
         BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
         int n_tests = 0, n_extra = 0;
         if (slot >= 0) {
-            const int root = m.hvals[slot];
+            const int root = m.htab[slot].root;
             if (root >= 0) match_tree(m, root, pw, var, sp.sigma_num, best, n_tests);
             if (root >= 0 && !best.ok) {  // near-voxel retry with the literal unit mismatch
                 int64_t nk[3] = {kx[0], kx[1], kx[2]};
-                const float ql = m.n_quarter[root];
+                const float ql = m.nodes[root].quarter;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const double c = m.n_center[(size_t)root * 3 + j];
+                    const double c = m.nodes[root].center[j];
                     if ((double)loc[j] > (c + (double)ql)) nk[j] = nk[j] + 1;
                     else if ((double)loc[j] < (c - (double)ql)) nk[j] = nk[j] - 1;
                 }
                 n_extra = 1;
                 const int64_t s2 = hash_find(m, pack_key(nk[0], nk[1], nk[2]));
-                if (s2 >= 0 && m.hvals[s2] >= 0) match_tree(m, m.hvals[s2], pw, var, sp.sigma_num, best, n_tests);
+                if (s2 >= 0 && m.htab[s2].root >= 0) match_tree(m, m.htab[s2].root, pw, var, sp.sigma_num, best, n_tests);
             }
         }
-        acc[44] = (double)n_tests; acc[45] = (double)n_extra;
+        acc[29] = (double)n_tests; acc[30] = (double)n_extra;
         o_match[i] = best.ok ? 1 : 0;
         o_node[i] = best.node;
         if (best.ok) {
             const int nd = best.node;
-            const double nrm_d[3] = {m.p_normal[(size_t)nd * 3 + 0], m.p_normal[(size_t)nd * 3 + 1], m.p_normal[(size_t)nd * 3 + 2]};
-            const double cen[3] = {m.p_center[(size_t)nd * 3 + 0], m.p_center[(size_t)nd * 3 + 1], m.p_center[(size_t)nd * 3 + 2]};
+            const double nrm_d[3] = {m.nodes[nd].p_normal[0], m.nodes[nd].p_normal[1], m.nodes[nd].p_normal[2]};
+            const double cen[3] = {m.nodes[nd].p_center[0], m.nodes[nd].p_center[1], m.nodes[nd].p_center[2]};
             // residual (:1372-1392): float normals, unrounded world point
             const float nxf = (float)nrm_d[0], nyf = (float)nrm_d[1], nzf = (float)nrm_d[2];
-            const float dis = (float)(pwd[0] * (double)nxf + pwd[1] * (double)nyf + pwd[2] * (double)nzf + (double)m.p_d[nd]);
+            const float dis = (float)(pwd[0] * (double)nxf + pwd[1] * (double)nyf + pwd[2] * (double)nzf + (double)m.nodes[nd].d);
             o_dis[i] = dis;
             o_normal[(size_t)i * 3 + 0] = nrm_d[0]; o_normal[(size_t)i * 3 + 1] = nrm_d[1]; o_normal[(size_t)i * 3 + 2] = nrm_d[2];
             // H / R^-1 (:1493-1575)
@@ -180,35 +199,65 @@ __global__ __launch_bounds__(256) void residual_kernel(RegMapDev m, ScanParams s
             m3_vec(T1, nv, A);
             const double H[6] = {A[0], A[1], A[2], nv[0], nv[1], nv[2]};
             const double meas = -(double)dis;
+            int k = 0;
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const double hr = H[r] * ri;
 #pragma unroll
-                for (int c = 0; c < 6; c++) acc[r * 6 + c] = hr * H[c];
-                acc[36 + r] = hr * meas;
+                for (int c = r; c < 6; c++) acc[k++] = hr * H[c];   // (H^T R^-1) H is symmetric up to rounding of hr*H[c] vs hc*H[r]; see below
+                acc[21 + r] = hr * meas;
             }
-            acc[42] = 1.0;
-            acc[43] = fabs((double)dis);
+            acc[27] = 1.0;
+            acc[28] = fabs((double)dis);
         }
     }
-    // deterministic block reduction: wave butterflies, then the 4 waves in fixed order
-    __shared__ double red[4][RES_NV];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double red[RES_NR][65];
+    __shared__ int s_last;
+    const int lane = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < RES_NV; k++) {
-        const double s = wave_sum(acc[k]);
-        if (lane == 0) red[wv][k] = s;
+    for (int k = 0; k < RES_NR; k++) red[k][lane] = acc[k];
+    __syncthreads();
+    {
+        const int k = lane & 31, half = lane >> 5;
+        double ssum = 0;
+        for (int j = 0; j < 32; j++) ssum += red[k][half * 32 + j];
+        ssum += __shfl_xor(ssum, 32, 64);
+        if (lane < RES_NR) partials[(size_t)blockIdx.x * RES_NR + lane] = ssum;
+    }
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 8 independent (L2-served) loads in flight per
+    // lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
+    {
+        const int k = lane & 31;
+        const unsigned int nb = gridDim.x;
+        double tot = 0;
+        for (unsigned int b0 = (unsigned int)(lane >> 5); b0 < nb; b0 += 16) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned int b = b0 + 2u * u;
+                v[u] = b < nb ? __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&partials[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) tot += v[u];
+        }
+        tot += __shfl_xor(tot, 32, 64);
+        red[0][lane] = tot;
     }
     __syncthreads();
-    if (threadIdx.x < RES_NV) partials[(size_t)blockIdx.x * RES_NV + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-}
-
-__global__ void residual_reduce_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= RES_NV) return;
-    double s = 0;
-    for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * RES_NV + k];
-    out[k] = s;
+    if (lane < RES_NV) {  // expand to the host layout
+        double v = 0;
+        if (lane < 36) { const int r = lane / 6, c = lane % 6; v = red[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
+        else if (lane < 42) v = red[0][21 + (lane - 36)];
+        else if (lane < 46) v = red[0][27 + (lane - 42)];
+        out48[lane] = v;
+    }
+    if (lane == 0) { *done_counter = 0; __threadfence_system(); }
 }
 
 // =====================================================================================================================
@@ -217,7 +266,8 @@ __global__ void residual_reduce_kernel(const double* __restrict__ partials, int 
 // mode 0: map_incremental_grow  (var = (R extR) bcov (R extR)^T + (-[p_imu]x) Srot (-[p_imu]x)^T + St, p_imu with the z==0 -> 1e-3 quirk)
 // mode 1: voxel_map_init        (var = R bcov R^T + (-[p_lidar]x) Srot (..)^T + St, p_lidar after calcBodyVar's z==0 -> 1e-4 quirk)
 __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n, int stride, int mode,
-                                                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out) {
+                                                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out,
+                                                         int32_t* __restrict__ pt_next) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double p[3] = {(double)pts[(size_t)i * stride + 0], (double)pts[(size_t)i * stride + 1], (double)pts[(size_t)i * stride + 2]};
@@ -268,10 +318,16 @@ __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams 
         const float vs = m.voxel_size_f;
         const double c[3] = {(0.5 + (double)kx[0]) * (double)vs, (0.5 + (double)kx[1]) * (double)vs, (0.5 + (double)kx[2]) * (double)vs};
         const int node = node_alloc(m, 0, c, vs / 4, pk, 0);
-        m.hvals[slot] = node;
+        m.htab[slot].root = node;
         atomicAdd(&m.counters[6], 1);
     }
     slot_out[i] = (uint32_t)slot;
+    if (pt_next) {  // push the point on its root voxel's list for this update; the first point to arrive registers the voxel as touched
+        const unsigned long long mine = ((unsigned long long)(unsigned int)m.upd_seq << 32) | (unsigned int)i;
+        const unsigned long long old = atomicExch(&m.slot_head[slot], mine);
+        if ((unsigned int)(old >> 32) != (unsigned int)m.upd_seq) { pt_next[i] = -1; m.touched[atomicAdd(&m.counters[7], 1)] = (uint32_t)slot; }
+        else pt_next[i] = (int)(unsigned int)(old & 0xFFFFFFFFull);
+    }
 }
 
 // segment heads of the slot-sorted point list
@@ -364,20 +420,20 @@ __device__ bool wave_init_plane(const RegMapDev& m, int nd, int n, const WaveCtx
             double v = 0;
 #pragma unroll
             for (int k = 0; k < 21; k++) if (w.lane == k) v = pv[k];
-            m.p_var[(size_t)nd * 21 + w.lane] = v;
+            m.nodes[nd].p_var[w.lane] = v;
         }
         if (w.lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { m.p_center[(size_t)nd * 3 + k] = c[k]; m.p_normal[(size_t)nd * 3 + k] = Umin[k]; }
-            m.p_min_eig[nd] = (float)ev[imin];
-            m.p_radius[nd] = (float)sqrt(ev[imax]);
-            m.p_d[nd] = (float)(-(Umin[0] * c[0] + Umin[1] * c[1] + Umin[2] * c[2]));
+            for (int k = 0; k < 3; k++) { m.nodes[nd].p_center[k] = c[k]; m.nodes[nd].p_normal[k] = Umin[k]; }
+            m.nodes[nd].min_eig = (float)ev[imin];
+            m.nodes[nd].radius = (float)sqrt(ev[imax]);
+            m.nodes[nd].d = (float)(-(Umin[0] * c[0] + Umin[1] * c[1] + Umin[2] * c[2]));
         }
     } else if (w.lane == 0) {
         // reference zeroes centre/normal/plane_var before the test and leaves them zero when not planar; only the centre is observable (dump)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { m.p_center[(size_t)nd * 3 + k] = c[k]; m.p_normal[(size_t)nd * 3 + k] = 0.0; }
-        m.p_radius[nd] = 0.f;
+        for (int k = 0; k < 3; k++) { m.nodes[nd].p_center[k] = c[k]; m.nodes[nd].p_normal[k] = 0.0; }
+        m.nodes[nd].radius = 0.f;
     }
     return planar;
 }
@@ -403,14 +459,14 @@ IMD int octant_of(const double* q, const double* center) {  // strict > against 
 }
 // create child `oct` of `nd` (one lane) -- voxel_loc.cpp:184-190
 IMD int make_child(const RegMapDev& m, int nd, int oct) {
-    const float ql = m.n_quarter[nd];
+    const float ql = m.nodes[nd].quarter;
     const int xyz[3] = {(oct >> 2) & 1, (oct >> 1) & 1, oct & 1};
     double c[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = m.n_center[(size_t)nd * 3 + k] + (double)((float)(2 * xyz[k] - 1) * ql);
-    const int layer = m.n_layer[nd] + 1;
-    const int child = node_alloc(m, layer, c, ql / 2, m.n_key[nd], m.n_path[nd] | (oct << (3 * (layer - 1))));
-    m.n_child[(size_t)nd * 8 + oct] = child;
+    for (int k = 0; k < 3; k++) c[k] = m.nodes[nd].center[k] + (double)((float)(2 * xyz[k] - 1) * ql);
+    const int layer = m.nodes[nd].layer + 1;
+    const int child = node_alloc(m, layer, c, ql / 2, m.nodes[nd].key, m.nodes[nd].path | (oct << (3 * (layer - 1))));
+    m.nodes[nd].child[oct] = child;
     return child;
 }
 
@@ -424,21 +480,21 @@ __device__ void wave_init_octo_tree(const RegMapDev& m, int node, int* stack, co
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int nd = __shfl(stack[sp - 1], 0, 64);  // LDS read by every lane is fine too; shfl keeps it uniform
         sp--;
-        const int n = m.n_npts[nd];
+        const int n = m.nodes[nd].npts;
         const bool planar = wave_init_plane(m, nd, n, w);
-        const int layer = m.n_layer[nd];
+        const int layer = m.nodes[nd].layer;
         if (w.lane == 0) {
-            int f = m.n_flags[nd] | NF_INIT;
+            int f = m.nodes[nd].flags | NF_INIT;
             f = planar ? (f | NF_PLANE) : (f & ~NF_PLANE);
-            m.n_flags[nd] = f;
-            m.n_newpts[nd] = 0;
+            m.nodes[nd].flags = f;
+            m.nodes[nd].newpts = 0;
         }
         if (planar || layer >= m.max_layer) continue;
         // ---- cut_octo_tree: distribute the retained points to the 8 octants, order-preserving
-        const double ctr[3] = {m.n_center[(size_t)nd * 3 + 0], m.n_center[(size_t)nd * 3 + 1], m.n_center[(size_t)nd * 3 + 2]};
+        const double ctr[3] = {m.nodes[nd].center[0], m.nodes[nd].center[1], m.nodes[nd].center[2]};
         int child_id[8], child_n[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) { child_id[k] = m.n_child[(size_t)nd * 8 + k]; child_n[k] = child_id[k] >= 0 ? m.n_npts[child_id[k]] : 0; }
+        for (int k = 0; k < 8; k++) { child_id[k] = m.nodes[nd].child[k]; child_n[k] = child_id[k] >= 0 ? m.nodes[child_id[k]].npts : 0; }
         for (int base = 0; base < n; base += 64) {
             const int i = base + w.lane;
             const double* q = (i < n) ? node_point_ptr(m, nd, i) : nullptr;
@@ -474,7 +530,7 @@ __device__ void wave_init_octo_tree(const RegMapDev& m, int node, int* stack, co
         if (w.lane == 0) {
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                if (child_id[k] >= 0) { m.n_npts[child_id[k]] = child_n[k]; m.n_newpts[child_id[k]] = child_n[k]; }
+                if (child_id[k] >= 0) { m.nodes[child_id[k]].npts = child_n[k]; m.nodes[child_id[k]].newpts = child_n[k]; }
             node_free_points(m, nd);  // the parent's buffer is never read again (UpdateOctoTree drops it on the next visit, voxel_loc.cpp:263-266)
         }
         // children that exceed their init size are fitted next (depth-first like the reference; order does not affect results)
@@ -493,12 +549,12 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
     int nd = root;
     for (int depth = 0; depth < 8; depth++) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int flags = m.n_flags[nd];
-        const int layer = m.n_layer[nd];
-        const int n = m.n_npts[nd];
+        const int flags = m.nodes[nd].flags;
+        const int layer = m.nodes[nd].layer;
+        const int n = m.nodes[nd].npts;
         if (!(flags & NF_INIT)) {
             if (!wave_push_point(m, nd, n, src, w)) return;
-            if (w.lane == 0) { m.n_npts[nd] = n + 1; m.n_newpts[nd] = m.n_newpts[nd] + 1; }
+            if (w.lane == 0) { m.nodes[nd].npts = n + 1; m.nodes[nd].newpts = m.nodes[nd].newpts + 1; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (n + 1 > m.init_size[min(layer, 4)]) wave_init_octo_tree(m, nd, stack, w);
             return;
@@ -506,20 +562,20 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
         if (flags & NF_PLANE) {
             if (!(flags & NF_UPDATE_EN)) return;
             if (!wave_push_point(m, nd, n, src, w)) return;
-            int newp = m.n_newpts[nd] + 1;
-            if (w.lane == 0) m.n_npts[nd] = n + 1;
+            int newp = m.nodes[nd].newpts + 1;
+            if (w.lane == 0) m.nodes[nd].npts = n + 1;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (newp > 5) {  // m_update_size_threshold_
                 const bool planar = wave_init_plane(m, nd, n + 1, w);
-                if (w.lane == 0) m.n_flags[nd] = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+                if (w.lane == 0) m.nodes[nd].flags = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
                 newp = 0;
             }
             if (w.lane == 0) {
-                m.n_newpts[nd] = newp;
+                m.nodes[nd].newpts = newp;
                 if (n + 1 >= m.max_points_size) {
-                    m.n_flags[nd] = m.n_flags[nd] & ~NF_UPDATE_EN;
+                    m.nodes[nd].flags = m.nodes[nd].flags & ~NF_UPDATE_EN;
                     node_free_points(m, nd);
-                    m.n_newpts[nd] = 0;
+                    m.nodes[nd].newpts = 0;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -529,9 +585,9 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
             int child;
             if (w.lane == 0) {
                 if (n != 0) node_free_points(m, nd);
-                const double ctr[3] = {m.n_center[(size_t)nd * 3 + 0], m.n_center[(size_t)nd * 3 + 1], m.n_center[(size_t)nd * 3 + 2]};
+                const double ctr[3] = {m.nodes[nd].center[0], m.nodes[nd].center[1], m.nodes[nd].center[2]};
                 const int oct = octant_of(src, ctr);
-                child = m.n_child[(size_t)nd * 8 + oct];
+                child = m.nodes[nd].child[oct];
                 if (child < 0) child = make_child(m, nd, oct);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -543,17 +599,17 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
         // non-planar node at the last layer (voxel_loc.cpp:289-305)
         if (!(flags & NF_UPDATE_EN)) return;
         if (!wave_push_point(m, nd, n, src, w)) return;
-        int newp = m.n_newpts[nd] + 1;
-        if (w.lane == 0) m.n_npts[nd] = n + 1;
+        int newp = m.nodes[nd].newpts + 1;
+        if (w.lane == 0) m.nodes[nd].npts = n + 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (newp > 5) {
             const bool planar = wave_init_plane(m, nd, n + 1, w);
-            if (w.lane == 0) m.n_flags[nd] = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+            if (w.lane == 0) m.nodes[nd].flags = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
             newp = 0;
         }
         if (w.lane == 0) {
-            m.n_newpts[nd] = newp;
-            if (n + 1 > IM_G_MAX_POINTS) { m.n_flags[nd] = m.n_flags[nd] & ~NF_UPDATE_EN; node_free_points(m, nd); }
+            m.nodes[nd].newpts = newp;
+            if (n + 1 > IM_G_MAX_POINTS) { m.nodes[nd].flags = m.nodes[nd].flags & ~NF_UPDATE_EN; node_free_points(m, nd); }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         return;
@@ -571,21 +627,59 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
     const int start = seg_start[seg];
     const uint32_t slot = sorted_slot[start];
-    const int root = m.hvals[slot];
+    const int root = m.htab[slot].root;
     if (root < 0) return;
     if (mode == 0) {
         for (int j = start; j < n && sorted_slot[j] == slot; j++)
             wave_update_point(m, root, pt_data + (size_t)sorted_idx[j] * IM_PT_DOUBLES, stacks[wv], w);
     } else {
-        int cnt = m.n_npts[root];
+        int cnt = m.nodes[root].npts;
         for (int j = start; j < n && sorted_slot[j] == slot; j++) {
             if (!wave_push_point(m, root, cnt, pt_data + (size_t)sorted_idx[j] * IM_PT_DOUBLES, w)) return;
             cnt++;
         }
-        if (w.lane == 0) { m.n_npts[root] = cnt; m.n_newpts[root] = cnt; }
+        if (w.lane == 0) { m.nodes[root].npts = cnt; m.nodes[root].newpts = cnt; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (cnt > m.init_size[0]) wave_init_octo_tree(m, root, stacks[wv], w);
     }
+}
+
+// updateVoxelMap without any global sort: one wavefront per touched root voxel gathers that voxel's points of this scan from its
+// list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them.
+#define RL_CAP 512   /* points of one scan falling into one root voxel */
+__global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
+                                                           const double* __restrict__ pt_data, int64_t* stats) {
+    __shared__ unsigned long long skey[4][RL_CAP];
+    __shared__ int sidx[4][RL_CAP];
+    __shared__ int order[4][RL_CAP];
+    __shared__ int stacks[4][48];
+    const int wv = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= m.counters[7]) return;
+    WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
+    const uint32_t slot = m.touched[t];
+    const int root = m.htab[slot].root;
+    if (root < 0) return;
+    int cnt = 0;
+    for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
+        if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
+        cnt++;
+    }
+    if (cnt > RL_CAP) { m.counters[5] = 6; return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int e = w.lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique
+        const unsigned long long k = skey[wv][e];
+        const int id = sidx[wv][e];
+        int rank = 0;
+        for (int f = 0; f < cnt; f++) { const unsigned long long kf = skey[wv][f]; rank += (kf < k || (kf == k && sidx[wv][f] < id)) ? 1 : 0; }
+        order[wv][rank] = id;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int j = 0; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
 }
 
 // merge chunk ids freed by the previous kernel into the ready stack
@@ -594,7 +688,7 @@ __global__ void merge_free_kernel(RegMapDev m) {
     const int base = m.counters[2];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) m.free_ready[base + i] = m.free_pending[i];
 }
-__global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; }
+__global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; m.counters[7] = 0; }
 
 // =====================================================================================================================
 // introspection
@@ -602,21 +696,21 @@ __global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.count
 __global__ void dump_planes_kernel(RegMapDev m, PlaneRecDev* out, long long cap, unsigned long long* count) {
     const int nn = m.counters[0];
     for (int nd = blockIdx.x * blockDim.x + threadIdx.x; nd < nn; nd += gridDim.x * blockDim.x) {
-        const int f = m.n_flags[nd];
+        const int f = m.nodes[nd].flags;
         if (!(f & NF_INIT)) continue;
         const unsigned long long idx = atomicAdd(count, 1ull);
         if ((long long)idx >= cap || out == nullptr) continue;
         PlaneRecDev& r = out[idx];
-        const unsigned long long pk = m.n_key[nd];
+        const unsigned long long pk = m.nodes[nd].key;
         r.key[0] = (long long)(pk & IM_KEY_MASK) - IM_KEY_BIAS;
         r.key[1] = (long long)((pk >> 21) & IM_KEY_MASK) - IM_KEY_BIAS;
         r.key[2] = (long long)((pk >> 42) & IM_KEY_MASK) - IM_KEY_BIAS;
-        r.layer = m.n_layer[nd]; r.path = m.n_path[nd]; r.is_plane = (f & NF_PLANE) ? 1 : 0; r.n_points = m.n_npts[nd];
-        r.update_enable = (f & NF_UPDATE_EN) ? 1 : 0; r.new_points = m.n_newpts[nd];
-        r.radius = m.p_radius[nd]; r.min_eig = m.p_min_eig[nd]; r.d = m.p_d[nd]; r.pad = 0;
-        for (int k = 0; k < 3; k++) { r.center[k] = m.p_center[(size_t)nd * 3 + k]; r.normal[k] = m.p_normal[(size_t)nd * 3 + k]; }
+        r.layer = m.nodes[nd].layer; r.path = m.nodes[nd].path; r.is_plane = (f & NF_PLANE) ? 1 : 0; r.n_points = m.nodes[nd].npts;
+        r.update_enable = (f & NF_UPDATE_EN) ? 1 : 0; r.new_points = m.nodes[nd].newpts;
+        r.radius = m.nodes[nd].radius; r.min_eig = m.nodes[nd].min_eig; r.d = m.nodes[nd].d; r.pad = 0;
+        for (int k = 0; k < 3; k++) { r.center[k] = m.nodes[nd].p_center[k]; r.normal[k] = m.nodes[nd].p_normal[k]; }
         for (int a = 0; a < 6; a++)
-            for (int b = 0; b < 6; b++) r.plane_var[a * 6 + b] = (f & NF_PLANE) ? m.p_var[(size_t)nd * 21 + (a <= b ? sym21_index(a, b) : sym21_index(b, a))] : 0.0;
+            for (int b = 0; b < 6; b++) r.plane_var[a * 6 + b] = (f & NF_PLANE) ? m.nodes[nd].p_var[(a <= b ? sym21_index(a, b) : sym21_index(b, a))] : 0.0;
     }
 }
 
@@ -635,15 +729,20 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_
 // compact the matched points in ascending scan order is done on the host from o_match (tiny); see reg_host.cpp
 
 // ---- launchers (called from the host layer) -------------------------------------------------------------------------
-void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, double* out48,
-                     int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
-    const int nb = (n + 255) / 256;
-    KLAUNCH(residual_kernel, dim3(nb), dim3(256), 0, s, m, sp, pts, n, partials, o_match, o_node, o_dis, o_rinv, o_normal);
-    KLAUNCH(residual_reduce_kernel, dim3(1), dim3(64), 0, s, partials, nb, out48);
+void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
+                     double* out48, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+    const int nb = (n + 63) / 64;
+    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, sp, pts, n, partials, done_counter, out48, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
-                      unsigned long long* sort_key, uint32_t* slot) {
-    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot);
+                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next) {
+    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
+}
+void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
+                         int64_t* stats) {
+    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats);
+    KLAUNCH(merge_free_kernel, dim3(64), dim3(256), 0, s, m);
+    KLAUNCH(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
     hipMemsetAsync(nseg, 0, sizeof(int32_t), s);

@@ -1,8 +1,8 @@
 // HBM-resident registration map: what the reference keeps as std::unordered_map<VOXEL_LOC, OctoTree*> + heap OctoTree /
 // Plane objects (src/voxel_loc.hpp:89-177) laid out for the GPU:
-//   * open-addressing hash  packed 3x21-bit key -> slot ; slot -> root node id      (one 8-byte probe per lookup)
-//   * flat octree node pool, SoA                                                     (children[8], centre, flags, counts)
-//   * plane table, SoA, indexed by node id                                           (centre, normal, d/radius, 21-entry symmetric plane_var)
+//   * open-addressing hash  packed 3x21-bit key -> {key, root node id}                (one 16-byte probe per lookup)
+//   * flat pool of 384-byte octree-node records (children, flags, plane scalars, centres, normal, 21-entry symmetric plane_var):
+//     a plane test is one dependent gather of adjacent cache lines, not a pointer chase through hash -> OctoTree -> Plane
 //   * retained points (OctoTree::m_temp_points_) in 16-point chunks of a shared pool (xyz + symmetric 3x3 covariance = 9 doubles/pt)
 // All of it lives in one context and never leaves the device between scans.
 #pragma once
@@ -19,37 +19,42 @@
 #define NF_PLANE 2         /* m_plane_ptr_->m_is_plane */
 #define NF_UPDATE_EN 4     /* m_update_enable_ */
 
+// One octree node = one 384-byte record (6 cache lines): a point-to-plane test reads the topology / gate scalars (line 0), the
+// centres + normal (lines 1-2) and the symmetric plane covariance (lines 2-4) with ONE dependent gather instead of a dozen.
+struct alignas(64) NodeRec {
+    int32_t child[8];                      // m_leaves_ (-1 = none)
+    int32_t flags, layer, npts, newpts;    // NF_* bits, m_layer_, m_temp_points_.size(), m_new_points_
+    float quarter, d, radius, min_eig;     // m_quater_length_; Plane::m_d, m_radius, m_min_eigen_value
+    double center[3];                      // m_voxel_center_
+    double p_center[3];                    // Plane::m_center
+    double p_normal[3];                    // Plane::m_normal
+    double p_var[21];                      // upper triangle of the 6x6 Plane::m_plane_var, row-major
+    int32_t chunks[IM_INLINE_CHUNKS];      // chunk ids of the retained points (-1 = none)
+    int32_t ext, path;                     // extension table id or -1; child path from the root (3 bits per level)
+    unsigned long long key;                // packed root key (for dumps)
+    unsigned long long pad[4];
+};
+static_assert(sizeof(NodeRec) == 384, "NodeRec layout");
+
+struct HashEnt { unsigned long long key; int32_t root; int32_t pad; };  // one 16-byte probe yields key and root node
+
 struct RegMapDev {
-    // hash
-    unsigned long long* hkeys;  // [hcap]
-    int32_t* hvals;             // [hcap] root node id
+    // hash: open addressing, packed 3x21-bit VOXEL_LOC key -> root node id
+    HashEnt* htab;              // [hcap]
     uint64_t hmask;
     // node pool
-    int32_t* n_child;           // [cap_nodes*8]
-    double* n_center;           // [cap_nodes*3]  m_voxel_center_
-    float* n_quarter;           // m_quater_length_
-    int32_t* n_flags;
-    int32_t* n_layer;
-    int32_t* n_npts;            // m_temp_points_.size()
-    int32_t* n_newpts;          // m_new_points_
-    int32_t* n_chunks;          // [cap_nodes*IM_INLINE_CHUNKS] chunk ids (-1 = none)
-    int32_t* n_ext;             // extension table id or -1
-    unsigned long long* n_key;  // packed root key (for dumps)
-    int32_t* n_path;            // child path from the root, 3 bits per level
-    // plane table
-    double* p_center;           // [cap_nodes*3]
-    double* p_normal;           // [cap_nodes*3]
-    float* p_d;                 // Plane::m_d
-    float* p_radius;            // Plane::m_radius
-    float* p_min_eig;
-    double* p_var;              // [cap_nodes*21] upper triangle of the 6x6 plane covariance, row-major
+    NodeRec* nodes;             // [cap_nodes]
     // pools
     double* chunk_data;         // [cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES]
     int32_t* ext_tables;        // [cap_ext * IM_EXT_CHUNKS]
-    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels
+    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels [7] touched slots of the current update
     int32_t* counters;
     int32_t* free_ready;        // chunk ids available for allocation
     int32_t* free_pending;      // chunk ids freed by the running kernel (merged into ready afterwards)
+    // per-update root-voxel point lists (map_incremental_grow): head word per hash slot = (update seq << 32 | last point index), stamped so it never needs clearing
+    unsigned long long* slot_head;  // [hcap]
+    uint32_t* touched;          // hash slots touched by the current update (counters[7] entries)
+    int32_t upd_seq;
     int32_t cap_nodes, cap_chunks, cap_ext;
     // parameters
     int32_t max_layer, max_points_size, init_size[5];
@@ -68,7 +73,7 @@ IMD int sym21_index(int r, int c) {  // r <= c, 6x6 upper triangle row-major
 IMD int64_t hash_find(const RegMapDev& m, uint64_t key) {  // returns slot or -1
     uint64_t h = hash64(key) & m.hmask;
     for (int probe = 0; probe < 4096; probe++) {
-        const unsigned long long k = m.hkeys[h];
+        const unsigned long long k = m.htab[h].key;
         if (k == key) return (int64_t)h;
         if (k == IM_KEY_EMPTY) return -1;
         h = (h + 1) & m.hmask;
@@ -80,10 +85,10 @@ IMD int64_t hash_find_or_insert(const RegMapDev& m, uint64_t key, bool* created)
     uint64_t h = hash64(key) & m.hmask;
     *created = false;
     for (int probe = 0; probe < 4096; probe++) {
-        unsigned long long k = m.hkeys[h];
+        unsigned long long k = m.htab[h].key;
         if (k == key) return (int64_t)h;
         if (k == IM_KEY_EMPTY) {
-            const unsigned long long prev = atomicCAS(&m.hkeys[h], (unsigned long long)IM_KEY_EMPTY, (unsigned long long)key);
+            const unsigned long long prev = atomicCAS(&m.htab[h].key, (unsigned long long)IM_KEY_EMPTY, (unsigned long long)key);
             if (prev == IM_KEY_EMPTY) { *created = true; return (int64_t)h; }
             if (prev == key) return (int64_t)h;
         }
@@ -107,8 +112,8 @@ IMD void free_chunk(const RegMapDev& m, int c) {
     m.free_pending[i] = c;
 }
 IMD int node_chunk_id(const RegMapDev& m, int node, int ci) {
-    if (ci < IM_INLINE_CHUNKS) return m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
-    const int e = m.n_ext[node];
+    if (ci < IM_INLINE_CHUNKS) return m.nodes[node].chunks[ci];
+    const int e = m.nodes[node].ext;
     return m.ext_tables[(size_t)e * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
 }
 IMD double* node_point_ptr(const RegMapDev& m, int node, int i) {
@@ -118,52 +123,53 @@ IMD double* node_point_ptr(const RegMapDev& m, int node, int i) {
 // make sure chunk slot `ci` of `node` exists (called by one lane)
 IMD bool node_ensure_chunk(const RegMapDev& m, int node, int ci) {
     if (ci < IM_INLINE_CHUNKS) {
-        int* slot = &m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
+        int* slot = &m.nodes[node].chunks[ci];
         if (*slot < 0) { const int c = alloc_chunk(m); if (c < 0) return false; *slot = c; }
         return true;
     }
     if (ci - IM_INLINE_CHUNKS >= IM_EXT_CHUNKS) { m.counters[5] = 2; return false; }
-    if (m.n_ext[node] < 0) {
+    if (m.nodes[node].ext < 0) {
         const int e = atomicAdd(&m.counters[4], 1);
         if (e >= m.cap_ext) { m.counters[5] = 3; return false; }
         for (int k = 0; k < IM_EXT_CHUNKS; k++) m.ext_tables[(size_t)e * IM_EXT_CHUNKS + k] = -1;
-        m.n_ext[node] = e;
+        m.nodes[node].ext = e;
     }
-    int* slot = &m.ext_tables[(size_t)m.n_ext[node] * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
+    int* slot = &m.ext_tables[(size_t)m.nodes[node].ext * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
     if (*slot < 0) { const int c = alloc_chunk(m); if (c < 0) return false; *slot = c; }
     return true;
 }
 // release all retained points of a node (std::vector<Point_with_var>().swap(m_temp_points_)); one lane
 IMD void node_free_points(const RegMapDev& m, int node) {
-    const int n = m.n_npts[node];
+    const int n = m.nodes[node].npts;
     const int nch = (n + IM_CHUNK_PTS - 1) / IM_CHUNK_PTS;
     for (int ci = 0; ci < nch; ci++) {
         if (ci < IM_INLINE_CHUNKS) {
-            int* slot = &m.n_chunks[(size_t)node * IM_INLINE_CHUNKS + ci];
+            int* slot = &m.nodes[node].chunks[ci];
             free_chunk(m, *slot); *slot = -1;
         } else {
-            int* slot = &m.ext_tables[(size_t)m.n_ext[node] * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
+            int* slot = &m.ext_tables[(size_t)m.nodes[node].ext * IM_EXT_CHUNKS + (ci - IM_INLINE_CHUNKS)];
             free_chunk(m, *slot); *slot = -1;
         }
     }
-    m.n_npts[node] = 0;
+    m.nodes[node].npts = 0;
 }
 
 // allocate + initialise a node (one lane).  centre/quarter/layer as OctoTree ctor + caller-provided geometry.
 IMD int node_alloc(const RegMapDev& m, int layer, const double* center, float quarter, unsigned long long key, int path) {
     const int id = atomicAdd(&m.counters[0], 1);
     if (id >= m.cap_nodes) { m.counters[5] = 4; return -1; }
+    NodeRec& nd = m.nodes[id];
 #pragma unroll
-    for (int k = 0; k < 8; k++) m.n_child[(size_t)id * 8 + k] = -1;
+    for (int k = 0; k < 8; k++) nd.child[k] = -1;
 #pragma unroll
-    for (int k = 0; k < IM_INLINE_CHUNKS; k++) m.n_chunks[(size_t)id * IM_INLINE_CHUNKS + k] = -1;
-    m.n_center[(size_t)id * 3 + 0] = center[0]; m.n_center[(size_t)id * 3 + 1] = center[1]; m.n_center[(size_t)id * 3 + 2] = center[2];
-    m.n_quarter[id] = quarter;
-    m.n_flags[id] = NF_UPDATE_EN;
-    m.n_layer[id] = layer;
-    m.n_npts[id] = 0; m.n_newpts[id] = 0; m.n_ext[id] = -1;
-    m.n_key[id] = key; m.n_path[id] = path;
-    m.p_d[id] = 0.f; m.p_radius[id] = 0.f; m.p_min_eig[id] = 1.f;
+    for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = -1;
+    nd.center[0] = center[0]; nd.center[1] = center[1]; nd.center[2] = center[2];
+    nd.quarter = quarter;
+    nd.flags = NF_UPDATE_EN;
+    nd.layer = layer;
+    nd.npts = 0; nd.newpts = 0; nd.ext = -1;
+    nd.key = key; nd.path = path;
+    nd.d = 0.f; nd.radius = 0.f; nd.min_eig = 1.f;
     return id;
 }
 
