@@ -196,6 +196,10 @@ class HotPath:
         self._check(f(self.ctx, _ptr(pts_world_xyzi), n, _ptr(np.ascontiguousarray(sensor_pos, dtype=np.float64)), frame_idx), "mesh_scan")
         return self.mesh_fetch() if fetch else None
 
+    def mesh_wait(self):
+        f = self._f("mesh_wait"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx), "mesh_wait")
+
     def mesh_fetch(self):
         fs = self._f("mesh_sizes"); fs.argtypes = [C.c_void_p, C.POINTER(MeshSizes)]; fs.restype = C.c_int
         s = MeshSizes()
@@ -218,7 +222,7 @@ class HotPath:
         out = np.array(state, dtype=np.float64, copy=True)
         n_iter, n_match = C.c_int32(0), C.c_int32(0)
         self._check(f(self.ctx, _ptr(pts_down), n_ds, _ptr(pts_raw_xyzi), n_raw, _ptr(np.ascontiguousarray(state_prior, dtype=np.float64)),
-                      _ptr(out), frame_idx, 1 if do_mesh else 0, C.byref(n_iter), C.byref(n_match)), "process_scan")
+                      _ptr(out), frame_idx, int(do_mesh), C.byref(n_iter), C.byref(n_match)), "process_scan")
         return out, {"n_iter": n_iter.value, "n_match": n_match.value}
 
     def last_timing(self):

@@ -59,7 +59,7 @@ static int alloc_all(immesh_ctx* c) {
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
     c->cap_scan = ns;
-    A(c->d_pts_down, ns * 3); A(c->d_pts_raw, ns * 4); A(c->d_pts_world, ns * 4);
+    A(c->d_pts_down, ns * 3); A(c->d_pts_raw, ns * 4);
     A(c->d_partials, ((ns + 63) / 64) * RES_NR_HOST); A(c->d_out48, RES_NV_HOST); A(c->d_done, 4);
     HIPCHK(c, hipMemsetAsync(c->d_done, 0, 16, c->stream));
     A(c->d_match, ns); A(c->d_mnode, ns); A(c->d_dis, ns); A(c->d_rinv, ns); A(c->d_normal, ns * 3);
@@ -328,16 +328,21 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     hipEventRecord(c->ev[1], c->stream);
     if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0))) return rc;
     hipEventRecord(c->ev[2], c->stream);
+    long job = 0;
     if (do_mesh) {
-        if ((rc = mesh_transform_full(c, (const float*)d_raw, n_raw, st))) return rc;
-        if ((rc = mesh_scan_device(c, c->d_pts_world, n_raw, st.t, frame_idx))) return rc;
+        // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own stream + worker thread), as
+        // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417)
+        float* world = mesh_next_world_buffer(c);
+        if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
+        job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
     hipEventRecord(c->ev[3], c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->timing[0], c->ev[0], c->ev[3]);
     hipEventElapsedTime(&c->timing[1], c->ev[0], c->ev[1]);
     hipEventElapsedTime(&c->timing[2], c->ev[1], c->ev[2]);
-    hipEventElapsedTime(&c->timing[3], c->ev[2], c->ev[3]);
+    c->timing[3] = 0.f;
+    if (do_mesh == 1 && (rc = mesh_wait(c, job))) { imh::store_state(st, state_inout); return rc; }   // synchronous mode: results are current on return
+    c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
     imh::store_state(st, state_inout);
     if (n_iter_out) *n_iter_out = n_iter;
     if (n_match_out) *n_match_out = n_match;
@@ -391,7 +396,9 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
 
 int immesh_profile_enable(immesh_ctx* c, int32_t on) {
     if (!c) return IMMESH_E_INVAL;
+    mesh_wait_all(c);
     c->prof.on = on != 0;
+    c->mesh_host.prof.on = on != 0;
     return 0;
 }
 
@@ -399,15 +406,20 @@ int immesh_profile_read(immesh_ctx* c, immesh_kernel_stat* out, int32_t cap, int
     if (!c || !n_out) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
     if (c->stream) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->prof.flush(); }
-    const int n = (int)c->prof.names.size();
+    mesh_wait_all(c);   // the mesher's worker thread keeps its own table (flushed by the worker after every job)
+    std::vector<std::string> names = c->prof.names;
+    std::vector<double> ms = c->prof.ms;
+    std::vector<long long> cnt = c->prof.cnt;
+    for (size_t k = 0; k < c->mesh_host.prof.names.size(); k++) { names.push_back(c->mesh_host.prof.names[k]); ms.push_back(c->mesh_host.prof.ms[k]); cnt.push_back(c->mesh_host.prof.cnt[k]); }
+    const int n = (int)names.size();
     for (int i = 0; i < n && i < cap && out; i++) {
         std::memset(&out[i], 0, sizeof(out[i]));
-        std::strncpy(out[i].name, c->prof.names[i].c_str(), sizeof(out[i].name) - 1);
-        out[i].launches = c->prof.cnt[i];
-        out[i].total_ms = c->prof.ms[i];
+        std::strncpy(out[i].name, names[i].c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = cnt[i];
+        out[i].total_ms = ms[i];
     }
     *n_out = n;
-    if (reset) c->prof.reset();
+    if (reset) { c->prof.reset(); c->mesh_host.prof.reset(); }
     return 0;
 }
 

@@ -43,7 +43,6 @@ struct immesh_ctx {
     int64_t cap_scan = 0;
     float* d_pts_down = nullptr;     // staging for host inputs (n x 3)
     float* d_pts_raw = nullptr;      // staging (n x 4)
-    float* d_pts_world = nullptr;    // world_lidar_full (n x 4)
     double* d_partials = nullptr;    // residual block partials
     double* d_out48 = nullptr;
     double* h_out48 = nullptr;       // pinned, device-mapped
@@ -110,7 +109,10 @@ struct ProfBind {  // binds the ctx profiler to the calling thread for the durat
 // mesher host orchestration (mesh_host.cpp)
 int mesh_alloc(immesh_ctx* c);
 void mesh_free(immesh_ctx* c);
-int mesh_scan_device(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);
-int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, int n_raw, const imh::State& st);
+long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);
+float* mesh_next_world_buffer(immesh_ctx* c);
+int mesh_wait(immesh_ctx* c, long id);
+void mesh_wait_all(immesh_ctx* c);
+int mesh_transform_full(immesh_ctx* c, const float* d_pts_raw_xyzi, float* d_world, int n_raw, const imh::State& st);
 void mesh_counters(immesh_ctx* c, immesh_counters_t* out);
 void mesh_counters_reset(immesh_ctx* c);

@@ -7,13 +7,24 @@
 
 static int64_t np2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
+// worker-thread flavour of HIPCHK: the error text goes to MeshHost::err (the caller thread owns immesh_ctx::err)
+#define MHIPCHK(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) {                                                                             \
+            (ctx)->mesh_host.err = std::string(#expr) + ": " + hipGetErrorString(_e);                       \
+            return IMMESH_E_HIP;                                                                            \
+        }                                                                                                   \
+    } while (0)
+
+static void mesh_worker_main(immesh_ctx* c);
+
 int mesh_alloc(immesh_ctx* c) {
     const immesh_config& g = c->cfg;
     MeshDev& m = c->mesh;
     MeshHost& h = c->mesh_host;
     std::memset(&m, 0, sizeof(m));
     std::memset(h.cum, 0, sizeof(h.cum));
-    std::memset(&h.sizes, 0, sizeof(h.sizes));
     if (g.mesh_min_spacing <= 0 || g.mesh_voxel <= 0 || g.mesh_append_budget <= 0) { c->err = "invalid meshing parameters"; return IMMESH_E_INVAL; }
     {   // every dedupe cell holds at most one vertex, so a mesh voxel holds at most (cells per axis)^3
         const int per_axis = (int)(g.mesh_voxel / g.mesh_min_spacing) + 1;
@@ -46,8 +57,12 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active);
     A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
     A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
-    A(m.out_tri_add, cap_list * 3); A(m.out_flip_add, cap_list); A(m.out_tri_rem, cap_list * 3); A(m.out_tri_upd, cap_list * 3); A(m.out_flip_upd, cap_list);
-    A(m.out_smooth_ids, cap_list); A(m.out_smooth_xyz, cap_list * 3);
+    for (int k = 0; k < 2; k++) {
+        MeshOutSet& o = h.outs[k];
+        A(o.tri_add, cap_list * 3); A(o.flip_add, cap_list); A(o.tri_rem, cap_list * 3); A(o.tri_upd, cap_list * 3); A(o.flip_upd, cap_list);
+        A(o.smooth_ids, cap_list); A(o.smooth_xyz, cap_list * 3);
+        A(h.d_world[k], cap_cand * 4);
+    }
     A(h.k32_a, cap_list); A(h.k32_b, cap_list); A(h.k64_a, cap_list); A(h.k64_b, cap_list); A(h.p_a, cap_list); A(h.p_b, cap_list); A(h.p_c, cap_list);
     h.sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)cap_list), sort_pairs_u32_temp_bytes((int)cap_list), exclusive_sum_temp_bytes((int)cap_cand)}) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
@@ -66,12 +81,28 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&h.h_sc, SC_COUNT * 4));
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_sc, 0, SC_COUNT * 4); std::memset(h.h_pc, 0, PC_COUNT * 4);
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreate(&h.ev_t0)); HIPCHK(c, hipEventCreate(&h.ev_t1));
+    std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
+    h.stop = false;
+    h.worker = std::thread(mesh_worker_main, c);
     h.ready = true;
     return 0;
 }
 
 void mesh_free(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
+    if (h.worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(h.mu); h.stop = true; }
+        h.cv_job.notify_all();
+        h.worker.join();
+    }
+    if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); h.stream = nullptr; }
+    for (int k = 0; k < 2; k++) if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
+    if (h.ev_t0) (void)hipEventDestroy(h.ev_t0);
+    if (h.ev_t1) (void)hipEventDestroy(h.ev_t1);
     if (h.h_sc) (void)hipHostFree(h.h_sc);
     if (h.h_pc) (void)hipHostFree(h.h_pc);
     h.h_sc = h.h_pc = nullptr;
@@ -84,26 +115,33 @@ static int mesh_overflow(immesh_ctx* c) {
                                 "mesh voxel lookup failed", "dedupe grid hash full", "mesh voxel holds more than 128 vertices", "more active voxels than cap (131072 per scan)",
                                 "voxel neighbourhood above 1024 vertices", "triangle pool exhausted (cap_triangles)", "triangle hash full", "Delaunay cavity / triangle buffer overflow",
                                 "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries"};
-    c->err = std::string("mesh map capacity: ") + why[(f > 0 && f < 15) ? f : 0];
+    c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 15) ? f : 0];
     return IMMESH_E_CAPACITY;
 }
 
 // sort a list of triangle indices lexicographically by (v0, v1, v2): LSD with two stable radix passes; result in h.p_c
 static void sort_tris(immesh_ctx* c, const int32_t* list, int n) {
     MeshHost& h = c->mesh_host;
-    hipStream_t s = c->stream;
+    hipStream_t s = h.stream;
     launch_mesh_tri_keys(s, c->mesh, list, n, 0, h.k32_a, nullptr);
     sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, h.k32_a, h.k32_b, list, h.p_b, n, 32);
     launch_mesh_tri_keys(s, c->mesh, h.p_b, n, 1, nullptr, h.k64_a);
     sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, h.k64_a, h.k64_b, h.p_b, h.p_c, n);
 }
 
-int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx) {
-    (void)frame_idx;
+// runs on the worker thread, on the mesher's stream
+static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t& sizes) {
     MeshDev& m = c->mesh;
     MeshHost& h = c->mesh_host;
-    hipStream_t s = c->stream;
-    if (!h.ready) { c->err = "mesher not initialised"; return IMMESH_E_INVAL; }
+    hipStream_t s = h.stream;
+    const float* d_pts = job.d_pts;
+    const int n_raw = job.n_raw;
+    const double* sensor_pos = job.cam;
+    {   // this job's result lists
+        const MeshOutSet& o = h.outs[job.id & 1];
+        m.out_tri_add = o.tri_add; m.out_flip_add = o.flip_add; m.out_tri_rem = o.tri_rem; m.out_tri_upd = o.tri_upd; m.out_flip_upd = o.flip_upd;
+        m.out_smooth_ids = o.smooth_ids; m.out_smooth_xyz = o.smooth_xyz;
+    }
     h.seq++;
     m.seq = h.seq;
     MeshScanParams sp;
@@ -112,33 +150,33 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
     sp.step = std::max(1, (int)std::round((double)(n_raw / c->cfg.mesh_append_budget)));  // integer division first (ImMesh_mesh_reconstruction.cpp:111)
     sp.n_cand = (n_raw + sp.step - 1) / sp.step;
     sp.vtx_base = h.n_vertices;
-    if (sp.n_cand > m.cap_cand) { c->err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
+    if (sp.n_cand > m.cap_cand) { h.err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
     const int64_t ccap = np2((int64_t)sp.n_cand * 4);
     m.ch_mask = (uint64_t)ccap - 1;
-    HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-    HIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
-    HIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
+    MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+    MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
+    MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
     // ---- a17 append
     launch_mesh_append_prepare(s, m, sp, d_pts);
     for (int round = 0; round < 1000; round++) {
-        if (round > 0) HIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
+        if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
         launch_mesh_append_resolve(s, m, sp, d_pts);
-        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
         if (h.h_sc[SC_UNDECIDED] == 0) break;
     }
     launch_mesh_append_flags(s, m, sp.n_cand);
     exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
     launch_mesh_append_commit(s, m, sp, d_pts);
     launch_mesh_select_active(s, m, sp.n_cand);
-    HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(h.h_pc, m.pc, PC_COUNT * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipMemcpyAsync(h.h_pc, m.pc, PC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipStreamSynchronize(s));
     int rc = mesh_overflow(c);
     if (rc) return rc;
     const int n_new = h.h_sc[SC_ACCEPTED], n_active = h.h_sc[SC_ACTIVE];
-    h.sizes.vtx_base = sp.vtx_base; h.sizes.n_new_vtx = n_new; h.sizes.n_voxels_meshed = n_active;
-    h.sizes.n_add = h.sizes.n_rem = h.sizes.n_upd = h.sizes.n_smooth = 0; h.sizes.reserved = 0;
+    sizes.vtx_base = sp.vtx_base; sizes.n_new_vtx = n_new; sizes.n_voxels_meshed = n_active;
+    sizes.n_add = sizes.n_rem = sizes.n_upd = sizes.n_smooth = 0; sizes.reserved = 0;
     h.n_vertices = sp.vtx_base + n_new;
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
     h.cum[SC_RECENT] += sp.n_cand;  // n_app: candidates offered
@@ -154,8 +192,8 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
         launch_mesh_knn(s, m, n_active);                // a18-a19
         launch_mesh_delaunay(s, m, sp, n_active);       // a20-a23
         launch_mesh_finalize(s, m, n_active);
-        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
         if ((rc = mesh_overflow(c))) return rc;
         const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
         // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
@@ -177,10 +215,10 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
             sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, (const uint32_t*)m.list_smooth, h.k32_b, m.list_smooth, h.p_b, n_smooth, 32);
             launch_mesh_emit_smooth(s, m, h.p_b, n_smooth);
         }
-        HIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
         if ((rc = mesh_overflow(c))) return rc;
-        h.sizes.n_add = n_add; h.sizes.n_rem = n_rem; h.sizes.n_upd = n_upd; h.sizes.n_smooth = n_smooth;
+        sizes.n_add = n_add; sizes.n_rem = n_rem; sizes.n_upd = n_upd; sizes.n_smooth = n_smooth;
         h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
         h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
         h.n_live += n_add - n_rem;
@@ -188,18 +226,105 @@ int mesh_scan_device(immesh_ctx* c, const float* d_pts, int n_raw, const double*
     return 0;
 }
 
-int mesh_transform_full(immesh_ctx* c, const float* d_raw, int n_raw, const imh::State& st) {
-    launch_mesh_transform(c->stream, d_raw, c->d_pts_world, n_raw, st.R, st.t, c->cfg.extR, c->cfg.extT);
+static void mesh_worker_main(immesh_ctx* c) {
+    MeshHost& h = c->mesh_host;
+    (void)hipSetDevice(c->cfg.device);
+    g_kprof = &h.prof;
+    for (;;) {
+        MeshJob job;
+        {
+            std::unique_lock<std::mutex> lk(h.mu);
+            h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
+            if (h.q.empty()) break;   // stop requested and nothing left to do
+            job = h.q.front(); h.q.pop_front();
+        }
+        MeshResult r;
+        r.id = job.id;
+        std::memset(&r.sizes, 0, sizeof(r.sizes));
+        h.err.clear();
+        hipError_t e = hipStreamWaitEvent(h.stream, job.ready, 0);   // the scan (transform / host copy) was produced on the registration stream
+        if (e == hipSuccess) e = hipEventRecord(h.ev_t0, h.stream);
+        if (e != hipSuccess) { r.rc = IMMESH_E_HIP; r.err = std::string("mesh job setup: ") + hipGetErrorString(e); }
+        else {
+            r.rc = mesh_scan_run(c, job, r.sizes);
+            (void)hipEventRecord(h.ev_t1, h.stream);
+            (void)hipStreamSynchronize(h.stream);
+            (void)hipEventElapsedTime(&r.ms, h.ev_t0, h.ev_t1);
+            if (r.rc) r.err = h.err;
+        }
+        if (h.prof.on) h.prof.flush();
+        {
+            std::lock_guard<std::mutex> lk(h.mu);
+            h.res[job.id & 1] = r;
+            h.completed = job.id;
+        }
+        h.cv_done.notify_all();
+    }
+    g_kprof = nullptr;
+}
+
+// Called on the scan thread.  d_pts = world-frame xyzI already (being) produced on c->stream; returns the job id.
+// At most two jobs are outstanding (their scans live in the two world buffers), so this blocks while job id-2 is still running.
+long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx) {
+    MeshHost& h = c->mesh_host;
+    MeshJob job;
+    {
+        std::unique_lock<std::mutex> lk(h.mu);
+        job.id = h.submitted + 1;
+    }
+    job.d_pts = d_pts; job.n_raw = n_raw; job.frame_idx = frame_idx;
+    job.cam[0] = sensor_pos[0]; job.cam[1] = sensor_pos[1]; job.cam[2] = sensor_pos[2];
+    job.ready = h.ev_ready[job.id & 1];
+    (void)hipEventRecord(job.ready, c->stream);
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        h.q.push_back(job);
+        h.submitted = job.id;
+    }
+    h.cv_job.notify_one();
+    return job.id;
+}
+// world buffer the NEXT job will use; blocks until the job that last used it (next id - 2) has finished
+float* mesh_next_world_buffer(immesh_ctx* c) {
+    MeshHost& h = c->mesh_host;
+    std::unique_lock<std::mutex> lk(h.mu);
+    const long next = h.submitted + 1;
+    h.cv_done.wait(lk, [&] { return h.completed >= next - 2; });
+    return h.d_world[next & 1];
+}
+// wait for job `id` (0 = the newest submitted) and make it the one immesh_mesh_sizes / fetch / last_timing report
+int mesh_wait(immesh_ctx* c, long id) {
+    MeshHost& h = c->mesh_host;
+    std::unique_lock<std::mutex> lk(h.mu);
+    if (id <= 0) id = h.submitted;
+    if (id <= 0) return 0;
+    if (id < h.submitted - 1) { c->err = "mesh job results already overwritten (only the two newest jobs are kept)"; return IMMESH_E_INVAL; }
+    h.cv_done.wait(lk, [&] { return h.completed >= id; });
+    h.current = id;
+    const MeshResult& r = h.res[id & 1];
+    c->timing[3] = r.ms;
+    if (r.rc) c->err = r.err;
+    return r.rc;
+}
+void mesh_wait_all(immesh_ctx* c) {
+    MeshHost& h = c->mesh_host;
+    std::unique_lock<std::mutex> lk(h.mu);
+    h.cv_done.wait(lk, [&] { return h.completed >= h.submitted; });
+}
+
+int mesh_transform_full(immesh_ctx* c, const float* d_raw, float* d_world, int n_raw, const imh::State& st) {
+    launch_mesh_transform(c->stream, d_raw, d_world, n_raw, st.R, st.t, c->cfg.extR, c->cfg.extT);
     return 0;
 }
 
 void mesh_counters(immesh_ctx* c, immesh_counters_t* out) {
+    mesh_wait_all(c);
     const MeshHost& h = c->mesh_host;
     out->n_app = h.cum[SC_RECENT]; out->n_new = h.cum[SC_ACCEPTED]; out->v_act = h.cum[SC_ACTIVE]; out->n_v = h.cum[SC_NV]; out->n_u = h.cum[SC_NU];
     out->t_v = h.cum[SC_TV]; out->t_add = h.cum[SC_ADD]; out->t_rem = h.cum[SC_REM]; out->c1 = h.cum[SC_C1]; out->c20 = h.cum[SC_C20];
     out->n_vertices = h.n_vertices; out->n_triangles_live = h.n_live;
 }
-void mesh_counters_reset(immesh_ctx* c) { std::memset(c->mesh_host.cum, 0, sizeof(c->mesh_host.cum)); }
+void mesh_counters_reset(immesh_ctx* c) { mesh_wait_all(c); std::memset(c->mesh_host.cum, 0, sizeof(c->mesh_host.cum)); }
 
 extern "C" {
 
@@ -207,15 +332,25 @@ int immesh_mesh_scan(immesh_ctx* c, const float* pts_world_xyzi, int32_t n_raw, 
     if (!c || !pts_world_xyzi || n_raw <= 0 || n_raw > c->cap_scan || !sensor_pos) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    float* world = mesh_next_world_buffer(c);
     const void* d_pts;
-    int rc = resolve_input(c, pts_world_xyzi, (size_t)n_raw * 16, c->d_pts_world, &d_pts);
-    if (!rc) rc = mesh_scan_device(c, (const float*)d_pts, n_raw, sensor_pos, frame_idx);
-    return rc;
+    int rc = resolve_input(c, pts_world_xyzi, (size_t)n_raw * 16, world, &d_pts);
+    if (rc) return rc;
+    const long id = mesh_submit(c, (const float*)d_pts, n_raw, sensor_pos, frame_idx);
+    return mesh_wait(c, id);   // synchronous entry point: results are current when it returns
+}
+
+int immesh_mesh_wait(immesh_ctx* c) {
+    if (!c) return IMMESH_E_INVAL;
+    return mesh_wait(c, 0);
 }
 
 int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
     if (!c || !sizes) return IMMESH_E_INVAL;
-    *sizes = c->mesh_host.sizes;
+    MeshHost& h = c->mesh_host;
+    std::lock_guard<std::mutex> lk(h.mu);
+    if (h.current <= 0) { std::memset(sizes, 0, sizeof(*sizes)); return 0; }
+    *sizes = h.res[h.current & 1].sizes;
     return 0;
 }
 
@@ -223,17 +358,26 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
                       int32_t* smooth_ids, double* smooth_xyz) {
     if (!c) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
+    MeshHost& h = c->mesh_host;
+    immesh_mesh_sizes_t z;
+    MeshOutSet o;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        if (h.current <= 0) return 0;
+        if (h.current < h.submitted - 1) { c->err = "mesh job results already overwritten (only the two newest jobs are kept)"; return IMMESH_E_INVAL; }
+        z = h.res[h.current & 1].sizes;
+        o = h.outs[h.current & 1];
+    }
     const MeshDev& m = c->mesh;
-    const immesh_mesh_sizes_t& z = c->mesh_host.sizes;
     hipStream_t s = c->stream;
     if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
-    if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, m.out_tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
-    if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, m.out_flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));
-    if (tri_rem && z.n_rem) HIPCHK(c, hipMemcpyAsync(tri_rem, m.out_tri_rem, (size_t)z.n_rem * 12, hipMemcpyDeviceToHost, s));
-    if (tri_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(tri_upd, m.out_tri_upd, (size_t)z.n_upd * 12, hipMemcpyDeviceToHost, s));
-    if (flip_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(flip_upd, m.out_flip_upd, (size_t)z.n_upd, hipMemcpyDeviceToHost, s));
-    if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, m.out_smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
-    if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, m.out_smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
+    if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, o.tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
+    if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, o.flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));
+    if (tri_rem && z.n_rem) HIPCHK(c, hipMemcpyAsync(tri_rem, o.tri_rem, (size_t)z.n_rem * 12, hipMemcpyDeviceToHost, s));
+    if (tri_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(tri_upd, o.tri_upd, (size_t)z.n_upd * 12, hipMemcpyDeviceToHost, s));
+    if (flip_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(flip_upd, o.flip_upd, (size_t)z.n_upd, hipMemcpyDeviceToHost, s));
+    if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, o.smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
+    if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, o.smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     return 0;
 }

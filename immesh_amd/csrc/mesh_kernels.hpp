@@ -14,7 +14,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <vector>
+#include <string>
+#include <deque>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include "../../include/immesh_c_api.h"
+#include "prof.hpp"
 
 #define MV_VOX_CAP 128      /* vertices per mesh voxel: ((int)(voxel/min_spacing)+1)^3 = 125 for every shipped config */
 #define MV_KNN 20           /* neighbours pulled per vertex, mesh_rec_geometry.cpp:350 */
@@ -68,9 +74,15 @@ struct MeshScanParams {
     int32_t n_raw, step, n_cand, vtx_base;
 };
 
+// One queued incremental_mesh_reconstruction call.  The reference runs the mesher on its own service thread + pool
+// (service_reconstruct_mesh, ImMesh_mesh_reconstruction.cpp:272-310) so scan k's meshing overlaps scan k+1's registration; here a
+// worker thread drives a second HIP stream, strictly in submission order (the sequential-deterministic frame order of the checker).
+struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; };
+struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz; };
+struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; };
+
 struct MeshHost {
     int32_t seq = 0;
-    immesh_mesh_sizes_t sizes;
     int64_t cum[SC_COUNT];
     // sort scratch
     uint32_t *k32_a = nullptr, *k32_b = nullptr;
@@ -83,6 +95,20 @@ struct MeshHost {
     int32_t n_vertices = 0;
     int64_t n_live = 0;
     bool ready = false;
+    // asynchronous execution
+    hipStream_t stream = nullptr;            // the mesher's own stream
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
+    float* d_world[2] = {nullptr, nullptr};  // world-frame full scans, double-buffered (job id parity)
+    MeshOutSet outs[2];                      // result lists, double-buffered (job id parity)
+    MeshResult res[2];
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<MeshJob> q;
+    long submitted = 0, completed = 0, current = 0;   // job ids start at 1; `current` = job whose results sizes/fetch return
+    bool stop = false;
+    KProf prof;                              // kernels launched by the worker thread
+    std::string err;                         // worker-side error text (moved into the MeshResult of the failing job)
 };
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,

@@ -99,6 +99,12 @@ int immesh_map_update(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n
  * pts_world_xyzi = world_lidar_full (n_raw x 4 float).  Runs append + per-voxel retriangulation + diff + commit on
  * the device; results stay in the ctx until the next call and are read with immesh_mesh_sizes / immesh_mesh_fetch. */
 int immesh_mesh_scan(immesh_ctx* ctx, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
+/* Asynchronous meshing (immesh_process_scan with do_mesh == 2): the scan is queued for the mesher's own stream / worker thread -- the
+ * counterpart of the reference's service_reconstruct_mesh thread (ImMesh_mesh_reconstruction.cpp:272-310) -- and the call returns after
+ * registration + map update.  Jobs run strictly in submission order; at most two are outstanding (a third submission blocks) and the
+ * results of the two newest jobs are kept.  immesh_mesh_wait() blocks until the newest submitted job has finished and makes its
+ * results the ones immesh_mesh_sizes / immesh_mesh_fetch / immesh_last_timing report; it returns that job's status. */
+int immesh_mesh_wait(immesh_ctx* ctx);
 
 typedef struct immesh_mesh_sizes_t {
     int32_t vtx_base;   /* id of the first vertex appended by this scan */
@@ -119,7 +125,8 @@ int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uin
 /* ---- whole scan (what service_LiDAR_update does per scan, src/voxel_mapping.cpp:1959-1973) ---------------- */
 /* lio_state_estimation + map_incremental_grow (+ world transform of the full scan and incremental_mesh_reconstruction
  * when do_mesh != 0).  pts_raw_body_xyzi = m_feats_undistort (n_raw x 4).  Everything stays on the device between
- * stages; mesh results are read with immesh_mesh_sizes / immesh_mesh_fetch. */
+ * stages; mesh results are read with immesh_mesh_sizes / immesh_mesh_fetch.
+ * do_mesh: 0 = registration + map update only, 1 = mesh synchronously, 2 = queue the mesh job and return (see immesh_mesh_wait). */
 int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const float* pts_raw_body_xyzi, int32_t n_raw,
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);

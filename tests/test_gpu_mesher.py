@@ -104,8 +104,10 @@ def test_mesh_edge_cases(oracle_lib, hip_lib):
         h.mesh_scan(pts, cam, n=0)
 
 
-def test_process_scan_full_pipeline(oracle_lib, hip_lib):
-    """immesh_process_scan = lio_state_estimation + map_incremental_grow + incremental_mesh_reconstruction on device-resident inputs."""
+@pytest.mark.parametrize("mesh_mode", [1, 2])
+def test_process_scan_full_pipeline(oracle_lib, hip_lib, mesh_mode):
+    """immesh_process_scan = lio_state_estimation + map_incremental_grow + incremental_mesh_reconstruction on device-resident inputs.
+    mesh_mode 2 = the mesh job is queued for the mesher's worker thread / stream and collected with immesh_mesh_wait."""
     torch = pytest.importorskip("torch")
     cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
     o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
@@ -125,7 +127,9 @@ def test_process_scan_full_pipeline(oracle_lib, hip_lib):
         po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
         so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=True)
         d_down = torch.from_numpy(down).cuda(); d_raw = torch.from_numpy(raw).cuda()     # device-resident inputs are used in place
-        sh, ih = h.process_scan(d_down.data_ptr(), d_raw.data_ptr(), ph, ph, frame_idx=k, do_mesh=True, n_ds=len(down), n_raw=len(raw))
+        sh, ih = h.process_scan(d_down.data_ptr(), d_raw.data_ptr(), ph, ph, frame_idx=k, do_mesh=mesh_mode, n_ds=len(down), n_raw=len(raw))
+        if mesh_mode == 2:
+            h.mesh_wait()
         assert ih == io
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=1e-5)
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
@@ -138,3 +142,36 @@ def test_process_scan_full_pipeline(oracle_lib, hip_lib):
             assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50
         tm = h.last_timing()
         assert tm["total"] > 0 and tm["mesh"] > 0
+
+
+def test_async_pipeline_matches_serial(hip_lib):
+    """Queueing mesh jobs (depth 2) while later scans register must give the same mesh as the strictly serial order."""
+    torch = pytest.importorskip("torch")
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(6):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, Rk, tk, n_pts=30000, extT=extT)
+        scans.append((torch.from_numpy(synth.voxel_grid_downsample(raw, 0.4)).cuda(), torch.from_numpy(raw).cuda(), Rk, tk))
+    results = {}
+    for mode in (1, 2):
+        h = make_hip(hip_lib, cfg)
+        R0, t0 = scans[0][2], scans[0][3]
+        st = capi.make_state(R=R0, t=t0)
+        h.map_build(np.ascontiguousarray(scans[0][1].cpu().numpy()[:, :3]), st)
+        st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+        for k in range(1, 6):
+            down, raw = scans[k][0], scans[k][1]
+            prior = synth.forward_without_imu(st)
+            st, _ = h.process_scan(down.data_ptr(), raw.data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=down.shape[0], n_raw=raw.shape[0])
+        h.mesh_wait()
+        last = h.mesh_fetch()
+        results[mode] = (st.copy(), last, h.counters())
+        h.close()
+    s1, m1, c1 = results[1]; s2, m2, c2 = results[2]
+    np.testing.assert_array_equal(s1, s2)
+    for key in ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "smooth_ids"):
+        np.testing.assert_array_equal(m1[key], m2[key], err_msg=key)
+    for key in ("n_new", "v_act", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
+        assert c1[key] == c2[key], key
