@@ -66,6 +66,7 @@ int mesh_alloc(immesh_ctx* c) {
     A(h.k32_a, cap_list); A(h.k32_b, cap_list); A(h.k64_a, cap_list); A(h.k64_b, cap_list); A(h.p_a, cap_list); A(h.p_b, cap_list); A(h.p_c, cap_list);
     h.sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)cap_list), sort_pairs_u32_temp_bytes((int)cap_list), exclusive_sum_temp_bytes((int)cap_cand)}) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
+    { unsigned long long* t; A(t, (size_t)(4 * cap_list + cap_active + 5 * 1024) * 2); h.d_sort_recs = t; }
 #undef A
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
@@ -183,12 +184,7 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
     if (n_active > 0) {
         // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
         // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-        const int lcap = mesh_lsort_cap();
-        if (n_active <= lcap) launch_mesh_sort_active(s, m, n_active);   // one-workgroup LDS sort + rank assignment
-        else {
-            sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, m.act_key, m.act_key_s, m.act_vox, m.act_vox_s, n_active);
-            launch_mesh_rank(s, m, n_active);
-        }
+        { const int n5[5] = {0, 0, 0, 0, n_active}; launch_mesh_sort_emit(s, m, n5, h.d_sort_recs, nullptr); }   // sorted active list + ranks
         launch_mesh_knn(s, m, n_active);                // a18-a19
         launch_mesh_delaunay(s, m, sp, n_active);       // a20-a23
         launch_mesh_finalize(s, m, n_active);
@@ -197,24 +193,10 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
         if ((rc = mesh_overflow(c))) return rc;
         const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
         // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
-        // the four result lists are sorted and emitted by one launch (4 workgroups, LDS); longer lists take the radix-sort path
-        launch_mesh_sort_lists(s, m, n_rem, n_add, n_upd, n_smooth, h.p_a);
-        if (n_rem > 0) {
-            launch_mesh_commit_rem(s, m, m.list_rem, n_rem);
-            if (n_rem > lcap) { sort_tris(c, m.list_rem, n_rem); launch_mesh_emit(s, m, h.p_c, n_rem, m.out_tri_rem, nullptr); }
-        }
-        if (n_add > 0) {
-            if (n_add > lcap) {
-                sort_tris(c, m.list_add, n_add);
-                launch_mesh_emit(s, m, h.p_c, n_add, m.out_tri_add, m.out_flip_add);
-                launch_mesh_commit_add(s, m, h.p_c, n_add);
-            } else launch_mesh_commit_add(s, m, h.p_a, n_add);
-        }
-        if (n_upd > lcap) { sort_tris(c, m.list_upd, n_upd); launch_mesh_emit(s, m, h.p_c, n_upd, m.out_tri_upd, m.out_flip_upd); }
-        if (n_smooth > lcap) {
-            sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, (const uint32_t*)m.list_smooth, h.k32_b, m.list_smooth, h.p_b, n_smooth, 32);
-            launch_mesh_emit_smooth(s, m, h.p_b, n_smooth);
-        }
+        // the four result lists are sorted and emitted by two launches (chunk sort in LDS + rank merge)
+        if (n_rem > 0) launch_mesh_commit_rem(s, m, m.list_rem, n_rem);
+        { const int n5[5] = {n_rem, n_add, n_upd, n_smooth, 0}; launch_mesh_sort_emit(s, m, n5, h.d_sort_recs, h.p_a); }
+        if (n_add > 0) launch_mesh_commit_add(s, m, h.p_a, n_add);
         MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
         MHIPCHK(c, hipStreamSynchronize(s));
         if ((rc = mesh_overflow(c))) return rc;

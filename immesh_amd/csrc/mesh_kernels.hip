@@ -897,65 +897,90 @@ IMD void lds_sort_recs(SortRec* a, int np2, int tid) {
             __syncthreads();
         }
 }
-// block 0/1/2: the remove / add / flip-update triangle lists -> sorted by (v0, v1, v2) triplets (+ flips; the add list also as sorted
-// triangle indices for the commit); block 3: smoothed vertex ids ascending + their positions.  Lists above LSORT_CAP are left to the host's
-// radix-sort path.
-__global__ __launch_bounds__(1024) void mesh_sort_lists_kernel(MeshDev m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* __restrict__ add_sorted) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsort_smem[];
-    SortRec* recs = (SortRec*)lsort_smem;
-    const int job = blockIdx.x, tid = threadIdx.x;
-    const int n = job == 0 ? n_rem : (job == 1 ? n_add : (job == 2 ? n_upd : n_smooth));
-    if (n <= 0 || n > LSORT_CAP) return;
-    const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : m.list_smooth));
-    const int np2 = next_pow2_i(n);
-    for (int i = tid; i < np2; i += 1024) {
+// Sorting the per-scan result lists (remove / add / flip-update triangle lists by (v0, v1, v2); smoothed vertex ids; active voxels by
+// key) in two launches for all lists at once, any length:
+//   mesh_chunk_sort_kernel   one workgroup per 1024-record chunk: build the records, bitonic sort in 16 KB of LDS, store the sorted chunk
+//   mesh_merge_emit_kernel   one thread per record: final position = position in its own chunk + number of smaller records in every
+//                            other chunk (binary searches, 4 chunks in flight); the output entry is written directly at that position
+#define LS_CHUNK 1024
+IMD void lsort_locate(const LSortPlan& pl, int blk, const int* base, int& job, int& local) {
+    job = 0;
+#pragma unroll
+    for (int j = 1; j < LS_JOBS; j++) if (blk >= base[j]) job = j;
+    local = blk - base[job];
+}
+__global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m, LSortPlan pl, SortRec* __restrict__ recs_out) {
+    __shared__ SortRec recs[LS_CHUNK];
+    int job, chunk;
+    lsort_locate(pl, blockIdx.x, pl.blk_base, job, chunk);
+    const int tid = threadIdx.x;
+    const int n = pl.n[job];
+    const int first = chunk * LS_CHUNK, cnt = min(LS_CHUNK, n - first);
+    const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : (job == 3 ? m.list_smooth : nullptr)));
+    const int np2 = next_pow2_i(cnt);
+    for (int i = tid; i < np2; i += 256) {
         SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
-        if (i < n) {
-            const int t = list[i];
+        if (i < cnt) {
             if (job < 3) {
+                const int t = list[first + i];
                 r.k0 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
                 r.k1 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 2] << 32) | (unsigned long long)(unsigned int)t;
-            } else { r.k0 = (unsigned long long)(unsigned int)t; r.k1 = 0; }
+            } else if (job == 3) { r.k0 = (unsigned long long)(unsigned int)list[first + i]; r.k1 = 0; }
+            else { r.k0 = m.act_key[first + i]; r.k1 = (unsigned long long)(unsigned int)m.act_vox[first + i]; }
         }
         recs[i] = r;
     }
     __syncthreads();
-    lds_sort_recs<1024>(recs, np2, tid);
-    for (int i = tid; i < n; i += 1024) {
-        const SortRec r = recs[i];
-        if (job < 3) {
-            int32_t* out_tri = job == 0 ? m.out_tri_rem : (job == 1 ? m.out_tri_add : m.out_tri_upd);
-            uint8_t* out_flip = job == 0 ? nullptr : (job == 1 ? m.out_flip_add : m.out_flip_upd);
-            const int t = (int)(unsigned int)(r.k1 & 0xFFFFFFFFull);
-            out_tri[(size_t)i * 3 + 0] = (int)(r.k0 >> 32); out_tri[(size_t)i * 3 + 1] = (int)(unsigned int)(r.k0 & 0xFFFFFFFFull); out_tri[(size_t)i * 3 + 2] = (int)(r.k1 >> 32);
-            if (out_flip) out_flip[i] = (uint8_t)m.t_flip[t];
-            if (job == 1) add_sorted[i] = t;
-        } else {
-            const int id = (int)(unsigned int)r.k0;
-            m.out_smooth_ids[i] = id;
-            m.out_smooth_xyz[(size_t)i * 3 + 0] = m.v_smooth[(size_t)id * 3 + 0];
-            m.out_smooth_xyz[(size_t)i * 3 + 1] = m.v_smooth[(size_t)id * 3 + 1];
-            m.out_smooth_xyz[(size_t)i * 3 + 2] = m.v_smooth[(size_t)id * 3 + 2];
-        }
-    }
+    lds_sort_recs<256>(recs, np2, tid);
+    for (int i = tid; i < cnt; i += 256) recs_out[(size_t)pl.rec_off[job] + first + i] = recs[i];
 }
-// active voxels in ascending (x,y,z) key order + their ranks, one workgroup (n_active <= LSORT_CAP)
-__global__ __launch_bounds__(1024) void mesh_sort_active_kernel(MeshDev m, int n_active) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsort_smem[];
-    SortRec* recs = (SortRec*)lsort_smem;
-    const int tid = threadIdx.x;
-    const int np2 = next_pow2_i(n_active);
-    for (int i = tid; i < np2; i += 1024) {
-        SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
-        if (i < n_active) { r.k0 = m.act_key[i]; r.k1 = (unsigned long long)(unsigned int)m.act_vox[i]; }
-        recs[i] = r;
+IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& key) {  // number of records < key
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; const SortRec v = a[mid]; if (rec_gt(key, v)) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, LSortPlan pl, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+    int job, lb;
+    lsort_locate(pl, blockIdx.x, pl.eblk_base, job, lb);
+    const int i = lb * 256 + threadIdx.x;
+    const int n = pl.n[job];
+    if (i >= n) return;
+    const SortRec* base = recs + (size_t)pl.rec_off[job];
+    const SortRec r = base[i];
+    const int own = i / LS_CHUNK, nchunks = (n + LS_CHUNK - 1) / LS_CHUNK;
+    int rank = i - own * LS_CHUNK;
+    for (int c0 = 0; c0 < nchunks; c0 += 4) {  // four independent binary searches in flight
+        int lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int cc = c0 + u; lo[u] = 0; hi[u] = (cc < nchunks && cc != own) ? min(LS_CHUNK, n - cc * LS_CHUNK) : 0; }
+        for (int step = 0; step < 11; step++) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (lo[u] < hi[u]) {
+                    const int mid = (lo[u] + hi[u]) >> 1;
+                    const SortRec v = base[(size_t)(c0 + u) * LS_CHUNK + mid];
+                    if (rec_gt(r, v)) lo[u] = mid + 1; else hi[u] = mid;
+                }
+        }
+        rank += lo[0] + lo[1] + lo[2] + lo[3];
     }
-    __syncthreads();
-    lds_sort_recs<1024>(recs, np2, tid);
-    for (int i = tid; i < n_active; i += 1024) {
-        const int vi = (int)(unsigned int)recs[i].k1;
-        m.act_vox_s[i] = vi;
-        m.vx_rank[vi] = i;
+    if (job < 3) {
+        int32_t* out_tri = job == 0 ? m.out_tri_rem : (job == 1 ? m.out_tri_add : m.out_tri_upd);
+        uint8_t* out_flip = job == 0 ? nullptr : (job == 1 ? m.out_flip_add : m.out_flip_upd);
+        const int t = (int)(unsigned int)(r.k1 & 0xFFFFFFFFull);
+        out_tri[(size_t)rank * 3 + 0] = (int)(r.k0 >> 32); out_tri[(size_t)rank * 3 + 1] = (int)(unsigned int)(r.k0 & 0xFFFFFFFFull); out_tri[(size_t)rank * 3 + 2] = (int)(r.k1 >> 32);
+        if (out_flip) out_flip[rank] = (uint8_t)m.t_flip[t];
+        if (job == 1) add_sorted[rank] = t;
+    } else if (job == 3) {
+        const int id = (int)(unsigned int)r.k0;
+        m.out_smooth_ids[rank] = id;
+        m.out_smooth_xyz[(size_t)rank * 3 + 0] = m.v_smooth[(size_t)id * 3 + 0];
+        m.out_smooth_xyz[(size_t)rank * 3 + 1] = m.v_smooth[(size_t)id * 3 + 1];
+        m.out_smooth_xyz[(size_t)rank * 3 + 2] = m.v_smooth[(size_t)id * 3 + 2];
+    } else {
+        const int vi = (int)(unsigned int)r.k1;
+        m.act_vox_s[rank] = vi;
+        m.vx_rank[vi] = rank;
         m.vx_rank_seq[vi] = m.seq;
     }
 }
@@ -1072,24 +1097,21 @@ void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n) {
     KLAUNCH(mesh_emit_smooth_kernel, g1(n), dim3(256), 0, s, m, ids_sorted, n);
 }
-static void lsort_attr_once() {
-    static bool done = false;
-    if (done) return;
-    (void)hipFuncSetAttribute((const void*)mesh_sort_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSORT_CAP * 16);
-    (void)hipFuncSetAttribute((const void*)mesh_sort_active_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LSORT_CAP * 16);
-    done = true;
+static void lsort_plan(LSortPlan& pl, const int* n) {
+    int blk = 0, eblk = 0, off = 0;
+    for (int j = 0; j < LS_JOBS; j++) {
+        pl.n[j] = n[j]; pl.blk_base[j] = blk; pl.eblk_base[j] = eblk; pl.rec_off[j] = off;
+        const int chunks = (n[j] + LS_CHUNK - 1) / LS_CHUNK;
+        blk += chunks; eblk += (n[j] + 255) / 256; off += chunks * LS_CHUNK;
+    }
+    pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
 }
-static int lsort_np2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
-int mesh_lsort_cap() { return LSORT_CAP; }
-void launch_mesh_sort_lists(hipStream_t s, const MeshDev& m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* add_sorted) {
-    lsort_attr_once();
-    int mx = 1;
-    const int ns[4] = {n_rem, n_add, n_upd, n_smooth};
-    for (int k = 0; k < 4; k++) if (ns[k] <= LSORT_CAP && ns[k] > mx) mx = ns[k];
-    KLAUNCH(mesh_sort_lists_kernel, dim3(4), dim3(1024), (size_t)lsort_np2(mx) * 16, s, m, n_rem, n_add, n_upd, n_smooth, add_sorted);
-}
-void launch_mesh_sort_active(hipStream_t s, const MeshDev& m, int n_active) {
-    lsort_attr_once();
-    KLAUNCH(mesh_sort_active_kernel, dim3(1), dim3(1024), (size_t)lsort_np2(n_active) * 16, s, m, n_active);
+// n[5] = {rem, add, upd, smooth, active}; recs must hold sum(ceil(n/1024)*1024) records
+void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, const int* n, void* recs, int32_t* add_sorted) {
+    LSortPlan pl;
+    lsort_plan(pl, n);
+    if (pl.blk_base[LS_JOBS] == 0) return;
+    KLAUNCH(mesh_chunk_sort_kernel, dim3(pl.blk_base[LS_JOBS]), dim3(256), 0, s, m, pl, (SortRec*)recs);
+    KLAUNCH(mesh_merge_emit_kernel, dim3(pl.eblk_base[LS_JOBS]), dim3(256), 0, s, m, pl, (const SortRec*)recs, add_sorted);
 }
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n) { KLAUNCH(fill_i32_kernel, dim3(1024), dim3(256), 0, s, p, v, n); }

@@ -69,6 +69,9 @@ struct MeshDev {
     int32_t seq;                         // scan sequence number (>= 1)
 };
 
+#define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
+struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; };
+
 struct MeshScanParams {
     double cam[3];
     int32_t n_raw, step, n_cand, vtx_base;
@@ -92,6 +95,7 @@ struct MeshHost {
     int32_t* h_pc = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    void* d_sort_recs = nullptr;   // 16-byte sort records of the chunk sort
     int32_t n_vertices = 0;
     int64_t n_live = 0;
     bool ready = false;
@@ -128,9 +132,7 @@ void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n);
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n);
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n);
-int mesh_lsort_cap();
-void launch_mesh_sort_lists(hipStream_t s, const MeshDev& m, int n_rem, int n_add, int n_upd, int n_smooth, int32_t* add_sorted);
-void launch_mesh_sort_active(hipStream_t s, const MeshDev& m, int n_active);
+void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, const int* n5, void* recs, int32_t* add_sorted);
 
 // device prefix sum (sort.hip)
 size_t exclusive_sum_temp_bytes(int n);
