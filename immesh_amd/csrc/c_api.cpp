@@ -2,6 +2,8 @@
 // There is NO CPU compute path here: every per-point / per-voxel operation is a kernel in reg_kernels.hip / mesh_kernels.hip;
 // the host keeps only the 18x18 EKF algebra (as the reference does) and stream plumbing.
 #include "host_ctx.hpp"
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -147,8 +149,20 @@ static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh
     ScanParams sp;
     make_scan_params(c, st, prior_cov, sp);
     // the last block of the launch writes the 48 sums straight into pinned host memory: one launch + one stream sync per EKF iteration
-    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_done, c->d_out48_host, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // and a completion ticket after them; the host polls the ticket (a few microseconds) instead of paying a stream synchronisation
+    const double ticket = (double)(++c->res_ticket);
+    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_done, c->d_out48_host, ticket, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
+    {
+        volatile double* flag = c->h_out48 + (RES_NV_HOST - 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*flag != ticket) {
+            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // never spin unbounded: fall back to the stream
+        }
+        if (*flag != ticket || c->prof.on) HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*flag != ticket) { c->err = "residual kernel did not complete"; return IMMESH_E_HIP; }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     c->cnt.n_match += (int64_t)c->h_out48[42];
     c->cnt.n_plane_tests += (int64_t)c->h_out48[44];
     c->cnt.n_extra_probe += (int64_t)c->h_out48[45];

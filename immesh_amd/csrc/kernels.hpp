@@ -28,7 +28,7 @@ struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
 #define RES_NR_HOST 32
 
 void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
-                     double* out48, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+                     double* out48, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next);
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,

@@ -157,54 +157,51 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
     MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
     MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
     MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
-    // ---- a17 append
+    // ---- a17 append.  Every launch below has a fixed grid and takes its work-list length from device counters, so the whole scan is
+    //      enqueued without a host round trip; the host reads the counters once, at the end.
     launch_mesh_append_prepare(s, m, sp, d_pts);
-    for (int round = 0; round < 1000; round++) {
-        if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
-        launch_mesh_append_resolve(s, m, sp, d_pts);
-        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        MHIPCHK(c, hipStreamSynchronize(s));
-        if (h.h_sc[SC_UNDECIDED] == 0) break;
+    if (sp.n_cand <= 65536) {
+        // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
+        // the iteration bound only guards against a hung device and is checked below
+        launch_mesh_append_resolve(s, m, sp, d_pts, 1 << 16);
+    } else {
+        for (int round = 0; round < 100000; round++) {   // offline-sized clouds: bounded rounds, host checks in between
+            if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
+            launch_mesh_append_resolve(s, m, sp, d_pts, 64);
+            MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+            MHIPCHK(c, hipStreamSynchronize(s));
+            if (h.h_sc[SC_UNDECIDED] == 0) break;
+        }
     }
     launch_mesh_append_flags(s, m, sp.n_cand);
     exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
     launch_mesh_append_commit(s, m, sp, d_pts);
     launch_mesh_select_active(s, m, sp.n_cand);
+    // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
+    // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
+    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);   // sorted active list + ranks
+    launch_mesh_knn(s, m);                                    // a18-a19
+    launch_mesh_delaunay(s, m, sp);                           // a20-a23
+    launch_mesh_finalize(s, m);
+    // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
+    launch_mesh_commit_rem(s, m, m.list_rem);
+    launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
+    launch_mesh_commit_add(s, m, h.p_a);
     MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(c, hipMemcpyAsync(h.h_pc, m.pc, PC_COUNT * 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(c, hipStreamSynchronize(s));
     int rc = mesh_overflow(c);
     if (rc) return rc;
-    const int n_new = h.h_sc[SC_ACCEPTED], n_active = h.h_sc[SC_ACTIVE];
+    if (h.h_sc[SC_UNDECIDED] != 0) { h.err = "vertex admission did not converge (device hang guard)"; return IMMESH_E_HIP; }
+    const int n_new = h.h_sc[SC_ACCEPTED], n_active = std::min(h.h_sc[SC_ACTIVE], (int)m.cap_active);
+    const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
     sizes.vtx_base = sp.vtx_base; sizes.n_new_vtx = n_new; sizes.n_voxels_meshed = n_active;
-    sizes.n_add = sizes.n_rem = sizes.n_upd = sizes.n_smooth = 0; sizes.reserved = 0;
+    sizes.n_add = n_add; sizes.n_rem = n_rem; sizes.n_upd = n_upd; sizes.n_smooth = n_smooth; sizes.reserved = 0;
     h.n_vertices = sp.vtx_base + n_new;
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
     h.cum[SC_RECENT] += sp.n_cand;  // n_app: candidates offered
-    if (n_active > 0) {
-        // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
-        // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-        { const int n5[5] = {0, 0, 0, 0, n_active}; launch_mesh_sort_emit(s, m, n5, h.d_sort_recs, nullptr); }   // sorted active list + ranks
-        launch_mesh_knn(s, m, n_active);                // a18-a19
-        launch_mesh_delaunay(s, m, sp, n_active);       // a20-a23
-        launch_mesh_finalize(s, m, n_active);
-        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        MHIPCHK(c, hipStreamSynchronize(s));
-        if ((rc = mesh_overflow(c))) return rc;
-        const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
-        // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
-        // the four result lists are sorted and emitted by two launches (chunk sort in LDS + rank merge)
-        if (n_rem > 0) launch_mesh_commit_rem(s, m, m.list_rem, n_rem);
-        { const int n5[5] = {n_rem, n_add, n_upd, n_smooth, 0}; launch_mesh_sort_emit(s, m, n5, h.d_sort_recs, h.p_a); }
-        if (n_add > 0) launch_mesh_commit_add(s, m, h.p_a, n_add);
-        MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-        MHIPCHK(c, hipStreamSynchronize(s));
-        if ((rc = mesh_overflow(c))) return rc;
-        sizes.n_add = n_add; sizes.n_rem = n_rem; sizes.n_upd = n_upd; sizes.n_smooth = n_smooth;
-        h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
-        h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
-        h.n_live += n_add - n_rem;
-    }
+    h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
+    h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
+    h.n_live += n_add - n_rem;
     return 0;
 }
 

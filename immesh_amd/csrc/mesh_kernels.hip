@@ -165,47 +165,59 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m, Mes
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
 // loop's outcome.  Each lane re-evaluates until every lower-index conflicting candidate is decided (bounded; relaunched by the host).
-__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts, int max_iter) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sp.n_cand) return;
-    if (ld_agent(&m.cand_status[i]) != ST_UNDECIDED) return;
-    const float* p = pts + 4 * (size_t)i * sp.step;
-    const float px = p[0], py = p[1], pz = p[2];
-    const long gx = rnd_cell(px, m.min_spacing), gy = rnd_cell(py, m.min_spacing), gz = rnd_cell(pz, m.min_spacing);
-    const unsigned long long own = m.cand_cell[i];
-    for (int iter = 0; iter < 48; iter++) {
-        bool rej = false, blocked = false;
-        for (int dx = -1; dx <= 1 && !rej; dx++) {
-            unsigned long long key9[9], k9[9], h9[9];
-            int hd9[9];
+    // Lanes of one wavefront may depend on each other, so the decision store must happen INSIDE the loop body and the loop must be left
+    // by the whole wavefront together (__all): with a per-lane `return` the compiler may sink the store to the loop exit, which the
+    // waiting lanes of the same wavefront would then never see.
+    int my = ST_REJECT;   // lanes with nothing to decide just ride along
+    float px = 0, py = 0, pz = 0;
+    long gx = 0, gy = 0, gz = 0;
+    unsigned long long own = 0;
+    if (i < sp.n_cand && ld_agent(&m.cand_status[i]) == ST_UNDECIDED) {
+        my = ST_UNDECIDED;
+        const float* p = pts + 4 * (size_t)i * sp.step;
+        px = p[0]; py = p[1]; pz = p[2];
+        gx = rnd_cell(px, m.min_spacing); gy = rnd_cell(py, m.min_spacing); gz = rnd_cell(pz, m.min_spacing);
+        own = m.cand_cell[i];
+    }
+    for (int iter = 0; iter < max_iter; iter++) {
+        if (my == ST_UNDECIDED) {
+            bool rej = false, blocked = false;
+            for (int dx = -1; dx <= 1 && !rej; dx++) {
+                unsigned long long key9[9], k9[9], h9[9];
+                int hd9[9];
 #pragma unroll
-            for (int q = 0; q < 9; q++) {  // 9 independent cell lookups in flight
-                key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
-                h9[q] = hash64(key9[q]) & m.ch_mask;
-                k9[q] = m.ch_keys[h9[q]];
-                hd9[q] = m.ch_head[h9[q]];
-            }
+                for (int q = 0; q < 9; q++) {  // 9 independent cell lookups in flight
+                    key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
+                    h9[q] = hash64(key9[q]) & m.ch_mask;
+                    k9[q] = m.ch_keys[h9[q]];
+                    hd9[q] = m.ch_head[h9[q]];
+                }
 #pragma unroll
-            for (int q = 0; q < 9; q++) {
-                int head = -1;
-                if (k9[q] == key9[q]) head = hd9[q];
-                else if (k9[q] != MKEY_EMPTY) { const long long s2 = h_find(m.ch_keys, m.ch_mask, key9[q]); if (s2 >= 0) head = m.ch_head[s2]; }
-                for (int j = head; j >= 0 && !rej;) {
-                    const int nxt = m.cand_next[j];
-                    const int sj = ld_agent(&m.cand_status[j]);
-                    const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
-                    if (j < i && sj != ST_REJECT) {
-                        const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
-                        if (conflict) { if (sj == ST_ACCEPT) rej = true; else blocked = true; }
+                for (int q = 0; q < 9; q++) {
+                    int head = -1;
+                    if (k9[q] == key9[q]) head = hd9[q];
+                    else if (k9[q] != MKEY_EMPTY) { const long long s2 = h_find(m.ch_keys, m.ch_mask, key9[q]); if (s2 >= 0) head = m.ch_head[s2]; }
+                    for (int j = head; j >= 0 && !rej;) {
+                        const int nxt = m.cand_next[j];
+                        const int sj = ld_agent(&m.cand_status[j]);
+                        const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
+                        if (j < i && sj != ST_REJECT) {
+                            const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
+                            if (conflict) { if (sj == ST_ACCEPT) rej = true; else blocked = true; }
+                        }
+                        j = nxt;
                     }
-                    j = nxt;
                 }
             }
+            if (rej) my = ST_REJECT; else if (!blocked) my = ST_ACCEPT;
+            if (my != ST_UNDECIDED) st_agent(&m.cand_status[i], my);
         }
-        if (rej) { st_agent(&m.cand_status[i], ST_REJECT); return; }
-        if (!blocked) { st_agent(&m.cand_status[i], ST_ACCEPT); return; }
+        if (__all(my != ST_UNDECIDED)) break;
+        __builtin_amdgcn_s_sleep(2);
     }
-    atomicAdd(&m.sc[SC_UNDECIDED], 1);
+    if (my == ST_UNDECIDED) atomicAdd(&m.sc[SC_UNDECIDED], 1);
 }
 
 __global__ void mesh_append_flags_kernel(MeshDev m, int n) {
@@ -347,7 +359,9 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     __shared__ int s_misc[8];   // 0 ncand, 1 vend, 2 nrel, 3 any-needs-pass-2
     __shared__ long s_box[6];
 
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int vi = m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
     if (tid < nq) {
@@ -527,6 +541,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     for (int k = tid; k < nrel; k += 256) m.rel_ids[(size_t)r * MV_REL_CAP + k] = rel_l[k];
     if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); }
     if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
+    __syncthreads();
+    }
 }
 
 // =====================================================================================================================
@@ -624,9 +640,11 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     __shared__ double sm[CAP * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
     __shared__ int s_cnt[2];
 
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int n = m.rel_n[r];
-    if (n < n_lo || n > n_hi) return;  // size class of the other instantiation
+    if (n < n_lo || n > n_hi) continue;  // size class of the other instantiation
     const int vi = m.act_vox_s[r];
     for (int i = lane; i < n; i += 64) {
         const int id = m.rel_ids[(size_t)r * MV_REL_CAP + i];
@@ -849,12 +867,16 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     }
     __syncthreads();
     if (lane == 0) { m.vox_ntris[r] = s_cnt[0]; atomicAdd(&m.sc[SC_TV], nf); }
+    __syncthreads();
+    }
 }
 
 // cross-voxel resolution: the voxel with the highest rank that touched a triangle owns its flip (later voxel wins, as the
 // sequential loop); it also queues the triangle for insertion / reports a changed flip.  Then this scan's smoothed positions commit.
 __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
-    const int r = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int vi = m.act_vox_s[r];
     const int nt = m.vox_ntris[r];
     const int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
@@ -874,6 +896,7 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
         m.v_smooth[(size_t)id * 3 + 1] = m.v_smooth_new[(size_t)id * 3 + 1];
         m.v_smooth[(size_t)id * 3 + 2] = m.v_smooth_new[(size_t)id * 3 + 2];
         list_push(m, m.list_smooth, SC_SMOOTH, id);
+    }
     }
 }
 
@@ -909,42 +932,64 @@ IMD void lsort_locate(const LSortPlan& pl, int blk, const int* base, int& job, i
     for (int j = 1; j < LS_JOBS; j++) if (blk >= base[j]) job = j;
     local = blk - base[job];
 }
-__global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m, LSortPlan pl, SortRec* __restrict__ recs_out) {
-    __shared__ SortRec recs[LS_CHUNK];
-    int job, chunk;
-    lsort_locate(pl, blockIdx.x, pl.blk_base, job, chunk);
-    const int tid = threadIdx.x;
-    const int n = pl.n[job];
-    const int first = chunk * LS_CHUNK, cnt = min(LS_CHUNK, n - first);
-    const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : (job == 3 ? m.list_smooth : nullptr)));
-    const int np2 = next_pow2_i(cnt);
-    for (int i = tid; i < np2; i += 256) {
-        SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
-        if (i < cnt) {
-            if (job < 3) {
-                const int t = list[first + i];
-                r.k0 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
-                r.k1 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 2] << 32) | (unsigned long long)(unsigned int)t;
-            } else if (job == 3) { r.k0 = (unsigned long long)(unsigned int)list[first + i]; r.k1 = 0; }
-            else { r.k0 = m.act_key[first + i]; r.k1 = (unsigned long long)(unsigned int)m.act_vox[first + i]; }
-        }
-        recs[i] = r;
+// which 0: the active-voxel list; which 1: the four result lists.  Lengths are read from the device counters, so the launch needs no host sync.
+IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
+    int n[LS_JOBS] = {0, 0, 0, 0, 0};
+    if (which == 0) n[4] = min(m.sc[SC_ACTIVE], m.cap_active);
+    else { n[0] = min(m.sc[SC_REM], m.cap_list); n[1] = min(m.sc[SC_ADD], m.cap_list); n[2] = min(m.sc[SC_UPD], m.cap_list); n[3] = min(m.sc[SC_SMOOTH], m.cap_list); }
+    int blk = 0, eblk = 0, off = 0;
+#pragma unroll
+    for (int j = 0; j < LS_JOBS; j++) {
+        pl.n[j] = n[j]; pl.blk_base[j] = blk; pl.eblk_base[j] = eblk; pl.rec_off[j] = off;
+        const int chunks = (n[j] + LS_CHUNK - 1) / LS_CHUNK;
+        blk += chunks; eblk += (n[j] + 255) / 256; off += chunks * LS_CHUNK;
     }
-    __syncthreads();
-    lds_sort_recs<256>(recs, np2, tid);
-    for (int i = tid; i < cnt; i += 256) recs_out[(size_t)pl.rec_off[job] + first + i] = recs[i];
+    pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
+}
+__global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m, int which, SortRec* __restrict__ recs_out) {
+    __shared__ SortRec recs[LS_CHUNK];
+    LSortPlan pl;
+    lsort_plan_dev(m, which, pl);
+    const int tid = threadIdx.x;
+    for (int blk = blockIdx.x; blk < pl.blk_base[LS_JOBS]; blk += gridDim.x) {
+        int job, chunk;
+        lsort_locate(pl, blk, pl.blk_base, job, chunk);
+        const int n = pl.n[job];
+        const int first = chunk * LS_CHUNK, cnt = min(LS_CHUNK, n - first);
+        const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : (job == 3 ? m.list_smooth : nullptr)));
+        const int np2 = next_pow2_i(cnt);
+        for (int i = tid; i < np2; i += 256) {
+            SortRec r; r.k0 = ~0ull; r.k1 = ~0ull;
+            if (i < cnt) {
+                if (job < 3) {
+                    const int t = list[first + i];
+                    r.k0 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
+                    r.k1 = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 2] << 32) | (unsigned long long)(unsigned int)t;
+                } else if (job == 3) { r.k0 = (unsigned long long)(unsigned int)list[first + i]; r.k1 = 0; }
+                else { r.k0 = m.act_key[first + i]; r.k1 = (unsigned long long)(unsigned int)m.act_vox[first + i]; }
+            }
+            recs[i] = r;
+        }
+        __syncthreads();
+        lds_sort_recs<256>(recs, np2, tid);
+        for (int i = tid; i < cnt; i += 256) recs_out[(size_t)pl.rec_off[job] + first + i] = recs[i];
+        __syncthreads();
+    }
 }
 IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& key) {  // number of records < key
     int lo = 0, hi = n;
     while (lo < hi) { const int mid = (lo + hi) >> 1; const SortRec v = a[mid]; if (rec_gt(key, v)) lo = mid + 1; else hi = mid; }
     return lo;
 }
-__global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, LSortPlan pl, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+__global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+    LSortPlan pl;
+    lsort_plan_dev(m, which, pl);
+    for (int eblk = blockIdx.x; eblk < pl.eblk_base[LS_JOBS]; eblk += gridDim.x) {
     int job, lb;
-    lsort_locate(pl, blockIdx.x, pl.eblk_base, job, lb);
+    lsort_locate(pl, eblk, pl.eblk_base, job, lb);
     const int i = lb * 256 + threadIdx.x;
     const int n = pl.n[job];
-    if (i >= n) return;
+    if (i >= n) continue;
     const SortRec* base = recs + (size_t)pl.rec_off[job];
     const SortRec r = base[i];
     const int own = i / LS_CHUNK, nchunks = (n + LS_CHUNK - 1) / LS_CHUNK;
@@ -983,6 +1028,7 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, LSortPl
         m.vx_rank[vi] = rank;
         m.vx_rank_seq[vi] = m.seq;
     }
+    }
 }
 
 // sort keys of a triangle list: which 0 -> third vertex (32-bit), 1 -> (first, second) vertex (64-bit)
@@ -1001,23 +1047,25 @@ __global__ void mesh_emit_kernel(MeshDev m, const int32_t* __restrict__ tris, in
     if (out_flip) out_flip[i] = (uint8_t)m.t_flip[t];
 }
 // Triangle_manager::remove_triangle_list (triangle.hpp:212-221): drop from the live set and from its smallest vertex's list
-__global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tris, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int t = tris[i];
-    m.t_live[t] = 0;
-    const int v0 = m.t_v[(size_t)t * 3 + 0];
-    for (int ch = m.a_head[v0]; ch >= 0; ch = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + MV_ADJ_STRIDE - 1])
-        for (int s = 0; s < MV_ADJ_SLOTS; s++)
-            if (m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] == t) { m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] = -1; return; }
+__global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tris) {
+    const int n = min(m.sc[SC_REM], m.cap_list);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int t = tris[i];
+        m.t_live[t] = 0;
+        const int v0 = m.t_v[(size_t)t * 3 + 0];
+        bool done = false;
+        for (int ch = m.a_head[v0]; ch >= 0 && !done; ch = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + MV_ADJ_STRIDE - 1])
+            for (int s = 0; s < MV_ADJ_SLOTS; s++)
+                if (m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] == t) { m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] = -1; done = true; break; }
+    }
 }
 // Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
-__global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tris, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tris) {
+    const int n = min(m.sc[SC_ADD], m.cap_list);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int v0 = m.t_v[(size_t)tris[i] * 3 + 0];
-    if (i > 0 && m.t_v[(size_t)tris[i - 1] * 3 + 0] == v0) return;
+    if (i > 0 && m.t_v[(size_t)tris[i - 1] * 3 + 0] == v0) continue;
     int ch = m.a_head[v0], s = 0;
     for (int j = i; j < n; j++) {
         const int t = tris[j];
@@ -1033,7 +1081,7 @@ __global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tr
         }
         if (!placed) {  // every chunk of the chain is full: push a new chunk at the front
             const int nc = atomicAdd(&m.pc[PC_ADJ_CHUNKS], 1);
-            if (nc >= m.cap_adj_chunks) { m.sc[SC_OVERFLOW] = 13; return; }
+            if (nc >= m.cap_adj_chunks) { m.sc[SC_OVERFLOW] = 13; break; }
             int* cp = m.a_chunks + (size_t)nc * MV_ADJ_STRIDE;
             cp[0] = t; cp[1] = v1; cp[2] = v2;
             for (int k = 1; k < MV_ADJ_SLOTS; k++) cp[k * 3] = -1;
@@ -1041,6 +1089,7 @@ __global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tr
             m.a_head[v0] = nc;
             ch = nc; s = 1;
         }
+    }
     }
 }
 __global__ void mesh_emit_smooth_kernel(MeshDev m, const int32_t* __restrict__ ids, int n) {
@@ -1069,8 +1118,8 @@ void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xy
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
     KLAUNCH(mesh_append_prepare_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
 }
-void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
-    KLAUNCH(mesh_append_resolve_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts, int max_iter) {
+    KLAUNCH(mesh_append_resolve_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts, max_iter);
 }
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
     KLAUNCH(mesh_append_commit_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
@@ -1078,40 +1127,26 @@ void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanPa
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n) { KLAUNCH(mesh_append_flags_kernel, g1(n), dim3(256), 0, s, m, n); }
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
 void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_rank_kernel, g1(n_active), dim3(256), 0, s, m, n_active); }
-void launch_mesh_knn(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_knn_kernel, dim3(n_active), dim3(256), 0, s, m); }
-void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, int n_active) {
-    KLAUNCH(mesh_delaunay_kernel<256>, dim3(n_active), dim3(64), 0, s, m, sp, 0, 256);
-    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(n_active), dim3(64), 0, s, m, sp, 257, MV_REL_CAP);
+void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel, dim3(1024), dim3(256), 0, s, m); }
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp) {
+    KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, sp, 0, 256);
+    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, sp, 257, MV_REL_CAP);
 }
-void launch_mesh_finalize(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_finalize_kernel, dim3(n_active), dim3(64), 0, s, m); }
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
 void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64) {
     KLAUNCH(mesh_tri_keys_kernel, g1(n), dim3(256), 0, s, m, tris, n, which, k32, k64);
 }
 void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip) {
     KLAUNCH(mesh_emit_kernel, g1(n), dim3(256), 0, s, m, tris, n, out_tri, out_flip);
 }
-void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris, int n) { KLAUNCH(mesh_commit_rem_kernel, g1(n), dim3(256), 0, s, m, tris, n); }
-void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n) {
-    KLAUNCH(mesh_commit_add_kernel, g1(n), dim3(256), 0, s, m, tris_sorted, n);
-}
+void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }
+void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted) { KLAUNCH(mesh_commit_add_kernel, dim3(128), dim3(256), 0, s, m, tris_sorted); }
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n) {
     KLAUNCH(mesh_emit_smooth_kernel, g1(n), dim3(256), 0, s, m, ids_sorted, n);
 }
-static void lsort_plan(LSortPlan& pl, const int* n) {
-    int blk = 0, eblk = 0, off = 0;
-    for (int j = 0; j < LS_JOBS; j++) {
-        pl.n[j] = n[j]; pl.blk_base[j] = blk; pl.eblk_base[j] = eblk; pl.rec_off[j] = off;
-        const int chunks = (n[j] + LS_CHUNK - 1) / LS_CHUNK;
-        blk += chunks; eblk += (n[j] + 255) / 256; off += chunks * LS_CHUNK;
-    }
-    pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
-}
-// n[5] = {rem, add, upd, smooth, active}; recs must hold sum(ceil(n/1024)*1024) records
-void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, const int* n, void* recs, int32_t* add_sorted) {
-    LSortPlan pl;
-    lsort_plan(pl, n);
-    if (pl.blk_base[LS_JOBS] == 0) return;
-    KLAUNCH(mesh_chunk_sort_kernel, dim3(pl.blk_base[LS_JOBS]), dim3(256), 0, s, m, pl, (SortRec*)recs);
-    KLAUNCH(mesh_merge_emit_kernel, dim3(pl.eblk_base[LS_JOBS]), dim3(256), 0, s, m, pl, (const SortRec*)recs, add_sorted);
+// which 0: active-voxel list (-> act_vox_s + ranks); which 1: remove / add / flip-update / smooth lists (-> sorted outputs)
+void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted) {
+    KLAUNCH(mesh_chunk_sort_kernel, dim3(which == 0 ? 32 : 64), dim3(256), 0, s, m, which, (SortRec*)recs);
+    KLAUNCH(mesh_merge_emit_kernel, dim3(which == 0 ? 64 : 256), dim3(256), 0, s, m, which, (const SortRec*)recs, add_sorted);
 }
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n) { KLAUNCH(fill_i32_kernel, dim3(1024), dim3(256), 0, s, p, v, n); }

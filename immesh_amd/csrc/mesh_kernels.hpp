@@ -118,21 +118,21 @@ struct MeshHost {
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
                            const double* extT);
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
-void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts, int max_iter);
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active);
-void launch_mesh_knn(hipStream_t s, const MeshDev& m, int n_active);
-void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, int n_active);
-void launch_mesh_finalize(hipStream_t s, const MeshDev& m, int n_active);
+void launch_mesh_knn(hipStream_t s, const MeshDev& m);
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp);
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
 void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
 void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip);
-void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris, int n);
-void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted, int n);
+void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);
+void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted);
 void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n);
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n);
-void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, const int* n5, void* recs, int32_t* add_sorted);
+void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted);
 
 // device prefix sum (sort.hip)
 size_t exclusive_sum_temp_bytes(int n);

@@ -100,7 +100,7 @@ IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double
 // Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
 // finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
 __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n,
-                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
+                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48, double ticket,
                                                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,14 +250,16 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         red[0][lane] = tot;
     }
     __syncthreads();
-    if (lane < RES_NV) {  // expand to the host layout
+    if (lane < RES_NV - 1) {  // expand to the host layout (pinned, device-mapped host memory)
         double v = 0;
         if (lane < 36) { const int r = lane / 6, c = lane % 6; v = red[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
         else if (lane < 42) v = red[0][21 + (lane - 36)];
         else if (lane < 46) v = red[0][27 + (lane - 42)];
         out48[lane] = v;
     }
-    if (lane == 0) { *done_counter = 0; __threadfence_system(); }
+    __threadfence_system();
+    // slot 47 is the completion ticket the host polls: written after the 47 values are visible system-wide
+    if (lane == 0) { *done_counter = 0; __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
 // =====================================================================================================================
@@ -730,9 +732,9 @@ __global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_
 
 // ---- launchers (called from the host layer) -------------------------------------------------------------------------
 void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
-                     double* out48, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+                     double* out48, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = (n + 63) / 64;
-    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, sp, pts, n, partials, done_counter, out48, o_match, o_node, o_dis, o_rinv, o_normal);
+    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, sp, pts, n, partials, done_counter, out48, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next) {
