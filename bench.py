@@ -175,7 +175,7 @@ def main():
     mesh_mode = (2 if args.async_mesh else 1) if args.mesh else 0
 
     def run(k, state, mode=None):
-        prior = synth.forward_without_imu(state)
+        prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
         out, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode,
                                    n_ds=len(downs[k]), n_raw=len(raws[k]))
         return out, info

@@ -96,6 +96,17 @@ def make_state(R=None, t=None, cov_diag=1e-7, vel=None, gravity=None):
     return s
 
 
+def forward_without_imu_native(lib, state, dt=0.1, cov_gyr=0.3, cov_acc=0.5):
+    """immesh_forward_without_imu (C++ host code in the product library); same arithmetic as synth.forward_without_imu."""
+    f = lib.immesh_forward_without_imu
+    f.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]; f.restype = C.c_int
+    out = np.empty(STATE_DOUBLES)
+    s = np.ascontiguousarray(state, dtype=np.float64)
+    if f(s.ctypes.data_as(C.c_void_p), dt, cov_gyr, cov_acc, out.ctypes.data_as(C.c_void_p)) != 0:
+        raise RuntimeError("immesh_forward_without_imu failed")
+    return out
+
+
 def hip_library_path():
     return os.path.join(_HERE, "csrc", "libimmesh_hip.so")
 

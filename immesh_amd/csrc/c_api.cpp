@@ -408,6 +408,15 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     return 0;
 }
 
+int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out) {
+    if (!state_in || !state_out) return IMMESH_E_INVAL;
+    imh::State a, b;
+    imh::load_state(state_in, a);
+    imh::forward_without_imu(a, dt, cov_gyr, cov_acc, b);
+    imh::store_state(b, state_out);
+    return 0;
+}
+
 int immesh_profile_enable(immesh_ctx* c, int32_t on) {
     if (!c) return IMMESH_E_INVAL;
     mesh_wait_all(c);

@@ -30,7 +30,8 @@ inline void mat3_mul(const double* A, const double* B, double* C) {
 
 // dense inverse, Gauss-Jordan with partial pivoting (stands in for Eigen's Matrix<double,18,18>::inverse())
 inline bool invert(const double* A, double* Ainv, int n) {
-    std::vector<double> M(A, A + n * n);
+    double M[324];   // n <= 18
+    std::memcpy(M, A, sizeof(double) * n * n);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) Ainv[i * n + j] = (i == j) ? 1.0 : 0.0;
     for (int col = 0; col < n; col++) {
@@ -91,14 +92,16 @@ inline void state_minus(const State& a, const State& b, double* out) {  // a - b
 struct EkfLoop {
     int rematch_num = 0;
     double G[324];
+    double covinv[324];      // state.cov is the prior covariance for every iteration of a scan (overwritten only at stop): invert it once
+    bool have_covinv = false;
     EkfLoop() { std::memset(G, 0, sizeof(G)); }
     bool step(const double* HTH /*36*/, const double* HTz /*6*/, const State& prior, State& st, int it, int max_iter) {
         double HTH18[324];
         std::memset(HTH18, 0, sizeof(HTH18));
         for (int r = 0; r < 6; r++)
             for (int c = 0; c < 6; c++) HTH18[r * 18 + c] = HTH[r * 6 + c];
-        double covinv[324], S[324], K1[324];
-        invert(st.cov, covinv, 18);
+        double S[324], K1[324];
+        if (!have_covinv) { invert(st.cov, covinv, 18); have_covinv = true; }
         for (int k = 0; k < 324; k++) S[k] = HTH18[k] + covinv[k];
         invert(S, K1, 18);
         for (int r = 0; r < 18; r++)
@@ -131,5 +134,27 @@ struct EkfLoop {
         return false;
     }
 };
+
+// ImuProcess::Forward_without_imu (src/IMU_Processing.cpp:486-553): constant-velocity prior between two scans; bias_g plays the role of
+// the angular rate ("omega in constant model").  Host-side, 18x18 algebra only -- the step immediately before lio_state_estimation.
+inline void forward_without_imu(const State& in, double dt, double cov_gyr, double cov_acc, State& out) {
+    double F[324], W[324], FC[324];
+    for (int i = 0; i < 324; i++) { F[i] = (i % 19 == 0) ? 1.0 : 0.0; W[i] = 0.0; }
+    double E[9];
+    so3_exp(-in.bg[0] * dt, -in.bg[1] * dt, -in.bg[2] * dt, E);
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) F[r * 18 + c] = E[r * 3 + c];
+    for (int k = 0; k < 3; k++) { F[k * 18 + 9 + k] = dt; F[(3 + k) * 18 + 6 + k] = dt; W[(9 + k) * 18 + 9 + k] = cov_gyr * dt * dt; W[(6 + k) * 18 + 6 + k] = cov_acc * dt * dt; }
+    for (int r = 0; r < 18; r++)
+        for (int c = 0; c < 18; c++) { double s = 0; for (int k = 0; k < 18; k++) s += F[r * 18 + k] * in.cov[k * 18 + c]; FC[r * 18 + c] = s; }
+    out = in;
+    for (int r = 0; r < 18; r++)
+        for (int c = 0; c < 18; c++) { double s = 0; for (int k = 0; k < 18; k++) s += FC[r * 18 + k] * F[c * 18 + k]; out.cov[r * 18 + c] = s + W[r * 18 + c]; }
+    double Ep[9], Rn[9];
+    so3_exp(in.bg[0] * dt, in.bg[1] * dt, in.bg[2] * dt, Ep);
+    mat3_mul(in.R, Ep, Rn);
+    std::memcpy(out.R, Rn, sizeof(Rn));
+    for (int k = 0; k < 3; k++) out.t[k] = in.t[k] + in.vel[k] * dt;
+}
 
 }  // namespace imh

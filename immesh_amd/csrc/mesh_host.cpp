@@ -71,6 +71,8 @@ int mesh_alloc(immesh_ctx* c) {
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
     m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
+    m.dbg = nullptr;
+    if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 16))) return rc; m.dbg = t; (void)hipMemset(t, 0, 128); }
     hipStream_t s = c->stream;
     launch_fill_u64(s, m.g_keys, ~0ull, (size_t)gcap);
     launch_fill_u64(s, m.x_keys, ~0ull, (size_t)xcap);
@@ -115,8 +117,8 @@ static int mesh_overflow(immesh_ctx* c) {
     static const char* why[] = {"", "mesh-voxel hash full", "mesh-voxel pool exhausted (cap_vertices)", "candidate-cell table full", "vertex pool exhausted (cap_vertices)",
                                 "mesh voxel lookup failed", "dedupe grid hash full", "mesh voxel holds more than 128 vertices", "more active voxels than cap (131072 per scan)",
                                 "voxel neighbourhood above 1024 vertices", "triangle pool exhausted (cap_triangles)", "triangle hash full", "Delaunay cavity / triangle buffer overflow",
-                                "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries"};
-    c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 15) ? f : 0];
+                                "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries", "more live triangles around one voxel than 2 x neighbourhood cap"};
+    c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 16) ? f : 0];
     return IMMESH_E_CAPACITY;
 }
 
@@ -202,6 +204,14 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
     h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
     h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
     h.n_live += n_add - n_rem;
+    h.cum[SC_MAXNU] = std::max<int64_t>(h.cum[SC_MAXNU], h.h_sc[SC_MAXNU]); h.cum[SC_PASS2] += h.h_sc[SC_PASS2];
+    if (m.dbg) {
+        unsigned long long t[16];
+        (void)hipMemcpy(t, m.dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 128);
+        fprintf(stderr, "[delaunay cycles/voxel] load %llu pca+proj %llu sort %llu insert %llu filter %llu oldset %llu adds %llu\n", t[0] / std::max(1, n_active), t[1] / std::max(1, n_active),
+                t[2] / std::max(1, n_active), t[3] / std::max(1, n_active), t[4] / std::max(1, n_active), t[5] / std::max(1, n_active), t[6] / std::max(1, n_active));
+    }
+    if (getenv("IMMESH_DEBUG")) fprintf(stderr, "[mesh] cand %d new %d active %d maxnu %d pass2 %d add %d rem %d\n", sp.n_cand, n_new, n_active, h.h_sc[SC_MAXNU], h.h_sc[SC_PASS2], n_add, n_rem);
     return 0;
 }
 

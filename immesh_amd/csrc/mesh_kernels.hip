@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
             if (tid < nq) { const bool need = nbest[tid] < MV_KNN; if (need) { nbest[tid] = 0; s_misc[3] = 1; } else nbest[tid] = nbest[tid] | 0x10000; }
             __syncthreads();
             if (!s_misc[3]) break;
+            if (tid == 0) atomicAdd(&m.sc[SC_PASS2], 1);
         }
         if (wv == 0) {  // voxel-index box covering every query's ball (index of x is round(x/voxel): monotone)
             float mnx = 3e38f, mny = 3e38f, mnz = 3e38f, mxx = -3e38f, mxy = -3e38f, mxz = -3e38f;
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     __syncthreads();
     lds_bitonic_sort<int, 256>(rel_l, np2, tid);
     for (int k = tid; k < nrel; k += 256) m.rel_ids[(size_t)r * MV_REL_CAP + k] = rel_l[k];
-    if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); }
+    if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); atomicMax(&m.sc[SC_MAXNU], nrel); }
     if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
     __syncthreads();
     }
@@ -625,6 +626,7 @@ IMD int tri_find_or_insert(const MeshDev& m, int a, int b, int c, int* spare) {
     return -1;
 }
 
+#define DBG_T(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
 template <int CAP>
 __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanParams sp, int n_lo, int n_hi) {
     constexpr int TCAP = 2 * CAP + 8;
@@ -632,19 +634,22 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     __shared__ float pf[CAP * 3];
     __shared__ double xy[CAP * 2];
     __shared__ unsigned long long keys[CAP];
-    __shared__ unsigned short tri[TCAP * 4];
+    __shared__ __attribute__((aligned(16))) unsigned short tri[TCAP * 4];
     __shared__ unsigned short cav[DT_CAV_CAP];
     __shared__ unsigned short ea[DT_CAV_CAP * 3], eb[DT_CAV_CAP * 3];
     __shared__ unsigned int fresh[TCAP];
     __shared__ unsigned char fhit[TCAP];
     __shared__ double sm[CAP * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
     __shared__ int s_cnt[2];
+    __shared__ int old_t[2 * CAP], old_v1[2 * CAP], old_v2[2 * CAP];   // live triangles whose smallest vertex is in the neighbourhood
+    __shared__ unsigned short old_i[2 * CAP];
 
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int n = m.rel_n[r];
     if (n < n_lo || n > n_hi) continue;  // size class of the other instantiation
+    unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
     const int vi = m.act_vox_s[r];
     for (int i = lane; i < n; i += 64) {
         const int id = m.rel_ids[(size_t)r * MV_REL_CAP + i];
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     }
     if (lane == 0) { s_cnt[0] = 0; s_cnt[1] = 0; }
     __syncthreads();
+    DBG_T(0);
     int nf = 0;
     if (n >= 3) {
         // ---- centre and covariance: sequential sums in vertex order (bit-identical to the CPU path), one lane per component
@@ -710,7 +716,9 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
             keys[i] = key;
         }
         __syncthreads();
+        DBG_T(1);
         lds_bitonic_sort<unsigned long long, 64>(keys, np2, lane);
+        DBG_T(2);
         // ---- first non-degenerate triangle
         const int i0 = (int)(keys[0] & 0xFFFF);
         int i1 = -1, i2 = -1;
@@ -728,29 +736,42 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
             nt = 4;
             __syncthreads();
             bool fail = false;
+
+            const unsigned long long* tri64 = (const unsigned long long*)tri;
+            int pin = (int)(keys[0] & 0xFFFF);
+            double pnx = xy[2 * pin], pny = xy[2 * pin + 1];
             for (int oi = 0; oi < n && !fail; oi++) {
-                const int pi = (int)(keys[oi] & 0xFFFF);
+                const int pi = pin;
+                const double p[2] = {pnx, pny};
+                if (oi + 1 < n) { pin = (int)(keys[oi + 1] & 0xFFFF); pnx = xy[2 * pin]; pny = xy[2 * pin + 1]; }   // the next point's fetch overlaps this step
                 if (pi == i0 || pi == i1 || pi == i2) continue;
-                const double p[2] = {xy[2 * pi], xy[2 * pi + 1]};
-                // cavity: every triangle whose circumdisk contains p
+                // cavity: every triangle whose circumdisk contains p; each member immediately publishes its three directed edges
                 int ncav = 0;
                 for (int base = 0; base < nt; base += 64) {
                     const int t = base + lane;
                     bool in = false;
-                    if (t < nt) in = dt_in_disk(xy, tri[t * 4 + 0], tri[t * 4 + 1], tri[t * 4 + 2], p);
+                    unsigned v0 = 0, v1 = 0, v2 = 0;
+                    if (t < nt) {
+                        const unsigned long long tv = tri64[t];
+                        v0 = (unsigned)(tv & 0xFFFF); v1 = (unsigned)((tv >> 16) & 0xFFFF); v2 = (unsigned)((tv >> 32) & 0xFFFF);
+                        in = dt_in_disk(xy, v0, v1, v2, p);
+                    }
                     const unsigned long long mask = __ballot(in);
-                    if (in) { const int pos = ncav + __popcll(mask & ((1ull << lane) - 1ull)); if (pos < DT_CAV_CAP) cav[pos] = (unsigned short)t; }
+                    if (in) {
+                        const int pos = ncav + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (pos < DT_CAV_CAP) {
+                            cav[pos] = (unsigned short)t;
+                            ea[pos * 3 + 0] = (unsigned short)v1; eb[pos * 3 + 0] = (unsigned short)v2;   // edge k: v[(k+1)%3] -> v[(k+2)%3]
+                            ea[pos * 3 + 1] = (unsigned short)v2; eb[pos * 3 + 1] = (unsigned short)v0;
+                            ea[pos * 3 + 2] = (unsigned short)v0; eb[pos * 3 + 2] = (unsigned short)v1;
+                        }
+                    }
                     ncav += __popcll(mask);
                 }
                 if (ncav == 0) continue;  // duplicate / on every circle: not inserted
                 if (ncav > DT_CAV_CAP) { fail = true; break; }
                 __syncthreads();
                 const int ne = 3 * ncav;
-                for (int e = lane; e < ne; e += 64) {
-                    const int cc = cav[e / 3], k = e % 3;
-                    ea[e] = tri[cc * 4 + (k + 1) % 3]; eb[e] = tri[cc * 4 + (k + 2) % 3];
-                }
-                __syncthreads();
                 // boundary edges (twin not in the cavity) -> fan of new triangles (a, b, p), reusing the cavity slots first
                 int nb = 0;
                 for (int base = 0; base < ne; base += 64) {
@@ -787,6 +808,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
             }
             if (fail) { if (lane == 0) m.sc[SC_OVERFLOW] = 12; nt = 0; }
         }
+        DBG_T(3);
         // ---- finite faces that pass the skinny-face filter (is_face_is_ok: every interior angle * 57.3 <= 150) as sorted local triplets
         for (int base = 0; base < nt; base += 64) {
             const int t = base + lane;
@@ -817,6 +839,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
         for (int k = lane; k < nf; k += 64) fhit[k] = 0;
         __syncthreads();
         lds_bitonic_sort<unsigned int, 64>(fresh, nfp, lane);
+        DBG_T(4);
     }
     __syncthreads();
     // ---- old = live triangles with all three vertices in the neighbourhood (find_relative_triangulation_combination), via the
@@ -825,6 +848,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     const double short_axis[3] = {sa[0], sa[1], sa[2]};
     int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
     const unsigned long long wbase = ((unsigned long long)(unsigned int)m.seq << 32) | ((unsigned long long)(unsigned int)r << 1);
+    // (1) gather: every lane walks the min-vertex list of its vertex and appends the live triangles to one LDS list ...
     for (int i = lane; i < n; i += 64) {
         const int id = ids[i];
         for (int ch = m.a_head[id]; ch >= 0;) {
@@ -834,25 +858,33 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
             for (int k = 0; k < MV_ADJ_STRIDE; k++) e[k] = cp[k];   // one 64-byte chunk: 5 x (triangle, v1, v2) + next
 #pragma unroll
             for (int sl = 0; sl < MV_ADJ_SLOTS; sl++) {
-                const int t = e[sl * 3];
-                if (t < 0) continue;
-                const int v1 = e[sl * 3 + 1], v2 = e[sl * 3 + 2];
-                const int l1 = lds_bsearch_i32(ids, n, v1), l2 = lds_bsearch_i32(ids, n, v2);
-                if (l1 < 0 || l2 < 0) continue;
-                const int pos = lds_bsearch_u32(fresh, nf, ((unsigned int)i << 20) | ((unsigned int)l1 << 10) | (unsigned int)l2);
-                if (pos >= 0) {
-                    fhit[pos] = 1;
-                    const int fl = flip_of(&sm[i * 3], &sm[l1 * 3], &sm[l2 * 3], sp.cam, short_axis);
-                    atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
-                    touched[atomicAdd(&s_cnt[0], 1)] = t;
-                } else if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) {
-                    list_push(m, m.list_rem, SC_REM, t);
-                }
+                if (e[sl * 3] < 0) continue;
+                const int pos = atomicAdd(&s_cnt[1], 1);
+                if (pos < 2 * CAP) { old_t[pos] = e[sl * 3]; old_v1[pos] = e[sl * 3 + 1]; old_v2[pos] = e[sl * 3 + 2]; old_i[pos] = (unsigned short)i; }
             }
             ch = e[MV_ADJ_STRIDE - 1];
         }
     }
     __syncthreads();
+    // (2) ... then the list is classified with all lanes busy and uniform control flow
+    const int nold = s_cnt[1];
+    if (nold > 2 * CAP) { if (lane == 0) m.sc[SC_OVERFLOW] = 15; }
+    for (int k = lane; k < min(nold, 2 * CAP); k += 64) {
+        const int t = old_t[k], i = old_i[k];
+        const int l1 = lds_bsearch_i32(ids, n, old_v1[k]), l2 = lds_bsearch_i32(ids, n, old_v2[k]);
+        if (l1 < 0 || l2 < 0) continue;   // not entirely inside this neighbourhood
+        const int pos = lds_bsearch_u32(fresh, nf, ((unsigned int)i << 20) | ((unsigned int)l1 << 10) | (unsigned int)l2);
+        if (pos >= 0) {
+            fhit[pos] = 1;
+            const int fl = flip_of(&sm[i * 3], &sm[l1 * 3], &sm[l2 * 3], sp.cam, short_axis);
+            atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
+            touched[atomicAdd(&s_cnt[0], 1)] = t;
+        } else if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) {
+            list_push(m, m.list_rem, SC_REM, t);
+        }
+    }
+    __syncthreads();
+    DBG_T(5);
     int spare = -1;
     for (int k = lane; k < nf; k += 64) {
         if (fhit[k]) continue;
@@ -868,6 +900,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
     __syncthreads();
     if (lane == 0) { m.vox_ntris[r] = s_cnt[0]; atomicAdd(&m.sc[SC_TV], nf); }
     __syncthreads();
+    DBG_T(6);
     }
 }
 

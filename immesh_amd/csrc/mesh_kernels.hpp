@@ -30,7 +30,7 @@
 
 // per-scan device counters (MeshDev::sc)
 enum {
-    SC_UNDECIDED = 0, SC_ACCEPTED, SC_RECENT, SC_ACTIVE, SC_ADD, SC_REM, SC_UPD, SC_SMOOTH, SC_OVERFLOW, SC_C1, SC_C20, SC_NV, SC_NU, SC_TV,
+    SC_UNDECIDED = 0, SC_ACCEPTED, SC_RECENT, SC_ACTIVE, SC_ADD, SC_REM, SC_UPD, SC_SMOOTH, SC_OVERFLOW, SC_C1, SC_C20, SC_NV, SC_NU, SC_TV, SC_MAXNU, SC_PASS2,
     SC_COUNT = 16
 };
 // persistent device counters (MeshDev::pc)
@@ -67,6 +67,7 @@ struct MeshDev {
     // parameters
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
     int32_t seq;                         // scan sequence number (>= 1)
+    unsigned long long* dbg;             // optional phase timers (IMMESH_DEBUG): [16] sums of s_memtime deltas, nullptr = off
 };
 
 #define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */

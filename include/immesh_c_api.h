@@ -131,6 +131,10 @@ int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);
 
+/* ---- the step before the path (host-side 18x18 algebra, no device work) ------------------------------ */
+/* ImuProcess::Forward_without_imu   src/IMU_Processing.cpp:486-553 : constant-velocity prior (state + covariance) for the next scan. */
+int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out);
+
 /* ---- introspection (parity tests, roofline denominators) -------------------------------------------------- */
 typedef struct immesh_plane_rec {  /* one initialised octree node */
     int64_t key[3];      /* root voxel key (VOXEL_LOC) */

@@ -62,3 +62,17 @@ def test_no_cpu_fallback_without_a_device():
     lib = capi.load_hip_library()
     with pytest.raises(RuntimeError, match="no usable HIP device|fallback"):
         capi.HotPath(lib, capi.avia_config(), "immesh_")
+
+
+def test_forward_without_imu_matches_harness():
+    """immesh_forward_without_imu (host-side C++ in the product library) against the numpy harness version used by the oracle legs."""
+    import numpy as np
+    from immesh_amd import synth
+    lib = capi.load_hip_library()
+    rng = np.random.default_rng(3)
+    st = capi.make_state(R=synth.so3_exp(rng.normal(0, 0.3, 3)), t=rng.normal(0, 5, 3), cov_diag=1e-4, vel=rng.normal(0, 1, 3))
+    st[15:18] = rng.normal(0, 0.05, 3)
+    c = rng.normal(0, 1e-3, (18, 18)); st[24:] = (c @ c.T + np.eye(18) * 1e-5).reshape(-1)
+    a = capi.forward_without_imu_native(lib, st)
+    b = synth.forward_without_imu(st)
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
