@@ -57,6 +57,7 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
     m.upd_seq = 0;
     A(c->d_stats, 8);
+    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 8); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 64, c->stream)); }
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
@@ -131,6 +132,7 @@ static void make_scan_params(const immesh_ctx* c, const imh::State& st, const do
         for (int j = 0; j < 3; j++) { sp.rot_var[i * 3 + j] = prior_cov[i * 18 + j]; sp.t_var[i * 3 + j] = prior_cov[(3 + i) * 18 + (3 + j)]; }
     sp.dvar_beam = c->dvar_beam; sp.dvar_calib = c->dvar_calib; sp.sigma_num = g.sigma_num;
     sp.dept_err = (float)g.dept_err; sp.calib_laser = g.calib_laser;
+    sp.dbg = c->reg_dbg;
 }
 
 static int check_overflow(immesh_ctx* c) {  // after a stream sync
@@ -190,6 +192,12 @@ static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const im
         if (n_match) *n_match = (int)o[42];
         if (res_mean) *res_mean = o[42] > 0 ? o[43] / o[42] : 0.0;
         if (ekf.step(o, o + 36, prior, st, it, max_iter)) break;
+    }
+    if (c->reg_dbg) {
+        unsigned long long t[8];
+        (void)hipMemcpy(t, c->reg_dbg, 64, hipMemcpyDeviceToHost); (void)hipMemset(c->reg_dbg, 0, 64);
+        const unsigned long long nw = (unsigned long long)iters * ((n_ds + 63) / 64);
+        fprintf(stderr, "[residual cycles/wave] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block final %llu\n", t[0] / nw, t[1] / nw, t[2] / nw, t[3] / nw, t[4] / nw, t[5] / (unsigned long long)iters);
     }
     c->cnt.n_iter += iters;
     c->cnt.n_ds = n_ds;

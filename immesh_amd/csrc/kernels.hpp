@@ -15,6 +15,7 @@ struct ScanParams {          // everything a per-point kernel needs about the cu
     double sigma_num;
     float dept_err;
     int calib_laser;
+    unsigned long long* dbg;  // optional phase timers (IMMESH_DEBUG), nullptr = off
 };
 
 struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)

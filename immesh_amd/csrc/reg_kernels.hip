@@ -104,6 +104,8 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
                                                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+#define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
     double acc[RES_NR];
 #pragma unroll
     for (int k = 0; k < RES_NR; k++) acc[k] = 0;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
 #pragma unroll
             for (int k = 0; k < 9; k++) var[k] = (a[k] + b[k]) + sp.t_var[k];
         }
+        RDBG(0);
         // --- BuildResidualListOMP (:171-222)
         float loc[3];
         int64_t kx[3];
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         if (slot >= 0) {
             const int root = m.htab[slot].root;
             if (root >= 0) match_tree(m, root, pw, var, sp.sigma_num, best, n_tests);
+            RDBG(1);
             if (root >= 0 && !best.ok) {  // near-voxel retry with the literal unit mismatch
                 int64_t nk[3] = {kx[0], kx[1], kx[2]};
                 const float ql = m.nodes[root].quarter;
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
                 if (s2 >= 0 && m.htab[s2].root >= 0) match_tree(m, m.htab[s2].root, pw, var, sp.sigma_num, best, n_tests);
             }
         }
+        RDBG(2);
         acc[29] = (double)n_tests; acc[30] = (double)n_extra;
         o_match[i] = best.ok ? 1 : 0;
         o_node[i] = best.node;
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
             acc[28] = fabs((double)dis);
         }
     }
+    RDBG(3);
     __shared__ double red[RES_NR][65];
     __shared__ int s_last;
     const int lane = threadIdx.x;
@@ -222,14 +228,14 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         double ssum = 0;
         for (int j = 0; j < 32; j++) ssum += red[k][half * 32 + j];
         ssum += __shfl_xor(ssum, 32, 64);
-        if (lane < RES_NR) partials[(size_t)blockIdx.x * RES_NR + lane] = ssum;
+        // write-through (sc1) stores + a drained store queue publish the partials; no agent-scope release fence (a ~3 us L2 write-back) needed
+        if (lane < RES_NR) __hip_atomic_store((unsigned long long*)&partials[(size_t)blockIdx.x * RES_NR + lane], (unsigned long long)__double_as_longlong(ssum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) s_last = (atomicAdd(done_counter, 1u) == gridDim.x - 1) ? 1 : 0;
     __syncthreads();
+    RDBG(4);
     if (!s_last) return;
-    __threadfence();
     // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 8 independent (L2-served) loads in flight per
     // lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
     {
@@ -255,10 +261,11 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         if (lane < 36) { const int r = lane / 6, c = lane % 6; v = red[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
         else if (lane < 42) v = red[0][21 + (lane - 36)];
         else if (lane < 46) v = red[0][27 + (lane - 42)];
-        out48[lane] = v;
+        __hip_atomic_store((unsigned long long*)&out48[lane], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
-    // slot 47 is the completion ticket the host polls: written after the 47 values are visible system-wide
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slot 47 is the completion ticket the host polls: a release store, issued after the 47 value stores of this (single) wavefront drained
+    RDBG(5);
     if (lane == 0) { *done_counter = 0; __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 }
 
