@@ -89,23 +89,23 @@ def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924):
     return nv
 
 
-def make_scans(n_scans, n_pts, cfg, cache_dir):
+def make_scans(n_scans, n_pts, cfg, cache_dir, kitti=False):
     """Synthetic Livox-shaped stream: raw scans (lidar frame, xyzI) + the VoxelGrid-downsampled clouds."""
     os.makedirs(cache_dir, exist_ok=True)
     extT = np.array(list(cfg.extT))
     raws, downs = [], []
     for k in range(n_scans):
-        f = os.path.join(cache_dir, f"livox_{n_pts}_{k}.npy")
+        f = os.path.join(cache_dir, f"hdl64_{k}.npy" if kitti else f"livox_{n_pts}_{k}.npy")
         if os.path.exists(f):
             raw = np.load(f)
         else:
             R, t = synth.trajectory_pose(k)
-            raw = synth.livox_scan(k, R, t, n_pts=n_pts, extT=extT)
+            raw = synth.hdl64_scan(k, R, t) if kitti else synth.livox_scan(k, R, t, n_pts=n_pts, extT=extT)
             tmp = f + f".{os.getpid()}.tmp.npy"     # ranks generate the same scans concurrently: publish atomically
             np.save(tmp, raw)
             os.replace(tmp, f)
         raws.append(raw)
-        downs.append(synth.voxel_grid_downsample(raw, 0.4))
+        downs.append(synth.voxel_grid_downsample(raw, 0.5 if kitti else 0.4))   # filter_size_surf: avia.yaml:5 / velodyne.yaml:5
     return raws, downs
 
 
@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--mesh", type=int, default=1, help="1 = full pipeline (configs[2]); 0 = registration + map update only (configs[1])")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the oracle baseline leg (0 = skip)")
     ap.add_argument("--profile-scans", type=int, default=5)
+    ap.add_argument("--config", choices=["avia", "velodyne"], default="avia", help="avia = BASELINE configs[1]/[2] (the metric's workload); velodyne = configs[3], KITTI-shaped HDL-64 scans with velodyne.yaml parameters")
+    ap.add_argument("--shard", type=int, default=0, help="N>1 only. 0 = replicas (every rank its own stream + map, weak scaling); 1 = ONE stream, registration map sharded by "
+                    "root-voxel bricks over the ranks, 46-double all-reduce per EKF iteration, meshing on rank 0 (strong scaling; the capacity mode of configs[4])")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     args = ap.parse_args()
 
@@ -145,20 +149,42 @@ def main():
     rank, world, local = D.env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    local = local % torch.cuda.device_count()   # one GPU per rank on a real node; functional tests may stack ranks on one device (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = D.init("nccl", dev) if world > 1 else None
+    dist = D.init(args.backend, dev if args.backend == "nccl" else None) if world > 1 else None
+    sharded = bool(args.shard) and world > 1
 
     hip = capi.load_hip_library()
     side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0     # ~8.8 root voxels per m^2 of this world (ground + walls)
-    cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3) + (1 << 16), cap_scan_points=2_500_000,
-                           cap_vertices=1 << 24, cap_triangles=1 << 25)
+    kitti = args.config == "velodyne"
+    if kitti:
+        cfg = capi.velodyne_config(device=local, cap_root_voxels=1 << 18, cap_scan_points=400_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
+    else:
+        cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3) + (1 << 16), cap_scan_points=2_500_000,
+                               cap_vertices=1 << 24, cap_triangles=1 << 25)
+    if sharded:
+        cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2 = rank, world, 5
     h = capi.HotPath(hip, cfg, "immesh_")
-    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
+    if sharded:
+        if args.backend == "nccl":
+            red = torch.zeros(46, dtype=torch.float64, device=dev)
 
+            def _allreduce(buf):                      # 46 doubles: H^T R^-1 H, H^T R^-1 z, counters -- RCCL all-reduce over xGMI
+                red.copy_(torch.from_numpy(buf)); dist.all_reduce(red); buf[:] = red.cpu().numpy()
+        else:
+            def _allreduce(buf):
+                dist.all_reduce(torch.from_numpy(buf))
+        h.set_allreduce(_allreduce)
     n_total = args.warmup + args.steps + args.profile_scans
-    raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"))
-    idx = D.stream_of_rank(rank, n_total)       # replicas-only multi-GPU: rank r replays the stream phase-shifted by r scans
+    raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
+    if kitti:   # the map grows from the stream itself (3 m root voxels, max_layer 4)
+        R0_, t0_ = synth.trajectory_pose(0)
+        h.map_build(np.ascontiguousarray(raws[0][:, :3]), capi.make_state(R=R0_, t=t0_))
+        n_map = h.counters()["n_root_voxels"]
+    else:
+        n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
+    idx = D.stream_of_rank(0 if sharded else rank, n_total)   # replicas: rank r replays the stream phase-shifted by r scans; sharded: one stream
     raws, downs = [raws[i] for i in idx], [downs[i] for i in idx]
     d_raw = [torch.from_numpy(r).to(dev) for r in raws]
     d_down = [torch.from_numpy(d).to(dev) for d in downs]
@@ -168,11 +194,11 @@ def main():
     R0, t0 = synth.trajectory_pose(idx[0])
     st = capi.make_state(R=R0, t=t0)
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
-    if args.mesh:
-        # mesh map is seeded by scan 0 (the registration map is the pre-built survey)
-        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=True, n_ds=len(downs[0]), n_raw=len(raws[0]))
+    mesh_mode = (2 if args.async_mesh else 1) if (args.mesh and (not sharded or rank == 0)) else 0   # sharded: the mesher runs on rank 0
+    if mesh_mode or (sharded and args.mesh):
+        # mesh map is seeded by scan 0 (the registration map is the pre-built survey); sharded: every rank takes part in the scan's all-reduces
+        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1 if mesh_mode else 0, n_ds=len(downs[0]), n_raw=len(raws[0]))
 
-    mesh_mode = (2 if args.async_mesh else 1) if args.mesh else 0
 
     def run(k, state, mode=None):
         prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
@@ -204,12 +230,12 @@ def main():
     # ---- roofline leg: per-kernel HIP-event timing (events recorded on the library's own stream) over extra scans
     roofline = None
     kstats = {}
-    if rank == 0 and args.profile_scans > 0:
+    if (rank == 0 or sharded) and args.profile_scans > 0:   # sharded: every rank takes part in the all-reduces of the extra scans
         h.counters(reset=True)
         h.profile_enable(True)
         pstage = np.zeros(4)
         for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if args.mesh else 0); k += 1    # serial mode: per-stage times of one scan
+            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode: per-stage times of one scan
             tm = h.last_timing()
             pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
         stage = pstage * (args.steps / max(1, args.profile_scans))
@@ -246,7 +272,7 @@ def main():
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
         o = capi.HotPath(ctypes.CDLL(orc_so), cfg, "orc_")
         so = capi.make_state(R=R0, t=t0)
-        o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)
+        o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # (kitti: exactly the GPU leg's map; avia: a local map instead of the 10M-voxel survey)
         so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
         if args.mesh:
             o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
@@ -263,14 +289,16 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "scans/sec (reg+mesh), 100k-pt scan into 10M-voxel map" if args.mesh else "scans/sec (registration + map update, meshing off), 100k-pt scan into 10M-voxel map",
-            "value": round(D.aggregate_throughput(args.steps, world, elapsed), 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": ("scans/sec (reg+mesh), KITTI-shaped 130k-ray scans" if kitti else "scans/sec (reg+mesh), 100k-pt scan into 10M-voxel map") if args.mesh else
+                      "scans/sec (registration + map update, meshing off), 100k-pt scan into 10M-voxel map",
+            "value": round(D.aggregate_throughput(args.steps, 1 if sharded else world, elapsed), 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("synthetic Livox-Avia 100k-pt/scan stream, full pipeline (registration + map update + voxel meshing)" if args.mesh else
-                                    "synthetic Livox-Avia 100k-pt/scan stream, registration + map update, meshing off"),
-                       "n_raw": args.pts, "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/avia.yaml",
-                       "parallelism": f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU",
+            "config": {"workload": (("synthetic KITTI-shaped HDL-64 scan stream (velodyne.yaml), " if kitti else "synthetic Livox-Avia 100k-pt/scan stream, ") +
+                                    ("full pipeline (registration + map update + voxel meshing)" if args.mesh else "registration + map update, meshing off")),
+                       "n_raw": int(np.mean([len(r) for r in raws])), "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
+                       "parallelism": (f"one stream, registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration), mesher on rank 0" if sharded
+                                       else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1)"}[mesh_mode]},
             "stages_ms_serial": {"gpu_total": round(stage[0] / args.steps, 4), "register": round(stage[1] / args.steps, 4),
                           "map_update": round(stage[2] / args.steps, 4), "mesh": round(stage[3] / args.steps, 4)},

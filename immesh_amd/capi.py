@@ -20,6 +20,7 @@ class Config(C.Structure):
         ("mesh_min_spacing", C.c_double), ("mesh_voxel", C.c_double), ("mesh_region", C.c_double), ("mesh_append_budget", C.c_int32),
         ("device", C.c_int32), ("cap_root_voxels", C.c_int64), ("cap_nodes", C.c_int64), ("cap_point_chunks", C.c_int64),
         ("cap_vertices", C.c_int64), ("cap_triangles", C.c_int64), ("cap_scan_points", C.c_int64),
+        ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_brick_log2", C.c_int32), ("shard_pad", C.c_int32),
     ]
 
 
@@ -105,6 +106,12 @@ def forward_without_imu_native(lib, state, dt=0.1, cov_gyr=0.3, cov_acc=0.5):
     if f(s.ctypes.data_as(C.c_void_p), dt, cov_gyr, cov_acc, out.ctypes.data_as(C.c_void_p)) != 0:
         raise RuntimeError("immesh_forward_without_imu failed")
     return out
+
+
+def shard_owner(lib, cfg, key3):
+    f = lib.immesh_shard_owner; f.argtypes = [C.POINTER(Config), C.c_void_p]; f.restype = C.c_int
+    k = np.ascontiguousarray(key3, dtype=np.int64)
+    return f(C.byref(cfg), k.ctypes.data_as(C.c_void_p))
 
 
 def hip_library_path():
@@ -241,6 +248,21 @@ class HotPath:
         ms = np.zeros(4, np.float32)
         self._check(f(self.ctx, _ptr(ms)), "last_timing")
         return {"total": float(ms[0]), "register": float(ms[1]), "map_update": float(ms[2]), "mesh": float(ms[3])}
+
+    # -- multi-GPU sharding ------------------------------------------------------------------------------------
+    def set_allreduce(self, fn):
+        """fn(np.ndarray float64 view of the library's buffer) must sum it over all ranks IN PLACE (e.g. torch.distributed.all_reduce)."""
+        proto = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+
+        def _cb(buf, n, user):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(n,)))
+                return 0
+            except Exception:   # never raise through the C frame
+                return -1
+        self._allreduce_cb = proto(_cb)   # keep alive
+        f = self._f("set_allreduce"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx, self._allreduce_cb, None), "set_allreduce")
 
     # -- per-kernel timing (product library only) --------------------------------------------------------------
     def profile_enable(self, on=True):

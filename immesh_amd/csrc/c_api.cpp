@@ -52,6 +52,8 @@ static int alloc_all(immesh_ctx* c) {
     m.planer_threshold = (float)g.planer_threshold;
     m.voxel_size_f = (float)g.voxel_size;
     m.voxel_size_d = g.voxel_size;
+    m.shard_rank = g.shard_world > 1 ? g.shard_rank : 0; m.shard_world = g.shard_world > 1 ? g.shard_world : 1;
+    m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
     HIPCHK(c, hipMemsetAsync(m.counters, 0, 16 * sizeof(int32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(m.htab, 0xFF, hcap * sizeof(HashEnt), c->stream));   // key = IM_KEY_EMPTY, root = -1
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
@@ -91,6 +93,7 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "device ordinal out of range"; return nullptr; }
     if (cfg->max_layer < 0 || cfg->max_layer > 4 || cfg->voxel_size <= 0 || cfg->max_iter < 1) { g_create_error = "invalid config"; return nullptr; }
+    if (cfg->shard_world > 1 && (cfg->shard_rank < 0 || cfg->shard_rank >= cfg->shard_world || cfg->shard_brick_log2 < 0 || cfg->shard_brick_log2 > 16)) { g_create_error = "invalid shard configuration"; return nullptr; }
     immesh_ctx* c = new (std::nothrow) immesh_ctx();
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
     c->cfg = *cfg;
@@ -164,6 +167,10 @@ static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh
         if (*flag != ticket || c->prof.on) HIPCHK(c, hipStreamSynchronize(c->stream));
         if (*flag != ticket) { c->err = "residual kernel did not complete"; return IMMESH_E_HIP; }
         std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (c->allreduce) {   // sharded map: sum the partial normal equations (36 + 6) and the 4 counters over the ranks -- RCCL / gloo behind the callback
+        const int rc = c->allreduce(c->h_out48, RES_NV_HOST - 2, c->allreduce_user);
+        if (rc) { c->err = "all-reduce callback failed"; return IMMESH_E_INVAL; }
     }
     c->cnt.n_match += (int64_t)c->h_out48[42];
     c->cnt.n_plane_tests += (int64_t)c->h_out48[44];
@@ -423,6 +430,25 @@ int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr
     imh::forward_without_imu(a, dt, cov_gyr, cov_acc, b);
     imh::store_state(b, state_out);
     return 0;
+}
+
+int immesh_set_allreduce(immesh_ctx* c, immesh_allreduce_fn fn, void* user) {
+    if (!c) return IMMESH_E_INVAL;
+    c->allreduce = fn; c->allreduce_user = user;
+    return 0;
+}
+
+// host mirror of the device ownership function (regmap.hpp shard_owner): lets callers / tests partition keys exactly as the kernels do
+static uint64_t h_hash64(uint64_t k) { k ^= k >> 30; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 27; k *= 0x94d049bb133111ebull; k ^= k >> 31; return k; }
+static uint64_t h_pack(int64_t x, int64_t y, int64_t z) {
+    const uint64_t B = 1 << 20, M = (1ull << 21) - 1;
+    return ((uint64_t)(x + B) & M) | (((uint64_t)(y + B) & M) << 21) | (((uint64_t)(z + B) & M) << 42);
+}
+int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3) {
+    if (!cfg || !key3) return IMMESH_E_INVAL;
+    if (cfg->shard_world <= 1) return 0;
+    const int b = cfg->shard_brick_log2 > 0 ? cfg->shard_brick_log2 : 5;
+    return (int)(h_hash64(h_pack(key3[0] >> b, key3[1] >> b, key3[2] >> b)) % (uint64_t)cfg->shard_world);
 }
 
 int immesh_profile_enable(immesh_ctx* c, int32_t on) {

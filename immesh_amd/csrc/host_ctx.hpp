@@ -48,6 +48,8 @@ struct immesh_ctx {
     double* h_out48 = nullptr;       // pinned, device-mapped
     double* d_out48_host = nullptr;  // device view of h_out48
     unsigned int* d_done = nullptr;  // residual_kernel's "blocks finished" counter
+    immesh_allreduce_fn allreduce = nullptr;   // sharded map: sums the per-rank partial normal equations
+    void* allreduce_user = nullptr;
     unsigned long long* reg_dbg = nullptr;  // phase timers of residual_kernel (IMMESH_DEBUG)
     unsigned long long res_ticket = 0;  // completion ticket of the last residual launch (polled in h_out48[47])
     int8_t* d_match = nullptr;

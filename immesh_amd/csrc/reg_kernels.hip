@@ -149,7 +149,9 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         int64_t kx[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) { loc[j] = loc_axis(pw[j] / m.voxel_size_d); kx[j] = (int64_t)loc[j]; }
-        const int64_t slot = hash_find(m, pack_key(kx[0], kx[1], kx[2]));
+        // sharded map: a point is matched by the rank that owns its root voxel (every rank sees the whole scan; the 48 sums are all-reduced)
+        const bool mine = m.shard_world <= 1 || shard_owner(m, kx[0], kx[1], kx[2]) == m.shard_rank;
+        const int64_t slot = mine ? hash_find(m, pack_key(kx[0], kx[1], kx[2])) : -1;
         BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
         int n_tests = 0, n_extra = 0;
         if (slot >= 0) {
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams 
 #pragma unroll
     for (int j = 0; j < 3; j++) kx[j] = key_axis(pw[j] / (double)m.voxel_size_f);
     const uint64_t pk = pack_key(kx[0], kx[1], kx[2]);
+    if (m.shard_world > 1 && !shard_keeps(m, kx[0], kx[1], kx[2])) { slot_out[i] = 0xFFFFFFFFu; return; }   // another rank's voxel (outside our halo)
     bool created;
     const int64_t slot = hash_find_or_insert(m, pk, &created);
     if (slot < 0) { m.counters[5] = 5; slot_out[i] = 0xFFFFFFFFu; return; }

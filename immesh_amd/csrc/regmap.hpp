@@ -55,6 +55,9 @@ struct RegMapDev {
     unsigned long long* slot_head;  // [hcap]
     uint32_t* touched;          // hash slots touched by the current update (counters[7] entries)
     int32_t upd_seq;
+    // multi-GPU sharding of the registration map: root voxels are owned in bricks of 2^shard_brick_log2 voxels per axis,
+    // owner = hash(brick) mod shard_world; a rank also keeps the 1-voxel halo around its bricks (the near-voxel retry looks one voxel over)
+    int32_t shard_rank, shard_world, shard_brick_log2;
     int32_t cap_nodes, cap_chunks, cap_ext;
     // parameters
     int32_t max_layer, max_points_size, init_size[5];
@@ -67,6 +70,24 @@ namespace imd {
 
 IMD int sym21_index(int r, int c) {  // r <= c, 6x6 upper triangle row-major
     return r * 6 - (r * (r - 1)) / 2 + (c - r);
+}
+
+// ---- sharding ---------------------------------------------------------------------------------------------------
+IMD int shard_owner(const RegMapDev& m, int64_t kx, int64_t ky, int64_t kz) {
+    const int b = m.shard_brick_log2;
+    return (int)(hash64(pack_key(kx >> b, ky >> b, kz >> b)) % (uint64_t)m.shard_world);   // arithmetic shift: bricks tile negative keys too
+}
+// does this rank keep voxel k ?  (owned, or within one voxel of an owned brick)
+IMD bool shard_keeps(const RegMapDev& m, int64_t kx, int64_t ky, int64_t kz) {
+    if (shard_owner(m, kx, ky, kz) == m.shard_rank) return true;
+    const int64_t msk = ((int64_t)1 << m.shard_brick_log2) - 1;
+    const int64_t lx = kx & msk, ly = ky & msk, lz = kz & msk;
+    if (lx != 0 && lx != msk && ly != 0 && ly != msk && lz != 0 && lz != msk) return false;   // interior of a foreign brick
+    for (int dx = -1; dx <= 1; dx++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dz = -1; dz <= 1; dz++)
+                if ((dx | dy | dz) != 0 && shard_owner(m, kx + dx, ky + dy, kz + dz) == m.shard_rank) return true;
+    return false;
 }
 
 // ---- hash ---------------------------------------------------------------------------------------------------

@@ -59,6 +59,12 @@ typedef struct immesh_config {
     int64_t cap_vertices;     /* mesh vertices (Global_map::m_rgb_pts_vec) */
     int64_t cap_triangles;    /* distinct triangles ever inserted (Triangle_manager::m_triangle_hash) */
     int64_t cap_scan_points;  /* largest scan (raw points) */
+    /* multi-GPU sharding of the registration map (0 / 1 = off): this context keeps the root voxels whose 2^shard_brick_log2-voxel brick
+     * hashes to shard_rank (plus a one-voxel halo) and matches only the scan points falling into voxels it owns; see immesh_set_allreduce */
+    int32_t shard_rank;
+    int32_t shard_world;
+    int32_t shard_brick_log2;  /* 0 = default 5: 32^3-voxel bricks */
+    int32_t shard_pad;
 } immesh_config;
 
 void immesh_default_config(immesh_config* cfg); /* avia.yaml + mapping_avia.launch values */
@@ -130,6 +136,16 @@ int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uin
 int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const float* pts_raw_body_xyzi, int32_t n_raw,
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);
+
+/* ---- multi-GPU: voxel-hash sharded registration map ------------------------------------------------------------ */
+/* One context per GPU / process, all configured with the same shard_world.  Every rank is handed the same scans; each matches the points
+ * whose root voxel it owns and replays only its own voxels (+ halo) in immesh_map_update.  After every residual pass the library calls
+ * `fn(buf, n, user)` which must sum buf[0..n) over all ranks in place (n = 46: H^T R^-1 H, H^T R^-1 z, 4 counters) and return 0 -- e.g.
+ * torch.distributed.all_reduce / ncclAllReduce over xGMI.  The 18-state update then runs identically on every rank. */
+typedef int (*immesh_allreduce_fn)(double* buf, int32_t n, void* user);
+int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
+/* rank owning root voxel key3 under cfg's shard settings (host mirror of the kernels' ownership function) */
+int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
 
 /* ---- the step before the path (host-side 18x18 algebra, no device work) ------------------------------ */
 /* ImuProcess::Forward_without_imu   src/IMU_Processing.cpp:486-553 : constant-velocity prior (state + covariance) for the next scan. */

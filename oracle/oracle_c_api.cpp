@@ -114,6 +114,8 @@ int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const dou
     return 0;
 }
 int orc_forward_without_imu(const double*, double, double, double, double*) { return -1; }  // harness-side prior lives in synth.py for the checker
+int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
+int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
 int orc_mesh_wait(void* p) { (void)p; return 0; }  // the checker is synchronous
 int orc_mesh_sizes(void* p, immesh_mesh_sizes_t* s) {
     OrcCtx* o = (OrcCtx*)p;

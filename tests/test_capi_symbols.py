@@ -51,7 +51,7 @@ def test_struct_layouts_match_header():
     # immesh_config: field order / padding as the C compiler lays it out
     src = open(HEADER).read()
     body = src[src.index("typedef struct immesh_config {"):src.index("} immesh_config;")]
-    names = re.findall(r"\b(?:double|int32_t|int64_t)\s+([A-Za-z_]+)(?:\[\d+\])?;", body)
+    names = re.findall(r"\b(?:double|int32_t|int64_t)\s+([A-Za-z_0-9]+)(?:\[\d+\])?;", body)
     assert names == [n for n, _ in capi.Config._fields_]
 
 

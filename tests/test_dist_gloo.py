@@ -40,3 +40,24 @@ def test_single_process_is_identity():
     from immesh_amd import dist as D
     assert D.max_over_ranks(1.25) == 1.25
     assert D.aggregate_throughput(10, 1, 2.0) == 5.0
+
+
+def test_shard_owner_partitions_bricks():
+    """Host mirror of the kernels' ownership function (no GPU needed): every key has exactly one owner, all voxels of a brick share
+    it (negative keys included), and the bricks spread evenly over the ranks."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from immesh_amd import capi
+    lib = capi.load_hip_library()
+    rng = np.random.default_rng(1)
+    for world in (2, 4, 8):
+        cfg = capi.avia_config(shard_rank=0, shard_world=world, shard_brick_log2=5)
+        keys = rng.integers(-4000, 4000, size=(4000, 3))
+        owners = np.array([capi.shard_owner(lib, cfg, k) for k in keys])
+        assert owners.min() >= 0 and owners.max() < world
+        counts = np.bincount(owners, minlength=world)
+        assert counts.min() > 0.7 * len(keys) / world             # balanced
+        for k, o in zip(keys[:200], owners[:200]):                 # constant inside a 32^3 brick, also across the origin
+            base = (k >> 5) << 5
+            assert capi.shard_owner(lib, cfg, base) == o and capi.shard_owner(lib, cfg, base + 31) == o
+    assert capi.shard_owner(lib, capi.avia_config(), np.array([5, -7, 9])) == 0     # sharding off

@@ -1,0 +1,113 @@
+"""Voxel-hash sharded registration map, GPU tests.
+1. one process, two sharded contexts + one unsharded: the ranks' partial normal equations add up to the unsharded ones, their
+   match sets partition the unsharded match set, and the owned parts of their plane tables tile the unsharded table;
+2. two processes (gloo, both on cuda:0 -- the pool has one GPU per box; production uses backend "nccl" = RCCL over xGMI with one
+   GPU per rank): the iterated EKF with the all-reduce callback reproduces the unsharded poses."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from immesh_amd import capi, synth
+from conftest import make_hip
+from parity_utils import compare_plane_tables
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(rank=0, world=0):
+    return capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 16, cap_triangles=1 << 18,
+                            shard_rank=rank, shard_world=world, shard_brick_log2=3)   # 8-voxel (4 m) bricks: many bricks in a 100 m scene
+
+
+def _scans(n, npts=30000):
+    cfg = _cfg()
+    extT = np.array(list(cfg.extT))
+    out = []
+    for k in range(n):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, R, t, n_pts=npts, extT=extT)
+        out.append((R, t, raw, synth.voxel_grid_downsample(raw, 0.4)))
+    return out
+
+
+def test_partial_sums_and_plane_tables_tile(hip_lib):
+    P = 2
+    scans = _scans(3)
+    ref = make_hip(hip_lib, _cfg())
+    shards = [make_hip(hip_lib, _cfg(r, P)) for r in range(P)]
+    R0, t0, raw0, _ = scans[0]
+    st0 = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    for h in [ref] + shards:
+        h.map_build(p0, st0)
+    R1, t1, _, down1 = scans[1]
+    st = capi.make_state(R=R1 @ synth.so3_exp(np.array([1e-3, -2e-3, 1.5e-3])), t=t1 + np.array([0.02, -0.01, 0.01]), cov_diag=1e-4)
+    rr = ref.residuals(down1, st)
+    rs = [h.residuals(down1, st) for h in shards]
+    assert all(r["n_match"] > 100 for r in rs)                       # both ranks really own part of the scene
+    np.testing.assert_array_equal(np.sort(np.concatenate([r["match_idx"] for r in rs])), rr["match_idx"])
+    np.testing.assert_allclose(sum(r["HTH"] for r in rs), rr["HTH"], rtol=1e-9, atol=1e-9 * np.abs(rr["HTH"]).max())
+    np.testing.assert_allclose(sum(r["HTz"] for r in rs), rr["HTz"], rtol=1e-9, atol=1e-9 * np.abs(rr["HTz"]).max())
+    # map growth: every rank replays only its voxels (+ halo); owned parts tile the unsharded table exactly
+    for h in [ref] + shards:
+        h.map_update(down1, st)
+        h.map_update(scans[2][3], capi.make_state(R=scans[2][0], t=scans[2][1]))
+    full = ref.dump_planes()
+    owned = []
+    for r, h in enumerate(shards):
+        d = h.dump_planes()
+        mine = np.array([capi.shard_owner(hip_lib, _cfg(r, P), k) == r for k in d["key"]])
+        assert mine.sum() > 100 and (~mine).sum() > 0                # has a halo
+        owned.append(d[mine])
+    tiled = np.concatenate(owned)
+    assert len(tiled) == len(full)
+    compare_plane_tables(full, tiled, 1e-12)
+    assert sum(h.counters()["n_root_voxels"] for h in shards) > ref.counters()["n_root_voxels"]   # halos are replicated
+
+
+def _rank_main(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    lib = capi.load_hip_library()
+    h = capi.HotPath(lib, _cfg(rank, world), "immesh_")
+    h.set_allreduce(lambda buf: dist.all_reduce(torch.from_numpy(buf)))          # in place on the library's buffer
+    ref = capi.HotPath(lib, _cfg(), "immesh_") if rank == 0 else None
+    scans = _scans(5)
+    R0, t0, raw0, _ = scans[0]
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    h.map_build(p0, st)
+    if ref: ref.map_build(p0, st)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    sr = st.copy()
+    err = 0.0
+    for k in range(1, 5):
+        down = scans[k][3]
+        prior = synth.forward_without_imu(st)
+        st, info = h.register(down, prior, prior)
+        h.map_update(down, st)
+        if ref:
+            pr = synth.forward_without_imu(sr)
+            sr, ir = ref.register(down, pr, pr)
+            ref.map_update(down, sr)
+            assert info["n_iter"] == ir["n_iter"] and info["n_match"] == ir["n_match"]
+            err = max(err, float(np.abs(st[:24] - sr[:24]).max()))
+    out[rank] = (st[:24].copy(), err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_register_matches_unsharded():
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 300)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank_main, args=(2, port, out), nprocs=2, join=True)
+    np.testing.assert_array_equal(out[0][0], out[1][0])       # the ranks stay in lock step (identical all-reduced sums -> identical states)
+    assert out[0][1] < 1e-9                                    # and agree with the unsharded run up to summation order
