@@ -249,6 +249,22 @@ class HotPath:
         self._check(f(self.ctx, _ptr(ms)), "last_timing")
         return {"total": float(ms[0]), "register": float(ms[1]), "map_update": float(ms[2]), "mesh": float(ms[3])}
 
+    # -- the stage before the path: VoxelGrid down-sampling ----------------------------------------------------
+    def downsample(self, pts, leaf, n=None, stride=None, to_host=True):
+        """pts: host ndarray (n x 3 or n x 4 float32) or device pointer (then pass n and stride).  Returns (host array | None, n_out)."""
+        f = self._f("downsample"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p]
+        if n is None:
+            n, stride = pts.shape[0], pts.shape[1]
+        out = np.zeros((n, 3), np.float32) if to_host else None
+        n_out = C.c_int32(0)
+        self._check(f(self.ctx, _ptr(pts), n, stride, leaf, _ptr(out), n, C.byref(n_out)), "downsample")
+        return (out[:n_out.value] if to_host else None), n_out.value
+
+    def downsample_result_ptr(self):
+        f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
+        return f(self.ctx)
+
     # -- multi-GPU sharding ------------------------------------------------------------------------------------
     def set_allreduce(self, fn):
         """fn(np.ndarray float64 view of the library's buffer) must sum it over all ranks IN PLACE (e.g. torch.distributed.all_reduce)."""

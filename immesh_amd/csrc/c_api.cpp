@@ -70,8 +70,8 @@ static int alloc_all(immesh_ctx* c) {
     A(c->d_match, ns); A(c->d_mnode, ns); A(c->d_dis, ns); A(c->d_rinv, ns); A(c->d_normal, ns * 3);
     A(c->d_ptdata, ns * IM_PT_DOUBLES);
     A(c->d_key_a, ns); A(c->d_key_b, ns); A(c->d_idx_a, ns); A(c->d_idx_b, ns); A(c->d_idx_c, ns);
-    A(c->d_slot, ns); A(c->d_slot_g, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 4);
-    c->sort_temp_bytes = std::max(sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns)) + 256;
+    A(c->d_slot, ns); A(c->d_slot_g, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 16); A(c->d_ds_out, ns * 3);
+    c->sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns), exclusive_sum_temp_bytes((int)ns)}) + 256;
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
     A(c->d_dump_count, 2);
 #undef A
@@ -422,6 +422,42 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     }
     return 0;
 }
+
+// pcl::VoxelGrid stand-in on the device (the stage before lio_state_estimation, src/voxel_mapping.cpp:1888-1891)
+int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out) {
+    if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0 || !n_out) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    hipStream_t s = c->stream;
+    const void* d_pts;
+    int rc = resolve_input(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts);
+    if (rc) return rc;
+    const float inv = (float)(1.0 / leaf);   // np.float32(1.0 / leaf)
+    int32_t* mm = c->d_nseg;                 // 6 ints of scratch: floor(min), floor(max)
+    const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    HIPCHK(c, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, s));
+    launch_ds_minmax(s, (const float*)d_pts, n, stride, inv, mm);
+    launch_ds_index(s, (const float*)d_pts, n, stride, inv, mm, c->d_key_a, c->d_idx_a);
+    sort_pairs_u64(s, c->d_sort_temp, c->sort_temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n);   // stable: ties keep scan order
+    launch_ds_heads(s, c->d_key_b, n, c->d_idx_c);
+    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_idx_c, c->d_idx_c, n);
+    float* d_out = c->d_ds_out;
+    launch_ds_centroid(s, (const float*)d_pts, n, stride, c->d_key_b, c->d_idx_b, c->d_idx_c, d_out, c->d_nseg + 8);
+    int32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_nseg + 8, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *n_out = cnt;
+    if (out_xyz) {
+        if (cnt > cap_out) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
+        hipPointerAttribute_t attr;
+        const bool dev_out = hipPointerGetAttributes(&attr, out_xyz) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+        if (!dev_out) (void)hipGetLastError();
+        HIPCHK(c, hipMemcpyAsync(out_xyz, d_out, (size_t)cnt * 12, dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : nullptr; }
 
 int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out) {
     if (!state_in || !state_out) return IMMESH_E_INVAL;

@@ -1,0 +1,82 @@
+// pcl::VoxelGrid down-sampling on the device: the stage immediately before the hot path
+// (src/voxel_mapping.cpp:1715, :1888-1891).  Spec = the harness's voxel_grid_downsample (immesh_amd/synth.py), which both the CPU checker and
+// the GPU path consume: leaf index ijk = floor(p * inv_leaf) - floor(min * inv_leaf) in float32, linear index i + j*dx + k*dx*dy, points
+// ordered by index (stable), one output point per occupied leaf = float32 centroid accumulated in point order, output ordered by index.
+//   ds_minmax_kernel   per-axis floor(min) / floor(max) of the cloud (block reduction + integer atomics)
+//   ds_index_kernel    linear leaf index per point
+//   (stable radix sort of (index, point) pairs: rocPRIM)
+//   ds_heads_kernel    run heads -> 0/1 flags        (exclusive scan: rocPRIM)
+//   ds_centroid_kernel one thread per run head: sequential float32 sum of its run, in order -> bit-identical to the CPU spec
+// Bound: HBM streaming (12-16 B per point per pass); the sort dominates.
+#include "kernels.hpp"
+#include "prof.hpp"
+
+__global__ __launch_bounds__(256) void ds_minmax_kernel(const float* __restrict__ pts, int n, int stride, float inv, int* __restrict__ mm /*[6]: min xyz, max xyz*/) {
+    __shared__ int smin[3], smax[3];
+    if (threadIdx.x < 3) { smin[threadIdx.x] = 0x7FFFFFFF; smax[threadIdx.x] = (int)0x80000000; }
+    __syncthreads();
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int c = (int)floorf(pts[(size_t)i * stride + a] * inv);   // floor is monotone: floor(min * inv) == min over points of floor(p * inv)
+            lo[a] = min(lo[a], c); hi[a] = max(hi[a], c);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { atomicMin(&smin[a], lo[a]); atomicMax(&smax[a], hi[a]); }
+    __syncthreads();
+    if (threadIdx.x < 3) { atomicMin(&mm[threadIdx.x], smin[threadIdx.x]); atomicMax(&mm[3 + threadIdx.x], smax[threadIdx.x]); }
+}
+
+__global__ __launch_bounds__(256) void ds_index_kernel(const float* __restrict__ pts, int n, int stride, float inv, const int* __restrict__ mm,
+                                                        unsigned long long* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long dx = (long long)mm[3] - mm[0] + 1, dy = (long long)mm[4] - mm[1] + 1;
+    const long long ix = (long long)floorf(pts[(size_t)i * stride + 0] * inv) - mm[0];
+    const long long iy = (long long)floorf(pts[(size_t)i * stride + 1] * inv) - mm[1];
+    const long long iz = (long long)floorf(pts[(size_t)i * stride + 2] * inv) - mm[2];
+    keys[i] = (unsigned long long)(ix + iy * dx + iz * dx * dy);
+    vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void ds_heads_kernel(const unsigned long long* __restrict__ keys_sorted, int n, int32_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restrict__ pts, int n, int stride, const unsigned long long* __restrict__ keys_sorted,
+                                                           const int32_t* __restrict__ idx_sorted, const int32_t* __restrict__ rank, float* __restrict__ out,
+                                                           int32_t* __restrict__ n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys_sorted[i];
+    if (i > 0 && keys_sorted[i - 1] == k) return;   // not a run head
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int cnt = 0;
+    for (int j = i; j < n && keys_sorted[j] == k; j++) {   // float32 accumulation in (stable) point order, as the CPU spec
+        const int p = idx_sorted[j];
+        sx += pts[(size_t)p * stride + 0]; sy += pts[(size_t)p * stride + 1]; sz += pts[(size_t)p * stride + 2];
+        cnt++;
+    }
+    const float c = (float)cnt;
+    const int r = rank[i];
+    out[(size_t)r * 3 + 0] = sx / c; out[(size_t)r * 3 + 1] = sy / c; out[(size_t)r * 3 + 2] = sz / c;
+    if (i + cnt == n) *n_out = r + 1;   // the last run writes the number of occupied leaves
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm) {
+    KLAUNCH(ds_minmax_kernel, dim3(min(1024, (n + 255) / 256)), dim3(256), 0, s, pts, n, stride, inv, mm);
+}
+void launch_ds_index(hipStream_t s, const float* pts, int n, int stride, float inv, const int* mm, unsigned long long* keys, int32_t* vals) {
+    KLAUNCH(ds_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, stride, inv, mm, keys, vals);
+}
+void launch_ds_heads(hipStream_t s, const unsigned long long* keys_sorted, int n, int32_t* flags) {
+    KLAUNCH(ds_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys_sorted, n, flags);
+}
+void launch_ds_centroid(hipStream_t s, const float* pts, int n, int stride, const unsigned long long* keys_sorted, const int32_t* idx_sorted, const int32_t* rank,
+                        float* out, int32_t* n_out) {
+    KLAUNCH(ds_centroid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, stride, keys_sorted, idx_sorted, rank, out, n_out);
+}

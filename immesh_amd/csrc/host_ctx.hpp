@@ -43,6 +43,7 @@ struct immesh_ctx {
     int64_t cap_scan = 0;
     float* d_pts_down = nullptr;     // staging for host inputs (n x 3)
     float* d_pts_raw = nullptr;      // staging (n x 4)
+    float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     double* d_partials = nullptr;    // residual block partials
     double* d_out48 = nullptr;
     double* h_out48 = nullptr;       // pinned, device-mapped

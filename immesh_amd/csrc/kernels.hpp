@@ -42,6 +42,15 @@ void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v,
 void launch_iota(hipStream_t s, int32_t* p, int n);
 void launch_gather_u32(hipStream_t s, const uint32_t* src, const int32_t* idx, uint32_t* dst, int n);
 
+// VoxelGrid down-sampling (ds_kernels.hip)
+void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm);
+void launch_ds_index(hipStream_t s, const float* pts, int n, int stride, float inv, const int* mm, unsigned long long* keys, int32_t* vals);
+void launch_ds_heads(hipStream_t s, const unsigned long long* keys_sorted, int n, int32_t* flags);
+void launch_ds_centroid(hipStream_t s, const float* pts, int n, int stride, const unsigned long long* keys_sorted, const int32_t* idx_sorted, const int32_t* rank,
+                        float* out, int32_t* n_out);
+size_t exclusive_sum_temp_bytes(int n);
+void exclusive_sum_i32(hipStream_t s, void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n);
+
 // stable LSD radix sort of (key,value) pairs, device-resident (sort.hip)
 size_t sort_pairs_u64_temp_bytes(int n);
 size_t sort_pairs_u32_temp_bytes(int n);

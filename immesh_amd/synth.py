@@ -129,9 +129,15 @@ def voxel_grid_downsample(pts_xyz, leaf):
     order = np.argsort(idx, kind="stable")
     sidx = idx[order]
     starts = np.flatnonzero(np.concatenate([[True], sidx[1:] != sidx[:-1]]))
-    counts = np.diff(np.concatenate([starts, [len(sidx)]])).astype(np.float32)
-    sums = np.add.reduceat(p[order], starts, axis=0)
-    return np.ascontiguousarray((sums / counts[:, None]).astype(np.float32))
+    cnt = np.diff(np.concatenate([starts, [len(sidx)]]))
+    # centroid accumulated sequentially in float32, point by point in (stable) index order, as PCL's `centroid += pt` does (np.add.reduceat
+    # would sum long runs pairwise): the k-th point of every leaf is added in lock step
+    ps = p[order]
+    sums = np.zeros((len(starts), 3), np.float32)
+    for k in range(int(cnt.max())):
+        live = cnt > k
+        sums[live] = sums[live] + ps[starts[live] + k]
+    return np.ascontiguousarray((sums / cnt.astype(np.float32)[:, None]).astype(np.float32))
 
 
 def forward_without_imu(state, dt=0.1, cov_gyr=0.3, cov_acc=0.5):

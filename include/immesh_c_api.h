@@ -148,6 +148,13 @@ int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
 int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
 
 /* ---- the step before the path (host-side 18x18 algebra, no device work) ------------------------------ */
+/* pcl::VoxelGrid (m_downSizeFilterSurf.filter, src/voxel_mapping.cpp:1888-1891) on the device: pts = n points of `stride` (3 or 4) floats, host or
+ * device; result = one float32 centroid per occupied leaf, ordered by linear leaf index (SURVEY A.15 spec).  *n_out = number of leaves.  out_xyz
+ * (host or device, may be NULL) receives n_out x 3 floats; the result also stays on the device (immesh_downsample_result) so that it can be fed
+ * to immesh_register / immesh_process_scan without leaving HBM. */
+int immesh_downsample(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out);
+const float* immesh_downsample_result(immesh_ctx* ctx);
+
 /* ImuProcess::Forward_without_imu   src/IMU_Processing.cpp:486-553 : constant-velocity prior (state + covariance) for the next scan. */
 int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out);
 

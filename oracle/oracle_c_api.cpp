@@ -6,6 +6,7 @@
 #include "orc_mesher.hpp"
 #include <string>
 #include <chrono>
+#include <climits>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -114,6 +115,32 @@ int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const dou
     return 0;
 }
 int orc_forward_without_imu(const double*, double, double, double, double*) { return -1; }  // harness-side prior lives in synth.py for the checker
+// pcl::VoxelGrid stand-in (SURVEY A.15 spec, the harness's voxel_grid_downsample): float32 arithmetic, stable order, sequential centroid sums
+int orc_downsample(void* p, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out) {
+    (void)p;
+    const float inv = (float)(1.0 / leaf);
+    long mn[3] = {LONG_MAX, LONG_MAX, LONG_MAX}, mx[3] = {LONG_MIN, LONG_MIN, LONG_MIN};
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) { const long c = (long)std::floor(pts[(size_t)i * stride + a] * inv); mn[a] = std::min(mn[a], c); mx[a] = std::max(mx[a], c); }
+    const long dx = mx[0] - mn[0] + 1, dy = mx[1] - mn[1] + 1;
+    std::vector<std::pair<unsigned long long, int>> kv(n);
+    for (int i = 0; i < n; i++) {
+        const long ix = (long)std::floor(pts[(size_t)i * stride + 0] * inv) - mn[0], iy = (long)std::floor(pts[(size_t)i * stride + 1] * inv) - mn[1],
+                   iz = (long)std::floor(pts[(size_t)i * stride + 2] * inv) - mn[2];
+        kv[i] = {(unsigned long long)(ix + iy * dx + iz * dx * dy), i};
+    }
+    std::stable_sort(kv.begin(), kv.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    int cnt = 0;
+    for (int i = 0; i < n;) {
+        float sx = 0.f, sy = 0.f, sz = 0.f; int c = 0, j = i;
+        for (; j < n && kv[j].first == kv[i].first; j++) { const int q = kv[j].second; sx += pts[(size_t)q * stride]; sy += pts[(size_t)q * stride + 1]; sz += pts[(size_t)q * stride + 2]; c++; }
+        if (out_xyz && cnt < cap_out) { out_xyz[cnt * 3] = sx / (float)c; out_xyz[cnt * 3 + 1] = sy / (float)c; out_xyz[cnt * 3 + 2] = sz / (float)c; }
+        cnt++; i = j;
+    }
+    *n_out = cnt;
+    return (out_xyz && cnt > cap_out) ? IMMESH_E_CAPACITY : 0;
+}
+const float* orc_downsample_result(void*) { return nullptr; }
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
 int orc_mesh_wait(void* p) { (void)p; return 0; }  // the checker is synchronous
