@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--shard", type=int, default=0, help="N>1 only. 0 = replicas (every rank its own stream + map, weak scaling); 1 = ONE stream, registration map sharded by "
                     "root-voxel bricks over the ranks, 46-double all-reduce per EKF iteration, meshing on rank 0 (strong scaling; the capacity mode of configs[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
+    ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     args = ap.parse_args()
 
@@ -202,8 +203,12 @@ def main():
 
     def run(k, state, mode=None):
         prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
-        out, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode,
-                                   n_ds=len(downs[k]), n_raw=len(raws[k]))
+        down_ptr, n_ds = d_down[k].data_ptr(), len(downs[k])
+        if args.device_downsample:
+            _, n_ds = h.downsample(d_raw[k].data_ptr(), 0.5 if kitti else 0.4, n=len(raws[k]), stride=4, to_host=False)
+            down_ptr = h.downsample_result_ptr()
+        out, info = h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode,
+                                   n_ds=n_ds, n_raw=len(raws[k]))
         return out, info
 
     k = 1
@@ -299,7 +304,8 @@ def main():
                        "n_raw": int(np.mean([len(r) for r in raws])), "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
                        "parallelism": (f"one stream, registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration), mesher on rank 0" if sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
-                       "mesh_mode": {0: "off", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1)"}[mesh_mode]},
+                       "mesh_mode": {0: "off", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1)"}[mesh_mode],
+                       "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},
             "stages_ms_serial": {"gpu_total": round(stage[0] / args.steps, 4), "register": round(stage[1] / args.steps, 4),
                           "map_update": round(stage[2] / args.steps, 4), "mesh": round(stage[3] / args.steps, 4)},
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_new", "v_act", "n_u", "t_add", "t_rem")},

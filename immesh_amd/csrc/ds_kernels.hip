@@ -46,24 +46,70 @@ __global__ __launch_bounds__(256) void ds_heads_kernel(const unsigned long long*
     if (i < n) flags[i] = (i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1 : 0;
 }
 
+// One wavefront per tile of 64 sorted points.  The wave owns the runs (= leaves) whose first point lies in its tile and follows the last of them
+// past the tile end if it must.  A batch of 64 points is fetched by the 64 lanes at once; the float32 sums are then formed strictly in point
+// order by a wave-uniform loop over the lanes (v_readlane), i.e. the same sequential `centroid += pt` as the CPU spec, with all memory latency
+// taken once per 64 points instead of once per point.
 __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restrict__ pts, int n, int stride, const unsigned long long* __restrict__ keys_sorted,
                                                            const int32_t* __restrict__ idx_sorted, const int32_t* __restrict__ rank, float* __restrict__ out,
                                                            int32_t* __restrict__ n_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const unsigned long long k = keys_sorted[i];
-    if (i > 0 && keys_sorted[i - 1] == k) return;   // not a run head
+    const int lane = threadIdx.x & 63;
+    const int tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((long long)tile * 64 >= n) return;
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    int cnt = 0;
-    for (int j = i; j < n && keys_sorted[j] == k; j++) {   // float32 accumulation in (stable) point order, as the CPU spec
-        const int p = idx_sorted[j];
-        sx += pts[(size_t)p * stride + 0]; sy += pts[(size_t)p * stride + 1]; sz += pts[(size_t)p * stride + 2];
-        cnt++;
+    int cnt = 0, orank = -1;
+    bool open = false;
+    // software pipeline: the next batch's gathers are in flight while this batch is summed
+    unsigned long long k = ~0ull, kprev = ~0ull;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int rk = 0;
+    auto fetch = [&](int base, unsigned long long& fk, unsigned long long& fkp, float& fx, float& fy, float& fz, int& frk) {
+        const int i = base + lane;
+        fk = ~0ull; fkp = ~0ull; fx = fy = fz = 0.f; frk = 0;
+        if (i < n) {
+            fk = keys_sorted[i];
+            fkp = i > 0 ? keys_sorted[i - 1] : ~0ull;
+            const int p = idx_sorted[i];
+            fx = pts[(size_t)p * stride + 0]; fy = pts[(size_t)p * stride + 1]; fz = pts[(size_t)p * stride + 2];
+            frk = rank[i];
+        }
+    };
+    fetch(tile * 64, k, kprev, x, y, z, rk);
+    for (int b = 0;; b++) {
+        const int base = tile * 64 + b * 64;
+        if (base >= n) break;
+        const int i = base + lane;
+        unsigned long long nk, nkp; float nx, ny, nz; int nrk;
+        fetch(base + 64, nk, nkp, nx, ny, nz, nrk);
+        const unsigned long long valid = __ballot(i < n);
+        const unsigned long long heads = __ballot(i < n && (i == 0 || k != kprev));
+        bool stop = false;
+        for (int l = 0; l < 64; l++) {
+            if (!((valid >> l) & 1ull)) break;
+            const bool hd = (heads >> l) & 1ull;
+            if (hd && b > 0) { stop = true; break; }            // the next run starts in another wave's tile
+            const float xl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+            const float yl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
+            const float zl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
+            if (hd) {
+                if (open && lane == 0) { const float c = (float)cnt; out[(size_t)orank * 3 + 0] = sx / c; out[(size_t)orank * 3 + 1] = sy / c; out[(size_t)orank * 3 + 2] = sz / c; }
+                open = true; orank = __builtin_amdgcn_readlane(rk, l);
+                sx = 0.f + xl; sy = 0.f + yl; sz = 0.f + zl; cnt = 1;
+            } else if (open) { sx += xl; sy += yl; sz += zl; cnt++; }
+        }
+        if (stop || !open) break;
+        k = nk; kprev = nkp; x = nx; y = ny; z = nz; rk = nrk;
     }
-    const float c = (float)cnt;
-    const int r = rank[i];
-    out[(size_t)r * 3 + 0] = sx / c; out[(size_t)r * 3 + 1] = sy / c; out[(size_t)r * 3 + 2] = sz / c;
-    if (i + cnt == n) *n_out = r + 1;   // the last run writes the number of occupied leaves
+    if (open && lane == 0) {
+        const float c = (float)cnt;
+        out[(size_t)orank * 3 + 0] = sx / c; out[(size_t)orank * 3 + 1] = sy / c; out[(size_t)orank * 3 + 2] = sz / c;
+    }
+    // the run containing the last point is the last leaf
+    if (lane == 0 && (long long)tile * 64 <= (long long)n - 1 && (long long)tile * 64 + 64 > (long long)n - 1) {
+        const int i = n - 1;
+        const int last_head_rank = rank[i] + ((i == 0 || keys_sorted[i] != keys_sorted[i - 1]) ? 1 : 0);   // exclusive scan + own flag
+        *n_out = last_head_rank;
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
