@@ -293,13 +293,15 @@ class HotPath:
         return {buf[i].name.decode(): {"launches": buf[i].launches, "total_ms": buf[i].total_ms} for i in range(min(n.value, 128))}
 
     # -- introspection ----------------------------------------------------------------------------------------
-    def dump_planes(self):
+    def dump_planes(self, cap=None):
+        """all initialised octree nodes (unordered); cap = at most that many records (a sample of a big map)"""
         f = self._f("dump_planes"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
         n = C.c_int64(0)
         self._check(f(self.ctx, None, 0, C.byref(n)), "dump_planes")
-        recs = np.zeros(n.value, PLANE_DTYPE)
-        if n.value:
-            self._check(f(self.ctx, _ptr(recs), n.value, C.byref(n)), "dump_planes")
+        m = n.value if cap is None else min(n.value, int(cap))
+        recs = np.zeros(m, PLANE_DTYPE)
+        if m:
+            self._check(f(self.ctx, _ptr(recs), m, C.byref(n)), "dump_planes")
         return recs
 
     def counters(self, reset=False):
