@@ -44,6 +44,8 @@ static int alloc_all(immesh_ctx* c) {
     A(m.htab, hcap); A(m.slot_head, hcap);
     m.hmask = (uint64_t)hcap - 1;
     A(m.nodes, cap_nodes);
+    const int64_t cap_leaf = std::max<int64_t>(4096, cap_nodes / 2);
+    A(m.leaf_chunks, cap_leaf * 16); m.cap_leaf_chunks = (int32_t)cap_leaf;
     A(m.chunk_data, cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES); A(m.ext_tables, cap_ext * IM_EXT_CHUNKS);
     A(m.counters, 16); A(m.free_ready, cap_chunks); A(m.free_pending, cap_chunks);
     m.cap_nodes = (int32_t)cap_nodes; m.cap_chunks = (int32_t)cap_chunks; m.cap_ext = (int32_t)cap_ext;
@@ -143,8 +145,9 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
     if (f) {
         static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 32896 retained points", "extension-table pool exhausted",
                                     "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)",
-                                    "more than 512 points of one scan fall into one root voxel (down-sample the scan, or use immesh_map_build)"};
-        c->err = std::string("registration map capacity: ") + why[f < 7 ? f : 0];
+                                    "more than 512 points of one scan fall into one root voxel (down-sample the scan, or use immesh_map_build)",
+                                    "leaf-list pool exhausted (cap_nodes)"};
+        c->err = std::string("registration map capacity: ") + why[f < 8 ? f : 0];
         return IMMESH_E_CAPACITY;
     }
     return 0;

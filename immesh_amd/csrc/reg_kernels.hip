@@ -39,18 +39,28 @@ IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigm
 // build_single_residual on one plane node (voxel_mapping.cpp:252-290).  The whole plane record (normal, centre, d, radius, 21-entry
 // covariance) is fetched up front -- one gather latency -- and both gates are evaluated from registers; computing sigma_l before
 // knowing that the range gate passed has no side effect, so the accept set is the reference's.
+// EAGER (planar root voxel, the common avia case): everything in one gather.  !EAGER (leaves of a subdivided voxel, where most of the many
+// candidates fail the range gate): the covariance is fetched only for the survivors.
+template <bool EAGER>
 IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
     n_tests++;
     const NodeRec& nr = m.nodes[node];
     double pv[21];
+    if (EAGER) {
 #pragma unroll
-    for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
+        for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
+    }
     const double nx = nr.p_normal[0], ny = nr.p_normal[1], nz = nr.p_normal[2];
     const double cx = nr.p_center[0], cy = nr.p_center[1], cz = nr.p_center[2];
     const float pd = nr.d, radius = nr.radius;
     const float dis_to_plane = (float)fabs(nx * pw[0] + ny * pw[1] + nz * pw[2] + (double)pd);
     const float dis_to_center = (float)((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2]));
     const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);  // NaN compares false below
+    if (!EAGER) {
+        if (!((double)range_dis <= 3.0 * (double)radius)) return;
+#pragma unroll
+        for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
+    }
     const double J[6] = {pw[0] - cx, pw[1] - cy, pw[2] - cz, -nx, -ny, -nz};
     double tmp[6];
 #pragma unroll
@@ -74,21 +84,19 @@ IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, c
     }
 }
 
-// recursive descent over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312), explicit stack
+// build_single_residual's recursion over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312): the planes it reaches are the
+// root's flat leaf list.  Equal probabilities keep the reference's "first in depth-first order wins" through dfs_key.
 IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
-    if (m.nodes[root].flags & NF_PLANE) { test_plane(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
+    if (m.nodes[root].flags & NF_PLANE) { test_plane<true>(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
     if (m.max_layer <= 0) return;
-    int st_node[5], st_k[5];
-    int sp = 0;
-    st_node[0] = root; st_k[0] = 0;
-    while (sp >= 0) {
-        if (st_k[sp] >= 8) { sp--; continue; }
-        const int k = st_k[sp]++;
-        const int child = m.nodes[st_node[sp]].child[k];
-        if (child < 0) continue;
-        const int layer = sp + 1;
-        if (m.nodes[child].flags & NF_PLANE) test_plane(m, child, layer, pw, var, sigma_num, best, n_tests);
-        else if (layer < m.max_layer) { sp++; st_node[sp] = child; st_k[sp] = 0; }
+    for (int ch = m.nodes[root].leaf_head; ch >= 0;) {
+        int e[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = m.leaf_chunks[(size_t)ch * 16 + k];   // one 64-byte line: 15 node ids + next
+#pragma unroll
+        for (int s2 = 0; s2 < IM_LEAF_SLOTS; s2++)
+            if (e[s2] >= 0) test_plane<false>(m, e[s2], 1, pw, var, sigma_num, best, n_tests);
+        ch = e[15];
     }
 }
 
@@ -353,7 +361,7 @@ __global__ void segment_heads_kernel(const uint32_t* __restrict__ sorted_slot, i
 // =====================================================================================================================
 // wave-cooperative octree maintenance
 // =====================================================================================================================
-struct WaveCtx { int lane; int64_t* stats; };  // stats[0] refits, stats[1] refit points
+struct WaveCtx { int lane; int64_t* stats; int root; };  // stats[0] refits, stats[1] refit points
 
 // OctoTree::init_plane (src/voxel_loc.cpp:47-139) for node `nd` holding `n` points; returns planar?  All lanes get the result.
 __device__ bool wave_init_plane(const RegMapDev& m, int nd, int n, const WaveCtx& w) {
@@ -496,9 +504,10 @@ __device__ void wave_init_octo_tree(const RegMapDev& m, int node, int* stack, co
         const bool planar = wave_init_plane(m, nd, n, w);
         const int layer = m.nodes[nd].layer;
         if (w.lane == 0) {
-            int f = m.nodes[nd].flags | NF_INIT;
+            const int f0 = m.nodes[nd].flags;
+            int f = f0 | NF_INIT;
             f = planar ? (f | NF_PLANE) : (f & ~NF_PLANE);
-            m.nodes[nd].flags = f;
+            node_set_flags(m, w.root, nd, f0, f);
             m.nodes[nd].newpts = 0;
         }
         if (planar || layer >= m.max_layer) continue;
@@ -579,7 +588,7 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (newp > 5) {  // m_update_size_threshold_
                 const bool planar = wave_init_plane(m, nd, n + 1, w);
-                if (w.lane == 0) m.nodes[nd].flags = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+                if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE));
                 newp = 0;
             }
             if (w.lane == 0) {
@@ -616,7 +625,7 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (newp > 5) {
             const bool planar = wave_init_plane(m, nd, n + 1, w);
-            if (w.lane == 0) m.nodes[nd].flags = planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE);
+            if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE));
             newp = 0;
         }
         if (w.lane == 0) {
@@ -641,6 +650,7 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
     const uint32_t slot = sorted_slot[start];
     const int root = m.htab[slot].root;
     if (root < 0) return;
+    w.root = root;
     if (mode == 0) {
         for (int j = start; j < n && sorted_slot[j] == slot; j++)
             wave_update_point(m, root, pt_data + (size_t)sorted_idx[j] * IM_PT_DOUBLES, stacks[wv], w);
@@ -672,6 +682,7 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     const uint32_t slot = m.touched[t];
     const int root = m.htab[slot].root;
     if (root < 0) return;
+    w.root = root;
     int cnt = 0;
     for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
         if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }

@@ -12,6 +12,7 @@
 #define IM_PT_DOUBLES 9           /* x y z + var(00 01 02 11 12 22) */
 #define IM_INLINE_CHUNKS 8        /* 128 points inline per node; beyond that an extension table */
 #define IM_EXT_CHUNKS 2048        /* + 32768 points: KITTI max_points_size / g_max_points 1000, and buildVoxelMap roots that hold a whole 3 m voxel of the first scan */
+#define IM_LEAF_SLOTS 15          /* node ids per leaf-list chunk (+ next pointer = one 64-byte line) */
 #define IM_G_MAX_POINTS 1000      /* g_max_points, src/voxel_loc.cpp:45 */
 
 // node flag bits
@@ -32,7 +33,9 @@ struct alignas(64) NodeRec {
     int32_t chunks[IM_INLINE_CHUNKS];      // chunk ids of the retained points (-1 = none)
     int32_t ext, path;                     // extension table id or -1; child path from the root (3 bits per level)
     unsigned long long key;                // packed root key (for dumps)
-    unsigned long long pad[4];
+    int32_t leaf_head;                     // root nodes: chain of the planar descendants (what build_single_residual's recursion would reach)
+    int32_t pad0;
+    unsigned long long pad[3];
 };
 static_assert(sizeof(NodeRec) == 384, "NodeRec layout");
 
@@ -51,6 +54,9 @@ struct RegMapDev {
     int32_t* counters;
     int32_t* free_ready;        // chunk ids available for allocation
     int32_t* free_pending;      // chunk ids freed by the running kernel (merged into ready afterwards)
+    // per-root flat lists of planar descendants: chunks of IM_LEAF_SLOTS node ids + next pointer (counters[8] = chunks used)
+    int32_t* leaf_chunks;
+    int32_t cap_leaf_chunks;
     // per-update root-voxel point lists (map_incremental_grow): head word per hash slot = (update seq << 32 | last point index), stamped so it never needs clearing
     unsigned long long* slot_head;  // [hcap]
     uint32_t* touched;          // hash slots touched by the current update (counters[7] entries)
@@ -189,9 +195,41 @@ IMD int node_alloc(const RegMapDev& m, int layer, const double* center, float qu
     nd.flags = NF_UPDATE_EN;
     nd.layer = layer;
     nd.npts = 0; nd.newpts = 0; nd.ext = -1;
-    nd.key = key; nd.path = path;
+    nd.key = key; nd.path = path; nd.leaf_head = -1;
     nd.d = 0.f; nd.radius = 0.f; nd.min_eig = 1.f;
     return id;
+}
+
+// ---- per-root list of planar descendants (maintained by the voxel's own wavefront during map build / update; one lane) -----------------
+// The matcher's recursion "test every plane reachable through non-planar ancestors" visits exactly the nodes with NF_PLANE set below a
+// non-planar root (a planar node never has children), so a flat list turns a pointer chase over hundreds of internal nodes into a scan.
+IMD void leaf_add(const RegMapDev& m, int root, int nd) {
+    for (int ch = m.nodes[root].leaf_head; ch >= 0; ch = m.leaf_chunks[(size_t)ch * 16 + 15])
+        for (int s = 0; s < IM_LEAF_SLOTS; s++)
+            if (m.leaf_chunks[(size_t)ch * 16 + s] < 0) { m.leaf_chunks[(size_t)ch * 16 + s] = nd; return; }
+    const int nc = atomicAdd(&m.counters[8], 1);
+    if (nc >= m.cap_leaf_chunks) { m.counters[5] = 7; return; }
+    m.leaf_chunks[(size_t)nc * 16 + 0] = nd;
+    for (int s = 1; s < IM_LEAF_SLOTS; s++) m.leaf_chunks[(size_t)nc * 16 + s] = -1;
+    m.leaf_chunks[(size_t)nc * 16 + 15] = m.nodes[root].leaf_head;
+    m.nodes[root].leaf_head = nc;
+}
+IMD void leaf_remove(const RegMapDev& m, int root, int nd) {
+    for (int ch = m.nodes[root].leaf_head; ch >= 0; ch = m.leaf_chunks[(size_t)ch * 16 + 15])
+        for (int s = 0; s < IM_LEAF_SLOTS; s++)
+            if (m.leaf_chunks[(size_t)ch * 16 + s] == nd) { m.leaf_chunks[(size_t)ch * 16 + s] = -1; return; }
+}
+// write a node's flags; keeps the root's leaf list in step with the plane bit (one lane)
+IMD void node_set_flags(const RegMapDev& m, int root, int nd, int old_flags, int new_flags) {
+    m.nodes[nd].flags = new_flags;
+    if (nd != root && ((old_flags ^ new_flags) & NF_PLANE)) { if (new_flags & NF_PLANE) leaf_add(m, root, nd); else leaf_remove(m, root, nd); }
+}
+// position of a node in the depth-first order of the reference's recursion (child indices, first level most significant)
+IMD unsigned int dfs_key(const RegMapDev& m, int nd) {
+    const int path = m.nodes[nd].path, layer = m.nodes[nd].layer;
+    unsigned int k = 0;
+    for (int l = 1; l <= layer; l++) k |= (unsigned int)((path >> (3 * (l - 1))) & 7) << (3 * (4 - l));
+    return k;
 }
 
 }  // namespace imd
