@@ -72,7 +72,7 @@ static int alloc_all(immesh_ctx* c) {
     A(c->d_match, ns); A(c->d_mnode, ns); A(c->d_dis, ns); A(c->d_rinv, ns); A(c->d_normal, ns * 3);
     A(c->d_ptdata, ns * IM_PT_DOUBLES);
     A(c->d_key_a, ns); A(c->d_key_b, ns); A(c->d_idx_a, ns); A(c->d_idx_b, ns); A(c->d_idx_c, ns);
-    A(c->d_slot, ns); A(c->d_slot_g, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 16); A(c->d_ds_out, ns * 3);
+    A(c->d_slot, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 16); A(c->d_ds_out, ns * 3);
     c->sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns), exclusive_sum_temp_bytes((int)ns)}) + 256;
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
     A(c->d_dump_count, 2);

@@ -61,7 +61,7 @@ struct immesh_ctx {
     double* d_ptdata = nullptr;      // n x 9
     unsigned long long *d_key_a = nullptr, *d_key_b = nullptr;
     int32_t *d_idx_a = nullptr, *d_idx_b = nullptr, *d_idx_c = nullptr;
-    uint32_t *d_slot = nullptr, *d_slot_g = nullptr, *d_slot_s = nullptr;
+    uint32_t *d_slot = nullptr, *d_slot_s = nullptr;
     int32_t* d_seg_start = nullptr;
     int32_t* d_nseg = nullptr;
     void* d_sort_temp = nullptr;

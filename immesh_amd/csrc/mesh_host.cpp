@@ -63,8 +63,8 @@ int mesh_alloc(immesh_ctx* c) {
         A(o.smooth_ids, cap_list); A(o.smooth_xyz, cap_list * 3);
         A(h.d_world[k], cap_cand * 4);
     }
-    A(h.k32_a, cap_list); A(h.k32_b, cap_list); A(h.k64_a, cap_list); A(h.k64_b, cap_list); A(h.p_a, cap_list); A(h.p_b, cap_list); A(h.p_c, cap_list);
-    h.sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)cap_list), sort_pairs_u32_temp_bytes((int)cap_list), exclusive_sum_temp_bytes((int)cap_cand)}) + 256;
+    A(h.p_a, cap_list);
+    h.sort_temp_bytes = exclusive_sum_temp_bytes((int)cap_cand) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
     { unsigned long long* t; A(t, (size_t)(4 * cap_list + cap_active + 5 * 1024) * 2); h.d_sort_recs = t; }
 #undef A
@@ -120,16 +120,6 @@ static int mesh_overflow(immesh_ctx* c) {
                                 "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries", "more live triangles around one voxel than 2 x neighbourhood cap"};
     c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 16) ? f : 0];
     return IMMESH_E_CAPACITY;
-}
-
-// sort a list of triangle indices lexicographically by (v0, v1, v2): LSD with two stable radix passes; result in h.p_c
-static void sort_tris(immesh_ctx* c, const int32_t* list, int n) {
-    MeshHost& h = c->mesh_host;
-    hipStream_t s = h.stream;
-    launch_mesh_tri_keys(s, c->mesh, list, n, 0, h.k32_a, nullptr);
-    sort_pairs_u32(s, h.d_sort_temp, h.sort_temp_bytes, h.k32_a, h.k32_b, list, h.p_b, n, 32);
-    launch_mesh_tri_keys(s, c->mesh, h.p_b, n, 1, nullptr, h.k64_a);
-    sort_pairs_u64(s, h.d_sort_temp, h.sort_temp_bytes, h.k64_a, h.k64_b, h.p_b, h.p_c, n);
 }
 
 // runs on the worker thread, on the mesher's stream

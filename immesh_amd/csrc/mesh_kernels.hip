@@ -275,13 +275,6 @@ __global__ void mesh_select_active_kernel(MeshDev m) {
     m.act_key[a] = m.vx_key[vi];
     m.act_vox[a] = vi;
 }
-__global__ void mesh_rank_kernel(MeshDev m, int n_active) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_active) return;
-    const int vi = m.act_vox_s[r];
-    m.vx_rank[vi] = r;
-    m.vx_rank_seq[vi] = m.seq;
-}
 
 // =====================================================================================================================
 // LDS helpers
@@ -937,7 +930,6 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
 // small sorts: one workgroup, 16-byte records in LDS (<= 8192 records = 128 KB), bitonic network with a lexicographic (k0, k1)
 // comparator.  Replaces ~10 multi-kernel device-wide radix sorts per scan whose cost at these sizes is pure launch latency.
 // =====================================================================================================================
-#define LSORT_CAP 8192
 struct SortRec { unsigned long long k0, k1; };
 IMD bool rec_gt(const SortRec& a, const SortRec& b) { return a.k0 > b.k0 || (a.k0 == b.k0 && a.k1 > b.k1); }
 template <int NT>
@@ -1064,21 +1056,6 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, int whi
     }
 }
 
-// sort keys of a triangle list: which 0 -> third vertex (32-bit), 1 -> (first, second) vertex (64-bit)
-__global__ void mesh_tri_keys_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int which, uint32_t* __restrict__ k32, unsigned long long* __restrict__ k64) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int t = tris[i];
-    if (which == 0) k32[i] = (uint32_t)m.t_v[(size_t)t * 3 + 2];
-    else k64[i] = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
-}
-__global__ void mesh_emit_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int32_t* __restrict__ out_tri, uint8_t* __restrict__ out_flip) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int t = tris[i];
-    out_tri[(size_t)i * 3 + 0] = m.t_v[(size_t)t * 3 + 0]; out_tri[(size_t)i * 3 + 1] = m.t_v[(size_t)t * 3 + 1]; out_tri[(size_t)i * 3 + 2] = m.t_v[(size_t)t * 3 + 2];
-    if (out_flip) out_flip[i] = (uint8_t)m.t_flip[t];
-}
 // Triangle_manager::remove_triangle_list (triangle.hpp:212-221): drop from the live set and from its smallest vertex's list
 __global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tris) {
     const int n = min(m.sc[SC_REM], m.cap_list);
@@ -1125,19 +1102,6 @@ __global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tr
     }
     }
 }
-__global__ void mesh_emit_smooth_kernel(MeshDev m, const int32_t* __restrict__ ids, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int id = ids[i];
-    m.out_smooth_ids[i] = id;
-    m.out_smooth_xyz[(size_t)i * 3 + 0] = m.v_smooth[(size_t)id * 3 + 0];
-    m.out_smooth_xyz[(size_t)i * 3 + 1] = m.v_smooth[(size_t)id * 3 + 1];
-    m.out_smooth_xyz[(size_t)i * 3 + 2] = m.v_smooth[(size_t)id * 3 + 2];
-}
-__global__ void fill_i32_kernel(int32_t* p, int32_t v, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
-}
-
 // ---- launchers ------------------------------------------------------------------------------------------------------
 static inline dim3 g1(int n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
@@ -1159,27 +1123,16 @@ void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanPa
 }
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n) { KLAUNCH(mesh_append_flags_kernel, g1(n), dim3(256), 0, s, m, n); }
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
-void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active) { KLAUNCH(mesh_rank_kernel, g1(n_active), dim3(256), 0, s, m, n_active); }
 void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel, dim3(1024), dim3(256), 0, s, m); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp) {
     KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, sp, 0, 256);
     KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, sp, 257, MV_REL_CAP);
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
-void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64) {
-    KLAUNCH(mesh_tri_keys_kernel, g1(n), dim3(256), 0, s, m, tris, n, which, k32, k64);
-}
-void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip) {
-    KLAUNCH(mesh_emit_kernel, g1(n), dim3(256), 0, s, m, tris, n, out_tri, out_flip);
-}
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted) { KLAUNCH(mesh_commit_add_kernel, dim3(128), dim3(256), 0, s, m, tris_sorted); }
-void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n) {
-    KLAUNCH(mesh_emit_smooth_kernel, g1(n), dim3(256), 0, s, m, ids_sorted, n);
-}
 // which 0: active-voxel list (-> act_vox_s + ranks); which 1: remove / add / flip-update / smooth lists (-> sorted outputs)
 void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted) {
     KLAUNCH(mesh_chunk_sort_kernel, dim3(which == 0 ? 32 : 64), dim3(256), 0, s, m, which, (SortRec*)recs);
     KLAUNCH(mesh_merge_emit_kernel, dim3(which == 0 ? 64 : 256), dim3(256), 0, s, m, which, (const SortRec*)recs, add_sorted);
 }
-void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n) { KLAUNCH(fill_i32_kernel, dim3(1024), dim3(256), 0, s, p, v, n); }

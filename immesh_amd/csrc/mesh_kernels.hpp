@@ -88,10 +88,7 @@ struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; floa
 struct MeshHost {
     int32_t seq = 0;
     int64_t cum[SC_COUNT];
-    // sort scratch
-    uint32_t *k32_a = nullptr, *k32_b = nullptr;
-    unsigned long long *k64_a = nullptr, *k64_b = nullptr;
-    int32_t *p_a = nullptr, *p_b = nullptr, *p_c = nullptr;
+    int32_t* p_a = nullptr;    // add list as sorted triangle indices (input of the adjacency commit)
     int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters
     int32_t* h_pc = nullptr;
     void* d_sort_temp = nullptr;
@@ -123,16 +120,11 @@ void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanP
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
-void launch_mesh_rank(hipStream_t s, const MeshDev& m, int n_active);
 void launch_mesh_knn(hipStream_t s, const MeshDev& m);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
-void launch_mesh_tri_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
-void launch_mesh_emit(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int32_t* out_tri, uint8_t* out_flip);
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted);
-void launch_mesh_emit_smooth(hipStream_t s, const MeshDev& m, const int32_t* ids_sorted, int n);
-void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, size_t n);
 void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted);
 
 // device prefix sum (sort.hip)

@@ -745,11 +745,6 @@ __global__ void iota_kernel(int32_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
 }
-__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, uint32_t* __restrict__ dst, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
-}
-// compact the matched points in ascending scan order is done on the host from o_match (tiny); see reg_host.cpp
 
 // ---- launchers (called from the host layer) -------------------------------------------------------------------------
 void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
@@ -785,6 +780,3 @@ void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v,
     KLAUNCH(fill_u64_kernel, dim3(2048), dim3(256), 0, s, p, v, n);
 }
 void launch_iota(hipStream_t s, int32_t* p, int n) { KLAUNCH(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n); }
-void launch_gather_u32(hipStream_t s, const uint32_t* src, const int32_t* idx, uint32_t* dst, int n) {
-    KLAUNCH(gather_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, dst, n);
-}
