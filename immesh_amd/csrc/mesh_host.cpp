@@ -81,6 +81,10 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
+    { MeshDyn* t; if ((rc = c->dalloc(&t, 1))) return rc; h.d_dyn = t; m.dyn = t; }
+    HIPCHK(c, hipHostMalloc((void**)&h.h_dyn, sizeof(MeshDyn)));
+    std::memset(h.h_dyn, 0, sizeof(MeshDyn));
+    h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
     HIPCHK(c, hipHostMalloc((void**)&h.h_sc, SC_COUNT * 4));
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_sc, 0, SC_COUNT * 4); std::memset(h.h_pc, 0, PC_COUNT * 4);
@@ -106,6 +110,8 @@ void mesh_free(immesh_ctx* c) {
     for (int k = 0; k < 2; k++) if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
     if (h.ev_t0) (void)hipEventDestroy(h.ev_t0);
     if (h.ev_t1) (void)hipEventDestroy(h.ev_t1);
+    for (int k = 0; k < 2; k++) if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
+    if (h.h_dyn) (void)hipHostFree(h.h_dyn);
     if (h.h_sc) (void)hipHostFree(h.h_sc);
     if (h.h_pc) (void)hipHostFree(h.h_pc);
     h.h_sc = h.h_pc = nullptr;
@@ -122,6 +128,38 @@ static int mesh_overflow(immesh_ctx* c) {
     return IMMESH_E_CAPACITY;
 }
 
+// the launch sequence of one scan (fixed grids; everything scan-specific is read from MeshDev::dyn on the device)
+static int mesh_enqueue(immesh_ctx* c, const MeshDev& m, const float* d_pts, int n_cand, int64_t ccap) {
+    MeshHost& h = c->mesh_host;
+    hipStream_t s = h.stream;
+    MHIPCHK(c, hipMemcpyAsync(h.d_dyn, h.h_dyn, sizeof(MeshDyn), hipMemcpyHostToDevice, s));
+    MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+    MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
+    MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
+    // ---- a17 append.  Every launch below has a fixed grid and takes its work-list length from device counters, so the whole scan is
+    //      enqueued without a host round trip; the host reads the counters once, at the end.
+    launch_mesh_append_prepare(s, m, n_cand, d_pts);
+    // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
+    // the iteration bound only guards against a hung device and is checked by the caller
+    launch_mesh_append_resolve(s, m, n_cand, d_pts, 1 << 16);
+    launch_mesh_append_flags(s, m, n_cand);
+    exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, n_cand);
+    launch_mesh_append_commit(s, m, n_cand, d_pts);
+    launch_mesh_select_active(s, m, n_cand);
+    // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
+    // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
+    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);   // sorted active list + ranks
+    launch_mesh_knn(s, m);                                    // a18-a19
+    launch_mesh_delaunay(s, m);                               // a20-a23
+    launch_mesh_finalize(s, m);
+    // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
+    launch_mesh_commit_rem(s, m, m.list_rem);
+    launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
+    launch_mesh_commit_add(s, m, h.p_a);
+    MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
 // runs on the worker thread, on the mesher's stream
 static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t& sizes) {
     MeshDev& m = c->mesh;
@@ -129,58 +167,75 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
     hipStream_t s = h.stream;
     const float* d_pts = job.d_pts;
     const int n_raw = job.n_raw;
-    const double* sensor_pos = job.cam;
+    const int par = (int)(job.id & 1);
     {   // this job's result lists
-        const MeshOutSet& o = h.outs[job.id & 1];
+        const MeshOutSet& o = h.outs[par];
         m.out_tri_add = o.tri_add; m.out_flip_add = o.flip_add; m.out_tri_rem = o.tri_rem; m.out_tri_upd = o.tri_upd; m.out_flip_upd = o.flip_upd;
         m.out_smooth_ids = o.smooth_ids; m.out_smooth_xyz = o.smooth_xyz;
     }
     h.seq++;
-    m.seq = h.seq;
     MeshScanParams sp;
-    sp.cam[0] = sensor_pos[0]; sp.cam[1] = sensor_pos[1]; sp.cam[2] = sensor_pos[2];
+    sp.cam[0] = job.cam[0]; sp.cam[1] = job.cam[1]; sp.cam[2] = job.cam[2];
     sp.n_raw = n_raw;
     sp.step = std::max(1, (int)std::round((double)(n_raw / c->cfg.mesh_append_budget)));  // integer division first (ImMesh_mesh_reconstruction.cpp:111)
     sp.n_cand = (n_raw + sp.step - 1) / sp.step;
     sp.vtx_base = h.n_vertices;
     if (sp.n_cand > m.cap_cand) { h.err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
     const int64_t ccap = np2((int64_t)sp.n_cand * 4);
-    m.ch_mask = (uint64_t)ccap - 1;
-    MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-    MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
-    MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
-    // ---- a17 append.  Every launch below has a fixed grid and takes its work-list length from device counters, so the whole scan is
-    //      enqueued without a host round trip; the host reads the counters once, at the end.
-    launch_mesh_append_prepare(s, m, sp, d_pts);
-    if (sp.n_cand <= 65536) {
-        // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
-        // the iteration bound only guards against a hung device and is checked below
-        launch_mesh_append_resolve(s, m, sp, d_pts, 1 << 16);
-    } else {
-        for (int round = 0; round < 100000; round++) {   // offline-sized clouds: bounded rounds, host checks in between
+    h.h_dyn->sp = sp; h.h_dyn->seq = h.seq; h.h_dyn->ch_mask = (uint64_t)ccap - 1;
+    m.seq = h.seq; m.ch_mask = (uint64_t)ccap - 1;   // (host copies; the kernels read *dyn)
+    if (sp.n_cand > 65536) {
+        // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
+        MHIPCHK(c, hipMemcpyAsync(h.d_dyn, h.h_dyn, sizeof(MeshDyn), hipMemcpyHostToDevice, s));
+        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
+        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
+        launch_mesh_append_prepare(s, m, sp.n_cand, d_pts);
+        for (int round = 0; round < 100000; round++) {
             if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
-            launch_mesh_append_resolve(s, m, sp, d_pts, 64);
+            launch_mesh_append_resolve(s, m, sp.n_cand, d_pts, 64);
             MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
             MHIPCHK(c, hipStreamSynchronize(s));
             if (h.h_sc[SC_UNDECIDED] == 0) break;
         }
+        launch_mesh_append_flags(s, m, sp.n_cand);
+        exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
+        launch_mesh_append_commit(s, m, sp.n_cand, d_pts);
+        launch_mesh_select_active(s, m, sp.n_cand);
+        launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);
+        launch_mesh_knn(s, m);
+        launch_mesh_delaunay(s, m);
+        launch_mesh_finalize(s, m);
+        launch_mesh_commit_rem(s, m, m.list_rem);
+        launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
+        launch_mesh_commit_add(s, m, h.p_a);
+    } else if (h.use_graph && !h.prof.on && d_pts == h.d_world[par]) {
+        // steady state: the ~25 launches of a scan are captured once per (parity, candidate count) and replayed as one hipGraph --
+        // the sequence is launch-bound (tens of microsecond-scale kernels), per-launch host and dispatch gaps are what the graph removes
+        if (h.graph_exec[par] == nullptr || h.graph_ncand[par] != sp.n_cand) {
+            if (h.graph_exec[par]) { (void)hipGraphExecDestroy(h.graph_exec[par]); h.graph_exec[par] = nullptr; }
+            hipGraph_t g = nullptr;
+            MHIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int erc = mesh_enqueue(c, m, d_pts, sp.n_cand, ccap);
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (erc || ce != hipSuccess || g == nullptr) { if (g) (void)hipGraphDestroy(g); h.err = "hipGraph capture of the mesher failed"; return IMMESH_E_HIP; }
+            const hipError_t ie = hipGraphInstantiate(&h.graph_exec[par], g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ie != hipSuccess) { h.graph_exec[par] = nullptr; h.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
+            h.graph_ncand[par] = sp.n_cand;
+        }
+        MHIPCHK(c, hipGraphLaunch(h.graph_exec[par], s));
+        MHIPCHK(c, hipStreamSynchronize(s));
+        goto scan_done;
+    } else {
+        const int erc = mesh_enqueue(c, m, d_pts, sp.n_cand, ccap);
+        if (erc) return erc;
+        MHIPCHK(c, hipStreamSynchronize(s));
+        goto scan_done;
     }
-    launch_mesh_append_flags(s, m, sp.n_cand);
-    exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
-    launch_mesh_append_commit(s, m, sp, d_pts);
-    launch_mesh_select_active(s, m, sp.n_cand);
-    // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
-    // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);   // sorted active list + ranks
-    launch_mesh_knn(s, m);                                    // a18-a19
-    launch_mesh_delaunay(s, m, sp);                           // a20-a23
-    launch_mesh_finalize(s, m);
-    // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
-    launch_mesh_commit_rem(s, m, m.list_rem);
-    launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
-    launch_mesh_commit_add(s, m, h.p_a);
     MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(c, hipStreamSynchronize(s));
+scan_done:
     int rc = mesh_overflow(c);
     if (rc) return rc;
     if (h.h_sc[SC_UNDECIDED] != 0) { h.err = "vertex admission did not converge (device hang guard)"; return IMMESH_E_HIP; }
@@ -198,6 +253,8 @@ static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t&
     if (m.dbg) {
         unsigned long long t[16];
         (void)hipMemcpy(t, m.dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 128);
+        fprintf(stderr, "[knn cycles/voxel] stage0 %llu query0 %llu stage1 %llu query1 %llu final %llu\n", t[8] / std::max(1, n_active), t[9] / std::max(1, n_active), t[10] / std::max(1, n_active),
+                t[11] / std::max(1, n_active), t[12] / std::max(1, n_active));
         fprintf(stderr, "[delaunay cycles/voxel] load %llu pca+proj %llu sort %llu insert %llu filter %llu oldset %llu adds %llu\n", t[0] / std::max(1, n_active), t[1] / std::max(1, n_active),
                 t[2] / std::max(1, n_active), t[3] / std::max(1, n_active), t[4] / std::max(1, n_active), t[5] / std::max(1, n_active), t[6] / std::max(1, n_active));
     }

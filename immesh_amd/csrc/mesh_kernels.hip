@@ -68,6 +68,15 @@ IMD float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
     return (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
 }
 
+// Per-scan parameters live in device memory (MeshDev::dyn, refreshed by a copy at the head of every scan) so that the kernel arguments
+// are identical from scan to scan and the whole launch sequence can be replayed as a hipGraph.
+#define MESH_DYN(arg)                                  \
+    MeshDev m = (arg);                                 \
+    const MeshScanParams sp = (arg).dyn->sp;           \
+    m.seq = (arg).dyn->seq;                            \
+    m.ch_mask = (arg).dyn->ch_mask;                    \
+    (void)sp
+
 IMD void list_push(const MeshDev& m, int32_t* list, int counter, int v) {
     const int pos = atomicAdd(&m.sc[counter], 1);
     if (pos < m.cap_list) list[pos] = v; else m.sc[SC_OVERFLOW] = 14;
@@ -92,7 +101,8 @@ __global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __res
 // =====================================================================================================================
 // append_points_to_global_map
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts) {
+    MESH_DYN(m_in);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n_cand) return;
     const float* p = pts + 4 * (size_t)i * sp.step;
@@ -165,7 +175,8 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m, Mes
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
 // loop's outcome.  Each lane re-evaluates until every lower-index conflicting candidate is decided (bounded; relaunched by the host).
-__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts, int max_iter) {
+__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, const float* __restrict__ pts, int max_iter) {
+    MESH_DYN(m_in);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // Lanes of one wavefront may depend on each other, so the decision store must happen INSIDE the loop body and the loop must be left
     // by the whole wavefront together (__all): with a per-lane `return` the compiler may sink the store to the loop exit, which the
@@ -220,13 +231,16 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m, Mes
     if (my == ST_UNDECIDED) atomicAdd(&m.sc[SC_UNDECIDED], 1);
 }
 
-__global__ void mesh_append_flags_kernel(MeshDev m, int n) {
+__global__ void mesh_append_flags_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
+    const int n = sp.n_cand;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) m.cand_rank[i] = (m.cand_status[i] == ST_ACCEPT) ? 1 : 0;
 }
 
 // new vertex id = vtx_base + (number of accepted candidates with a lower scan index): ids grow in scan order as in the reference
-__global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m, MeshScanParams sp, const float* __restrict__ pts) {
+__global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m_in, const float* __restrict__ pts) {
+    MESH_DYN(m_in);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n_cand) return;
     const bool acc = m.cand_status[i] == ST_ACCEPT;
@@ -262,7 +276,8 @@ __global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m, Mesh
 
 // voxels to (re)mesh this scan: visited, m_meshing_times < 1, m_new_added_pts_count >= 0, >= 3 vertices
 // (ImMesh_mesh_reconstruction.cpp:132-151)
-__global__ void mesh_select_active_kernel(MeshDev m) {
+__global__ void mesh_select_active_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m.sc[SC_RECENT]) return;
     const int vi = m.recent[r];
@@ -338,7 +353,8 @@ IMD double wave_max_d(double x) {
 #define WL (KC + MV_KNN + 4)    /* per-wave work list */
 #define HSET 4096
 
-__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
+__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
     __shared__ float cx[KC], cy[KC], cz[KC];
     __shared__ int cid[KC];
     __shared__ unsigned long long best[MV_VOX_CAP][MV_KNN];
@@ -355,6 +371,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
+    unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
+#define KDBG(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
     const int vi = m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
     if (tid < nq) {
@@ -434,6 +452,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
                 }
             }
             __syncthreads();
+            KDBG(8 + 2 * pass);
             const int ncand = s_misc[0];
             vstart = s_misc[1];
             // ---- every query against the staged candidates: one wavefront per query
@@ -477,6 +496,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             __syncthreads();
+            KDBG(9 + 2 * pass);
         }
     }
     __syncthreads();
@@ -536,6 +556,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m) {
     if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); atomicMax(&m.sc[SC_MAXNU], nrel); }
     if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
     __syncthreads();
+    KDBG(12);
     }
 }
 
@@ -621,7 +642,8 @@ IMD int tri_find_or_insert(const MeshDev& m, int a, int b, int c, int* spare) {
 
 #define DBG_T(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
 template <int CAP>
-__global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanParams sp, int n_lo, int n_hi) {
+__global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_lo, int n_hi) {
+    MESH_DYN(m_in);
     constexpr int TCAP = 2 * CAP + 8;
     __shared__ int ids[CAP];
     __shared__ float pf[CAP * 3];
@@ -899,7 +921,8 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m, MeshScanPa
 
 // cross-voxel resolution: the voxel with the highest rank that touched a triangle owns its flip (later voxel wins, as the
 // sequential loop); it also queues the triangle for insertion / reports a changed flip.  Then this scan's smoothed positions commit.
-__global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m) {
+__global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
@@ -971,7 +994,8 @@ IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
     }
     pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
 }
-__global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m, int which, SortRec* __restrict__ recs_out) {
+__global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int which, SortRec* __restrict__ recs_out) {
+    MESH_DYN(m_in);
     __shared__ SortRec recs[LS_CHUNK];
     LSortPlan pl;
     lsort_plan_dev(m, which, pl);
@@ -1006,7 +1030,8 @@ IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& k
     while (lo < hi) { const int mid = (lo + hi) >> 1; const SortRec v = a[mid]; if (rec_gt(key, v)) lo = mid + 1; else hi = mid; }
     return lo;
 }
-__global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+__global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+    MESH_DYN(m_in);
     LSortPlan pl;
     lsort_plan_dev(m, which, pl);
     for (int eblk = blockIdx.x; eblk < pl.eblk_base[LS_JOBS]; eblk += gridDim.x) {
@@ -1057,7 +1082,8 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m, int whi
 }
 
 // Triangle_manager::remove_triangle_list (triangle.hpp:212-221): drop from the live set and from its smallest vertex's list
-__global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tris) {
+__global__ void mesh_commit_rem_kernel(MeshDev m_in, const int32_t* __restrict__ tris) {
+    MESH_DYN(m_in);
     const int n = min(m.sc[SC_REM], m.cap_list);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int t = tris[i];
@@ -1071,7 +1097,8 @@ __global__ void mesh_commit_rem_kernel(MeshDev m, const int32_t* __restrict__ tr
 }
 // Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
-__global__ void mesh_commit_add_kernel(MeshDev m, const int32_t* __restrict__ tris) {
+__global__ void mesh_commit_add_kernel(MeshDev m_in, const int32_t* __restrict__ tris) {
+    MESH_DYN(m_in);
     const int n = min(m.sc[SC_ADD], m.cap_list);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int v0 = m.t_v[(size_t)tris[i] * 3 + 0];
@@ -1112,21 +1139,22 @@ void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xy
     for (int i = 0; i < 3; i++) { xp.t[i] = t[i]; xp.extT[i] = extT[i]; }
     KLAUNCH(mesh_transform_kernel, g1(n), dim3(256), 0, s, (const float4*)raw_xyzi, (float4*)world_xyzi, n, xp);
 }
-void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
-    KLAUNCH(mesh_append_prepare_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+// n_cand only sizes the grids here; the kernels take every per-scan value from MeshDev::dyn
+void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts) {
+    KLAUNCH(mesh_append_prepare_kernel, g1(n_cand), dim3(256), 0, s, m, pts);
 }
-void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts, int max_iter) {
-    KLAUNCH(mesh_append_resolve_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts, max_iter);
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter) {
+    KLAUNCH(mesh_append_resolve_kernel, g1(n_cand), dim3(256), 0, s, m, pts, max_iter);
 }
-void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts) {
-    KLAUNCH(mesh_append_commit_kernel, g1(sp.n_cand), dim3(256), 0, s, m, sp, pts);
+void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, const float* pts) {
+    KLAUNCH(mesh_append_commit_kernel, g1(n_cand), dim3(256), 0, s, m, pts);
 }
-void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n) { KLAUNCH(mesh_append_flags_kernel, g1(n), dim3(256), 0, s, m, n); }
+void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_append_flags_kernel, g1(n_cand), dim3(256), 0, s, m); }
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
 void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel, dim3(1024), dim3(256), 0, s, m); }
-void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp) {
-    KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, sp, 0, 256);
-    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, sp, 257, MV_REL_CAP);
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
+    KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, 0, 256);
+    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, 257, MV_REL_CAP);
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }

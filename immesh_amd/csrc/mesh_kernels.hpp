@@ -36,6 +36,20 @@ enum {
 // persistent device counters (MeshDev::pc)
 enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
 
+#define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
+struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; };
+
+struct MeshScanParams {
+    double cam[3];
+    int32_t n_raw, step, n_cand, vtx_base;
+};
+// everything that changes from scan to scan, in device memory (the kernels' arguments stay constant -> graph replay)
+struct MeshDyn {
+    MeshScanParams sp;
+    int32_t seq, pad;
+    unsigned long long ch_mask;
+};
+
 struct MeshDev {
     // vertices
     float* v_pos; double* v_smooth; double* v_smooth_new; int32_t* v_voxel;
@@ -66,16 +80,9 @@ struct MeshDev {
     int32_t cap_verts, cap_voxels, cap_tris, cap_adj_chunks, cap_cand, cap_active, cap_list;
     // parameters
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
-    int32_t seq;                         // scan sequence number (>= 1)
+    int32_t seq;                         // scan sequence number (>= 1); kernels take it (and ch_mask) from *dyn
+    const MeshDyn* dyn;                  // per-scan parameters (device memory)
     unsigned long long* dbg;             // optional phase timers (IMMESH_DEBUG): [16] sums of s_memtime deltas, nullptr = off
-};
-
-#define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
-struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; };
-
-struct MeshScanParams {
-    double cam[3];
-    int32_t n_raw, step, n_cand, vtx_base;
 };
 
 // One queued incremental_mesh_reconstruction call.  The reference runs the mesher on its own service thread + pool
@@ -109,19 +116,25 @@ struct MeshHost {
     std::deque<MeshJob> q;
     long submitted = 0, completed = 0, current = 0;   // job ids start at 1; `current` = job whose results sizes/fetch return
     bool stop = false;
+    // per-scan parameters + graph replay
+    MeshDyn* d_dyn = nullptr;                // device copy read by the kernels
+    MeshDyn* h_dyn = nullptr;                // pinned host copy (source of the copy node at the head of the graph)
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // one per job parity (world buffer / result set pointers differ)
+    int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
+    bool use_graph = true;
     KProf prof;                              // kernels launched by the worker thread
     std::string err;                         // worker-side error text (moved into the MeshResult of the failing job)
 };
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
                            const double* extT);
-void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
-void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts, int max_iter);
-void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, const MeshScanParams& sp, const float* pts);
-void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n);
+void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
+void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter);
+void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
+void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_knn(hipStream_t s, const MeshDev& m);
-void launch_mesh_delaunay(hipStream_t s, const MeshDev& m, const MeshScanParams& sp);
+void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted);
