@@ -315,6 +315,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        D.barrier()          # rank 0 may still be in its roofline / CPU-baseline legs: leave together
         dist.destroy_process_group()
 
 

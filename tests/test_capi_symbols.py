@@ -76,3 +76,15 @@ def test_forward_without_imu_matches_harness():
     a = capi.forward_without_imu_native(lib, st)
     b = synth.forward_without_imu(st)
     np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-15)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/immesh_c_api.h compiled as C99 with -Wall -Werror, linked against the product library, host-only entry points exercised."""
+    import subprocess
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.dirname(capi.hip_library_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "c_abi_smoke.c"),
+                           "-o", exe, "-L", libdir, "-limmesh_hip", "-lm", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c abi ok" in out.stdout
