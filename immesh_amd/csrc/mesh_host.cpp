@@ -123,8 +123,8 @@ static int mesh_overflow(immesh_ctx* c) {
     static const char* why[] = {"", "mesh-voxel hash full", "mesh-voxel pool exhausted (cap_vertices)", "candidate-cell table full", "vertex pool exhausted (cap_vertices)",
                                 "mesh voxel lookup failed", "dedupe grid hash full", "mesh voxel holds more than 128 vertices", "more active voxels than cap (131072 per scan)",
                                 "voxel neighbourhood above 1024 vertices", "triangle pool exhausted (cap_triangles)", "triangle hash full", "Delaunay cavity / triangle buffer overflow",
-                                "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries", "more live triangles around one voxel than 2 x neighbourhood cap"};
-    c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 16) ? f : 0];
+                                "adjacency chunk pool exhausted", "per-scan result list above 4194304 entries"};
+    c->mesh_host.err = std::string("mesh map capacity: ") + why[(f > 0 && f < 15) ? f : 0];
     return IMMESH_E_CAPACITY;
 }
 

@@ -883,8 +883,31 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     __syncthreads();
     // (2) ... then the list is classified with all lanes busy and uniform control flow
     const int nold = s_cnt[1];
-    if (nold > 2 * CAP) { if (lane == 0) m.sc[SC_OVERFLOW] = 15; }
-    for (int k = lane; k < min(nold, 2 * CAP); k += 64) {
+    if (nold > 2 * CAP) {
+        // more live triangles around this voxel than the LDS list holds (space-filling clouds pile up triangles of many projection planes):
+        // classify them straight from the vertex lists -- same decisions, divergent lanes
+        for (int i = lane; i < n; i += 64) {
+            const int id = ids[i];
+            for (int ch = m.a_head[id]; ch >= 0; ch = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + MV_ADJ_STRIDE - 1])
+                for (int sl = 0; sl < MV_ADJ_SLOTS; sl++) {
+                    const int t = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + sl * 3];
+                    if (t < 0) continue;
+                    const int l1 = lds_bsearch_i32(ids, n, m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + sl * 3 + 1]);
+                    const int l2 = lds_bsearch_i32(ids, n, m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + sl * 3 + 2]);
+                    if (l1 < 0 || l2 < 0) continue;
+                    const int pos = lds_bsearch_u32(fresh, nf, ((unsigned int)i << 20) | ((unsigned int)l1 << 10) | (unsigned int)l2);
+                    if (pos >= 0) {
+                        fhit[pos] = 1;
+                        const int fl = flip_of(&sm[i * 3], &sm[l1 * 3], &sm[l2 * 3], sp.cam, short_axis);
+                        atomicMax(&m.t_word[t], wbase | (unsigned long long)fl);
+                        touched[atomicAdd(&s_cnt[0], 1)] = t;
+                    } else if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) {
+                        list_push(m, m.list_rem, SC_REM, t);
+                    }
+                }
+        }
+    }
+    for (int k = lane; k < (nold > 2 * CAP ? 0 : nold); k += 64) {
         const int t = old_t[k], i = old_i[k];
         const int l1 = lds_bsearch_i32(ids, n, old_v1[k]), l2 = lds_bsearch_i32(ids, n, old_v2[k]);
         if (l1 < 0 || l2 < 0) continue;   // not entirely inside this neighbourhood

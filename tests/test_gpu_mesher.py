@@ -175,3 +175,38 @@ def test_async_pipeline_matches_serial(hip_lib):
         np.testing.assert_array_equal(m1[key], m2[key], err_msg=key)
     for key in ("n_new", "v_act", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
         assert c1[key] == c2[key], key
+
+
+def test_mesh_volumetric_cloud(oracle_lib, hip_lib):
+    """A space-filling cloud (vegetation-like): up to ~45 vertices per mesh voxel, thousands of candidates around a voxel (the kNN kernel
+    stages them in several LDS batches), neighbourhoods above 256 vertices (the large-neighbourhood Delaunay instantiation)."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000, cap_vertices=1 << 16, cap_triangles=1 << 20, mesh_append_budget=20000)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    rng = np.random.default_rng(21)
+    cam = np.array([-3.0, 1.0, 1.0])
+    for k in range(3):
+        n = 20000
+        pts = np.concatenate([rng.uniform(0.0, 2.0, (n, 3)), np.ones((n, 1))], axis=1).astype(np.float32)
+        mo = o.mesh_scan(pts, cam, frame_idx=k)
+        mh = h.mesh_scan(pts, cam, frame_idx=k)
+        _compare_scan(mo, mh, f"scan {k}")
+    co = o.counters()
+    assert co["n_u"] / max(1, co["v_act"]) > 60 and co["n_vertices"] > 2500
+
+
+def test_mesh_offline_sized_cloud(oracle_lib, hip_lib):
+    """More than 65536 candidates in one call (reconstruct_mesh_from_pointcloud-sized input, step 1): the vertex-admission kernel is
+    driven in bounded rounds with host checks instead of one resident launch."""
+    n = 90000
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 17, cap_triangles=1 << 20, mesh_append_budget=n)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    rng = np.random.default_rng(22)
+    # a 30 m x 30 m undulating floor, points in random order (long dependency chains between neighbouring candidates)
+    x = rng.uniform(0, 30, n); y = rng.uniform(0, 30, n)
+    z = 0.3 * np.sin(x * 0.5) * np.cos(y * 0.4) + rng.normal(0, 0.005, n)
+    pts = np.stack([x, y, z, np.ones(n)], axis=1).astype(np.float32)
+    cam = np.array([15.0, 15.0, 10.0])
+    mo = o.mesh_scan(pts, cam)
+    mh = h.mesh_scan(pts, cam)
+    _compare_scan(mo, mh, "offline")
+    assert len(mo["new_vtx"]) > 30000
