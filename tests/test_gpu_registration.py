@@ -143,3 +143,49 @@ def test_edge_cases(oracle_lib, hip_lib):
     # bad arguments are errors, not crashes
     with pytest.raises(RuntimeError):
         h.map_update(one, st, n=0)
+
+
+def test_register_and_update_stream_parity_kitti(oracle_lib, hip_lib):
+    """velodyne.yaml (3 m root voxels, max_layer 4, max_points_size 1000): deep octrees.  The matcher scans the per-root flat lists of planar
+    descendants, which the map update keeps in step with every plane-flag change -- match sets, poses and the whole plane table must agree."""
+    cfg = capi.velodyne_config(cap_root_voxels=1 << 14, cap_scan_points=200000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R0, t0, raw0 = _scan(0, 700, cfg, kind="hdl64")
+    st0 = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st0); h.map_build(p0, st0)
+    so = st0.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    for k in range(1, 6):
+        _, tk, raw = _scan(k, 700, cfg, kind="hdl64")
+        down = synth.voxel_grid_downsample(raw, 0.5)
+        if k == 1:
+            ro, rh = o.residuals(down, synth.forward_without_imu(so)), h.residuals(down, synth.forward_without_imu(sh))
+            assert ro["n_match"] > 1000
+            np.testing.assert_array_equal(rh["match_idx"], ro["match_idx"])
+            co, ch = o.counters(), h.counters()
+            assert ch["n_plane_tests"] == co["n_plane_tests"] and co["n_plane_tests"] > 2 * ro["n_match"]   # several leaves tested per point
+        po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
+        so, io = o.register(down, po, po)
+        sh, ih = h.register(down, ph, ph)
+        assert ih["n_iter"] == io["n_iter"] and ih["n_match"] == io["n_match"]
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+        o.map_update(down, so); h.map_update(down, sh)
+    a, b = o.dump_planes(), h.dump_planes()
+    assert a["layer"].max() >= 2 and compare_plane_tables(a, b, TOL) > 300
+
+
+def test_register_without_overlap(oracle_lib, hip_lib):
+    """A scan that hits no mapped voxel: zero matches; the update degenerates to the prior (state_propagat) on both sides."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    R0, t0, raw0 = _scan(0, 5000, cfg)
+    st0 = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st0); h.map_build(p0, st0)
+    far = (np.random.default_rng(3).uniform(-1, 1, (500, 3)) + [0, 0, 500.0]).astype(np.float32)
+    prior = capi.make_state(R=R0, t=t0 + np.array([0.1, 0.0, 0.0]), cov_diag=1e-4)
+    so, io = o.register(far, prior, prior)
+    sh, ih = h.register(far, prior, prior)
+    assert io["n_match"] == 0 and ih["n_match"] == 0 and ih["n_iter"] == io["n_iter"]
+    np.testing.assert_allclose(sh, so, rtol=0, atol=1e-12)
