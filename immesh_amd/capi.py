@@ -231,6 +231,20 @@ class HotPath:
                        _ptr(r["flip_upd"]), _ptr(r["smooth_ids"]), _ptr(r["smooth_xyz"])), "mesh_fetch")
         return r
 
+    # -- mesh export ------------------------------------------------------------------------------------------
+    def mesh_export(self, smooth_factor=1.0, knn=20):
+        f = self._f("mesh_export"); f.argtypes = [C.c_void_p, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        nv, nf = C.c_int64(0), C.c_int64(0)
+        self._check(f(self.ctx, smooth_factor, knn, C.byref(nv), C.byref(nf)), "mesh_export")
+        vtx, faces = np.zeros((nv.value, 3), np.float32), np.zeros((nf.value, 3), np.int32)
+        g = self._f("mesh_export_fetch"); g.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; g.restype = C.c_int
+        self._check(g(self.ctx, _ptr(vtx), _ptr(faces)), "mesh_export_fetch")
+        return vtx, faces
+
+    def save_ply(self, path, smooth_factor=1.0, knn=20):
+        f = self._f("save_ply"); f.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_int32]; f.restype = C.c_int
+        self._check(f(self.ctx, path.encode(), smooth_factor, knn), "save_ply")
+
     # -- whole scan -------------------------------------------------------------------------------------------
     def process_scan(self, pts_down, pts_raw_xyzi, state_prior, state, frame_idx=0, do_mesh=True, n_ds=None, n_raw=None):
         f = self._f("process_scan"); f.restype = C.c_int

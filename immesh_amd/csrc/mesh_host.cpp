@@ -107,6 +107,10 @@ void mesh_free(immesh_ctx* c) {
         h.worker.join();
     }
     if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); h.stream = nullptr; }
+    if (h.exp_vtx) (void)hipFree(h.exp_vtx);
+    if (h.exp_work) (void)hipFree(h.exp_work);
+    if (h.exp_tmp) (void)hipFree(h.exp_tmp);
+    h.exp_vtx = h.exp_work = h.exp_tmp = nullptr;
     for (int k = 0; k < 2; k++) if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
     if (h.ev_t0) (void)hipEventDestroy(h.ev_t0);
     if (h.ev_t1) (void)hipEventDestroy(h.ev_t1);
@@ -415,6 +419,91 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
     if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, o.smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
     if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, o.smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- mesh export (save_to_ply_file, mesh_rec_geometry.cpp:71-131): the consumer after the path -----------------------------------------
+static int grow(immesh_ctx* c, void** p, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) { c->err = std::string("hipMalloc(export): ") + hipGetErrorString(e); return IMMESH_E_NOMEM; }
+    *have = need;
+    return 0;
+}
+
+int immesh_mesh_export(immesh_ctx* c, double smooth_factor, int32_t knn, int64_t* n_vtx_out, int64_t* n_faces_out) {
+    if (!c) return IMMESH_E_INVAL;
+    if (smooth_factor != 0.0 && knn != MV_KNN) { c->err = "mesh export: only knn = 20 (the reference's g_ply_smooth_k) is supported"; return IMMESH_E_INVAL; }
+    hipSetDevice(c->cfg.device);
+    mesh_wait_all(c);
+    ProfBind _pb(c);
+    MeshHost& h = c->mesh_host;
+    const MeshDev& m = c->mesh;
+    hipStream_t s = c->stream;
+    const int64_t nv = h.n_vertices, nf = h.n_live;
+    int rc;
+    if ((rc = grow(c, &h.exp_vtx, &h.exp_vtx_bytes, (size_t)std::max<int64_t>(nv, 1) * 12))) return rc;
+    const size_t per = (size_t)std::max<int64_t>(nf, 1);
+    if ((rc = grow(c, &h.exp_work, &h.exp_work_bytes, per * (4 + 4 + 4 + 4 + 8 + 8 + 12) + 64))) return rc;
+    int32_t* idx_a = (int32_t*)h.exp_work; int32_t* idx_b = idx_a + per; int32_t* idx_c = idx_b + per;
+    uint32_t* k32a = (uint32_t*)(idx_c + per);
+    unsigned long long* k64a = (unsigned long long*)(((uintptr_t)(k32a + per) + 15) & ~(uintptr_t)15);
+    unsigned long long* k64b = k64a + per;
+    int32_t* faces = (int32_t*)(k64b + per);
+    const size_t tmp_need = std::max(sort_pairs_u64_temp_bytes((int)per), sort_pairs_u32_temp_bytes((int)per)) + 256;
+    if ((rc = grow(c, &h.exp_tmp, &h.exp_tmp_bytes, tmp_need))) return rc;
+    if (nv > 0) {
+        if (smooth_factor != 0.0) launch_mesh_export_vertices(s, m, (float*)h.exp_vtx, smooth_factor);
+        else HIPCHK(c, hipMemcpyAsync(h.exp_vtx, m.v_pos, (size_t)nv * 12, hipMemcpyDeviceToDevice, s));
+    }
+    if (nf > 0) {
+        int32_t* cnt = m.sc + SC_COUNT - 1;   // spare per-scan counter slot (the mesher is idle)
+        HIPCHK(c, hipMemsetAsync(cnt, 0, 4, s));
+        launch_mesh_export_faces(s, m, idx_a, cnt);
+        // deterministic face order: lexicographic by (v0, v1, v2) -- two stable radix passes
+        launch_mesh_export_keys(s, m, idx_a, (int)nf, 0, k32a, nullptr);
+        sort_pairs_u32(s, h.exp_tmp, h.exp_tmp_bytes, k32a, (uint32_t*)k64b, idx_a, idx_b, (int)nf, 32);
+        launch_mesh_export_keys(s, m, idx_b, (int)nf, 1, nullptr, k64a);
+        sort_pairs_u64(s, h.exp_tmp, h.exp_tmp_bytes, k64a, k64b, idx_b, idx_c, (int)nf);
+        launch_mesh_export_wind(s, m, idx_c, (int)nf, faces);
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    h.exp_faces = faces; h.exp_nv = nv; h.exp_nf = nf;
+    if (n_vtx_out) *n_vtx_out = nv;
+    if (n_faces_out) *n_faces_out = nf;
+    return 0;
+}
+
+int immesh_mesh_export_fetch(immesh_ctx* c, float* vtx_xyz, int32_t* faces) {
+    if (!c) return IMMESH_E_INVAL;
+    hipSetDevice(c->cfg.device);
+    MeshHost& h = c->mesh_host;
+    if (vtx_xyz && h.exp_nv) HIPCHK(c, hipMemcpy(vtx_xyz, h.exp_vtx, (size_t)h.exp_nv * 12, hipMemcpyDeviceToHost));
+    if (faces && h.exp_nf) HIPCHK(c, hipMemcpy(faces, h.exp_faces, (size_t)h.exp_nf * 12, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// binary little-endian PLY with the element / property layout pcl::io::savePLYFileBinary writes for a PolygonMesh of PointXYZ
+int immesh_save_ply(immesh_ctx* c, const char* path, double smooth_factor, int32_t knn) {
+    if (!c || !path) return IMMESH_E_INVAL;
+    int64_t nv = 0, nf = 0;
+    int rc = immesh_mesh_export(c, smooth_factor, knn, &nv, &nf);
+    if (rc) return rc;
+    std::vector<float> v((size_t)nv * 3);
+    std::vector<int32_t> f((size_t)nf * 3);
+    if ((rc = immesh_mesh_export_fetch(c, v.data(), f.data()))) return rc;
+    FILE* fp = std::fopen(path, "wb");
+    if (!fp) { c->err = std::string("cannot open ") + path; return IMMESH_E_INVAL; }
+    std::fprintf(fp, "ply\nformat binary_little_endian 1.0\ncomment immesh-mi355x\nelement vertex %lld\nproperty float x\nproperty float y\nproperty float z\n"
+                     "element face %lld\nproperty list uchar int vertex_indices\nend_header\n", (long long)nv, (long long)nf);
+    std::fwrite(v.data(), 4, v.size(), fp);
+    std::vector<unsigned char> rec((size_t)nf * 13);
+    for (int64_t i = 0; i < nf; i++) { rec[(size_t)i * 13] = 3; std::memcpy(&rec[(size_t)i * 13 + 1], &f[(size_t)i * 3], 12); }
+    std::fwrite(rec.data(), 1, rec.size(), fp);
+    const bool ok = std::fclose(fp) == 0;
+    if (!ok) { c->err = std::string("write failed: ") + path; return IMMESH_E_INVAL; }
     return 0;
 }
 

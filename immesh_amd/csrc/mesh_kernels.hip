@@ -353,7 +353,12 @@ IMD double wave_max_d(double x) {
 #define WL (KC + MV_KNN + 4)    /* per-wave work list */
 #define HSET 4096
 
-__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in) {
+// EXPORT = false: the per-scan neighbourhood pull.  EXPORT = true: Global_map::smooth_pts over EVERY vertex for save_to_ply_file
+// (mesh_rec_geometry.cpp:71-131, pointcloud_rgbd.cpp:932-958): the same 20-NN machinery run over all mesh voxels, output = the exported
+// vertex position pt*(1-f) + mean(neighbours 1..19 closer than accept)*f  (the nearest neighbour, the vertex itself, is skipped; no neighbour
+// -> 0/0 = NaN, as in the reference); nothing of the map is modified.
+template <bool EXPORT>
+__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __restrict__ export_vtx, double smooth_factor) {
     MESH_DYN(m_in);
     __shared__ float cx[KC], cy[KC], cz[KC];
     __shared__ int cid[KC];
@@ -369,12 +374,13 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in) {
     __shared__ long s_box[6];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
+    const int n_active = EXPORT ? m.pc[PC_VOXELS] : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
 #define KDBG(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
-    const int vi = m.act_vox_s[r];
+    const int vi = EXPORT ? r : m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
+    if (EXPORT && nq == 0) continue;
     if (tid < nq) {
         const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + tid];
         qid[tid] = id;
@@ -500,6 +506,34 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in) {
         }
     }
     __syncthreads();
+    if (EXPORT) {
+        for (int q = wv; q < nq; q += 4) {
+            const int nb = nbest[q] & 0xFFFF;
+            float nxp = 0, nyp = 0, nzp = 0;
+            bool use_l = false;
+            if (lane < nb) {
+                const unsigned long long key = best[q][lane];
+                const int id = (int)(unsigned int)(key & 0xFFFFFFFFull);
+                use_l = lane >= 1 && (double)sqrtf(__uint_as_float((unsigned int)(key >> 32))) < m.accept;   // k = 1 .. size-1, sqrt(dis) < maximum_smooth_dis
+                nxp = m.v_pos[(size_t)id * 3 + 0]; nyp = m.v_pos[(size_t)id * 3 + 1]; nzp = m.v_pos[(size_t)id * 3 + 2];
+            }
+            double sx = 0, sy = 0, sz = 0, valid = 0.0;
+            for (int k = 1; k < nb; k++) {
+                const int use = __shfl((int)use_l, k, 64);
+                const float x = __shfl(nxp, k, 64), y = __shfl(nyp, k, 64), z = __shfl(nzp, k, 64);
+                if (use) { valid += 1.0; sx += (double)x; sy += (double)y; sz += (double)z; }
+            }
+            if (lane == 0) {
+                const int id = qid[q];
+                const double p0 = (double)qx[q], p1 = (double)qy[q], p2 = (double)qz[q];
+                export_vtx[(size_t)id * 3 + 0] = (float)(p0 * (1.0 - smooth_factor) + sx * smooth_factor / valid);
+                export_vtx[(size_t)id * 3 + 1] = (float)(p1 * (1.0 - smooth_factor) + sy * smooth_factor / valid);
+                export_vtx[(size_t)id * 3 + 2] = (float)(p2 * (1.0 - smooth_factor) + sz * smooth_factor / valid);
+            }
+        }
+        __syncthreads();
+        continue;
+    }
     // ---- smoothing (mean of the neighbours closer than 2 x accept, smooth_factor 1.0) and the neighbourhood union (closer than accept)
     int* hset = (int*)&wl[0][0];
     for (int k = tid; k < HSET; k += 256) hset[k] = -1;
@@ -1174,7 +1208,36 @@ void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, cons
 }
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_append_flags_kernel, g1(n_cand), dim3(256), 0, s, m); }
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
-void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel, dim3(1024), dim3(256), 0, s, m); }
+void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(1024), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
+void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor) {
+    KLAUNCH(mesh_knn_kernel<true>, dim3(2048), dim3(256), 0, s, m, export_vtx, smooth_factor);
+}
+// live triangles with the winding save_to_ply_file writes: m_index_flip != 0 -> (v0, v1, v2), else (v0, v2, v1)
+__global__ void mesh_export_faces_kernel(MeshDev m, int32_t* __restrict__ tri_idx, int32_t* __restrict__ count) {
+    const int nt = m.pc[PC_TRIS];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x)
+        if (m.t_live[t]) tri_idx[atomicAdd(count, 1)] = t;
+}
+__global__ void mesh_export_wind_kernel(MeshDev m, const int32_t* __restrict__ tri_sorted, int n, int32_t* __restrict__ faces) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tri_sorted[i];
+    const int a = m.t_v[(size_t)t * 3 + 0], b = m.t_v[(size_t)t * 3 + 1], c = m.t_v[(size_t)t * 3 + 2];
+    const bool keep = m.t_flip[t] != 0;
+    faces[(size_t)i * 3 + 0] = a; faces[(size_t)i * 3 + 1] = keep ? b : c; faces[(size_t)i * 3 + 2] = keep ? c : b;
+}
+__global__ void mesh_export_keys_kernel(MeshDev m, const int32_t* __restrict__ tris, int n, int which, uint32_t* __restrict__ k32, unsigned long long* __restrict__ k64) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = tris[i];
+    if (which == 0) k32[i] = (uint32_t)m.t_v[(size_t)t * 3 + 2];
+    else k64[i] = ((unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 0] << 32) | (unsigned long long)(unsigned int)m.t_v[(size_t)t * 3 + 1];
+}
+void launch_mesh_export_faces(hipStream_t s, const MeshDev& m, int32_t* tri_idx, int32_t* count) { KLAUNCH(mesh_export_faces_kernel, dim3(1024), dim3(256), 0, s, m, tri_idx, count); }
+void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64) {
+    KLAUNCH(mesh_export_keys_kernel, g1(n), dim3(256), 0, s, m, tris, n, which, k32, k64);
+}
+void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
     KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, 0, 256);
     KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, 257, MV_REL_CAP);

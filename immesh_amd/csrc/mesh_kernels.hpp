@@ -122,6 +122,11 @@ struct MeshHost {
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // one per job parity (world buffer / result set pointers differ)
     int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
     bool use_graph = true;
+    // mesh export scratch (grow-only)
+    void *exp_vtx = nullptr, *exp_work = nullptr, *exp_tmp = nullptr;
+    size_t exp_vtx_bytes = 0, exp_work_bytes = 0, exp_tmp_bytes = 0;
+    int32_t* exp_faces = nullptr;
+    int64_t exp_nv = 0, exp_nf = 0;
     KProf prof;                              // kernels launched by the worker thread
     std::string err;                         // worker-side error text (moved into the MeshResult of the failing job)
 };
@@ -134,6 +139,10 @@ void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, cons
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_knn(hipStream_t s, const MeshDev& m);
+void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor);
+void launch_mesh_export_faces(hipStream_t s, const MeshDev& m, int32_t* tri_idx, int32_t* count);
+void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
+void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);

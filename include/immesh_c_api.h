@@ -128,6 +128,17 @@ int immesh_mesh_sizes(immesh_ctx* ctx, immesh_mesh_sizes_t* sizes);
 int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd,
                       uint8_t* flip_upd, int32_t* smooth_ids, double* smooth_xyz);
 
+/* ---- mesh export: the consumer after the path --------------------------------------------------------------- */
+/* void save_to_ply_file(std::string ply_file, double smooth_factor, double knn)   src/meshing/mesh_rec_geometry.cpp:71-131
+ * Vertices: smooth_factor == 0 -> raw positions; else Global_map::smooth_pts (pointcloud_rgbd.cpp:932-958) with knn = 20 (g_ply_smooth_k) and
+ * maximum distance 1.25 x mesh voxel: pt*(1-f) + f * mean of the 2nd..20th nearest vertices closer than that (none -> NaN, as the reference).
+ * Faces: every live triangle, (v0,v1,v2) when m_index_flip != 0 else (v0,v2,v1), ordered lexicographically by sorted triplet.
+ * immesh_mesh_export leaves both arrays on the device (immesh_mesh_export_fetch copies them out); immesh_save_ply writes the binary
+ * little-endian PLY layout of pcl::io::savePLYFileBinary (float x y z; list uchar int vertex_indices).  The map is not modified. */
+int immesh_mesh_export(immesh_ctx* ctx, double smooth_factor, int32_t knn, int64_t* n_vtx_out, int64_t* n_faces_out);
+int immesh_mesh_export_fetch(immesh_ctx* ctx, float* vtx_xyz, int32_t* faces);
+int immesh_save_ply(immesh_ctx* ctx, const char* path, double smooth_factor, int32_t knn);
+
 /* ---- whole scan (what service_LiDAR_update does per scan, src/voxel_mapping.cpp:1959-1973) ---------------- */
 /* lio_state_estimation + map_incremental_grow (+ world transform of the full scan and incremental_mesh_reconstruction
  * when do_mesh != 0).  pts_raw_body_xyzi = m_feats_undistort (n_raw x 4).  Everything stays on the device between

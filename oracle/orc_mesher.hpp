@@ -287,6 +287,36 @@ struct Mesher {
         if (cnt) { cnt->t_add += (long)out.tri_add.size() / 3; cnt->t_rem += (long)out.tri_rem.size() / 3; }
     }
 
+    // ---- save_to_ply_file (mesh_rec_geometry.cpp:71-131) + Global_map::smooth_pts (pointcloud_rgbd.cpp:932-958) ------------------------
+    // vertices: smooth_factor == 0 -> raw; else pt*(1-f) + f * (sum of the 2nd..k-th nearest closer than accept) / valid (0/0 -> NaN as the reference).
+    // faces: live triangles, winding from m_index_flip, ordered by sorted triplet.
+    void export_mesh(double smooth_factor, int knn_k, std::vector<float>& vtx, std::vector<int>& faces) const {
+        const double accept = cfg.mesh_voxel * 1.25;
+        vtx.resize(verts.size() * 3);
+        std::vector<NN> nn;
+        for (size_t i = 0; i < verts.size(); i++) {
+            const double* p = verts[i].pos;
+            double out[3] = {p[0], p[1], p[2]};
+            if (smooth_factor != 0) {
+                const float q[3] = {(float)p[0], (float)p[1], (float)p[2]};
+                knn(q, knn_k, accept * 2, nn);
+                double s[3] = {0, 0, 0}, valid = 0.0;
+                for (size_t k = 1; k < nn.size(); k++)
+                    if ((double)std::sqrt(nn[k].d2) < accept) { for (int a = 0; a < 3; a++) s[a] += verts[nn[k].id].pos[a]; valid += 1.0; }
+                for (int a = 0; a < 3; a++) out[a] = p[a] * (1.0 - smooth_factor) + s[a] * smooth_factor / valid;
+            }
+            for (int a = 0; a < 3; a++) vtx[i * 3 + a] = (float)out[a];
+        }
+        std::vector<int> live;
+        live_triangles(live);
+        faces.resize(live.size());
+        for (size_t f = 0; f + 2 < live.size(); f += 3) {
+            const Tri t = {live[f], live[f + 1], live[f + 2]};
+            const bool keep = tri_flip.at(t) != 0;
+            faces[f] = t[0]; faces[f + 1] = keep ? t[1] : t[2]; faces[f + 2] = keep ? t[2] : t[1];
+        }
+    }
+
     size_t live_triangle_count() const {
         size_t s = 0;
         for (const auto& kv : adj) s += kv.second.size();

@@ -210,3 +210,35 @@ def test_mesh_offline_sized_cloud(oracle_lib, hip_lib):
     mh = h.mesh_scan(pts, cam)
     _compare_scan(mo, mh, "offline")
     assert len(mo["new_vtx"]) > 30000
+
+
+def test_mesh_export_and_ply(oracle_lib, hip_lib, tmp_path):
+    """save_to_ply_file: smoothed vertex positions (Global_map::smooth_pts over every vertex) and the live triangles with their winding."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    for k in range(4):
+        pts, cam = _world_scan(k, 40000, cfg)
+        o.mesh_scan(pts, cam, frame_idx=k); h.mesh_scan(pts, cam, frame_idx=k)
+    for factor in (1.0, 0.5, 0.0):
+        vo, fo = o.mesh_export(factor, 20)
+        vh, fh = h.mesh_export(factor, 20)
+        np.testing.assert_array_equal(fh, fo)                                   # same faces, same winding, same order
+        assert np.array_equal(np.isnan(vh), np.isnan(vo))                       # isolated vertices export as NaN, as in the reference
+        np.testing.assert_allclose(np.nan_to_num(vh), np.nan_to_num(vo), rtol=0, atol=1e-6)
+    assert len(fo) == o.counters()["n_triangles_live"] > 10000
+    # binary PLY round trip
+    path = str(tmp_path / "rec_mesh.ply")
+    h.save_ply(path, 1.0, 20)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert b"format binary_little_endian 1.0" in head and b"property list uchar int vertex_indices" in head
+    nv = int([l for l in head.split(b"\n") if l.startswith(b"element vertex")][0].split()[-1])
+    nf = int([l for l in head.split(b"\n") if l.startswith(b"element face")][0].split()[-1])
+    v = np.frombuffer(body[:nv * 12], np.float32).reshape(-1, 3)
+    rec = np.frombuffer(body[nv * 12:], np.uint8).reshape(nf, 13)
+    assert np.all(rec[:, 0] == 3)
+    f = rec[:, 1:].copy().view(np.int32).reshape(nf, 3)
+    vh, fh = h.mesh_export(1.0, 20)
+    assert np.array_equal(f, fh) and np.array_equal(np.nan_to_num(v), np.nan_to_num(vh))
+    with pytest.raises(RuntimeError):
+        h.mesh_export(1.0, 10)                                                  # only the reference's k = 20 is supported
