@@ -214,6 +214,11 @@ class HotPath:
         self._check(f(self.ctx, _ptr(pts_world_xyzi), n, _ptr(np.ascontiguousarray(sensor_pos, dtype=np.float64)), frame_idx), "mesh_scan")
         return self.mesh_fetch() if fetch else None
 
+    def reconstruct_mesh_from_pointcloud(self, pts_xyzi, leaf=0.01):
+        f = self._f("reconstruct_mesh_from_pointcloud"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double]; f.restype = C.c_int
+        self._check(f(self.ctx, _ptr(pts_xyzi), len(pts_xyzi), leaf), "reconstruct_mesh_from_pointcloud")
+        return self.mesh_fetch()
+
     def mesh_wait(self):
         f = self._f("mesh_wait"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx), "mesh_wait")

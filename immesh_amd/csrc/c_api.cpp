@@ -462,6 +462,22 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
 }
 const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : nullptr; }
 
+// void reconstruct_mesh_from_pointcloud(pcl::PointCloud<pcl::PointXYZI>::Ptr, double)   src/ImMesh_mesh_reconstruction.cpp:328-345:
+// VoxelGrid(leaf) -> one package with the identity pose, frame 0 -> incremental_mesh_reconstruction
+int immesh_reconstruct_mesh_from_pointcloud(immesh_ctx* c, const float* pts_xyzi, int32_t n, double leaf) {
+    if (!c || !pts_xyzi || n <= 0 || n > c->cap_scan || leaf <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    int32_t n_ds = 0;
+    int rc = immesh_downsample(c, pts_xyzi, n, 4, leaf, nullptr, 0, &n_ds);
+    if (rc) return rc;
+    hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    float* world = mesh_next_world_buffer(c);
+    launch_ds_expand_xyzi(c->stream, c->d_ds_out, n_ds, world);
+    const double origin[3] = {0.0, 0.0, 0.0};   // pose_t of the package: Eigen::Vector3d::Zero()
+    const long id = mesh_submit(c, world, n_ds, origin, 0);
+    return mesh_wait(c, id);
+}
+
 int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out) {
     if (!state_in || !state_out) return IMMESH_E_INVAL;
     imh::State a, b;

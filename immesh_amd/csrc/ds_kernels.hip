@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
     }
 }
 
+// xyz (3 floats) -> xyzI (4 floats, intensity 0): the mesher consumes pcl::PointXYZI-shaped clouds
+__global__ void ds_expand_xyzi_kernel(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = make_float4(xyz[(size_t)i * 3], xyz[(size_t)i * 3 + 1], xyz[(size_t)i * 3 + 2], 0.f);
+}
+void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xyzi) {
+    KLAUNCH(ds_expand_xyzi_kernel, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, (float4*)out_xyzi);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm) {
     KLAUNCH(ds_minmax_kernel, dim3(min(1024, (n + 255) / 256)), dim3(256), 0, s, pts, n, stride, inv, mm);

@@ -105,6 +105,10 @@ int immesh_map_update(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n
  * pts_world_xyzi = world_lidar_full (n_raw x 4 float).  Runs append + per-voxel retriangulation + diff + commit on
  * the device; results stay in the ctx until the next call and are read with immesh_mesh_sizes / immesh_mesh_fetch. */
 int immesh_mesh_scan(immesh_ctx* ctx, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
+/* void reconstruct_mesh_from_pointcloud(cloud, double)   src/ImMesh_mesh_reconstruction.cpp:328-345  (offline entry of ImMesh_node.cpp:235-244)
+ * VoxelGrid(leaf, the reference passes 0.01) of the whole cloud, then one incremental_mesh_reconstruction call with the identity pose.  Set
+ * mesh_append_budget >= the cloud size (config/offline_pointcloud.yaml:71: 50000000) so that every point is offered. */
+int immesh_reconstruct_mesh_from_pointcloud(immesh_ctx* ctx, const float* pts_xyzi, int32_t n, double leaf);
 /* Asynchronous meshing (immesh_process_scan with do_mesh == 2): the scan is queued for the mesher's own stream / worker thread -- the
  * counterpart of the reference's service_reconstruct_mesh thread (ImMesh_mesh_reconstruction.cpp:272-310) -- and the call returns after
  * registration + map update.  Jobs run strictly in submission order; at most two are outstanding (a third submission blocks) and the

@@ -143,6 +143,16 @@ int orc_downsample(void* p, const float* pts, int32_t n, int32_t stride, double 
     return (out_xyz && cnt > cap_out) ? IMMESH_E_CAPACITY : 0;
 }
 const float* orc_downsample_result(void*) { return nullptr; }
+int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
+int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t n, double leaf) {   // ImMesh_mesh_reconstruction.cpp:328-345
+    std::vector<float> ds((size_t)n * 3);
+    int32_t n_ds = 0;
+    orc_downsample(p, pts_xyzi, n, 4, leaf, ds.data(), n, &n_ds);
+    std::vector<float> w((size_t)n_ds * 4, 0.f);
+    for (int i = 0; i < n_ds; i++) for (int a = 0; a < 3; a++) w[(size_t)i * 4 + a] = ds[(size_t)i * 3 + a];
+    const double origin[3] = {0, 0, 0};
+    return orc_mesh_scan(p, w.data(), n_ds, origin, 0);
+}
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
 int orc_mesh_wait(void* p) { (void)p; return 0; }

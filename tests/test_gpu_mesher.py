@@ -242,3 +242,18 @@ def test_mesh_export_and_ply(oracle_lib, hip_lib, tmp_path):
     assert np.array_equal(f, fh) and np.array_equal(np.nan_to_num(v), np.nan_to_num(vh))
     with pytest.raises(RuntimeError):
         h.mesh_export(1.0, 10)                                                  # only the reference's k = 20 is supported
+
+
+def test_reconstruct_mesh_from_pointcloud(oracle_lib, hip_lib):
+    """Offline entry (ImMesh_node.cpp:235-244 -> reconstruct_mesh_from_pointcloud): VoxelGrid(0.01) + one meshing call, identity pose."""
+    n = 40000
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 17, cap_triangles=1 << 20, mesh_append_budget=50000000)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    rng = np.random.default_rng(31)
+    x = rng.uniform(-6, 6, n); y = rng.uniform(-6, 6, n)
+    z = 0.2 * np.sin(x) + 0.1 * np.cos(1.7 * y) + rng.normal(0, 0.003, n)
+    pts = np.stack([x, y, z, rng.uniform(0, 100, n)], axis=1).astype(np.float32)
+    mo = o.reconstruct_mesh_from_pointcloud(pts, 0.01)
+    mh = h.reconstruct_mesh_from_pointcloud(pts, 0.01)
+    _compare_scan(mo, mh, "offline cloud")
+    assert len(mo["new_vtx"]) > 8000 and len(mo["tri_add"]) > 15000
