@@ -112,6 +112,7 @@ def make_scans(n_scans, n_pts, cfg, cache_dir, kitti=False):
 # algorithmic bytes of one launch of each kernel (SURVEY.md 8(d) record sizes; DESIGN.md "Kernels")
 def algorithmic_bytes(kname, c, n_scans, n_raw):
     n_ds = c["_n_ds_mean"]; iters = max(1, c["n_iter"]) / n_scans
+    kname = kname.split("<")[0]
     if kname == "residual_kernel":      # per EKF iteration: point 12 B + key/slot 12 B per point, 12 B per extra probe, 229 B per plane test
         launches = c["n_iter"]
         return (n_ds * 24 * launches + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / launches
@@ -177,7 +178,7 @@ def main():
             def _allreduce(buf):
                 dist.all_reduce(torch.from_numpy(buf))
         h.set_allreduce(_allreduce)
-    n_total = args.warmup + args.steps + args.profile_scans
+    n_total = args.warmup + args.steps + 2 * args.profile_scans
     raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
     if kitti:   # the map grows from the stream itself (3 m root voxels, max_layer 4)
         R0_, t0_ = synth.trajectory_pose(0)
@@ -236,14 +237,16 @@ def main():
     roofline = None
     kstats = {}
     if (rank == 0 or sharded) and args.profile_scans > 0:   # sharded: every rank takes part in the all-reduces of the extra scans
-        h.counters(reset=True)
-        h.profile_enable(True)
         pstage = np.zeros(4)
         for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode: per-stage times of one scan
+            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
             tm = h.last_timing()
             pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
         stage = pstage * (args.steps / max(1, args.profile_scans))
+        h.counters(reset=True)
+        h.profile_enable(True)
+        for _ in range(args.profile_scans):
+            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode, HIP events around every launch
         kstats = h.profile_read()
         h.profile_enable(False)
         pc = h.counters(); pc["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k - args.profile_scans:k]]))
@@ -255,7 +258,7 @@ def main():
         if best:
             per_scan_launches = kstats[best]["launches"] / args.profile_scans
             by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
-            if best not in ("residual_kernel",):
+            if best.split("<")[0] not in ("residual_kernel",):
                 by = by / max(1.0, per_scan_launches)
             avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]
             ach = by / (avg_ms * 1e-3) / 1e9

@@ -121,6 +121,13 @@ void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xy
     KLAUNCH(ds_expand_xyzi_kernel, dim3((n + 255) / 256), dim3(256), 0, s, xyz, n, (float4*)out_xyzi);
 }
 
+// profiler prelude (prof.hpp): keep the stream busy for ~25 us (wall_clock64 ticks at 100 MHz)
+__global__ void kprof_spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void kprof_spin(hipStream_t s) { hipLaunchKernelGGL(kprof_spin_kernel, dim3(1), dim3(1), 0, s, 2500LL); }
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm) {
     KLAUNCH(ds_minmax_kernel, dim3(min(1024, (n + 255) / 256)), dim3(256), 0, s, pts, n, stride, inv, mm);

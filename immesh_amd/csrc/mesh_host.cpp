@@ -257,6 +257,7 @@ scan_done:
     if (m.dbg) {
         unsigned long long t[16];
         (void)hipMemcpy(t, m.dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 128);
+        fprintf(stderr, "[slowest voxel] knn %llu cycles (nq %llu)  delaunay %llu cycles (n_u %llu)\n", t[13] >> 16, t[13] & 0xFFFF, t[14] >> 16, t[14] & 0xFFFF);
         fprintf(stderr, "[knn cycles/voxel] stage0 %llu query0 %llu stage1 %llu query1 %llu final %llu\n", t[8] / std::max(1, n_active), t[9] / std::max(1, n_active), t[10] / std::max(1, n_active),
                 t[11] / std::max(1, n_active), t[12] / std::max(1, n_active));
         fprintf(stderr, "[delaunay cycles/voxel] load %llu pca+proj %llu sort %llu insert %llu filter %llu oldset %llu adds %llu\n", t[0] / std::max(1, n_active), t[1] / std::max(1, n_active),

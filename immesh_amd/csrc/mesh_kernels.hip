@@ -320,6 +320,7 @@ IMD int lds_bsearch_u32(const unsigned int* a, int n, unsigned int key) {
     while (lo <= hi) { const int mid = (lo + hi) >> 1; const unsigned int v = a[mid]; if (v == key) return mid; if (v < key) lo = mid + 1; else hi = mid - 1; }
     return -1;
 }
+IMD float readlane_f(float x, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k)); }
 IMD unsigned long long wave_min_u64(unsigned long long x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const unsigned long long y = __shfl_xor(x, off, 64); x = y < x ? y : x; }
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     __shared__ int cid[KC];
     __shared__ unsigned long long best[MV_VOX_CAP][MV_KNN];
     __shared__ unsigned long long wl[4][WL];
+    __shared__ unsigned long long sel[4][64];
     __shared__ int nbest[MV_VOX_CAP];
     __shared__ float qx[MV_VOX_CAP], qy[MV_VOX_CAP], qz[MV_VOX_CAP];
     __shared__ int qid[MV_VOX_CAP];
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     const int n_active = EXPORT ? m.pc[PC_VOXELS] : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
+    const unsigned long long tvox0 = tprev;
 #define KDBG(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
     const int vi = EXPORT ? r : m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
@@ -484,17 +487,63 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // the MV_KNN smallest (d2, id) keys, ascending: repeated "smallest key above the previous one"
+                // the MV_KNN smallest (d2, id) keys, ascending.  Keys are distinct (ids are), so a key's output slot is the number of
+                // smaller keys.  More than 64 keys: first a bisection on the d2 bit pattern (ballot counts, no cross-lane reduction)
+                // finds the 20th smallest d2; the (normally exactly 20) keys at or below it are compacted and ranked the same way.
                 const int cnt = min(MV_KNN, nl);
-                unsigned long long prev = 0;
-                for (int k = 0; k < cnt; k++) {
-                    unsigned long long mine = ~0ull;
-                    for (int e = lane; e < nl; e += 64) {
-                        const unsigned long long v = wl[wv][e];
-                        if ((k == 0 || v > prev) && v < mine) mine = v;
+                const unsigned long long* src = wl[wv];
+                int nsel = nl;
+                bool ranked = true;
+                if (nl > 64) {
+                    unsigned int hreg[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int e = u * 64 + lane; hreg[u] = e < nl ? (unsigned int)(wl[wv][e] >> 32) : 0xFFFFFFFFu; }
+                    auto count_le = [&](unsigned int mid) -> int {
+                        int c = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) c += __popcll(__ballot(hreg[u] <= mid));
+                        for (int e0 = 256; e0 < nl; e0 += 64) { const int e = e0 + lane; c += __popcll(__ballot(e < nl && (unsigned int)(wl[wv][e] >> 32) <= mid)); }
+                        return c;
+                    };
+                    unsigned int lo = 0, hi = 0x7F7FFFFFu;
+                    while (lo < hi) { const unsigned int mid = lo + ((hi - lo) >> 1); if (count_le(mid) >= cnt) hi = mid; else lo = mid + 1; }
+                    nsel = count_le(lo);
+                    if (nsel <= 64) {
+                        int base = 0;
+                        for (int e0 = 0; e0 < nl; e0 += 64) {
+                            const int e = e0 + lane;
+                            const unsigned long long key = e < nl ? wl[wv][e] : ~0ull;
+                            const bool in = e < nl && (unsigned int)(key >> 32) <= lo;
+                            const unsigned long long mask = __ballot(in);
+                            if (in) sel[wv][base + __popcll(mask & ((1ull << lane) - 1ull))] = key;
+                            base += __popcll(mask);
+                        }
+                        src = sel[wv];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    } else ranked = false;   // > 44 exact distance ties at the 20th neighbour: the slow, general extraction below
+                }
+                if (ranked) {
+                    const unsigned long long mykey = lane < nsel ? src[lane] : ~0ull;
+                    const unsigned int klo = (unsigned int)mykey, khi = (unsigned int)(mykey >> 32);
+                    int rank = 0;
+                    for (int j = 0; j < nsel; j++) {
+                        const unsigned long long other = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)khi, j) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)klo, j);
+                        rank += other < mykey ? 1 : 0;
                     }
-                    prev = wave_min_u64(mine);
-                    if (lane == 0) best[q][k] = prev;
+                    if (lane < nsel && rank < MV_KNN) best[q][rank] = mykey;
+                } else {
+                    unsigned long long prev = 0;
+                    for (int k = 0; k < cnt; k++) {
+                        unsigned long long mine = ~0ull;
+                        for (int e = lane; e < nl; e += 64) {
+                            const unsigned long long v = wl[wv][e];
+                            if ((k == 0 || v > prev) && v < mine) mine = v;
+                        }
+                        prev = wave_min_u64(mine);
+                        if (lane == 0) best[q][k] = prev;
+                    }
                 }
                 if (lane == 0) nbest[q] = cnt;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -519,8 +568,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
             }
             double sx = 0, sy = 0, sz = 0, valid = 0.0;
             for (int k = 1; k < nb; k++) {
-                const int use = __shfl((int)use_l, k, 64);
-                const float x = __shfl(nxp, k, 64), y = __shfl(nyp, k, 64), z = __shfl(nzp, k, 64);
+                const int use = __builtin_amdgcn_readlane((int)use_l, k);
+                const float x = readlane_f(nxp, k), y = readlane_f(nyp, k), z = readlane_f(nzp, k);
                 if (use) { valid += 1.0; sx += (double)x; sy += (double)y; sz += (double)z; }
             }
             if (lane == 0) {
@@ -563,8 +612,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
         double sx = 0, sy = 0, sz = 0;
         int sc = 0;
         for (int k = 0; k < nb; k++) {  // neighbour order = ascending (d2, id), as returned by the tree search
-            const int use = __shfl((int)in_sm, k, 64);
-            const float x = __shfl(nxp, k, 64), y = __shfl(nyp, k, 64), z = __shfl(nzp, k, 64);
+            const int use = __builtin_amdgcn_readlane((int)in_sm, k);
+            const float x = readlane_f(nxp, k), y = readlane_f(nyp, k), z = readlane_f(nzp, k);
             if (use) { sc++; sx += (double)x; sy += (double)y; sz += (double)z; }
         }
         if (lane == 0 && sc > 0) {
@@ -591,6 +640,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
     __syncthreads();
     KDBG(12);
+    if (m.dbg && tid == 0) atomicMax(&m.dbg[13], ((__builtin_readcyclecounter() - tvox0) << 16) | (unsigned long long)nq);
     }
 }
 
@@ -699,6 +749,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     const int n = m.rel_n[r];
     if (n < n_lo || n > n_hi) continue;  // size class of the other instantiation
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
+    const unsigned long long tvox0 = tprev;
     const int vi = m.act_vox_s[r];
     for (int i = lane; i < n; i += 64) {
         const int id = m.rel_ids[(size_t)r * MV_REL_CAP + i];
@@ -973,6 +1024,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     if (lane == 0) { m.vox_ntris[r] = s_cnt[0]; atomicAdd(&m.sc[SC_TV], nf); }
     __syncthreads();
     DBG_T(6);
+    if (m.dbg && lane == 0) atomicMax(&m.dbg[14], ((__builtin_readcyclecounter() - tvox0) << 16) | (unsigned long long)n);
     }
 }
 

@@ -37,11 +37,15 @@ struct KProf {
 };
 
 extern thread_local KProf* g_kprof;
+// The pipeline is latency-bound: the stream is usually idle when a kernel is submitted, so a start event would execute at once and the
+// measured interval would include the host's submission latency (several us, more than some kernels run).  A short spin kernel ahead of
+// the start event keeps the queue busy until start event, kernel and stop event are all enqueued; they then execute back to back.
+void kprof_spin(hipStream_t s);
 
 struct KProfScope {
     KProf* p; hipStream_t s; KProf::Rec r;
     KProfScope(const char* name, hipStream_t stream) : p(g_kprof), s(stream) {
-        if (p && p->on) { r.id = p->id_of(name); r.a = p->get_event(); r.b = p->get_event(); (void)hipEventRecord(r.a, s); } else p = nullptr;
+        if (p && p->on) { r.id = p->id_of(name); r.a = p->get_event(); r.b = p->get_event(); kprof_spin(s); (void)hipEventRecord(r.a, s); } else p = nullptr;
     }
     ~KProfScope() { if (p) { (void)hipEventRecord(r.b, s); p->pending.push_back(r); } }
 };
