@@ -4,6 +4,7 @@
 #include "host_ctx.hpp"
 #include <algorithm>
 #include <cmath>
+#include <functional>
 
 static int64_t np2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -54,7 +55,7 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.ch_keys, ccap); A(m.ch_head, ccap);
     A(m.recent, cap_cand);
     A(m.act_key, cap_active); A(m.act_vox, cap_active); A(m.act_key_s, cap_active); A(m.act_vox_s, cap_active);
-    A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active);
+    A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active); A(m.rel_nq, cap_active);
     A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
     A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
     for (int k = 0; k < 2; k++) {
@@ -67,6 +68,14 @@ int mesh_alloc(immesh_ctx* c) {
     h.sort_temp_bytes = exclusive_sum_temp_bytes((int)cap_cand) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
     { unsigned long long* t; A(t, (size_t)(4 * cap_list + cap_active + 5 * 1024) * 2); h.d_sort_recs = t; }
+    { unsigned long long* t; A(t, (size_t)(cap_active + 5 * 1024) * 2); h.d_sort_recs_a = t; }
+    // parity 1 copies of everything phase A of scan k+1 writes while phase B of scan k still reads it (parity 0 = the arrays above)
+    MeshDev m1;
+    std::memset(&m1, 0, sizeof(m1));
+    A(m1.v_smooth_new, cap_verts * 3); A(m1.vx_rank, cap_voxels); A(m1.vx_rank_seq, cap_voxels);
+    A(m1.sc, SC_COUNT);
+    A(m1.act_key, cap_active); A(m1.act_vox, cap_active); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
+    A(m1.rel_ids, cap_active * MV_REL_CAP); A(m1.rel_n, cap_active); A(m1.rel_nq, cap_active);
 #undef A
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
@@ -81,17 +90,47 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
-    { MeshDyn* t; if ((rc = c->dalloc(&t, 1))) return rc; h.d_dyn = t; m.dyn = t; }
-    HIPCHK(c, hipHostMalloc((void**)&h.h_dyn, sizeof(MeshDyn)));
-    std::memset(h.h_dyn, 0, sizeof(MeshDyn));
+    HIPCHK(c, hipMemsetAsync(m1.sc, 0, SC_COUNT * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
+    HIPCHK(c, hipMemsetAsync(m1.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
+    for (int k = 0; k < 2; k++) {
+        MeshDyn* t; if ((rc = c->dalloc(&t, 1))) return rc; h.d_dyn[k] = t;
+        HIPCHK(c, hipHostMalloc((void**)&h.h_dyn[k], sizeof(MeshDyn)));
+        std::memset(h.h_dyn[k], 0, sizeof(MeshDyn));
+        HIPCHK(c, hipHostMalloc((void**)&h.h_sc2[k], SC_COUNT * 4));
+        std::memset(h.h_sc2[k], 0, SC_COUNT * 4);
+    }
+    h.h_sc = h.h_sc2[0];
+    m.dyn = h.d_dyn[0];
+    m.vx_rank_seq_alt = m1.vx_rank_seq;
+    {   // the two parity views
+        h.mpar[0] = m;
+        MeshDev& v = h.mpar[1];
+        v = m;
+        v.v_smooth_new = m1.v_smooth_new; v.vx_rank = m1.vx_rank; v.vx_rank_seq = m1.vx_rank_seq; v.vx_rank_seq_alt = m.vx_rank_seq;
+        v.sc = m1.sc; v.act_key = m1.act_key; v.act_vox = m1.act_vox; v.act_key_s = m1.act_key_s; v.act_vox_s = m1.act_vox_s;
+        v.rel_ids = m1.rel_ids; v.rel_n = m1.rel_n; v.rel_nq = m1.rel_nq;
+        v.dyn = h.d_dyn[1];
+        for (int k = 0; k < 2; k++) {
+            const MeshOutSet& o = h.outs[k];
+            MeshDev& w = h.mpar[k];
+            w.out_tri_add = o.tri_add; w.out_flip_add = o.flip_add; w.out_tri_rem = o.tri_rem; w.out_tri_upd = o.tri_upd; w.out_flip_upd = o.flip_upd;
+            w.out_smooth_ids = o.smooth_ids; w.out_smooth_xyz = o.smooth_xyz;
+        }
+    }
     h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
-    HIPCHK(c, hipHostMalloc((void**)&h.h_sc, SC_COUNT * 4));
+    h.pipeline = getenv("IMMESH_NO_PIPELINE") == nullptr;
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
-    std::memset(h.h_sc, 0, SC_COUNT * 4); std::memset(h.h_pc, 0, PC_COUNT * 4);
+    std::memset(h.h_pc, 0, PC_COUNT * 4);
     HIPCHK(c, hipStreamSynchronize(s));
     HIPCHK(c, hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreate(&h.ev_t0)); HIPCHK(c, hipEventCreate(&h.ev_t1));
+    HIPCHK(c, hipStreamCreateWithFlags(&h.stream_b, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&h.ev_b[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreate(&h.ev_t0[k])); HIPCHK(c, hipEventCreate(&h.ev_t1[k]));
+    }
     std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
     h.stop = false;
     h.worker = std::thread(mesh_worker_main, c);
@@ -107,16 +146,23 @@ void mesh_free(immesh_ctx* c) {
         h.worker.join();
     }
     if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); h.stream = nullptr; }
+    if (h.stream_b) { (void)hipStreamSynchronize(h.stream_b); (void)hipStreamDestroy(h.stream_b); h.stream_b = nullptr; }
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
     h.exp_vtx = h.exp_work = h.exp_tmp = nullptr;
-    for (int k = 0; k < 2; k++) if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
-    if (h.ev_t0) (void)hipEventDestroy(h.ev_t0);
-    if (h.ev_t1) (void)hipEventDestroy(h.ev_t1);
-    for (int k = 0; k < 2; k++) if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
-    if (h.h_dyn) (void)hipHostFree(h.h_dyn);
-    if (h.h_sc) (void)hipHostFree(h.h_sc);
+    for (int k = 0; k < 2; k++) {
+        if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
+        if (h.ev_a[k]) (void)hipEventDestroy(h.ev_a[k]);
+        if (h.ev_b[k]) (void)hipEventDestroy(h.ev_b[k]);
+        if (h.ev_t0[k]) (void)hipEventDestroy(h.ev_t0[k]);
+        if (h.ev_t1[k]) (void)hipEventDestroy(h.ev_t1[k]);
+        if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
+        if (h.graph_exec_b[k]) { (void)hipGraphExecDestroy(h.graph_exec_b[k]); h.graph_exec_b[k] = nullptr; }
+        if (h.h_dyn[k]) (void)hipHostFree(h.h_dyn[k]);
+        if (h.h_sc2[k]) (void)hipHostFree(h.h_sc2[k]);
+        h.h_dyn[k] = nullptr; h.h_sc2[k] = nullptr;
+    }
     if (h.h_pc) (void)hipHostFree(h.h_pc);
     h.h_sc = h.h_pc = nullptr;
 }
@@ -132,124 +178,139 @@ static int mesh_overflow(immesh_ctx* c) {
     return IMMESH_E_CAPACITY;
 }
 
-// the launch sequence of one scan (fixed grids; everything scan-specific is read from MeshDev::dyn on the device)
-static int mesh_enqueue(immesh_ctx* c, const MeshDev& m, const float* d_pts, int n_cand, int64_t ccap) {
+// The launch sequence of one scan, in two phases (fixed grids; everything scan-specific is read from MeshDev::dyn on the device).
+// Every launch has a fixed grid and takes its work-list length from device counters, so a whole scan is enqueued without a host round
+// trip; the host reads the counters once, at the end of phase B.
+// Phase A: a17-a19 (vertex admission, active voxels in rank order, neighbourhood search).
+static int mesh_enqueue_a(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s, const float* d_pts, int n_cand, int64_t ccap, bool resolve) {
     MeshHost& h = c->mesh_host;
-    hipStream_t s = h.stream;
-    MHIPCHK(c, hipMemcpyAsync(h.d_dyn, h.h_dyn, sizeof(MeshDyn), hipMemcpyHostToDevice, s));
-    MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-    MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
-    MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
-    // ---- a17 append.  Every launch below has a fixed grid and takes its work-list length from device counters, so the whole scan is
-    //      enqueued without a host round trip; the host reads the counters once, at the end.
-    launch_mesh_append_prepare(s, m, n_cand, d_pts);
-    // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
-    // the iteration bound only guards against a hung device and is checked by the caller
-    launch_mesh_append_resolve(s, m, n_cand, d_pts, 1 << 16);
+    if (resolve) {
+        MHIPCHK(c, hipMemcpyAsync(h.d_dyn[par], h.h_dyn[par], sizeof(MeshDyn), hipMemcpyHostToDevice, s));
+        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
+        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
+        launch_mesh_begin_scan(s, m);
+        launch_mesh_append_prepare(s, m, n_cand, d_pts);
+        // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
+        // the iteration bound only guards against a hung device and is checked by the caller
+        launch_mesh_append_resolve(s, m, n_cand, d_pts, 1 << 16);
+    }
     launch_mesh_append_flags(s, m, n_cand);
     exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, n_cand);
     launch_mesh_append_commit(s, m, n_cand, d_pts);
     launch_mesh_select_active(s, m, n_cand);
     // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
     // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);   // sorted active list + ranks
-    launch_mesh_knn(s, m);                                    // a18-a19
+    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs_a, nullptr);   // sorted active list + ranks
+    launch_mesh_knn(s, m);                                      // a18-a19
+    return 0;
+}
+// Phase B: a20-a24 (triangulation, diff against the live set, commit: all removes, then all adds -- ImMesh_mesh_reconstruction.cpp:228-244;
+// result lists sorted by triplet), then the counters go to the host.
+static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s) {
+    MeshHost& h = c->mesh_host;
     launch_mesh_delaunay(s, m);                               // a20-a23
     launch_mesh_finalize(s, m);
-    // ---- a24 commit: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244); result lists sorted by triplet
     launch_mesh_commit_rem(s, m, m.list_rem);
     launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
     launch_mesh_commit_add(s, m, h.p_a);
-    MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipMemcpyAsync(h.h_sc2[par], m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
     return 0;
 }
 
-// runs on the worker thread, on the mesher's stream
-static int mesh_scan_run(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t& sizes) {
-    MeshDev& m = c->mesh;
+static int mesh_graph_run(immesh_ctx* c, hipGraphExec_t& exec, hipStream_t s, const std::function<int()>& enqueue) {
+    if (exec == nullptr) {
+        hipGraph_t g = nullptr;
+        MHIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int erc = enqueue();
+        const hipError_t ce = hipStreamEndCapture(s, &g);
+        if (erc || ce != hipSuccess || g == nullptr) { if (g) (void)hipGraphDestroy(g); c->mesh_host.err = "hipGraph capture of the mesher failed"; return IMMESH_E_HIP; }
+        const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) { exec = nullptr; c->mesh_host.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
+    }
+    MHIPCHK(c, hipGraphLaunch(exec, s));
+    return 0;
+}
+
+// Worker thread: enqueue one scan (phase A on h.stream, phase B on h.stream_b behind it).  Returns without waiting unless the scan is
+// offline-sized.  `synced` tells the caller that both streams are already drained.
+static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     MeshHost& h = c->mesh_host;
-    hipStream_t s = h.stream;
+    const int par = (int)(job.id & 1);
+    const MeshDev& m = h.mpar[par];
+    hipStream_t sa = h.stream, sb = h.stream_b;
     const float* d_pts = job.d_pts;
     const int n_raw = job.n_raw;
-    const int par = (int)(job.id & 1);
-    {   // this job's result lists
-        const MeshOutSet& o = h.outs[par];
-        m.out_tri_add = o.tri_add; m.out_flip_add = o.flip_add; m.out_tri_rem = o.tri_rem; m.out_tri_upd = o.tri_upd; m.out_flip_upd = o.flip_upd;
-        m.out_smooth_ids = o.smooth_ids; m.out_smooth_xyz = o.smooth_xyz;
-    }
+    synced = false;
     h.seq++;
     MeshScanParams sp;
     sp.cam[0] = job.cam[0]; sp.cam[1] = job.cam[1]; sp.cam[2] = job.cam[2];
     sp.n_raw = n_raw;
     sp.step = std::max(1, (int)std::round((double)(n_raw / c->cfg.mesh_append_budget)));  // integer division first (ImMesh_mesh_reconstruction.cpp:111)
     sp.n_cand = (n_raw + sp.step - 1) / sp.step;
-    sp.vtx_base = h.n_vertices;
+    sp.vtx_base = 0;   // filled in on the device (mesh_begin_scan_kernel)
     if (sp.n_cand > m.cap_cand) { h.err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
     const int64_t ccap = np2((int64_t)sp.n_cand * 4);
-    h.h_dyn->sp = sp; h.h_dyn->seq = h.seq; h.h_dyn->ch_mask = (uint64_t)ccap - 1;
-    m.seq = h.seq; m.ch_mask = (uint64_t)ccap - 1;   // (host copies; the kernels read *dyn)
+    h.h_dyn[par]->sp = sp; h.h_dyn[par]->seq = h.seq; h.h_dyn[par]->ch_mask = (uint64_t)ccap - 1;
+    MHIPCHK(c, hipStreamWaitEvent(sa, job.ready, 0));   // the scan (transform / host copy) was produced on the registration stream
+    MHIPCHK(c, hipEventRecord(h.ev_t0[par], sa));
+    int rc = 0;
     if (sp.n_cand > 65536) {
         // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
-        MHIPCHK(c, hipMemcpyAsync(h.d_dyn, h.h_dyn, sizeof(MeshDyn), hipMemcpyHostToDevice, s));
-        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
-        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
-        launch_mesh_append_prepare(s, m, sp.n_cand, d_pts);
+        MHIPCHK(c, hipMemcpyAsync(h.d_dyn[par], h.h_dyn[par], sizeof(MeshDyn), hipMemcpyHostToDevice, sa));
+        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, sa));
+        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, sa));
+        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, sa));
+        launch_mesh_begin_scan(sa, m);
+        launch_mesh_append_prepare(sa, m, sp.n_cand, d_pts);
         for (int round = 0; round < 100000; round++) {
-            if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, s));
-            launch_mesh_append_resolve(s, m, sp.n_cand, d_pts, 64);
-            MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-            MHIPCHK(c, hipStreamSynchronize(s));
-            if (h.h_sc[SC_UNDECIDED] == 0) break;
+            if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, sa));
+            launch_mesh_append_resolve(sa, m, sp.n_cand, d_pts, 64);
+            MHIPCHK(c, hipMemcpyAsync(h.h_sc2[par], m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, sa));
+            MHIPCHK(c, hipStreamSynchronize(sa));
+            if (h.h_sc2[par][SC_UNDECIDED] == 0) break;
         }
-        launch_mesh_append_flags(s, m, sp.n_cand);
-        exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, sp.n_cand);
-        launch_mesh_append_commit(s, m, sp.n_cand, d_pts);
-        launch_mesh_select_active(s, m, sp.n_cand);
-        launch_mesh_sort_emit(s, m, 0, h.d_sort_recs, nullptr);
-        launch_mesh_knn(s, m);
-        launch_mesh_delaunay(s, m);
-        launch_mesh_finalize(s, m);
-        launch_mesh_commit_rem(s, m, m.list_rem);
-        launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
-        launch_mesh_commit_add(s, m, h.p_a);
+        if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
     } else if (h.use_graph && !h.prof.on && d_pts == h.d_world[par]) {
-        // steady state: the ~25 launches of a scan are captured once per (parity, candidate count) and replayed as one hipGraph --
-        // the sequence is launch-bound (tens of microsecond-scale kernels), per-launch host and dispatch gaps are what the graph removes
-        if (h.graph_exec[par] == nullptr || h.graph_ncand[par] != sp.n_cand) {
-            if (h.graph_exec[par]) { (void)hipGraphExecDestroy(h.graph_exec[par]); h.graph_exec[par] = nullptr; }
-            hipGraph_t g = nullptr;
-            MHIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int erc = mesh_enqueue(c, m, d_pts, sp.n_cand, ccap);
-            const hipError_t ce = hipStreamEndCapture(s, &g);
-            if (erc || ce != hipSuccess || g == nullptr) { if (g) (void)hipGraphDestroy(g); h.err = "hipGraph capture of the mesher failed"; return IMMESH_E_HIP; }
-            const hipError_t ie = hipGraphInstantiate(&h.graph_exec[par], g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (ie != hipSuccess) { h.graph_exec[par] = nullptr; h.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
+        // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
+        if (h.graph_ncand[par] != sp.n_cand) {
+            for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
             h.graph_ncand[par] = sp.n_cand;
         }
-        MHIPCHK(c, hipGraphLaunch(h.graph_exec[par], s));
-        MHIPCHK(c, hipStreamSynchronize(s));
-        goto scan_done;
+        if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true); }))) return rc;
     } else {
-        const int erc = mesh_enqueue(c, m, d_pts, sp.n_cand, ccap);
-        if (erc) return erc;
-        MHIPCHK(c, hipStreamSynchronize(s));
-        goto scan_done;
+        if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true))) return rc;
     }
-    MHIPCHK(c, hipMemcpyAsync(h.h_sc, m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
-    MHIPCHK(c, hipStreamSynchronize(s));
-scan_done:
+    MHIPCHK(c, hipEventRecord(h.ev_a[par], sa));
+    MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
+    if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && d_pts == h.d_world[par]) {
+        if ((rc = mesh_graph_run(c, h.graph_exec_b[par], sb, [&] { return mesh_enqueue_b(c, m, par, sb); }))) return rc;
+    } else {
+        if ((rc = mesh_enqueue_b(c, m, par, sb))) return rc;
+    }
+    MHIPCHK(c, hipEventRecord(h.ev_t1[par], sb));
+    MHIPCHK(c, hipEventRecord(h.ev_b[par], sb));
+    return 0;
+}
+
+// Worker thread, after ev_b of the job's parity has completed: sizes, cumulative counters, capacity / hang checks.
+static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t& sizes) {
+    MeshHost& h = c->mesh_host;
+    const int par = (int)(job.id & 1);
+    const MeshDev& m = h.mpar[par];
+    h.h_sc = h.h_sc2[par];
     int rc = mesh_overflow(c);
     if (rc) return rc;
     if (h.h_sc[SC_UNDECIDED] != 0) { h.err = "vertex admission did not converge (device hang guard)"; return IMMESH_E_HIP; }
+    const int n_cand = h.h_dyn[par]->sp.n_cand;
     const int n_new = h.h_sc[SC_ACCEPTED], n_active = std::min(h.h_sc[SC_ACTIVE], (int)m.cap_active);
     const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
-    sizes.vtx_base = sp.vtx_base; sizes.n_new_vtx = n_new; sizes.n_voxels_meshed = n_active;
+    sizes.vtx_base = h.h_sc[SC_VTXBASE]; sizes.n_new_vtx = n_new; sizes.n_voxels_meshed = n_active;
     sizes.n_add = n_add; sizes.n_rem = n_rem; sizes.n_upd = n_upd; sizes.n_smooth = n_smooth; sizes.reserved = 0;
-    h.n_vertices = sp.vtx_base + n_new;
+    h.n_vertices = sizes.vtx_base + n_new;
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
-    h.cum[SC_RECENT] += sp.n_cand;  // n_app: candidates offered
+    h.cum[SC_RECENT] += n_cand;  // n_app: candidates offered
     h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
     h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
     h.n_live += n_add - n_rem;
@@ -263,43 +324,69 @@ scan_done:
         fprintf(stderr, "[delaunay cycles/voxel] load %llu pca+proj %llu sort %llu insert %llu filter %llu oldset %llu adds %llu\n", t[0] / std::max(1, n_active), t[1] / std::max(1, n_active),
                 t[2] / std::max(1, n_active), t[3] / std::max(1, n_active), t[4] / std::max(1, n_active), t[5] / std::max(1, n_active), t[6] / std::max(1, n_active));
     }
-    if (getenv("IMMESH_DEBUG")) fprintf(stderr, "[mesh] cand %d new %d active %d maxnu %d pass2 %d add %d rem %d\n", sp.n_cand, n_new, n_active, h.h_sc[SC_MAXNU], h.h_sc[SC_PASS2], n_add, n_rem);
+    if (getenv("IMMESH_DEBUG")) fprintf(stderr, "[mesh] cand %d new %d active %d maxnu %d pass2 %d add %d rem %d\n", n_cand, n_new, n_active, h.h_sc[SC_MAXNU], h.h_sc[SC_PASS2], n_add, n_rem);
     return 0;
 }
 
+// The worker keeps up to two scans in flight on the device: as soon as the next job is queued it is enqueued behind the running one (phase A
+// of scan k+1 overlaps phase B of scan k), and jobs are finished -- counters read, results published -- strictly in order.
 static void mesh_worker_main(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     (void)hipSetDevice(c->cfg.device);
     g_kprof = &h.prof;
+    struct Flight { MeshJob job; MeshResult r; bool launched_ok; };
+    std::deque<Flight> fl;
     for (;;) {
+        // ---- take a new job when one is queued and the pipeline has room
+        bool have = false;
         MeshJob job;
         {
             std::unique_lock<std::mutex> lk(h.mu);
-            h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
-            if (h.q.empty()) break;   // stop requested and nothing left to do
-            job = h.q.front(); h.q.pop_front();
+            if (fl.empty()) h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
+            const size_t room = (h.pipeline && !h.prof.on) ? 2 : 1;
+            if (!h.q.empty() && fl.size() < room) { job = h.q.front(); h.q.pop_front(); have = true; }
+            else if (fl.empty() && h.q.empty()) break;   // stop requested and nothing left to do
         }
-        MeshResult r;
-        r.id = job.id;
-        std::memset(&r.sizes, 0, sizeof(r.sizes));
-        h.err.clear();
-        hipError_t e = hipStreamWaitEvent(h.stream, job.ready, 0);   // the scan (transform / host copy) was produced on the registration stream
-        if (e == hipSuccess) e = hipEventRecord(h.ev_t0, h.stream);
-        if (e != hipSuccess) { r.rc = IMMESH_E_HIP; r.err = std::string("mesh job setup: ") + hipGetErrorString(e); }
-        else {
-            r.rc = mesh_scan_run(c, job, r.sizes);
-            (void)hipEventRecord(h.ev_t1, h.stream);
-            (void)hipStreamSynchronize(h.stream);
-            (void)hipEventElapsedTime(&r.ms, h.ev_t0, h.ev_t1);
-            if (r.rc) r.err = h.err;
+        if (have) {
+            Flight f;
+            f.job = job; f.r.id = job.id; f.launched_ok = false;
+            std::memset(&f.r.sizes, 0, sizeof(f.r.sizes));
+            h.err.clear();
+            bool synced = false;
+            f.r.rc = mesh_scan_launch(c, job, synced);
+            if (f.r.rc) f.r.err = h.err; else f.launched_ok = true;
+            fl.push_back(f);
+            continue;
+        }
+        // ---- finish the oldest scan in flight once its phase B is done; meanwhile keep an eye on the queue
+        Flight& f = fl.front();
+        const int par = (int)(f.job.id & 1);
+        if (f.launched_ok) {
+            const hipError_t q = hipEventQuery(h.ev_b[par]);
+            if (q == hipErrorNotReady) {
+                bool more;
+                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on) ? 2u : 1u); }
+                if (!more) std::this_thread::yield();
+                continue;
+            }
+            h.err.clear();
+            if (q != hipSuccess) { f.r.rc = IMMESH_E_HIP; f.r.err = std::string("mesh job: ") + hipGetErrorString(q); }
+            else {
+                (void)hipEventElapsedTime(&f.r.ms, h.ev_t0[par], h.ev_t1[par]);
+                f.r.rc = mesh_scan_finish(c, f.job, f.r.sizes);
+                if (f.r.rc) f.r.err = h.err;
+            }
+        } else {
+            (void)hipStreamSynchronize(h.stream); (void)hipStreamSynchronize(h.stream_b);
         }
         if (h.prof.on) h.prof.flush();
         {
             std::lock_guard<std::mutex> lk(h.mu);
-            h.res[job.id & 1] = r;
-            h.completed = job.id;
+            h.res[f.job.id & 1] = f.r;
+            h.completed = f.job.id;
         }
         h.cv_done.notify_all();
+        fl.pop_front();
     }
     g_kprof = nullptr;
 }

@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __res
 // =====================================================================================================================
 // append_points_to_global_map
 // =====================================================================================================================
+// first kernel of a scan (after the copy of the host's parameters and the clear of the per-scan counters): the id of the scan's first new
+// vertex is the device's own vertex count, so the host can enqueue a scan before the previous one has reported its size
+__global__ void mesh_begin_scan_kernel(MeshDev m) {
+    const int base = m.pc[PC_VERTS];
+    m.dyn->sp.vtx_base = base;
+    m.sc[SC_VTXBASE] = base;
+}
+void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_begin_scan_kernel, dim3(1), dim3(1), 0, s, m); }
+
 __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts) {
     MESH_DYN(m_in);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
         vi = atomicAdd(&m.pc[PC_VOXELS], 1);
         if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
         else {
-            m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_stamp[vi] = m.seq;
+            m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_stamp[vi] = m.seq;
             m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
             m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
             __threadfence();
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     __syncthreads();
     lds_bitonic_sort<int, 256>(rel_l, np2, tid);
     for (int k = tid; k < nrel; k += 256) m.rel_ids[(size_t)r * MV_REL_CAP + k] = rel_l[k];
-    if (tid == 0) { m.rel_n[r] = nrel; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); atomicMax(&m.sc[SC_MAXNU], nrel); }
+    if (tid == 0) { m.rel_n[r] = nrel; m.rel_nq[r] = nq; atomicAdd(&m.sc[SC_NV], nq); atomicAdd(&m.sc[SC_NU], nrel); atomicMax(&m.sc[SC_MAXNU], nrel); }
     if (lane == 0 && inspected) atomicAdd(&m.sc[SC_C20], (int)inspected);
     __syncthreads();
     KDBG(12);
@@ -1047,7 +1056,7 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
         if (e & TRI_ADD_BIT) { m.t_flip[t] = fl; list_push(m, m.list_add, SC_ADD, t); }
         else if (m.t_flip[t] != fl) { m.t_flip[t] = fl; list_push(m, m.list_upd, SC_UPD, t); }
     }
-    const int np = min(m.vx_npts[vi], MV_VOX_CAP);
+    const int np = m.rel_nq[r];   // the vertices the voxel held when phase A searched it (phase A of the next scan may be appending already)
     for (int k = lane; k < np; k += 64) {
         const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + k];
         m.v_smooth[(size_t)id * 3 + 0] = m.v_smooth_new[(size_t)id * 3 + 0];

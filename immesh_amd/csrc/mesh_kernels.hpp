@@ -31,7 +31,8 @@
 // per-scan device counters (MeshDev::sc)
 enum {
     SC_UNDECIDED = 0, SC_ACCEPTED, SC_RECENT, SC_ACTIVE, SC_ADD, SC_REM, SC_UPD, SC_SMOOTH, SC_OVERFLOW, SC_C1, SC_C20, SC_NV, SC_NU, SC_TV, SC_MAXNU, SC_PASS2,
-    SC_COUNT = 16
+    SC_VTXBASE,      /* vertex count when the scan started (the id of its first new vertex) */
+    SC_COUNT = 24
 };
 // persistent device counters (MeshDev::pc)
 enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
@@ -58,7 +59,7 @@ struct MeshDev {
     // mesh voxels
     unsigned long long* x_keys; int32_t* x_vals; uint64_t x_mask;
     unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
-    int32_t* vx_rank; int32_t* vx_rank_seq; double* vx_short_axis;
+    int32_t* vx_rank; int32_t* vx_rank_seq; int32_t* vx_rank_seq_alt; double* vx_short_axis;   // (rank, stamp): per job parity; _alt = the other parity's stamps
     // triangles
     int32_t* t_v; unsigned long long* t_word; int32_t* t_live; int32_t* t_rem_seq; int8_t* t_flip;
     int32_t* th_slots; uint64_t th_mask;
@@ -70,7 +71,7 @@ struct MeshDev {
     unsigned long long* ch_keys; int32_t* ch_head; uint64_t ch_mask;       // candidate-cell chains
     int32_t* recent;                                                       // voxel indices visited this scan
     unsigned long long* act_key; int32_t* act_vox; unsigned long long* act_key_s; int32_t* act_vox_s;
-    int32_t* rel_ids; int32_t* rel_n;                                      // [n_active][MV_REL_CAP], [n_active]
+    int32_t* rel_ids; int32_t* rel_n; int32_t* rel_nq;                     // [n_active][MV_REL_CAP], [n_active], [n_active] (vertices the voxel held when it was searched)
     int32_t* vox_tris; int32_t* vox_ntris;                                 // [n_active][2*MV_REL_CAP] triangle ids touched (bit 31 = add)
     int32_t* list_add; int32_t* list_rem; int32_t* list_upd; int32_t* list_smooth;   // unsorted unique lists
     // sorted outputs
@@ -81,10 +82,15 @@ struct MeshDev {
     // parameters
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
     int32_t seq;                         // scan sequence number (>= 1); kernels take it (and ch_mask) from *dyn
-    const MeshDyn* dyn;                  // per-scan parameters (device memory)
+    MeshDyn* dyn;                        // per-scan parameters (device memory)
     unsigned long long* dbg;             // optional phase timers (IMMESH_DEBUG): [16] sums of s_memtime deltas, nullptr = off
 };
 
+// Two views of the mesh map, one per job parity.  A scan is meshed in two phases: A = vertex admission + neighbourhood search (a17-a19),
+// B = triangulation + diff + commit (a20-a24).  A(k+1) depends only on A(k); B(k) on A(k) and B(k-1) -- so A(k+1) runs on its own stream
+// while B(k) is still busy (the reference, too, lets frame k+1 append while frame k triangulates, ImMesh_mesh_reconstruction.cpp:60-61,
+// there without a defined order).  Everything A(k+1) writes and B(k) reads is double-buffered by parity: per-scan counters, dyn, the active
+// list + ranks, the neighbourhood lists, this scan's smoothed positions, the result lists.
 // One queued incremental_mesh_reconstruction call.  The reference runs the mesher on its own service thread + pool
 // (service_reconstruct_mesh, ImMesh_mesh_reconstruction.cpp:272-310) so scan k's meshing overlaps scan k+1's registration; here a
 // worker thread drives a second HIP stream, strictly in submission order (the sequential-deterministic frame order of the checker).
@@ -96,17 +102,22 @@ struct MeshHost {
     int32_t seq = 0;
     int64_t cum[SC_COUNT];
     int32_t* p_a = nullptr;    // add list as sorted triangle indices (input of the adjacency commit)
-    int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters
+    int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters of the job being finished (points into h_sc2)
+    int32_t* h_sc2[2] = {nullptr, nullptr};
     int32_t* h_pc = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
-    void* d_sort_recs = nullptr;   // 16-byte sort records of the chunk sort
+    void* d_sort_recs = nullptr;   // 16-byte sort records of the chunk sort (phase B: result lists)
+    void* d_sort_recs_a = nullptr; // same, phase A (active-voxel list)
+    MeshDev mpar[2];               // per-parity views
     int32_t n_vertices = 0;
     int64_t n_live = 0;
     bool ready = false;
     // asynchronous execution
-    hipStream_t stream = nullptr;            // the mesher's own stream
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_t0 = nullptr, ev_t1 = nullptr;
+    hipStream_t stream = nullptr;            // the mesher's own streams: phase A ...
+    hipStream_t stream_b = nullptr;          // ... and phase B
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
+    hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};   // phase A / B of the job of that parity finished
     float* d_world[2] = {nullptr, nullptr};  // world-frame full scans, double-buffered (job id parity)
     MeshOutSet outs[2];                      // result lists, double-buffered (job id parity)
     MeshResult res[2];
@@ -117,11 +128,13 @@ struct MeshHost {
     long submitted = 0, completed = 0, current = 0;   // job ids start at 1; `current` = job whose results sizes/fetch return
     bool stop = false;
     // per-scan parameters + graph replay
-    MeshDyn* d_dyn = nullptr;                // device copy read by the kernels
-    MeshDyn* h_dyn = nullptr;                // pinned host copy (source of the copy node at the head of the graph)
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // one per job parity (world buffer / result set pointers differ)
+    MeshDyn* d_dyn[2] = {nullptr, nullptr};  // device copies read by the kernels (job parity)
+    MeshDyn* h_dyn[2] = {nullptr, nullptr};  // pinned host copies (source of the copy node at the head of the graph)
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // phase A, one per job parity (world buffer / result set pointers differ)
+    hipGraphExec_t graph_exec_b[2] = {nullptr, nullptr}; // phase B
     int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
     bool use_graph = true;
+    bool pipeline = true;                    // phase A of scan k+1 may overlap phase B of scan k (IMMESH_NO_PIPELINE turns it off)
     // mesh export scratch (grow-only)
     void *exp_vtx = nullptr, *exp_work = nullptr, *exp_tmp = nullptr;
     size_t exp_vtx_bytes = 0, exp_work_bytes = 0, exp_tmp_bytes = 0;
@@ -133,6 +146,7 @@ struct MeshHost {
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
                            const double* extT);
+void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m);
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter);
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
