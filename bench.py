@@ -196,10 +196,11 @@ def main():
     R0, t0 = synth.trajectory_pose(idx[0])
     st = capi.make_state(R=R0, t=t0)
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
-    mesh_mode = (2 if args.async_mesh else 1) if (args.mesh and (not sharded or rank == 0)) else 0   # sharded: the mesher runs on rank 0
-    if mesh_mode or (sharded and args.mesh):
+    NOWAIT = 0x10   # IMMESH_SCAN_NOWAIT: return once the pose is final, map growth finishes on the stream ahead of the next scan's work
+    mesh_mode = (2 if args.async_mesh else 1) if (args.mesh and (not sharded or rank == 0)) else (NOWAIT if args.async_mesh else 0)   # sharded: the mesher runs on rank 0
+    if (mesh_mode & 3) or (sharded and args.mesh):
         # mesh map is seeded by scan 0 (the registration map is the pre-built survey); sharded: every rank takes part in the scan's all-reduces
-        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1 if mesh_mode else 0, n_ds=len(downs[0]), n_raw=len(raws[0]))
+        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1 if (mesh_mode & 3) else 0, n_ds=len(downs[0]), n_raw=len(raws[0]))
 
 
     def run(k, state, mode=None):
@@ -222,10 +223,9 @@ def main():
     t_begin = time.perf_counter()
     for _ in range(args.steps):
         st, info = run(k, st); k += 1
-        tm = h.last_timing()
-        stage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
     if mesh_mode == 2:
         h.mesh_wait()          # drain the mesher: every scan of the timed region is fully meshed before the clock stops
+    h.last_timing()            # waits for the last scan's map update (the library's own stream)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
@@ -239,14 +239,14 @@ def main():
     if (rank == 0 or sharded) and args.profile_scans > 0:   # sharded: every rank takes part in the all-reduces of the extra scans
         pstage = np.zeros(4)
         for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
+            st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
             tm = h.last_timing()
             pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
         stage = pstage * (args.steps / max(1, args.profile_scans))
         h.counters(reset=True)
         h.profile_enable(True)
         for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if mesh_mode else 0); k += 1    # serial mode, HIP events around every launch
+            st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, HIP events around every launch
         kstats = h.profile_read()
         h.profile_enable(False)
         pc = h.counters(); pc["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k - args.profile_scans:k]]))
@@ -307,7 +307,7 @@ def main():
                        "n_raw": int(np.mean([len(r) for r in raws])), "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
                        "parallelism": (f"one stream, registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration), mesher on rank 0" if sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
-                       "mesh_mode": {0: "off", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1)"}[mesh_mode],
+                       "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},
             "stages_ms_serial": {"gpu_total": round(stage[0] / args.steps, 4), "register": round(stage[1] / args.steps, 4),
                           "map_update": round(stage[2] / args.steps, 4), "mesh": round(stage[3] / args.steps, 4)},

@@ -153,6 +153,19 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
     return 0;
 }
 
+// An asynchronous immesh_process_scan leaves its map update (and the copy of the capacity flags) running; whoever needs the stream idle, the
+// stage timings or the flags settles it first.  `synced`: the caller knows the stream has already passed that work.
+static int settle(immesh_ctx* c, bool synced = false) {
+    if (!c->pending) return 0;
+    if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    hipEvent_t* e = c->ev + 4 * c->ev_par;
+    (void)hipEventElapsedTime(&c->timing[1], e[0], e[1]);
+    (void)hipEventElapsedTime(&c->timing[2], e[1], e[2]);
+    c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
+    return check_overflow(c);
+}
+
 static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh::State& st, const double* prior_cov) {
     ScanParams sp;
     make_scan_params(c, st, prior_cov, sp);
@@ -221,6 +234,7 @@ int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double*
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -257,6 +271,7 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state || !HTH36 || !HTz6) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -315,6 +330,7 @@ int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* s
     if (!c || !pts || n <= 0 || n > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -329,6 +345,7 @@ int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const doubl
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
     if (rc) return rc;
@@ -354,35 +371,44 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     if (do_mesh && (rc = resolve_input(c, pts_raw, (size_t)n_raw * 16, c->d_pts_raw, &d_raw))) return rc;
     imh::State prior, st;
     imh::load_state(state_prior, prior); imh::load_state(state_inout, st);
-    hipEventRecord(c->ev[0], c->stream);
+    const int mesh_mode = do_mesh & 3;
+    const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || (do_mesh & IMMESH_SCAN_NOWAIT);
+    const int par = c->ev_par ^ 1;
+    hipEvent_t* ev = c->ev + 4 * par;
+    hipEventRecord(ev[0], c->stream);
     int n_iter = 0, n_match = 0;
     if ((rc = register_device(c, (const float*)d_down, n_ds, prior, st, &n_iter, &n_match, nullptr))) return rc;
-    hipEventRecord(c->ev[1], c->stream);
+    // the residual passes of this scan ran behind the previous scan's map update on the same stream: that update is complete now
+    if ((rc = settle(c, true))) return rc;
+    c->ev_par = par;
+    hipEventRecord(ev[1], c->stream);
     if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0))) return rc;
-    hipEventRecord(c->ev[2], c->stream);
+    hipEventRecord(ev[2], c->stream);
     long job = 0;
-    if (do_mesh) {
-        // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own stream + worker thread), as
+    if (mesh_mode) {
+        // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own streams + worker thread), as
         // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417)
         float* world = mesh_next_world_buffer(c);
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
-    hipEventRecord(c->ev[3], c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hipEventElapsedTime(&c->timing[1], c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&c->timing[2], c->ev[1], c->ev[2]);
-    c->timing[3] = 0.f;
-    if (do_mesh == 1 && (rc = mesh_wait(c, job))) { imh::store_state(st, state_inout); return rc; }   // synchronous mode: results are current on return
-    c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
+    hipEventRecord(ev[3], c->stream);
+    c->timing[3] = 0.f;   // (immesh_mesh_wait fills in the mesher's time)
     imh::store_state(st, state_inout);
     if (n_iter_out) *n_iter_out = n_iter;
     if (n_match_out) *n_match_out = n_match;
-    return check_overflow(c);
+    c->pending = true;
+    if (nowait) return 0;   // the pose is final; map growth (and meshing) finish in the background, ordered before the next call's work
+    if ((rc = settle(c))) return rc;
+    if (mesh_mode == IMMESH_MESH_SYNC && (rc = mesh_wait(c, job))) return rc;   // synchronous mode: results are current on return
+    c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
+    return 0;
 }
 
 int immesh_last_timing(immesh_ctx* c, float ms[4]) {
     if (!c || !ms) return IMMESH_E_INVAL;
+    const int rc = settle(c);
+    if (rc) return rc;
     for (int i = 0; i < 4; i++) ms[i] = c->timing[i];
     return 0;
 }
@@ -391,6 +417,7 @@ int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_
     if (!c || !n_out) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     static_assert(sizeof(PlaneRecDev) == sizeof(immesh_plane_rec), "plane record layout");
     PlaneRecDev* d_out = nullptr;
     if (out && cap > 0) HIPCHK(c, hipMalloc((void**)&d_out, (size_t)cap * sizeof(PlaneRecDev)));
@@ -410,6 +437,7 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     if (!c || !out) return IMMESH_E_INVAL;
     hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
     int64_t stats[8];
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost));

@@ -29,7 +29,9 @@ struct immesh_ctx {
     immesh_config cfg;
     std::string err;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // two sets of four (scan parity)
+    int ev_par = 0;
+    bool pending = false;            // the last immesh_process_scan returned without waiting for its map update (IMMESH_SCAN_NOWAIT)
     float timing[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
     size_t bytes_allocated = 0;

@@ -147,7 +147,14 @@ int immesh_save_ply(immesh_ctx* ctx, const char* path, double smooth_factor, int
 /* lio_state_estimation + map_incremental_grow (+ world transform of the full scan and incremental_mesh_reconstruction
  * when do_mesh != 0).  pts_raw_body_xyzi = m_feats_undistort (n_raw x 4).  Everything stays on the device between
  * stages; mesh results are read with immesh_mesh_sizes / immesh_mesh_fetch.
- * do_mesh: 0 = registration + map update only, 1 = mesh synchronously, 2 = queue the mesh job and return (see immesh_mesh_wait). */
+ * do_mesh: IMMESH_MESH_OFF = registration + map update only, IMMESH_MESH_SYNC = mesh synchronously, IMMESH_MESH_ASYNC = queue the mesh job
+ * and return (see immesh_mesh_wait).  IMMESH_MESH_ASYNC, or IMMESH_SCAN_NOWAIT or-ed in, also returns without waiting for the map update: the
+ * pose is final when the call returns, map growth finishes on the stream ahead of the next call's work, and a capacity error of that update is
+ * reported by the next call on the context (immesh_last_timing / immesh_counters wait for it). */
+#define IMMESH_MESH_OFF 0
+#define IMMESH_MESH_SYNC 1
+#define IMMESH_MESH_ASYNC 2
+#define IMMESH_SCAN_NOWAIT 0x10
 int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const float* pts_raw_body_xyzi, int32_t n_raw,
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);

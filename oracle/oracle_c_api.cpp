@@ -214,7 +214,7 @@ int orc_process_scan(void* p, const float* pts_down, int32_t n_ds, const float* 
     State s; load_state(state_inout, s);
     o->reg.map_grow(pts_down, n_ds, s);
     auto t2 = std::chrono::steady_clock::now();
-    if (do_mesh) {
+    if (do_mesh & 3) {   // bit 4 (IMMESH_SCAN_NOWAIT) has no meaning for the synchronous checker
         std::vector<float> world;
         transform_full(o->cfg, s, pts_raw_xyzi, n_raw, world);
         o->mesher.mesh_scan(world.data(), n_raw, s.t, o->mout);
