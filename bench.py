@@ -132,8 +132,8 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pts", type=int, default=100000, help="raw points per scan")
     ap.add_argument("--map-voxels", type=float, default=10e6, help="root voxels of the pre-built registration map")
     ap.add_argument("--mesh", type=int, default=1, help="1 = full pipeline (configs[2]); 0 = registration + map update only (configs[1])")
