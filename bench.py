@@ -166,7 +166,7 @@ def main():
         cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3) + (1 << 16), cap_scan_points=2_500_000,
                                cap_vertices=1 << 24, cap_triangles=1 << 25)
     if sharded:
-        cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2 = rank, world, 5
+        cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, 5, 1 if args.mesh else 0
     h = capi.HotPath(hip, cfg, "immesh_")
     if sharded:
         if args.backend == "nccl":
@@ -178,6 +178,19 @@ def main():
             def _allreduce(buf):
                 dist.all_reduce(torch.from_numpy(buf))
         h.set_allreduce(_allreduce)
+        if args.mesh:   # sharded mesher: all-gather of this scan's smoothed vertices and triangle marks (two exchanges per scan)
+            def _allgather(send, recv):
+                if args.backend == "nccl":
+                    src = torch.from_numpy(send).to(dev)
+                    dst = torch.empty(len(send) * world, dtype=torch.uint8, device=dev)
+                    dist.all_gather_into_tensor(dst, src)
+                    recv[:] = dst.cpu().numpy()
+                else:
+                    parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
+                    dist.all_gather(parts, torch.from_numpy(send))
+                    for r_ in range(world):
+                        recv[r_ * len(send):(r_ + 1) * len(send)] = parts[r_].numpy()
+            h.set_allgather(_allgather)
     n_total = args.warmup + args.steps + 2 * args.profile_scans
     raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
     if kitti:   # the map grows from the stream itself (3 m root voxels, max_layer 4)
@@ -197,8 +210,8 @@ def main():
     st = capi.make_state(R=R0, t=t0)
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
     NOWAIT = 0x10   # IMMESH_SCAN_NOWAIT: return once the pose is final, map growth finishes on the stream ahead of the next scan's work
-    mesh_mode = (2 if args.async_mesh else 1) if (args.mesh and (not sharded or rank == 0)) else (NOWAIT if args.async_mesh else 0)   # sharded: the mesher runs on rank 0
-    if (mesh_mode & 3) or (sharded and args.mesh):
+    mesh_mode = (2 if (args.async_mesh and not sharded) else 1) if args.mesh else (NOWAIT if args.async_mesh else 0)   # sharded mesher: serial per scan (its collectives must not interleave)
+    if mesh_mode & 3:
         # mesh map is seeded by scan 0 (the registration map is the pre-built survey); sharded: every rank takes part in the scan's all-reduces
         h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1 if (mesh_mode & 3) else 0, n_ds=len(downs[0]), n_raw=len(raws[0]))
 
@@ -305,7 +318,7 @@ def main():
             "config": {"workload": (("synthetic KITTI-shaped HDL-64 scan stream (velodyne.yaml), " if kitti else "synthetic Livox-Avia 100k-pt/scan stream, ") +
                                     ("full pipeline (registration + map update + voxel meshing)" if args.mesh else "registration + map update, meshing off")),
                        "n_raw": int(np.mean([len(r) for r in raws])), "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
-                       "parallelism": (f"one stream, registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration), mesher on rank 0" if sharded
+                       "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks)" if sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},

@@ -20,7 +20,7 @@ class Config(C.Structure):
         ("mesh_min_spacing", C.c_double), ("mesh_voxel", C.c_double), ("mesh_region", C.c_double), ("mesh_append_budget", C.c_int32),
         ("device", C.c_int32), ("cap_root_voxels", C.c_int64), ("cap_nodes", C.c_int64), ("cap_point_chunks", C.c_int64),
         ("cap_vertices", C.c_int64), ("cap_triangles", C.c_int64), ("cap_scan_points", C.c_int64),
-        ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_brick_log2", C.c_int32), ("shard_pad", C.c_int32),
+        ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_brick_log2", C.c_int32), ("shard_mesh", C.c_int32),
     ]
 
 
@@ -298,6 +298,32 @@ class HotPath:
         self._allreduce_cb = proto(_cb)   # keep alive
         f = self._f("set_allreduce"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx, self._allreduce_cb, None), "set_allreduce")
+
+    def set_allgather(self, fn):
+        """Sharded mesher.  fn(send: uint8 view [nbytes], recv: uint8 view [world * nbytes]) gathers every rank's `send` into `recv` in
+        rank order (e.g. torch.distributed.all_gather_into_tensor)."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+        world = max(1, int(self.cfg.shard_world))
+
+        def _cb(send, nbytes, recv, user):
+            try:
+                s = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                fn(s, r)
+                return 0
+            except Exception:   # never raise through the C frame
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._allgather_cb = proto(_cb)   # keep alive
+        f = self._f("set_allgather"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx, self._allgather_cb, None), "set_allgather")
+
+    def shard_traffic(self):
+        f = self._f("shard_traffic"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        b, n = C.c_int64(0), C.c_int64(0)
+        self._check(f(self.ctx, C.byref(b), C.byref(n)), "shard_traffic")
+        return {"bytes": b.value, "calls": n.value}
 
     # -- per-kernel timing (product library only) --------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -371,7 +371,8 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     if (do_mesh && (rc = resolve_input(c, pts_raw, (size_t)n_raw * 16, c->d_pts_raw, &d_raw))) return rc;
     imh::State prior, st;
     imh::load_state(state_prior, prior); imh::load_state(state_inout, st);
-    const int mesh_mode = do_mesh & 3;
+    int mesh_mode = do_mesh & 3;
+    if (mesh_mode == IMMESH_MESH_ASYNC && c->mesh.shard_world > 1) mesh_mode = IMMESH_MESH_SYNC;   // sharded mesher: its collectives must not interleave with the next scan's all-reduces
     const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || (do_mesh & IMMESH_SCAN_NOWAIT);
     const int par = c->ev_par ^ 1;
     hipEvent_t* ev = c->ev + 4 * par;

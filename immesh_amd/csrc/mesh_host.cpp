@@ -80,6 +80,8 @@ int mesh_alloc(immesh_ctx* c) {
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
     m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
+    const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
+    m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
     m.dbg = nullptr;
     if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 16))) return rc; m.dbg = t; (void)hipMemset(t, 0, 128); }
     hipStream_t s = c->stream;
@@ -90,6 +92,12 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
+    if (m.shard_world > 1) {   // exchange staging of the sharded mesher
+        h.xcap_bytes = (size_t)cap_list * sizeof(MeshSmRec);
+        { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xsend = t; }
+        { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xrecv = t; }
+        { int32_t* t; if ((rc = c->dalloc(&t, 4))) return rc; h.d_xcount = t; }
+    }
     HIPCHK(c, hipMemsetAsync(m1.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
     HIPCHK(c, hipMemsetAsync(m1.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
@@ -207,14 +215,48 @@ static int mesh_enqueue_a(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
 }
 // Phase B: a20-a24 (triangulation, diff against the live set, commit: all removes, then all adds -- ImMesh_mesh_reconstruction.cpp:228-244;
 // result lists sorted by triplet), then the counters go to the host.
-static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s) {
+static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s, int part = 0) {   // part 1: triangulation only, 2: the rest
     MeshHost& h = c->mesh_host;
-    launch_mesh_delaunay(s, m);                               // a20-a23
+    if (part != 2) launch_mesh_delaunay(s, m);                // a20-a23
+    if (part == 1) return 0;
     launch_mesh_finalize(s, m);
     launch_mesh_commit_rem(s, m, m.list_rem);
     launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
     launch_mesh_commit_add(s, m, h.p_a);
     MHIPCHK(c, hipMemcpyAsync(h.h_sc2[par], m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+// Sharded mesher: all-gather `count` records of `rec` bytes from d_xsend over the ranks and hand every other rank's records to `unpack`.
+// Two collective calls: the counts, then the payload padded to the largest count.  Runs on the worker thread; the stream is idle on return
+// from the device-to-host copies and busy again with the unpack kernels when the function returns.
+static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::function<void(const void*, int)>& unpack) {
+    MeshHost& h = c->mesh_host;
+    const int world = c->cfg.shard_world, me = c->cfg.shard_rank;
+    if (!h.allgather) { h.err = "sharded mesher: no all-gather callback registered (immesh_set_allgather)"; return IMMESH_E_INVAL; }
+    int32_t cnt32 = 0;
+    MHIPCHK(c, hipMemcpyAsync(&cnt32, h.d_xcount, 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipStreamSynchronize(s));
+    if ((size_t)cnt32 * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
+    int64_t cnt = cnt32;
+    std::vector<int64_t> counts((size_t)world, 0);
+    if (h.allgather(&cnt, 8, counts.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+    int64_t maxc = 0;
+    for (int64_t v : counts) maxc = std::max(maxc, v);
+    h.xcalls++;
+    if (maxc == 0) return 0;
+    h.h_xsend.assign((size_t)maxc * rec, 0);
+    if (cnt) MHIPCHK(c, hipMemcpy(h.h_xsend.data(), h.d_xsend, (size_t)cnt * rec, hipMemcpyDeviceToHost));
+    h.h_xrecv.resize((size_t)world * maxc * rec);
+    if (h.allgather(h.h_xsend.data(), (int64_t)((size_t)maxc * rec), h.h_xrecv.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+    h.xcalls++; h.xbytes_sent += cnt * (int64_t)rec;
+    for (int r = 0; r < world; r++) {
+        if (r == me || counts[r] == 0) continue;
+        if ((size_t)counts[r] * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
+        MHIPCHK(c, hipMemcpyAsync(h.d_xrecv, h.h_xrecv.data() + (size_t)r * maxc * rec, (size_t)counts[r] * rec, hipMemcpyHostToDevice, s));
+        unpack(h.d_xrecv, (int)counts[r]);
+        MHIPCHK(c, hipStreamSynchronize(s));   // d_xrecv is reused for the next rank's records
+    }
     return 0;
 }
 
@@ -272,7 +314,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
             if (h.h_sc2[par][SC_UNDECIDED] == 0) break;
         }
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
-    } else if (h.use_graph && !h.prof.on && d_pts == h.d_world[par]) {
+    } else if (h.use_graph && !h.prof.on && m.shard_world <= 1 && d_pts == h.d_world[par]) {
         // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
         if (h.graph_ncand[par] != sp.n_cand) {
             for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
@@ -281,6 +323,21 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true); }))) return rc;
     } else {
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true))) return rc;
+    }
+    if (m.shard_world > 1) {
+        // owner-computes: phase A searched only this rank's voxels.  Exchange 1: this scan's smoothed positions (the boundary data
+        // correct_triangle_index reads across voxels); triangulate own voxels; exchange 2: triangle marks; then everybody commits the same diff.
+        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 4, sa));
+        launch_mesh_pack_smooth(sa, m, (MeshSmRec*)h.d_xsend, h.d_xcount);
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshSmRec), [&](const void* d, int n) { launch_mesh_unpack_smooth(sa, m, (const MeshSmRec*)d, n); }))) return rc;
+        if ((rc = mesh_enqueue_b(c, m, par, sa, 1))) return rc;
+        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 4, sa));
+        launch_mesh_pack_marks(sa, m, (MeshMkRec*)h.d_xsend, h.d_xcount);
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), [&](const void* d, int n) { launch_mesh_unpack_marks(sa, m, (const MeshMkRec*)d, n); }))) return rc;
+        if ((rc = mesh_enqueue_b(c, m, par, sa, 2))) return rc;
+        MHIPCHK(c, hipEventRecord(h.ev_t1[par], sa));
+        MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
+        return 0;
     }
     MHIPCHK(c, hipEventRecord(h.ev_a[par], sa));
     MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
@@ -343,7 +400,7 @@ static void mesh_worker_main(immesh_ctx* c) {
         {
             std::unique_lock<std::mutex> lk(h.mu);
             if (fl.empty()) h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
-            const size_t room = (h.pipeline && !h.prof.on) ? 2 : 1;
+            const size_t room = (h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? 2 : 1;
             if (!h.q.empty() && fl.size() < room) { job = h.q.front(); h.q.pop_front(); have = true; }
             else if (fl.empty() && h.q.empty()) break;   // stop requested and nothing left to do
         }
@@ -365,7 +422,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             const hipError_t q = hipEventQuery(h.ev_b[par]);
             if (q == hipErrorNotReady) {
                 bool more;
-                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on) ? 2u : 1u); }
+                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? 2u : 1u); }
                 if (!more) std::this_thread::yield();
                 continue;
             }
@@ -466,6 +523,20 @@ int immesh_mesh_scan(immesh_ctx* c, const float* pts_world_xyzi, int32_t n_raw, 
     if (rc) return rc;
     const long id = mesh_submit(c, (const float*)d_pts, n_raw, sensor_pos, frame_idx);
     return mesh_wait(c, id);   // synchronous entry point: results are current when it returns
+}
+
+int immesh_set_allgather(immesh_ctx* c, immesh_allgather_fn cb, void* user) {
+    if (!c) return IMMESH_E_INVAL;
+    mesh_wait_all(c);
+    c->mesh_host.allgather = cb; c->mesh_host.allgather_user = user;
+    return 0;
+}
+int immesh_shard_traffic(immesh_ctx* c, int64_t* bytes, int64_t* calls) {
+    if (!c) return IMMESH_E_INVAL;
+    mesh_wait_all(c);
+    if (bytes) *bytes = c->mesh_host.xbytes_sent;
+    if (calls) *calls = c->mesh_host.xcalls;
+    return 0;
 }
 
 int immesh_mesh_wait(immesh_ctx* c) {

@@ -34,6 +34,12 @@ IMD unsigned long long mkey(long x, long y, long z) {
            ((unsigned long long)(z + MKEY_BIAS) & MKEY_MASK);
 }
 IMD long rnd_cell(float p, double cell) { return (long)(int)round((double)p / cell); }  // std::round of the f64 quotient, pointcloud_rgbd.cpp:467-472
+// sharded mesher: mesh voxels are owned in bricks of 2^shard_brick_log2 voxels per axis, owner = hash(brick) mod world
+IMD int mesh_owner(const MeshDev& m, unsigned long long vkey) {
+    const long x = (long)((vkey >> 42) & MKEY_MASK) - MKEY_BIAS, y = (long)((vkey >> 21) & MKEY_MASK) - MKEY_BIAS, z = (long)(vkey & MKEY_MASK) - MKEY_BIAS;
+    const int b = m.shard_brick_log2;
+    return (int)(hash64(mkey(x >> b, y >> b, z >> b)) % (unsigned long long)m.shard_world);   // arithmetic shifts: bricks tile negative cells too
+}
 IMD int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IMD void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -393,6 +399,10 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     const int vi = EXPORT ? r : m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
     if (EXPORT && nq == 0) continue;
+    if (!EXPORT && m.shard_world > 1 && mesh_owner(m, m.vx_key[vi]) != m.shard_rank) {
+        if (tid == 0) { m.rel_n[r] = 0; m.rel_nq[r] = nq; }   // another rank searches and triangulates this voxel; its results arrive by all-gather
+        continue;
+    }
     if (tid < nq) {
         const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + tid];
         qid[tid] = id;
@@ -757,6 +767,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int n = m.rel_n[r];
     if (n < n_lo || n > n_hi) continue;  // size class of the other instantiation
+    if (n == 0) { if (threadIdx.x == 0) m.vox_ntris[r] = 0; continue; }   // sharded mesher: a voxel another rank triangulates (its marks arrive by all-gather)
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
     const unsigned long long tvox0 = tprev;
     const int vi = m.act_vox_s[r];
@@ -1065,6 +1076,108 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
         list_push(m, m.list_smooth, SC_SMOOTH, id);
     }
     }
+}
+
+// =====================================================================================================================
+// sharded mesher: exchange records (see immesh_set_allgather)
+// =====================================================================================================================
+__global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, MeshSmRec* __restrict__ out, int32_t* __restrict__ count) {
+    MESH_DYN(m_in);
+    const int lane = threadIdx.x;
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
+        const int vi = m.act_vox_s[r];
+        if (mesh_owner(m, m.vx_key[vi]) != m.shard_rank) continue;
+        const int nq = m.rel_nq[r];
+        int base = 0;
+        if (lane == 0) base = atomicAdd(count, nq);
+        base = __shfl(base, 0, 64);
+        for (int k = lane; k < nq; k += 64) {
+            if (base + k >= m.cap_list) { m.sc[SC_OVERFLOW] = 14; break; }
+            const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + k];
+            MeshSmRec rec;
+            rec.id = id; rec.pad = 0;
+            rec.x = m.v_smooth_new[(size_t)id * 3 + 0]; rec.y = m.v_smooth_new[(size_t)id * 3 + 1]; rec.z = m.v_smooth_new[(size_t)id * 3 + 2];
+            out[base + k] = rec;
+        }
+    }
+}
+__global__ void mesh_unpack_smooth_kernel(MeshDev m, const MeshSmRec* __restrict__ in, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MeshSmRec rec = in[i];
+    m.v_smooth_new[(size_t)rec.id * 3 + 0] = rec.x; m.v_smooth_new[(size_t)rec.id * 3 + 1] = rec.y; m.v_smooth_new[(size_t)rec.id * 3 + 2] = rec.z;
+}
+// blocks [0, n_active): the touched lists of the voxels this rank triangulated; the blocks after them: its removal marks
+__global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshMkRec* __restrict__ out, int32_t* __restrict__ count) {
+    MESH_DYN(m_in);
+    const int lane = threadIdx.x;
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    const int n_rem = min(m.sc[SC_REM], m.cap_list);
+    const int n_rem_blocks = (n_rem + 63) / 64;
+    for (int blk = blockIdx.x; blk < n_active + n_rem_blocks; blk += gridDim.x) {
+        if (blk < n_active) {
+            const int r = blk;
+            const int vi = m.act_vox_s[r];
+            if (mesh_owner(m, m.vx_key[vi]) != m.shard_rank) continue;
+            const int nt = m.vox_ntris[r];
+            const int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(count, nt);
+            base = __shfl(base, 0, 64);
+            for (int k = lane; k < nt; k += 64) {
+                if (base + k >= m.cap_list) { m.sc[SC_OVERFLOW] = 14; break; }
+                const unsigned int e = (unsigned int)touched[k];
+                const int t = (int)(e & 0x7FFFFFFFu);
+                MeshMkRec rec;
+                rec.a = m.t_v[(size_t)t * 3 + 0]; rec.b = m.t_v[(size_t)t * 3 + 1]; rec.c = m.t_v[(size_t)t * 3 + 2];
+                rec.rk = (r << 1) | ((e & TRI_ADD_BIT) ? 1 : 0);
+                rec.word = m.t_word[t];   // this rank's maximum so far; the receivers max it with their own
+                out[base + k] = rec;
+            }
+        } else {
+            const int i = (blk - n_active) * 64 + lane;
+            const bool has = i < n_rem;
+            const unsigned long long mask = __ballot(has);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(count, (int)__popcll(mask));
+            base = __shfl(base, 0, 64);
+            if (has && base + lane >= m.cap_list) m.sc[SC_OVERFLOW] = 14;
+            else if (has) {
+                const int t = m.list_rem[i];
+                MeshMkRec rec;
+                rec.a = m.t_v[(size_t)t * 3 + 0]; rec.b = m.t_v[(size_t)t * 3 + 1]; rec.c = m.t_v[(size_t)t * 3 + 2];
+                rec.rk = -1; rec.word = 0;
+                out[base + lane] = rec;
+            }
+        }
+    }
+}
+__global__ void mesh_unpack_marks_kernel(MeshDev m_in, const MeshMkRec* __restrict__ in, int n) {
+    MESH_DYN(m_in);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const MeshMkRec rec = in[i];
+    int spare = -1;
+    const int t = tri_find_or_insert(m, rec.a, rec.b, rec.c, &spare);
+    if (t < 0) return;
+    if (rec.rk < 0) {   // removal mark of another rank's voxel: same once-per-scan rule as the local ones
+        if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) list_push(m, m.list_rem, SC_REM, t);
+        return;
+    }
+    atomicMax(&m.t_word[t], rec.word);
+    const int r = rec.rk >> 1;
+    const int pos = atomicAdd(&m.vox_ntris[r], 1);
+    if (pos >= 2 * MV_REL_CAP) { m.sc[SC_OVERFLOW] = 12; return; }
+    m.vox_tris[(size_t)r * (2 * MV_REL_CAP) + pos] = (int)((unsigned int)t | ((rec.rk & 1) ? TRI_ADD_BIT : 0u));
+}
+void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count) { KLAUNCH(mesh_pack_smooth_kernel, dim3(1024), dim3(64), 0, s, m, out, count); }
+void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const MeshSmRec* in, int n) {
+    if (n > 0) KLAUNCH(mesh_unpack_smooth_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
+}
+void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count) { KLAUNCH(mesh_pack_marks_kernel, dim3(2048), dim3(64), 0, s, m, out, count); }
+void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const MeshMkRec* in, int n) {
+    if (n > 0) KLAUNCH(mesh_unpack_marks_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
 }
 
 // =====================================================================================================================

@@ -81,6 +81,7 @@ struct MeshDev {
     int32_t cap_verts, cap_voxels, cap_tris, cap_adj_chunks, cap_cand, cap_active, cap_list;
     // parameters
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
+    int32_t shard_rank, shard_world, shard_brick_log2;   // sharded mesher: owner-computes per mesh-voxel brick (shard_world <= 1: off)
     int32_t seq;                         // scan sequence number (>= 1); kernels take it (and ch_mask) from *dyn
     MeshDyn* dyn;                        // per-scan parameters (device memory)
     unsigned long long* dbg;             // optional phase timers (IMMESH_DEBUG): [16] sums of s_memtime deltas, nullptr = off
@@ -94,6 +95,10 @@ struct MeshDev {
 // One queued incremental_mesh_reconstruction call.  The reference runs the mesher on its own service thread + pool
 // (service_reconstruct_mesh, ImMesh_mesh_reconstruction.cpp:272-310) so scan k's meshing overlaps scan k+1's registration; here a
 // worker thread drives a second HIP stream, strictly in submission order (the sequential-deterministic frame order of the checker).
+// exchange records of the sharded mesher: this scan's smoothed positions of the vertices of the voxels a rank meshed, and the
+// triangle marks its triangulations produced (rk = (voxel rank << 1) | add, word = the rank's current flip word; rk = -1: removal mark)
+struct MeshSmRec { int32_t id, pad; double x, y, z; };
+struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; };
 struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz; };
 struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; };
@@ -140,6 +145,13 @@ struct MeshHost {
     size_t exp_vtx_bytes = 0, exp_work_bytes = 0, exp_tmp_bytes = 0;
     int32_t* exp_faces = nullptr;
     int64_t exp_nv = 0, exp_nf = 0;
+    // sharded mesher: all-gather callback + staging
+    immesh_allgather_fn allgather = nullptr;
+    void* allgather_user = nullptr;
+    void* d_xsend = nullptr; void* d_xrecv = nullptr; int32_t* d_xcount = nullptr;   // device staging (cap_list records each) + record counter
+    size_t xcap_bytes = 0;
+    std::vector<char> h_xsend, h_xrecv;
+    int64_t xbytes_sent = 0, xcalls = 0;     // cumulative exchange volume of this rank (payload bytes, collective calls)
     KProf prof;                              // kernels launched by the worker thread
     std::string err;                         // worker-side error text (moved into the MeshResult of the failing job)
 };
@@ -159,6 +171,10 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
+void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count);
+void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const MeshSmRec* in, int n);
+void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count);
+void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const MeshMkRec* in, int n);
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted);
 void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted);

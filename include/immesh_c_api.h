@@ -64,7 +64,7 @@ typedef struct immesh_config {
     int32_t shard_rank;
     int32_t shard_world;
     int32_t shard_brick_log2;  /* 0 = default 5: 32^3-voxel bricks */
-    int32_t shard_pad;
+    int32_t shard_mesh;        /* 1 = the mesher is sharded too (owner-computes per mesh-voxel brick, see immesh_set_allgather); 0 = every context meshes whatever it is handed */
 } immesh_config;
 
 void immesh_default_config(immesh_config* cfg); /* avia.yaml + mapping_avia.launch values */
@@ -166,6 +166,17 @@ int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t
  * torch.distributed.all_reduce / ncclAllReduce over xGMI.  The 18-state update then runs identically on every rank. */
 typedef int (*immesh_allreduce_fn)(double* buf, int32_t n, void* user);
 int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
+/* Sharded mesher (shard_world > 1, shard_mesh = 1): every rank is handed the same world-frame scans and admits the same vertices (ids stay
+ * the serial ones); the neighbourhood search + per-voxel triangulation of a mesh voxel run only on the rank owning its 2^shard_brick_log2-voxel
+ * brick.  Twice per scan the ranks exchange what the others' triangulations need: this scan's smoothed positions of the vertices of the
+ * voxels each rank searched (the vertices correct_triangle_index reads across voxel borders), then the triangle marks (add / keep / remove +
+ * flip word per voxel) -- after which every rank commits the same diff and immesh_mesh_fetch returns the same lists everywhere.
+ * cb gathers `bytes` bytes from every rank into recv (world x bytes, rank order); equal `bytes` on all ranks.  RCCL: ncclAllGather. */
+typedef int (*immesh_allgather_fn)(const void* send, int64_t bytes, void* recv, void* user);
+int immesh_set_allgather(immesh_ctx* ctx, immesh_allgather_fn cb, void* user);
+/* payload bytes this rank has contributed to the mesher's all-gathers, and the number of collective calls, since create */
+int immesh_shard_traffic(immesh_ctx* ctx, int64_t* bytes, int64_t* calls);
+
 /* rank owning root voxel key3 under cfg's shard settings (host mirror of the kernels' ownership function) */
 int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
 

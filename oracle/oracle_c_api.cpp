@@ -154,6 +154,8 @@ int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t
     return orc_mesh_scan(p, w.data(), n_ds, origin, 0);
 }
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
+int orc_set_allgather(void*, immesh_allgather_fn, void*) { return 0; }
+int orc_shard_traffic(void*, int64_t* bytes, int64_t* calls) { if (bytes) *bytes = 0; if (calls) *calls = 0; return 0; }
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
 int orc_mesh_wait(void* p) { (void)p; return 0; }
 int orc_mesh_export(void* p, double smooth_factor, int32_t knn, int64_t* n_vtx, int64_t* n_faces) {

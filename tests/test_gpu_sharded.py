@@ -111,3 +111,68 @@ def test_two_rank_register_matches_unsharded():
     mp.spawn(_rank_main, args=(2, port, out), nprocs=2, join=True)
     np.testing.assert_array_equal(out[0][0], out[1][0])       # the ranks stay in lock step (identical all-reduced sums -> identical states)
     assert out[0][1] < 1e-9                                    # and agree with the unsharded run up to summation order
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded mesher: owner-computes kNN + Delaunay per mesh-voxel brick, all-gather of smoothed vertices and triangle marks
+# ---------------------------------------------------------------------------------------------------------------------
+def _mesh_cfg(rank=0, world=0):
+    return capi.avia_config(cap_root_voxels=1 << 14, cap_scan_points=200000, cap_vertices=1 << 17, cap_triangles=1 << 19,
+                            shard_rank=rank, shard_world=world, shard_brick_log2=2, shard_mesh=1 if world > 1 else 0)   # 4-voxel (1.6 m) bricks
+
+
+def _mesh_rank_main(rank, world, port, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    lib = capi.load_hip_library()
+    h = capi.HotPath(lib, _mesh_cfg(rank, world), "immesh_")
+
+    def allgather(send, recv):
+        parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(send))
+        for r in range(world):
+            recv[r * len(send):(r + 1) * len(send)] = parts[r].numpy()
+    h.set_allgather(allgather)
+    ref = capi.HotPath(lib, _mesh_cfg(), "immesh_") if rank == 0 else None
+    cfg = _mesh_cfg()
+    extT = np.array(list(cfg.extT)); extR = np.array(list(cfg.extR)).reshape(3, 3)
+    same = True
+    n_tri = 0
+    for k in range(4):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, R, t, n_pts=40000, extT=extT)
+        world_pts = raw.copy()
+        world_pts[:, :3] = ((raw[:, :3].astype(np.float64) @ extR.T + extT) @ R.T + t).astype(np.float32)
+        m = h.mesh_scan(world_pts, t, frame_idx=k)
+        if ref:
+            mr = ref.mesh_scan(world_pts, t, frame_idx=k)
+            for key in ("new_vtx", "tri_add", "flip_add", "tri_rem", "tri_upd", "flip_upd", "smooth_ids", "smooth_xyz"):
+                same = same and np.array_equal(m[key], mr[key])
+            n_tri += len(mr["tri_add"])
+        out[(rank, k)] = (len(m["new_vtx"]), len(m["tri_add"]), len(m["tri_rem"]), int(m["tri_add"].sum()) if len(m["tri_add"]) else 0)
+    cnt = h.counters()
+    out[(rank, "cnt")] = (cnt["n_u"], cnt["n_vertices"], cnt["n_triangles_live"], ref.counters()["n_u"] if ref else 0)
+    out[(rank, "traffic")] = h.shard_traffic()
+    out[(rank, "same")] = (same, n_tri)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_mesher_matches_unsharded():
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 90)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_mesh_rank_main, args=(2, port, out), nprocs=2, join=True)
+    same, n_tri = out[(0, "same")]
+    assert same and n_tri > 5000                                 # rank 0: every result list bit-identical to the unsharded mesher
+    for k in range(4):
+        assert out[(0, k)] == out[(1, k)]                       # both ranks commit the same diff
+    nu0, nv0, nl0, nu_ref = out[(0, "cnt")]
+    nu1, nv1, nl1, _ = out[(1, "cnt")]
+    assert nv0 == nv1 and nl0 == nl1
+    assert nu0 > 0 and nu1 > 0 and nu0 + nu1 == nu_ref            # each rank searched / triangulated only its own voxels; together: all of them
+    assert out[(0, "traffic")]["bytes"] > 0 and out[(1, "traffic")]["bytes"] > 0 and out[(0, "traffic")]["calls"] == 4 * 4
