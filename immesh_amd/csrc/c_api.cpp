@@ -100,7 +100,11 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     if (!c) { g_create_error = "out of host memory"; return nullptr; }
     c->cfg = *cfg;
     std::memset(&c->cnt, 0, sizeof(c->cnt));
-    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    // the registration stream is the latency-critical chain (pose out per scan): highest priority; the mesher's streams take the lowest
+    int prio_least = 0, prio_greatest = 0;
+    if (hipSetDevice(cfg->device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (getenv("IMMESH_NO_PRIORITY")) prio_greatest = prio_least = 0;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
         g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
     }
     for (auto& ev : c->ev) hipEventCreate(&ev);

@@ -131,8 +131,11 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_pc, 0, PC_COUNT * 4);
     HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipStreamCreateWithFlags(&h.stream, hipStreamNonBlocking));
-    HIPCHK(c, hipStreamCreateWithFlags(&h.stream_b, hipStreamNonBlocking));
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (getenv("IMMESH_NO_PRIORITY")) prio_least = 0;
+    HIPCHK(c, hipStreamCreateWithPriority(&h.stream, hipStreamNonBlocking, prio_least));
+    HIPCHK(c, hipStreamCreateWithPriority(&h.stream_b, hipStreamNonBlocking, prio_least));
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
