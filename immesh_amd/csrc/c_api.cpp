@@ -104,7 +104,8 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     int prio_least = 0, prio_greatest = 0;
     if (hipSetDevice(cfg->device) == hipSuccess) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (getenv("IMMESH_NO_PRIORITY")) prio_greatest = prio_least = 0;
-    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+    const hipError_t se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_greatest);
+    if (se != hipSuccess) {
         g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
     }
     for (auto& ev : c->ev) hipEventCreate(&ev);

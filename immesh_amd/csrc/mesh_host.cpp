@@ -134,8 +134,26 @@ int mesh_alloc(immesh_ctx* c) {
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (getenv("IMMESH_NO_PRIORITY")) prio_least = 0;
-    HIPCHK(c, hipStreamCreateWithPriority(&h.stream, hipStreamNonBlocking, prio_least));
-    HIPCHK(c, hipStreamCreateWithPriority(&h.stream_b, hipStreamNonBlocking, prio_least));
+    {
+        // The registration stream is the pose chain and keeps the whole device; the mesher's two streams are confined to 5/8 of the CUs.
+        // Its kernels are swarms of lone, issue-bound wavefronts: sharing every SIMD with them slowed the pose chain's kernels by up to 2x
+        // (replay_list 73 -> 150 us), while the mesher loses ~2 % from the narrower device (measured: 3000 -> 3480 scans/s at 160 of 256 CUs;
+        // 128: 3320, 192: 3430, 224: 3130).  IMMESH_MESH_CUS=n overrides, 0 = no mask (lowest-priority streams instead).
+        hipDeviceProp_t prop;
+        int ncu = 0;
+        if (hipGetDeviceProperties(&prop, g.device) == hipSuccess) ncu = (prop.multiProcessorCount * 5 / 8) & ~7;
+        if (const char* e = getenv("IMMESH_MESH_CUS")) ncu = atoi(e);
+        if (ncu >= 8 && ncu < 1024) {
+            uint32_t mask[32];
+            std::memset(mask, 0, sizeof(mask));
+            for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
+            HIPCHK(c, hipExtStreamCreateWithCUMask(&h.stream, 32, mask));
+            HIPCHK(c, hipExtStreamCreateWithCUMask(&h.stream_b, 32, mask));
+        } else {
+            HIPCHK(c, hipStreamCreateWithPriority(&h.stream, hipStreamNonBlocking, prio_least));
+            HIPCHK(c, hipStreamCreateWithPriority(&h.stream_b, hipStreamNonBlocking, prio_least));
+        }
+    }
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));

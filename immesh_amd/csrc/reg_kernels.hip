@@ -111,6 +111,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
                                                        double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48, double ticket,
                                                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
     __shared__ int stacks[4][48];
+    __builtin_amdgcn_s_setprio(3);   // map growth is on the pose chain too (the next scan's registration waits for it)
     const int wv = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wv;
     if (t >= m.counters[7]) return;
