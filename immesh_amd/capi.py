@@ -97,6 +97,33 @@ def make_state(R=None, t=None, cov_diag=1e-7, vel=None, gravity=None):
     return s
 
 
+class ImuSample(C.Structure):
+    """immesh_imu_sample"""
+    _fields_ = [("t", C.c_double), ("gyr", C.c_double * 3), ("acc", C.c_double * 3)]
+
+
+class ImuCtx(C.Structure):
+    """immesh_imu_ctx: the ImuProcess members UndistortPcl carries from scan to scan"""
+    _fields_ = [("last_lidar_end_time", C.c_double), ("acc_s_last", C.c_double * 3), ("angvel_last", C.c_double * 3), ("last_imu", ImuSample),
+                ("mean_acc_norm", C.c_double), ("cov_gyr", C.c_double * 3), ("cov_acc", C.c_double * 3), ("cov_bias_gyr", C.c_double * 3),
+                ("cov_bias_acc", C.c_double * 3), ("lid_rot_to_imu", C.c_double * 9), ("lid_offset_to_imu", C.c_double * 3)]
+
+
+def make_imu_ctx(cfg, t0=0.0, gyr0=(0, 0, 0), acc0=(0, 0, 9.81)):
+    """ImuProcess after IMU_init (src/IMU_Processing.cpp:56-80, 186-230): noise parameters of config/avia.yaml, extrinsics of cfg."""
+    ic = ImuCtx()
+    ic.last_lidar_end_time = t0
+    ic.last_imu.t = t0
+    for a in range(3):
+        ic.last_imu.gyr[a] = gyr0[a]; ic.last_imu.acc[a] = acc0[a]
+        ic.cov_gyr[a] = 0.3; ic.cov_acc[a] = 0.5; ic.cov_bias_gyr[a] = 0.0001; ic.cov_bias_acc[a] = 0.0001
+        ic.lid_offset_to_imu[a] = cfg.extT[a]
+    ic.mean_acc_norm = float(np.linalg.norm(acc0))
+    for i in range(9):
+        ic.lid_rot_to_imu[i] = cfg.extR[i]
+    return ic
+
+
 def forward_without_imu_native(lib, state, dt=0.1, cov_gyr=0.3, cov_acc=0.5):
     """immesh_forward_without_imu (C++ host code in the product library); same arithmetic as synth.forward_without_imu."""
     f = lib.immesh_forward_without_imu
@@ -279,6 +306,23 @@ class HotPath:
         n_out = C.c_int32(0)
         self._check(f(self.ctx, _ptr(pts), n, stride, leaf, _ptr(out), n, C.byref(n_out)), "downsample")
         return (out[:n_out.value] if to_host else None), n_out.value
+
+    def undistort(self, pts_xyzit, imu, lidar_beg_time, last_update_time, imu_ctx, state, to_host=True):
+        """UndistortPcl.  pts_xyzit: n x 5 float32 (x y z intensity offset_ms); imu: m x 7 float64 (t, gyr, acc).
+        Returns (cloud n x 4 in time order | None, propagated state, last_update_time); imu_ctx is updated in place."""
+        f = self._f("undistort"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 7)
+        out = np.zeros((len(pts_xyzit), 4), np.float32) if to_host else None
+        st = np.array(state, dtype=np.float64, copy=True)
+        lut = C.c_double(last_update_time)
+        self._check(f(self.ctx, _ptr(np.ascontiguousarray(pts_xyzit, dtype=np.float32)), len(pts_xyzit), _ptr(imu), len(imu), lidar_beg_time,
+                      C.byref(lut), C.byref(imu_ctx), _ptr(st), _ptr(out)), "undistort")
+        return out, st, lut.value
+
+    def undistort_result_ptr(self):
+        f = self._f("undistort_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
+        return f(self.ctx)
 
     def downsample_result_ptr(self):
         f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p

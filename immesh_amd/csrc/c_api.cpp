@@ -2,6 +2,7 @@
 // There is NO CPU compute path here: every per-point / per-voxel operation is a kernel in reg_kernels.hip / mesh_kernels.hip;
 // the host keeps only the 18x18 EKF algebra (as the reference does) and stream plumbing.
 #include "host_ctx.hpp"
+#include "imu_host.hpp"
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -76,6 +77,7 @@ static int alloc_all(immesh_ctx* c) {
     c->sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns), exclusive_sum_temp_bytes((int)ns)}) + 256;
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
     A(c->d_dump_count, 2);
+    A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
 #undef A
     HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_out48_host, c->h_out48, 0));
@@ -108,7 +110,7 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     if (se != hipSuccess) {
         g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
     }
-    for (auto& ev : c->ev) hipEventCreate(&ev);
+    for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     // per-config constants of calcBodyVar: pow(sin(DEG2RAD(deg)),2) with PCL's DEG2RAD(x) = x*0.017453293 and float `degree_inc`
     { const double s = std::sin((double)(float)cfg->beam_err * 0.017453293); c->dvar_beam = s * s; }
     { const double s = std::sin((double)(float)0.01 * 0.017453293); c->dvar_calib = s * s; }
@@ -121,14 +123,14 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
 
 void immesh_destroy(immesh_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->cfg.device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     mesh_free(c);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->h_out48) hipHostFree(c->h_out48);
-    if (c->h_counters) hipHostFree(c->h_counters);
-    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_out48) (void)hipHostFree(c->h_out48);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -237,7 +239,7 @@ static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const im
 int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state_prior, double* state_inout, int32_t* n_iter_out,
                     int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
@@ -274,7 +276,7 @@ int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double*
 int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state, double* HTH36, double* HTz6, int32_t* n_match,
                      int32_t* match_idx, double* normals, float* dis, double* r_inv) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state || !HTH36 || !HTz6) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
@@ -333,7 +335,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
 
 int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* state) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
@@ -348,7 +350,7 @@ int immesh_map_build(immesh_ctx* c, const float* pts, int64_t n, const double* s
 
 int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const double* state) {
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
@@ -368,7 +370,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if (c) c->err = "bad arguments";
         return IMMESH_E_INVAL;
     }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     const void *d_down, *d_raw = nullptr;
     int rc = resolve_input(c, pts_down, (size_t)n_ds * 12, c->d_pts_down, &d_down);
@@ -381,15 +383,15 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || (do_mesh & IMMESH_SCAN_NOWAIT);
     const int par = c->ev_par ^ 1;
     hipEvent_t* ev = c->ev + 4 * par;
-    hipEventRecord(ev[0], c->stream);
+    (void)hipEventRecord(ev[0], c->stream);
     int n_iter = 0, n_match = 0;
     if ((rc = register_device(c, (const float*)d_down, n_ds, prior, st, &n_iter, &n_match, nullptr))) return rc;
     // the residual passes of this scan ran behind the previous scan's map update on the same stream: that update is complete now
     if ((rc = settle(c, true))) return rc;
     c->ev_par = par;
-    hipEventRecord(ev[1], c->stream);
+    (void)hipEventRecord(ev[1], c->stream);
     if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0))) return rc;
-    hipEventRecord(ev[2], c->stream);
+    (void)hipEventRecord(ev[2], c->stream);
     long job = 0;
     if (mesh_mode) {
         // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own streams + worker thread), as
@@ -398,7 +400,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
-    hipEventRecord(ev[3], c->stream);
+    (void)hipEventRecord(ev[3], c->stream);
     c->timing[3] = 0.f;   // (immesh_mesh_wait fills in the mesher's time)
     imh::store_state(st, state_inout);
     if (n_iter_out) *n_iter_out = n_iter;
@@ -411,6 +413,44 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     return 0;
 }
 
+// ImuProcess::UndistortPcl (src/IMU_Processing.cpp:755-958): IMU forward propagation on the host, per-point compensation on the device
+int immesh_undistort(immesh_ctx* c, const float* pts, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time,
+                     double* last_update_time, immesh_imu_ctx* ic, double* state_inout, float* out_xyzi) {
+    if (!c || !pts || n <= 0 || n > c->cap_scan || n_imu < 0 || (n_imu > 0 && !imu) || n_imu > 62 || !last_update_time || !ic || !state_inout) {
+        if (c) c->err = "bad arguments (at most 62 IMU samples per package)";
+        return IMMESH_E_INVAL;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
+    hipStream_t s = c->stream;
+    const void* d_in;
+    int rc = resolve_input(c, pts, (size_t)n * 20, c->d_und_in, &d_in);
+    if (rc) return rc;
+    float end_curv = 0.f;   // curvature of the package's last point in arrival order (pcl_end_time, :785)
+    HIPCHK(c, hipMemcpyAsync(&end_curv, (const float*)d_in + (size_t)(n - 1) * 5 + 4, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    imh::State st;
+    imh::load_state(state_inout, st);
+    std::vector<imh::ImuPose> poses;
+    imh::imu_forward(imu, n_imu, lidar_beg_time, last_update_time, end_curv, *ic, st, poses);
+    imh::store_state(st, state_inout);
+    std::vector<double> tab(poses.size() * 23 + 24);
+    for (size_t k = 0; k < poses.size(); k++) std::memcpy(&tab[k * 23], &poses[k], 23 * sizeof(double));
+    double* fe = &tab[poses.size() * 23];
+    std::memcpy(fe, st.R, 72); std::memcpy(fe + 9, st.t, 24); std::memcpy(fe + 12, ic->lid_rot_to_imu, 72); std::memcpy(fe + 21, ic->lid_offset_to_imu, 24);
+    HIPCHK(c, hipMemcpyAsync(c->d_und_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_undistort_keys(s, (const float*)d_in, n, c->d_slot, c->d_idx_a);
+    sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_slot, c->d_slot_s, c->d_idx_a, c->d_idx_c, n, 32);   // stable: equal stamps keep arrival order
+    launch_undistort(s, (const float*)d_in, c->d_idx_c, n, c->d_und_tab, (int)poses.size(), c->d_und_tab + poses.size() * 23, c->d_und_out);
+    if (out_xyzi) {
+        HIPCHK(c, hipMemcpyAsync(out_xyzi, c->d_und_out, (size_t)n * 16, hipMemcpyDefault, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));   // (also keeps `tab` alive until the upload has run)
+    return 0;
+}
+const float* immesh_undistort_result(immesh_ctx* c) { return c ? c->d_und_out : nullptr; }
+
 int immesh_last_timing(immesh_ctx* c, float ms[4]) {
     if (!c || !ms) return IMMESH_E_INVAL;
     const int rc = settle(c);
@@ -421,7 +461,7 @@ int immesh_last_timing(immesh_ctx* c, float ms[4]) {
 
 int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_t* n_out) {
     if (!c || !n_out) return IMMESH_E_INVAL;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     static_assert(sizeof(PlaneRecDev) == sizeof(immesh_plane_rec), "plane record layout");
@@ -432,7 +472,7 @@ int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_
     hipError_t e = hipMemcpyAsync(&cnt, c->d_dump_count, sizeof(cnt), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && d_out) e = hipMemcpy(out, d_out, (size_t)std::min<int64_t>(cap, (int64_t)cnt) * sizeof(PlaneRecDev), hipMemcpyDeviceToHost);
-    if (d_out) hipFree(d_out);
+    if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) { c->err = std::string("dump_planes: ") + hipGetErrorString(e); return IMMESH_E_HIP; }
     *n_out = (int64_t)cnt;
     return 0;
@@ -441,7 +481,7 @@ int immesh_dump_planes(immesh_ctx* c, immesh_plane_rec* out, int64_t cap, int64_
 
 int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     if (!c || !out) return IMMESH_E_INVAL;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     int64_t stats[8];
@@ -463,7 +503,7 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
 // pcl::VoxelGrid stand-in on the device (the stage before lio_state_estimation, src/voxel_mapping.cpp:1888-1891)
 int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0 || !n_out) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     hipStream_t s = c->stream;
     const void* d_pts;
@@ -503,7 +543,7 @@ int immesh_reconstruct_mesh_from_pointcloud(immesh_ctx* c, const float* pts_xyzi
     int32_t n_ds = 0;
     int rc = immesh_downsample(c, pts_xyzi, n, 4, leaf, nullptr, 0, &n_ds);
     if (rc) return rc;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     float* world = mesh_next_world_buffer(c);
     launch_ds_expand_xyzi(c->stream, c->d_ds_out, n_ds, world);
@@ -550,7 +590,7 @@ int immesh_profile_enable(immesh_ctx* c, int32_t on) {
 
 int immesh_profile_read(immesh_ctx* c, immesh_kernel_stat* out, int32_t cap, int32_t* n_out, int32_t reset) {
     if (!c || !n_out) return IMMESH_E_INVAL;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     if (c->stream) { HIPCHK(c, hipStreamSynchronize(c->stream)); c->prof.flush(); }
     mesh_wait_all(c);   // the mesher's worker thread keeps its own table (flushed by the worker after every job)
     std::vector<std::string> names = c->prof.names;

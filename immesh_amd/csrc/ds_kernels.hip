@@ -10,6 +10,8 @@
 // Bound: HBM streaming (12-16 B per point per pass); the sort dominates.
 #include "kernels.hpp"
 #include "prof.hpp"
+#include "dev_math.hpp"
+using namespace imd;
 
 __global__ __launch_bounds__(256) void ds_minmax_kernel(const float* __restrict__ pts, int n, int stride, float inv, int* __restrict__ mm /*[6]: min xyz, max xyz*/) {
     __shared__ int smin[3], smax[3];
@@ -127,6 +129,72 @@ __global__ void kprof_spin_kernel(long long ticks) {
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 void kprof_spin(hipStream_t s) { hipLaunchKernelGGL(kprof_spin_kernel, dim3(1), dim3(1), 0, s, 2500LL); }
+
+// =====================================================================================================================
+// ImuProcess::UndistortPcl, per-point part (src/IMU_Processing.cpp:914-957): sort key + compensation into the scan-end frame
+// =====================================================================================================================
+__global__ void undistort_keys_kernel(const float* __restrict__ pts5, int n, uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = __float_as_uint(pts5[(size_t)i * 5 + 4]);
+    key[i] = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // order-preserving map of float to uint (ascending offset time)
+    idx[i] = i;
+}
+IMD void und_exp_rate(const double* w, double dt, double* R) {   // Exp(ang_vel, dt), include/so3_math.h:30-50
+    const double nrm = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    if (nrm > 0.0000001) {
+        const double r[3] = {w[0] / nrm, w[1] / nrm, w[2] / nrm};
+        const double K[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
+        double KK[9];
+        m3_mul(K, K, KK);
+        const double ang = nrm * dt, s = sin(ang), c1 = 1.0 - cos(ang);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (R[i] + s * K[i]) + c1 * KK[i];
+    }
+}
+// poses: n_poses x 23 doubles {offset_time, acc[3], gyr[3], vel[3], pos[3], rot[9]}; fe: {R_end[9], p_end[3], Lr[9], Lo[3]}
+__global__ __launch_bounds__(256) void undistort_kernel(const float* __restrict__ pts5, const int32_t* __restrict__ order, int n,
+                                                        const double* __restrict__ poses, int n_poses, const double* __restrict__ fe,
+                                                        float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts5 + (size_t)order[i] * 5;
+    float x = p[0], y = p[1], z = p[2];
+    const double t = (double)p[4] / double(1000);
+    // interval: the last pose whose offset time lies strictly before the point (the reference walks the intervals backwards and takes every
+    // point with curvature/1000 > head->offset_time that a later interval has not taken)
+    int h = -1;
+    for (int k = n_poses - 2; k >= 0; k--) if (t > poses[(size_t)k * 23]) { h = k; break; }
+    const int h_last = (i == 0) ? 0 : h;   // the earliest point is compensated again by every earlier interval (the loop re-enters with it_pcl == begin)
+    for (int k = h; k >= h_last && k >= 0; k--) {
+        const double* q = poses + (size_t)k * 23;
+        if (!(t > q[0])) break;
+        const double dt = t - q[0];
+        double E[9], R_i[9];
+        und_exp_rate(q + 4, dt, E);
+        m3_mul(q + 13, E, R_i);
+        const double T_ei[3] = {((q[10] + q[7] * dt) + 0.5 * q[1] * dt * dt) - fe[9], ((q[11] + q[8] * dt) + 0.5 * q[2] * dt * dt) - fe[10],
+                                ((q[12] + q[9] * dt) + 0.5 * q[3] * dt * dt) - fe[11]};
+        const double P_i[3] = {(double)x, (double)y, (double)z};
+        double a1[3], a2[3], a3[3], a4[3];
+        m3_vec(fe + 12, P_i, a1);
+        a1[0] += fe[21]; a1[1] += fe[22]; a1[2] += fe[23];
+        m3_vec(R_i, a1, a2);
+        a2[0] += T_ei[0]; a2[1] += T_ei[1]; a2[2] += T_ei[2];
+        m3t_vec(fe, a2, a3);
+        a3[0] -= fe[21]; a3[1] -= fe[22]; a3[2] -= fe[23];
+        m3t_vec(fe + 12, a3, a4);
+        x = (float)a4[0]; y = (float)a4[1]; z = (float)a4[2];
+    }
+    out[i] = make_float4(x, y, z, p[3]);
+}
+void launch_undistort_keys(hipStream_t s, const float* pts5, int n, uint32_t* key, int32_t* idx) {
+    KLAUNCH(undistort_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts5, n, key, idx);
+}
+void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, int n, const double* poses, int n_poses, const double* fe, float* out_xyzi) {
+    KLAUNCH(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts5, order, n, poses, n_poses, fe, (float4*)out_xyzi);
+}
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm) {

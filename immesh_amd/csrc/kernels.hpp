@@ -47,6 +47,8 @@ void launch_ds_index(hipStream_t s, const float* pts, int n, int stride, float i
 void launch_ds_heads(hipStream_t s, const unsigned long long* keys_sorted, int n, int32_t* flags);
 void launch_ds_centroid(hipStream_t s, const float* pts, int n, int stride, const unsigned long long* keys_sorted, const int32_t* idx_sorted, const int32_t* rank,
                         float* out, int32_t* n_out);
+void launch_undistort_keys(hipStream_t s, const float* pts5, int n, uint32_t* key, int32_t* idx);
+void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, int n, const double* poses, int n_poses, const double* fe, float* out_xyzi);
 void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xyzi);
 size_t exclusive_sum_temp_bytes(int n);
 void exclusive_sum_i32(hipStream_t s, void* temp, size_t temp_bytes, const int32_t* in, int32_t* out, int n);

@@ -536,7 +536,7 @@ extern "C" {
 
 int immesh_mesh_scan(immesh_ctx* c, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx) {
     if (!c || !pts_world_xyzi || n_raw <= 0 || n_raw > c->cap_scan || !sensor_pos) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     float* world = mesh_next_world_buffer(c);
     const void* d_pts;
@@ -577,7 +577,7 @@ int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
 int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd, uint8_t* flip_upd,
                       int32_t* smooth_ids, double* smooth_xyz) {
     if (!c) return IMMESH_E_INVAL;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     MeshHost& h = c->mesh_host;
     immesh_mesh_sizes_t z;
     MeshOutSet o;
@@ -616,7 +616,7 @@ static int grow(immesh_ctx* c, void** p, size_t* have, size_t need) {
 int immesh_mesh_export(immesh_ctx* c, double smooth_factor, int32_t knn, int64_t* n_vtx_out, int64_t* n_faces_out) {
     if (!c) return IMMESH_E_INVAL;
     if (smooth_factor != 0.0 && knn != MV_KNN) { c->err = "mesh export: only knn = 20 (the reference's g_ply_smooth_k) is supported"; return IMMESH_E_INVAL; }
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     mesh_wait_all(c);
     ProfBind _pb(c);
     MeshHost& h = c->mesh_host;
@@ -658,7 +658,7 @@ int immesh_mesh_export(immesh_ctx* c, double smooth_factor, int32_t knn, int64_t
 
 int immesh_mesh_export_fetch(immesh_ctx* c, float* vtx_xyz, int32_t* faces) {
     if (!c) return IMMESH_E_INVAL;
-    hipSetDevice(c->cfg.device);
+    (void)hipSetDevice(c->cfg.device);
     MeshHost& h = c->mesh_host;
     if (vtx_xyz && h.exp_nv) HIPCHK(c, hipMemcpy(vtx_xyz, h.exp_vtx, (size_t)h.exp_nv * 12, hipMemcpyDeviceToHost));
     if (faces && h.exp_nf) HIPCHK(c, hipMemcpy(faces, h.exp_faces, (size_t)h.exp_nf * 12, hipMemcpyDeviceToHost));

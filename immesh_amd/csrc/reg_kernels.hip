@@ -765,7 +765,7 @@ void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_ne
     KLAUNCH(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
-    hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
+    (void)hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
     KLAUNCH(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, nseg);
 }
 void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
@@ -775,7 +775,7 @@ void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slo
     KLAUNCH(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
 }
 void launch_dump_planes(hipStream_t s, const RegMapDev& m, PlaneRecDev* out, long long cap, unsigned long long* count) {
-    hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(count, 0, sizeof(unsigned long long), s);
     KLAUNCH(dump_planes_kernel, dim3(1024), dim3(256), 0, s, m, out, cap, count);
 }
 void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v, size_t n) {

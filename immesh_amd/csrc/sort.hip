@@ -8,13 +8,13 @@
 
 size_t sort_pairs_u64_temp_bytes(int n) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const int32_t*)nullptr,
                                        (int32_t*)nullptr, n, 0, 64, (hipStream_t)0);
     return bytes;
 }
 size_t sort_pairs_u32_temp_bytes(int n) {
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, n,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const int32_t*)nullptr, (int32_t*)nullptr, n,
                                        0, 32, (hipStream_t)0);
     return bytes;
 }

@@ -159,6 +159,37 @@ int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);
 
+/* ---- before the path: motion undistortion ---------------------------------------------------------------- */
+typedef struct immesh_imu_sample {   /* sensor_msgs/Imu: header.stamp, angular_velocity, linear_acceleration */
+    double t;
+    double gyr[3];
+    double acc[3];
+} immesh_imu_sample;
+typedef struct immesh_imu_ctx {      /* the ImuProcess members UndistortPcl reads and carries to the next scan (src/IMU_Processing.h) */
+    double last_lidar_end_time;      /* last_lidar_end_time_ */
+    double acc_s_last[3];
+    double angvel_last[3];
+    immesh_imu_sample last_imu;      /* last_imu_ */
+    double mean_acc_norm;            /* mean_acc.norm() of IMU_init */
+    double cov_gyr[3];
+    double cov_acc[3];
+    double cov_bias_gyr[3];
+    double cov_bias_acc[3];
+    double lid_rot_to_imu[9];        /* Lid_rot_to_IMU, row-major */
+    double lid_offset_to_imu[3];     /* Lid_offset_to_IMU */
+} immesh_imu_ctx;
+/* void ImuProcess::UndistortPcl(LidarMeasureGroup&, StatesGroup&, PointCloudXYZI&)   src/IMU_Processing.cpp:755-958   (LiDAR-only packages:
+ * is_lidar_end == true).  pts_xyzit: n x 5 floats (x, y, z, intensity, curvature = offset from lidar_beg_time in milliseconds), the package's
+ * cloud in arrival order.  imu: the package's samples (meas.imu) in time order.  The forward propagation of state + covariance over the IMU
+ * samples is 18x18 host algebra (as in the reference); on the device the points are sorted by offset time (std::sort(time_list); equal stamps
+ * keep their arrival order) and each one is moved into the scan-end frame by the pose of its IMU interval (:925-955, including the repeated
+ * compensation of the earliest point that the reference's loop performs).
+ * out_xyzi: host or device, n x 4, time order; NULL leaves the cloud in the context (immesh_undistort_result) for immesh_downsample /
+ * immesh_process_scan.  state_inout: 348 doubles, propagated to the scan end.  last_update_time: LidarMeasureGroup::last_update_time, in/out. */
+int immesh_undistort(immesh_ctx* ctx, const float* pts_xyzit, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time,
+                     double* last_update_time, immesh_imu_ctx* imu_ctx, double* state_inout, float* out_xyzi);
+const float* immesh_undistort_result(immesh_ctx* ctx);
+
 /* ---- multi-GPU: voxel-hash sharded registration map ------------------------------------------------------------ */
 /* One context per GPU / process, all configured with the same shard_world.  Every rank is handed the same scans; each matches the points
  * whose root voxel it owns and replays only its own voxels (+ halo) in immesh_map_update.  After every residual pass the library calls

@@ -4,6 +4,7 @@
 // bench.py's cpu_baseline leg may load liboracle.so.
 #include "../include/immesh_c_api.h"
 #include "orc_mesher.hpp"
+#include "orc_imu.hpp"
 #include <string>
 #include <chrono>
 #include <climits>
@@ -154,6 +155,15 @@ int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t
     return orc_mesh_scan(p, w.data(), n_ds, origin, 0);
 }
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
+int orc_undistort(void* p, const float* pts_xyzit, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time, double* last_update_time,
+                  immesh_imu_ctx* ic, double* state_inout, float* out_xyzi) {   // ImuProcess::UndistortPcl, IMU_Processing.cpp:755-958
+    (void)p;
+    std::vector<float> out;
+    orc::undistort_pcl(pts_xyzit, n, imu, n_imu, lidar_beg_time, last_update_time, ic, state_inout, out);
+    if (out_xyzi) std::memcpy(out_xyzi, out.data(), out.size() * sizeof(float));
+    return 0;
+}
+const float* orc_undistort_result(void*) { return nullptr; }
 int orc_set_allgather(void*, immesh_allgather_fn, void*) { return 0; }
 int orc_shard_traffic(void*, int64_t* bytes, int64_t* calls) { if (bytes) *bytes = 0; if (calls) *calls = 0; return 0; }
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
