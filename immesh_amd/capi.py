@@ -324,6 +324,53 @@ class HotPath:
         f = self._f("undistort_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
         return f(self.ctx)
 
+    # -- legacy registration path ------------------------------------------------------------
+    def ikd_build(self, pts_world_xyz, downsample_size):
+        f = self._f("ikd_build"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double]; f.restype = C.c_int
+        p = np.ascontiguousarray(pts_world_xyz, dtype=np.float32)
+        self._check(f(self.ctx, _ptr(p), len(p), downsample_size), "ikd_build")
+
+    def ikd_add_points(self, pts_world_xyz):
+        f = self._f("ikd_add_points"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]; f.restype = C.c_int
+        p = np.ascontiguousarray(pts_world_xyz, dtype=np.float32)
+        self._check(f(self.ctx, _ptr(p), len(p)), "ikd_add_points")
+
+    def ikd_size(self):
+        f = self._f("ikd_size"); f.argtypes = [C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        n = C.c_int64(0)
+        self._check(f(self.ctx, C.byref(n)), "ikd_size")
+        return n.value
+
+    def ikd_dump(self):
+        """all map points, sorted lexicographically by (x, y, z)"""
+        f = self._f("ikd_dump"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]; f.restype = C.c_int
+        cap = self.ikd_size()
+        out = np.zeros((max(cap, 1), 3), np.float32)
+        n = C.c_int64(0)
+        self._check(f(self.ctx, _ptr(out), cap, C.byref(n)), "ikd_dump")
+        out = out[:min(cap, n.value)]
+        return out[np.lexsort((out[:, 2], out[:, 1], out[:, 0]))]
+
+    def ikd_knn(self, q_xyz):
+        f = self._f("ikd_knn"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        q = np.ascontiguousarray(q_xyz, dtype=np.float32)
+        nn = np.zeros((len(q), 5, 3), np.float32); d2 = np.zeros((len(q), 5), np.float32); nf = np.zeros(len(q), np.int32)
+        self._check(f(self.ctx, _ptr(q), len(q), _ptr(nn), _ptr(d2), _ptr(nf)), "ikd_knn")
+        return nn, d2, nf
+
+    def ikd_register(self, pts_down_body, state_prior, state, laser_point_cov=0.001):
+        f = self._f("ikd_register"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        p = np.ascontiguousarray(pts_down_body, dtype=np.float32)
+        n = len(p)
+        out = np.array(state, dtype=np.float64, copy=True)
+        n_iter, n_match, res = C.c_int32(0), C.c_int32(0), C.c_double(0)
+        idx = np.zeros(n, np.int32); nv = np.zeros((n, 4), np.float32)
+        self._check(f(self.ctx, _ptr(p), n, _ptr(np.ascontiguousarray(state_prior, dtype=np.float64)), _ptr(out), laser_point_cov, C.byref(n_iter),
+                      C.byref(n_match), C.byref(res), _ptr(idx), _ptr(nv)), "ikd_register")
+        m = n_match.value
+        return out, {"n_iter": n_iter.value, "n_match": m, "res_mean": res.value, "match_idx": idx[:m].copy(), "normals_pd2": nv[:m].copy()}
+
     def downsample_result_ptr(self):
         f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
         return f(self.ctx)

@@ -8,6 +8,7 @@
 #include "regmap.hpp"
 #include "kernels.hpp"
 #include "mesh_kernels.hpp"
+#include "ikd_map.hpp"
 #include "ekf_host.hpp"
 #include "prof.hpp"
 
@@ -38,6 +39,7 @@ struct immesh_ctx {
 
     // ---- registration map
     RegMapDev map;
+    IkdHost ikd;                     // legacy point-map path, allocated on first use
     int64_t* d_stats = nullptr;      // [8] refits, refit pts, ...
     double dvar_beam = 0, dvar_calib = 0;
 

@@ -159,6 +159,24 @@ int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);
 
+/* ---- legacy registration path ------------------------------------------------------------------------------- */
+/* `voxel_map_en = false` -- dead in every shipped config, kept behind these separate entry points: the ikd-Tree of map points and the "Old map
+ * ICP" matcher.  The tree is replaced by what it computes: exact float k-NN and the box-downsample insert (one survivor per downsample_size
+ * box, the point nearest to the box centre, a new point winning ties), on a device hash grid.
+ *   m_ikdtree.set_downsample_param(filter_size_map_min); m_ikdtree.Build(feats_down_world)   src/voxel_mapping.cpp:1906-1914 */
+int immesh_ikd_build(immesh_ctx* ctx, const float* pts_world_xyz, int32_t n, double downsample_size);
+/*   m_ikdtree.Add_Points(feats_down_world, true)   src/ImMesh_mesh_reconstruction.cpp:426-443 (KD_TREE::Add_Points, ikd_Tree.cpp:493-545) */
+int immesh_ikd_add_points(immesh_ctx* ctx, const float* pts_world_xyz, int32_t n);
+/*   Voxel_mapping::lio_state_estimation with m_use_new_map == false: 5-NN + esti_plane (include/common_lib.h:356-402) + gates
+ *   (src/voxel_mapping.cpp:1400-1480), H rows with R_inv = 1 / laser_point_cov and the iterated EKF incl. the re-match rule (:1487-1650).
+ *   match_idx (n_ds) / normals_pd2 (n_ds x 4: plane normal + signed distance) = m_laserCloudOri / m_corr_normvect of the last iteration; may be NULL. */
+int immesh_ikd_register(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state_prior, double* state_inout,
+                        double laser_point_cov, int32_t* n_iter, int32_t* n_match, double* res_mean, int32_t* match_idx, float* normals_pd2);
+/*   KD_TREE::size / flatten / Nearest_Search(point, 5, ..) -- introspection for parity (dump order unspecified; k-NN ascending distance) */
+int immesh_ikd_size(immesh_ctx* ctx, int64_t* n);
+int immesh_ikd_dump(immesh_ctx* ctx, float* xyz, int64_t cap, int64_t* n_out);
+int immesh_ikd_knn(immesh_ctx* ctx, const float* q_xyz, int32_t nq, float* nn_xyz /* nq x 5 x 3 */, float* d2 /* nq x 5 */, int32_t* n_found /* nq */);
+
 /* ---- before the path: motion undistortion ---------------------------------------------------------------- */
 typedef struct immesh_imu_sample {   /* sensor_msgs/Imu: header.stamp, angular_velocity, linear_acceleration */
     double t;

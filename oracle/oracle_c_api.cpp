@@ -5,6 +5,7 @@
 #include "../include/immesh_c_api.h"
 #include "orc_mesher.hpp"
 #include "orc_imu.hpp"
+#include "orc_ikdmap.hpp"
 #include <string>
 #include <chrono>
 #include <climits>
@@ -22,6 +23,7 @@ struct OrcCtx {
     Registration reg;
     Mesher mesher;
     MeshScanOut mout;
+    orc::IkdMap ikd;
     OrcCtx() : reg(&vm) {}
 };
 
@@ -155,6 +157,45 @@ int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t
     return orc_mesh_scan(p, w.data(), n_ds, origin, 0);
 }
 int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
+// ---- legacy registration path (a27)
+int orc_ikd_build(void* p, const float* xyz, int32_t n, double ds) { OrcCtx* o = (OrcCtx*)p; o->ikd.ds = (float)ds; o->ikd.build(xyz, n); return 0; }
+int orc_ikd_add_points(void* p, const float* xyz, int32_t n) { ((OrcCtx*)p)->ikd.add_points(xyz, n); return 0; }
+int orc_ikd_size(void* p, int64_t* n) { *n = (int64_t)((OrcCtx*)p)->ikd.count; return 0; }
+int orc_ikd_dump(void* p, float* xyz, int64_t cap, int64_t* n_out) {
+    std::vector<float> all;
+    ((OrcCtx*)p)->ikd.dump(all);
+    *n_out = (int64_t)all.size() / 3;
+    if (xyz) std::memcpy(xyz, all.data(), (size_t)std::min<int64_t>(cap, *n_out) * 12);
+    return 0;
+}
+int orc_ikd_knn(void* p, const float* q, int32_t nq, float* nn_xyz, float* d2, int32_t* n_found) {
+    OrcCtx* o = (OrcCtx*)p;
+    for (int i = 0; i < nq; i++) {
+        orc::IkdPt pt[5]; float dd[5];
+        const int k = o->ikd.knn(q[i * 3], q[i * 3 + 1], q[i * 3 + 2], 5, pt, dd);
+        for (int j = 0; j < 5; j++) {
+            if (nn_xyz) { nn_xyz[(i * 5 + j) * 3] = j < k ? pt[j].x : 0; nn_xyz[(i * 5 + j) * 3 + 1] = j < k ? pt[j].y : 0; nn_xyz[(i * 5 + j) * 3 + 2] = j < k ? pt[j].z : 0; }
+            if (d2) d2[i * 5 + j] = j < k ? dd[j] : 0;
+        }
+        if (n_found) n_found[i] = k;
+    }
+    return 0;
+}
+int orc_ikd_register(void* p, const float* body, int32_t n, const double* state_prior, double* state_inout, double laser_point_cov, int32_t* n_iter,
+                     int32_t* n_match, double* res_mean, int32_t* match_idx, float* normals_pd2) {
+    OrcCtx* o = (OrcCtx*)p;
+    orc::State prior, st;
+    load_state(state_prior, prior); load_state(state_inout, st);
+    orc::IkdRegResult r;
+    orc::ikd_register(o->ikd, o->vm.cfg, body, n, prior, st, laser_point_cov, r);
+    store_state(st, state_inout);
+    if (n_iter) *n_iter = r.n_iter;
+    if (n_match) *n_match = r.n_match;
+    if (res_mean) *res_mean = r.res_mean;
+    if (match_idx) std::memcpy(match_idx, r.match_idx.data(), r.match_idx.size() * sizeof(int));
+    if (normals_pd2) std::memcpy(normals_pd2, r.normals_pd2.data(), r.normals_pd2.size() * sizeof(float));
+    return 0;
+}
 int orc_undistort(void* p, const float* pts_xyzit, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time, double* last_update_time,
                   immesh_imu_ctx* ic, double* state_inout, float* out_xyzi) {   // ImuProcess::UndistortPcl, IMU_Processing.cpp:755-958
     (void)p;
