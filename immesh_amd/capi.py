@@ -335,6 +335,19 @@ class HotPath:
         p = np.ascontiguousarray(pts_world_xyz, dtype=np.float32)
         self._check(f(self.ctx, _ptr(p), len(p)), "ikd_add_points")
 
+    def ikd_delete_boxes(self, boxes):
+        f = self._f("ikd_delete_boxes"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]; f.restype = C.c_int
+        b = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+        n = C.c_int32(0)
+        self._check(f(self.ctx, _ptr(b), len(b), C.byref(n)), "ikd_delete_boxes")
+        return n.value
+
+    def ikd_fov_segment(self, pos_lid, cube_len, detection_range):
+        f = self._f("ikd_fov_segment"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]; f.restype = C.c_int
+        n = C.c_int32(0)
+        self._check(f(self.ctx, _ptr(np.ascontiguousarray(pos_lid, dtype=np.float64)), cube_len, detection_range, C.byref(n)), "ikd_fov_segment")
+        return n.value
+
     def ikd_size(self):
         f = self._f("ikd_size"); f.argtypes = [C.c_void_p, C.c_void_p]; f.restype = C.c_int
         n = C.c_int64(0)

@@ -32,6 +32,7 @@ static int ikd_reset(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(h.m.stamp, 0, slots * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(h.m.counters, 0, 8 * 4, c->stream));
     h.m.seq = 0;
+    h.localmap_initialized = false;
     return 0;
 }
 static int ikd_check(immesh_ctx* c) {   // after a stream sync
@@ -76,6 +77,63 @@ int immesh_ikd_add_points(immesh_ctx* c, const float* pts_world_xyz, int32_t n) 
     launch_ikd_add(c->stream, c->ikd.m, (const float*)d, n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ikd_check(c);
+}
+
+static int ikd_delete(immesh_ctx* c, const IkdBoxes& bx, int32_t* n_deleted) {
+    IkdHost& h = c->ikd;
+    int32_t* d_cnt = h.m.counters + 4;
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+    launch_ikd_delete_boxes(c->stream, h.m, bx, d_cnt);
+    int32_t v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_deleted) *n_deleted = v;
+    return 0;
+}
+// m_ikdtree.Delete_Point_Boxes(boxes)
+int immesh_ikd_delete_boxes(immesh_ctx* c, const float* boxes, int32_t nb, int32_t* n_deleted) {
+    if (!c || !boxes || nb < 0 || nb > 3 || !c->ikd.ready) { if (c) c->err = "bad arguments (at most 3 boxes per call)"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    IkdBoxes bx;
+    bx.n = nb;
+    std::memcpy(bx.b, boxes, (size_t)nb * 24);
+    if (n_deleted) *n_deleted = 0;
+    return nb ? ikd_delete(c, bx, n_deleted) : 0;
+}
+// Voxel_mapping::laser_map_fov_segment   src/voxel_mapping_common.cpp:214-288
+int immesh_ikd_fov_segment(immesh_ctx* c, const double* pos, double cube_len, double detection_range_d, int32_t* n_deleted) {
+    if (!c || !pos || !(cube_len > 0) || !c->ikd.ready) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    IkdHost& h = c->ikd;
+    const float MOV_THRESHOLD = 1.5f, det = (float)detection_range_d;   // src/voxel_mapping.hpp:136-137 (float members)
+    if (n_deleted) *n_deleted = 0;
+    if (!h.localmap_initialized) {
+        for (int i = 0; i < 3; i++) { h.lm_min[i] = (float)(pos[i] - cube_len / 2.0); h.lm_max[i] = (float)(pos[i] + cube_len / 2.0); }
+        h.localmap_initialized = true;
+        return 0;
+    }
+    float edge[3][2];
+    bool move = false;
+    for (int i = 0; i < 3; i++) {
+        edge[i][0] = (float)std::fabs(pos[i] - (double)h.lm_min[i]);
+        edge[i][1] = (float)std::fabs(pos[i] - (double)h.lm_max[i]);
+        move = move || edge[i][0] <= MOV_THRESHOLD * det || edge[i][1] <= MOV_THRESHOLD * det;
+    }
+    if (!move) return 0;
+    const float shift = (float)std::max((cube_len - 2.0 * MOV_THRESHOLD * det) * 0.5 * 0.9, double(det * (MOV_THRESHOLD - 1)));
+    float nmin[3] = {h.lm_min[0], h.lm_min[1], h.lm_min[2]}, nmax[3] = {h.lm_max[0], h.lm_max[1], h.lm_max[2]};
+    IkdBoxes bx;
+    bx.n = 0;
+    for (int i = 0; i < 3; i++) {
+        float* b = bx.b[bx.n];
+        for (int a = 0; a < 3; a++) { b[a] = h.lm_min[a]; b[3 + a] = h.lm_max[a]; }
+        if (edge[i][0] <= MOV_THRESHOLD * det) { nmax[i] -= shift; nmin[i] -= shift; b[i] = h.lm_max[i] - shift; bx.n++; }
+        else if (edge[i][1] <= MOV_THRESHOLD * det) { nmax[i] += shift; nmin[i] += shift; b[3 + i] = h.lm_min[i] + shift; bx.n++; }
+    }
+    std::memcpy(h.lm_min, nmin, sizeof(nmin)); std::memcpy(h.lm_max, nmax, sizeof(nmax));
+    return bx.n ? ikd_delete(c, bx, n_deleted) : 0;
 }
 
 int immesh_ikd_size(immesh_ctx* c, int64_t* n) {

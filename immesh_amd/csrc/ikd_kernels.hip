@@ -103,6 +103,22 @@ __global__ void ikd_add_settle_kernel(IkdMapDev m, const float* __restrict__ xyz
         atomicAdd(&m.counters[0], 1 - cnt);
     }
 }
+// KD_TREE::Delete_Point_Boxes (ikd_Tree.cpp:655-690): one thread per hash slot compacts its cell
+__global__ void ikd_delete_boxes_kernel(IkdMapDev m, IkdBoxes bx, int32_t* __restrict__ n_deleted) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > (long long)m.mask || m.keys[s] == IK_EMPTY) return;
+    const int cnt = m.count[s];
+    float4* cell = m.pts + (size_t)s * IKD_CELL_PTS;
+    int w = 0;
+    for (int j = 0; j < cnt; j++) {
+        const float4 q = cell[j];
+        bool in = false;
+        for (int b = 0; b < bx.n && !in; b++)
+            in = bx.b[b][0] <= q.x && bx.b[b][3] > q.x && bx.b[b][1] <= q.y && bx.b[b][4] > q.y && bx.b[b][2] <= q.z && bx.b[b][5] > q.z;
+        if (!in) cell[w++] = q;
+    }
+    if (w != cnt) { m.count[s] = w; atomicAdd(&m.counters[0], w - cnt); atomicAdd(n_deleted, cnt - w); }
+}
 __global__ void ikd_dump_kernel(IkdMapDev m, float* __restrict__ xyz, long long cap, unsigned long long* __restrict__ count) {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s > (long long)m.mask || m.keys[s] == IK_EMPTY) return;
@@ -372,6 +388,10 @@ void launch_ikd_add(hipStream_t s, const IkdMapDev& m, const float* xyz, int n) 
     KLAUNCH(ikd_add_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, xyz, n);
     KLAUNCH(ikd_add_min_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, xyz, n);
     KLAUNCH(ikd_add_settle_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, xyz);
+}
+void launch_ikd_delete_boxes(hipStream_t s, const IkdMapDev& m, const IkdBoxes& boxes, int32_t* n_deleted) {
+    const long long slots = (long long)m.mask + 1;
+    KLAUNCH(ikd_delete_boxes_kernel, dim3((unsigned int)((slots + 255) / 256)), dim3(256), 0, s, m, boxes, n_deleted);
 }
 void launch_ikd_dump(hipStream_t s, const IkdMapDev& m, float* xyz, long long cap, unsigned long long* count) {
     const long long slots = (long long)m.mask + 1;

@@ -35,10 +35,14 @@ struct IkdHost {
     double* d_out = nullptr;      // 48 sums
     float* d_q = nullptr;         // query / staging
     int64_t cap_pts = 0;
+    bool localmap_initialized = false;   // m_localmap_Initialized / m_LocalMap_Points (laser_map_fov_segment)
+    float lm_min[3] = {0, 0, 0}, lm_max[3] = {0, 0, 0};
 };
+struct IkdBoxes { float b[3][6]; int n; };   // at most one slab per axis
 
 void launch_ikd_build(hipStream_t s, const IkdMapDev& m, const float* xyz, int n);
 void launch_ikd_add(hipStream_t s, const IkdMapDev& m, const float* xyz, int n);
+void launch_ikd_delete_boxes(hipStream_t s, const IkdMapDev& m, const IkdBoxes& boxes, int32_t* n_deleted);
 void launch_ikd_dump(hipStream_t s, const IkdMapDev& m, float* xyz, long long cap, unsigned long long* count);
 // mode 0: k-NN only (nn_xyz / d2 out); mode 1: search + plane fit + gates; mode 2: plane fit + gates on the stored neighbours
 struct IkdMatchParams { double R[9], t[3], extR[9], extT[3]; double r_inv; };

@@ -172,7 +172,13 @@ int immesh_ikd_add_points(immesh_ctx* ctx, const float* pts_world_xyz, int32_t n
  *   match_idx (n_ds) / normals_pd2 (n_ds x 4: plane normal + signed distance) = m_laserCloudOri / m_corr_normvect of the last iteration; may be NULL. */
 int immesh_ikd_register(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state_prior, double* state_inout,
                         double laser_point_cov, int32_t* n_iter, int32_t* n_match, double* res_mean, int32_t* match_idx, float* normals_pd2);
-/*   KD_TREE::size / flatten / Nearest_Search(point, 5, ..) -- introspection for parity (dump order unspecified; k-NN ascending distance) */
+/*   m_ikdtree.Delete_Point_Boxes(boxes)   include/ikd-Tree/ikd_Tree.cpp:655-690: boxes = nb x 6 floats (min xyz, max xyz), a point goes when
+ *   min <= p < max on every axis.  immesh_ikd_fov_segment = Voxel_mapping::laser_map_fov_segment (src/voxel_mapping_common.cpp:214-288): the
+ *   local-map cube (side cube_len) follows pos_lid; when the sensor comes within 1.5 x detection_range of a face the cube is shifted and the
+ *   slabs that fall out are deleted.  The cube lives in the context (reset by immesh_ikd_build). */
+int immesh_ikd_delete_boxes(immesh_ctx* ctx, const float* boxes, int32_t nb, int32_t* n_deleted);
+int immesh_ikd_fov_segment(immesh_ctx* ctx, const double* pos_lid, double cube_len, double detection_range, int32_t* n_deleted);
+/*   KD_TREE::validnum / flatten / Nearest_Search(point, 5, ..) -- introspection for parity (dump order unspecified; k-NN ascending distance) */
 int immesh_ikd_size(immesh_ctx* ctx, int64_t* n);
 int immesh_ikd_dump(immesh_ctx* ctx, float* xyz, int64_t cap, int64_t* n_out);
 int immesh_ikd_knn(immesh_ctx* ctx, const float* q_xyz, int32_t nq, float* nn_xyz /* nq x 5 x 3 */, float* d2 /* nq x 5 */, int32_t* n_found /* nq */);

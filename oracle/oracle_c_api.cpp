@@ -160,6 +160,16 @@ int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the 
 // ---- legacy registration path (a27)
 int orc_ikd_build(void* p, const float* xyz, int32_t n, double ds) { OrcCtx* o = (OrcCtx*)p; o->ikd.ds = (float)ds; o->ikd.build(xyz, n); return 0; }
 int orc_ikd_add_points(void* p, const float* xyz, int32_t n) { ((OrcCtx*)p)->ikd.add_points(xyz, n); return 0; }
+int orc_ikd_delete_boxes(void* p, const float* boxes, int32_t nb, int32_t* n_deleted) {
+    const int r = ((OrcCtx*)p)->ikd.delete_boxes(boxes, nb);
+    if (n_deleted) *n_deleted = r;
+    return 0;
+}
+int orc_ikd_fov_segment(void* p, const double* pos_lid, double cube_len, double detection_range, int32_t* n_deleted) {
+    const int r = ((OrcCtx*)p)->ikd.fov_segment(pos_lid, cube_len, (float)detection_range);
+    if (n_deleted) *n_deleted = r;
+    return 0;
+}
 int orc_ikd_size(void* p, int64_t* n) { *n = (int64_t)((OrcCtx*)p)->ikd.count; return 0; }
 int orc_ikd_dump(void* p, float* xyz, int64_t cap, int64_t* n_out) {
     std::vector<float> all;

@@ -29,7 +29,7 @@ struct IkdMap {
     size_t count = 0;
     static uint64_t key(long x, long y, long z) { return (((uint64_t)(x + (1 << 20)) & 0x1FFFFF) << 42) | (((uint64_t)(y + (1 << 20)) & 0x1FFFFF) << 21) | ((uint64_t)(z + (1 << 20)) & 0x1FFFFF); }
     long cell(float v) const { return (long)std::floor(v / ds); }
-    void clear() { cells.clear(); next_id = 0; count = 0; }
+    void clear() { cells.clear(); next_id = 0; count = 0; localmap_initialized = false; }
     void insert_raw(float x, float y, float z) { cells[key(cell(x), cell(y), cell(z))].push_back({x, y, z, next_id++}); count++; }
     void build(const float* xyz, int n) { clear(); for (int i = 0; i < n; i++) insert_raw(xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]); }   // Build keeps every point
     // Add_Points(PointToAdd, true), ikd_Tree.cpp:493-545; returns the number of points actually added (tmp_counter)
@@ -78,6 +78,64 @@ struct IkdMap {
             }
         for (size_t i = 0; i < best.size(); i++) { out[i] = best[i].second; d2[i] = best[i].first.first; }
         return (int)best.size();
+    }
+    // KD_TREE::Delete_Point_Boxes -> Delete_by_range (ikd_Tree.cpp:655-690, 1340-1420): a point goes when min <= p < max on every axis
+    int delete_boxes(const float* boxes /* nb x 6: min xyz, max xyz */, int nb) {
+        int removed = 0;
+        for (auto& kv : cells) {
+            std::vector<IkdPt>& v = kv.second;
+            size_t w = 0;
+            for (size_t k = 0; k < v.size(); k++) {
+                bool in = false;
+                for (int b = 0; b < nb && !in; b++) {
+                    const float* q = boxes + b * 6;
+                    in = q[0] <= v[k].x && q[3] > v[k].x && q[1] <= v[k].y && q[4] > v[k].y && q[2] <= v[k].z && q[5] > v[k].z;
+                }
+                if (in) removed++; else v[w++] = v[k];
+            }
+            v.resize(w);
+        }
+        count -= (size_t)removed;
+        return removed;
+    }
+    // Voxel_mapping::laser_map_fov_segment (src/voxel_mapping_common.cpp:214-288): the local-map cube follows the sensor; what falls out is deleted
+    bool localmap_initialized = false;
+    float lm_min[3] = {0, 0, 0}, lm_max[3] = {0, 0, 0};
+    int fov_segment(const double* pos_lid, double cube_len, float detection_range, std::vector<float>* boxes_out = nullptr) {
+        const float MOV_THRESHOLD = 1.5f;   // src/voxel_mapping.hpp:137
+        if (boxes_out) boxes_out->clear();
+        if (!localmap_initialized) {
+            for (int i = 0; i < 3; i++) { lm_min[i] = (float)(pos_lid[i] - cube_len / 2.0); lm_max[i] = (float)(pos_lid[i] + cube_len / 2.0); }
+            localmap_initialized = true;
+            return 0;
+        }
+        float dist[3][2];
+        bool need_move = false;
+        for (int i = 0; i < 3; i++) {
+            dist[i][0] = (float)std::fabs(pos_lid[i] - (double)lm_min[i]);
+            dist[i][1] = (float)std::fabs(pos_lid[i] - (double)lm_max[i]);
+            if (dist[i][0] <= MOV_THRESHOLD * detection_range || dist[i][1] <= MOV_THRESHOLD * detection_range) need_move = true;
+        }
+        if (!need_move) return 0;
+        float nmin[3], nmax[3];
+        std::memcpy(nmin, lm_min, sizeof(nmin)); std::memcpy(nmax, lm_max, sizeof(nmax));
+        const float mov_dist = (float)std::max((cube_len - 2.0 * MOV_THRESHOLD * detection_range) * 0.5 * 0.9, double(detection_range * (MOV_THRESHOLD - 1)));
+        std::vector<float> boxes;
+        for (int i = 0; i < 3; i++) {
+            float b[6] = {lm_min[0], lm_min[1], lm_min[2], lm_max[0], lm_max[1], lm_max[2]};
+            if (dist[i][0] <= MOV_THRESHOLD * detection_range) {
+                nmax[i] -= mov_dist; nmin[i] -= mov_dist;
+                b[i] = lm_max[i] - mov_dist;
+                boxes.insert(boxes.end(), b, b + 6);
+            } else if (dist[i][1] <= MOV_THRESHOLD * detection_range) {
+                nmax[i] += mov_dist; nmin[i] += mov_dist;
+                b[3 + i] = lm_min[i] + mov_dist;
+                boxes.insert(boxes.end(), b, b + 6);
+            }
+        }
+        std::memcpy(lm_min, nmin, sizeof(nmin)); std::memcpy(lm_max, nmax, sizeof(nmax));
+        if (boxes_out) *boxes_out = boxes;
+        return boxes.empty() ? 0 : delete_boxes(boxes.data(), (int)boxes.size() / 6);
     }
     void dump(std::vector<float>& xyz) const {   // ascending (cell key, insertion id)
         std::vector<std::pair<std::pair<uint64_t, long>, IkdPt>> all;

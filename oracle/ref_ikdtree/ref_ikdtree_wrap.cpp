@@ -25,6 +25,11 @@ int ref_ikd_knn(void* t, const float* xyz, int k, long* idx_out, float* d2_out) 
 int ref_ikd_size(void* t) { return ((Tree*)t)->size(); }
 // the legacy registration map: set_downsample_param + Build (voxel_mapping.cpp:1906-1914), Add_Points(.., true)
 // (ImMesh_mesh_reconstruction.cpp:439), flatten for a dump of the surviving points
+int ref_ikd_delete_boxes(void* t, const float* boxes, int nb) {   // Delete_Point_Boxes, as laser_map_fov_segment calls it
+    std::vector<BoxPointType> v;
+    for (int b = 0; b < nb; b++) { BoxPointType q; for (int a = 0; a < 3; a++) { q.vertex_min[a] = boxes[b * 6 + a]; q.vertex_max[a] = boxes[b * 6 + 3 + a]; } v.push_back(q); }
+    return ((Tree*)t)->Delete_Point_Boxes(v);
+}
 int ref_ikd_validnum(void* t) { return ((Tree*)t)->validnum(); }
 void ref_ikd_set_downsample(void* t, float ds) { ((Tree*)t)->set_downsample_param(ds); }
 void ref_ikd_build(void* t, const float* xyz, int n) {

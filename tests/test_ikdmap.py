@@ -31,6 +31,9 @@ def _check_against_golden(h):
     assert np.all(nf == 5)
     np.testing.assert_array_equal(d2, g["d2"])                         # float squared distances, ascending
     np.testing.assert_array_equal(nn, g["nn"])                         # and the neighbours themselves
+    # note: the reference counts a point once per box that covers it; the two slabs overlap in a corner, the survivors are what is pinned
+    h.ikd_delete_boxes(g["boxes"])                                     # Delete_Point_Boxes with two slabs
+    np.testing.assert_array_equal(h.ikd_dump(), g["points_after_delete"])
 
 
 def test_oracle_map_matches_reference_ikdtree_golden(oracle_lib):
@@ -85,6 +88,47 @@ def test_oracle_legacy_registration_recovers_pose(oracle_lib):
     np.testing.assert_allclose(np.linalg.norm(nv[:, :3], axis=1), 1.0, atol=1e-5)
     assert np.all(np.abs(nv[:, 3]) <= 2.0) and np.all(np.diff(info["match_idx"]) > 0)
     assert truth is not None
+
+
+def _fov_run(h, pts):
+    """laser_map_fov_segment: a 120 m cube, 20 m detection range -> the cube shifts when the sensor is within 30 m of a face"""
+    h.ikd_build(pts, 0.5)
+    out = []
+    for pos in ([0, 0, 0], [10, 0, 0], [31, 0, 0], [31, -32, 0], [80, -32, 2]):
+        n_del = h.ikd_fov_segment(np.array(pos, np.float64), 120.0, 20.0)
+        out.append((n_del, h.ikd_size()))
+    return out, h.ikd_dump()
+
+
+def test_oracle_fov_segment_known_answers(oracle_lib):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-70, 70, (20000, 3)).astype(np.float32); pts[:, 2] *= 0.05
+    o = make_oracle(oracle_lib, _cfg())
+    hist, left = _fov_run(o, pts)
+    # by hand: the first call initialises the cube [-60, 60)^3; at x = 10 no face is within 1.5 * 20 m; at x = 31 the +x face is 29 m away ->
+    # shift by mov_dist = max((120 - 60) * 0.45, 20 * 0.5) = 27 m and delete the slab x in [-60, -33); then the -y face (y = -32: 28 m) ->
+    # slab y in [33, 60) of the shifted cube; then +x again (x = 80: 7 m) -> slab x in [-33, -6)
+    def slab(p, lo, hi):
+        return np.all((p >= np.array(lo, np.float32)) & (p < np.array(hi, np.float32)), axis=1)
+    keep = np.ones(len(pts), bool)
+    expect = [(0, len(pts)), (0, len(pts))]
+    for lo, hi in (([-60, -60, -60], [-33, 60, 60]), ([-33, 33, -60], [87, 60, 60]), ([-33, -87, -60], [-6, 33, 60])):
+        gone = keep & slab(pts, lo, hi)
+        keep &= ~gone
+        expect.append((int(gone.sum()), int(keep.sum())))
+    assert hist == expect and expect[2][0] > 1000 and expect[3][0] > 500 and expect[4][0] > 1000
+    rest = pts[keep]
+    np.testing.assert_array_equal(left, rest[np.lexsort((rest[:, 2], rest[:, 1], rest[:, 0]))])
+
+
+@pytest.mark.gpu
+def test_hip_fov_segment_matches_oracle(oracle_lib, hip_lib):
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(-70, 70, (20000, 3)).astype(np.float32); pts[:, 2] *= 0.05
+    ho, lo = _fov_run(make_oracle(oracle_lib, _cfg()), pts)
+    hh, lh = _fov_run(make_hip(hip_lib, _cfg()), pts)
+    assert hh == ho
+    np.testing.assert_array_equal(lh, lo)
 
 
 @pytest.mark.gpu

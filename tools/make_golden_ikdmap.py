@@ -58,8 +58,20 @@ def main():
     for i in range(len(q)):
         k = L.ref_ikd_knn_xyz(tree, dp(np.ascontiguousarray(q[i])), 5, dp(nn[i]), dp(d2[i]))
         assert k == 5
+    # Delete_Point_Boxes with two slabs, as laser_map_fov_segment produces them (voxel_mapping_common.cpp:258-276)
+    lo, hi = pts.min(axis=0) - 1.0, pts.max(axis=0) + 1.0
+    boxes = np.array([[lo[0], lo[1], lo[2], lo[0] + 0.3 * (hi[0] - lo[0]), hi[1], hi[2]],
+                      [lo[0], hi[1] - 0.25 * (hi[1] - lo[1]), lo[2], hi[0], hi[1], hi[2]]], np.float32)
+    n_del = L.ref_ikd_delete_boxes(tree, dp(boxes), 2)
+    left = np.zeros((cap, 3), np.float32)
+    n_left = L.ref_ikd_flatten(tree, dp(left), cap)
+    assert n_left == L.ref_ikd_validnum(tree)
+    left = left[:n_left]
+    left = left[np.lexsort((left[:, 2], left[:, 1], left[:, 0]))]
     out = os.path.join(ROOT, "tests", "golden", "ikdmap_r01.npz")
-    np.savez_compressed(out, ds=np.float32(DS), scan0=scans[0], scan1=scans[1], scan2=scans[2], scan3=scans[3], sizes=np.array(sizes), points=pts, queries=q, nn=nn, d2=d2)
+    np.savez_compressed(out, ds=np.float32(DS), scan0=scans[0], scan1=scans[1], scan2=scans[2], scan3=scans[3], sizes=np.array(sizes), points=pts, queries=q, nn=nn, d2=d2,
+                        boxes=boxes, n_deleted=np.int64(n_del), points_after_delete=left)
+    print("deleted", n_del, "left", n_left)
     print("wrote", out, "sizes", sizes)
 
 
