@@ -307,6 +307,30 @@ class HotPath:
         self._check(f(self.ctx, _ptr(pts), n, stride, leaf, _ptr(out), n, C.byref(n_out)), "downsample")
         return (out[:n_out.value] if to_host else None), n_out.value
 
+    def decode_livox(self, wire_points, n_scans=6, point_filter_num=1, blind=1.0, to_host=True):
+        """avia_handler: wire_points = n x 19 uint8 (serialised livox CustomPoint).  Returns (n_out x 5 float32 | None, n_out)."""
+        f = self._f("decode_livox"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p]
+        w = np.ascontiguousarray(wire_points, dtype=np.uint8).reshape(-1, 19)
+        out = np.zeros((len(w), 5), np.float32) if to_host else None
+        n_out = C.c_int32(0)
+        self._check(f(self.ctx, _ptr(w), len(w), n_scans, point_filter_num, blind, _ptr(out), C.byref(n_out)), "decode_livox")
+        return (out[:n_out.value] if to_host else None), n_out.value
+
+    def decode_velodyne(self, data, point_step, offsets, n_scans=64, to_host=True):
+        """velodyne_handler: data = n x point_step uint8 (PointCloud2.data); offsets = byte offsets of x, y, z, intensity."""
+        f = self._f("decode_velodyne"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 7 + [C.c_void_p, C.c_void_p]
+        d = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, point_step)
+        out = np.zeros((len(d), 5), np.float32) if to_host else None
+        n_out = C.c_int32(0)
+        self._check(f(self.ctx, _ptr(d), len(d), point_step, offsets[0], offsets[1], offsets[2], offsets[3], n_scans, _ptr(out), C.byref(n_out)), "decode_velodyne")
+        return (out[:n_out.value] if to_host else None), n_out.value
+
+    def decode_result_ptr(self):
+        f = self._f("decode_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
+        return f(self.ctx)
+
     def undistort(self, pts_xyzit, imu, lidar_beg_time, last_update_time, imu_ctx, state, to_host=True):
         """UndistortPcl.  pts_xyzit: n x 5 float32 (x y z intensity offset_ms); imu: m x 7 float64 (t, gyr, acc).
         Returns (cloud n x 4 in time order | None, propagated state, last_update_time); imu_ctx is updated in place."""

@@ -413,6 +413,59 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     return 0;
 }
 
+// ---- sensor decode: flag -> exclusive scan -> compact, in arrival order
+static int decode_finish(immesh_ctx* c, int n, float* out_xyzit, int32_t* n_out) {
+    int32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_nseg, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (out_xyzit && cnt > 0) HIPCHK(c, hipMemcpy(out_xyzit, c->d_und_in, (size_t)cnt * 20, hipMemcpyDefault));
+    if (n_out) *n_out = cnt;
+    (void)n;
+    return 0;
+}
+// Preprocess::avia_handler, feature_enabled == false   src/preprocess.cpp:139-232
+int immesh_decode_livox(immesh_ctx* c, const uint8_t* wire, int32_t n, int32_t n_scans, int32_t point_filter_num, double blind, float* out_xyzit, int32_t* n_out) {
+    if (!c || !wire || n <= 0 || n > c->cap_scan || n_scans <= 0 || point_filter_num <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
+    hipStream_t s = c->stream;
+    const void* d_in;
+    int rc;
+    if (!c->d_raw_stage && (rc = c->dalloc(&c->d_raw_stage, (size_t)c->cap_scan * 64))) return rc;
+    if ((rc = resolve_input(c, wire, (size_t)n * 19, c->d_raw_stage, &d_in))) return rc;
+    int32_t* flag = c->d_idx_a; int32_t* scan = c->d_idx_b; int32_t* keep = c->d_idx_c; int32_t* pos = c->d_seg_start;
+    launch_decode_livox_count(s, (const uint8_t*)d_in, n, n_scans, flag);
+    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, flag, scan, n);
+    launch_decode_livox_keep(s, (const uint8_t*)d_in, n, n_scans, point_filter_num, blind * blind, scan, keep);
+    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, keep, pos, n);
+    launch_decode_livox_emit(s, (const uint8_t*)d_in, n, keep, pos, c->d_und_in, c->d_nseg);
+    return decode_finish(c, n, out_xyzit, n_out);
+}
+// Preprocess::velodyne_handler   src/preprocess.cpp:497-526
+int immesh_decode_velodyne(immesh_ctx* c, const uint8_t* data, int32_t n, int32_t point_step, int32_t off_x, int32_t off_y, int32_t off_z, int32_t off_intensity,
+                           int32_t n_scans, float* out_xyzit, int32_t* n_out) {
+    const int32_t mx = std::max(std::max(off_x, off_y), std::max(off_z, off_intensity));
+    if (!c || !data || n <= 0 || n > c->cap_scan || point_step < 16 || point_step > 64 || std::min(std::min(off_x, off_y), std::min(off_z, off_intensity)) < 0 || mx + 4 > point_step) {
+        if (c) c->err = "bad arguments (point_step 16..64, float32 fields inside the point)";
+        return IMMESH_E_INVAL;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    if (const int s_rc = settle(c)) return s_rc;
+    hipStream_t s = c->stream;
+    const void* d_in;
+    int rc;
+    if (!c->d_raw_stage && (rc = c->dalloc(&c->d_raw_stage, (size_t)c->cap_scan * 64))) return rc;
+    if ((rc = resolve_input(c, data, (size_t)n * point_step, c->d_raw_stage, &d_in))) return rc;
+    int32_t* keep = c->d_idx_c; int32_t* pos = c->d_seg_start;
+    launch_decode_velodyne_keep(s, (const uint8_t*)d_in, n, point_step, off_x, off_y, off_z, n_scans, keep);
+    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, keep, pos, n);
+    launch_decode_velodyne_emit(s, (const uint8_t*)d_in, n, point_step, off_x, off_y, off_z, off_intensity, keep, pos, c->d_und_in, c->d_nseg);
+    return decode_finish(c, n, out_xyzit, n_out);
+}
+const float* immesh_decode_result(immesh_ctx* c) { return c ? c->d_und_in : nullptr; }
+
 // ImuProcess::UndistortPcl (src/IMU_Processing.cpp:755-958): IMU forward propagation on the host, per-point compensation on the device
 int immesh_undistort(immesh_ctx* c, const float* pts, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time,
                      double* last_update_time, immesh_imu_ctx* ic, double* state_inout, float* out_xyzi) {

@@ -196,6 +196,84 @@ void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, in
     KLAUNCH(undistort_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts5, order, n, poses, n_poses, fe, (float4*)out_xyzi);
 }
 
+// =====================================================================================================================
+// sensor decode: Preprocess::avia_handler / velodyne_handler as flag -> scan -> compact
+// =====================================================================================================================
+IMD float rd_f32(const uint8_t* p) { uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); return __uint_as_float(v); }
+IMD uint32_t rd_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+// pass 0: counted[i] = 1 when the point takes part in the valid_num count (i >= 1 && line < N_SCANS)
+__global__ void decode_livox_count_kernel(const uint8_t* __restrict__ w, int n, int n_scans, int32_t* __restrict__ counted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    counted[i] = (i >= 1 && (int)w[(size_t)i * 19 + 18] < n_scans) ? 1 : 0;
+}
+// pass 1 (after an exclusive scan of counted): keep[i]
+__global__ void decode_livox_keep_kernel(const uint8_t* __restrict__ w, int n, int n_scans, int filter, double blind_sqr, const int32_t* __restrict__ valid_excl,
+                                         int32_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int k = 0;
+    const uint8_t* p = w + (size_t)i * 19;
+    if (i >= 1 && (int)p[18] < n_scans) {
+        const int valid_num = valid_excl[i] + 1;   // valid_num++ happens before the test
+        if (valid_num % filter == 0) {
+            const float x = rd_f32(p + 4), y = rd_f32(p + 8), z = rd_f32(p + 12), inten = (float)p[16];
+            if (inten > 4 && (double)(x * x + y * y + z * z) > blind_sqr) k = 1;
+        }
+    }
+    keep[i] = k;
+}
+__global__ void decode_livox_emit_kernel(const uint8_t* __restrict__ w, int n, const int32_t* __restrict__ keep_flag, const int32_t* __restrict__ pos, float* __restrict__ out,
+                                         int32_t* __restrict__ n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (keep_flag[i]) {
+        const uint8_t* p = w + (size_t)i * 19;
+        float* o = out + (size_t)pos[i] * 5;
+        o[0] = rd_f32(p + 4); o[1] = rd_f32(p + 8); o[2] = rd_f32(p + 12); o[3] = (float)p[16];
+        o[4] = (float)rd_u32(p) / float(1000000);   // offset_time / float(1000000): curvature = time of the point in ms
+    }
+    if (i == n - 1) *n_out = pos[i] + keep_flag[i];
+}
+__global__ void decode_velodyne_keep_kernel(const uint8_t* __restrict__ d, int n, int step, int ox, int oy, int oz, int n_scans, int32_t* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* p = d + (size_t)i * step;
+    const float x = rd_f32(p + ox), y = rd_f32(p + oy), z = rd_f32(p + oz);
+    const float angle = (float)((double)(atanf(z / sqrtf(x * x + y * y)) * 180) / 3.14159265358979323846);
+    int scan_id;
+    if ((double)angle >= -8.83) scan_id = (int)((2 - (double)angle) * 3.0 + 0.5);
+    else scan_id = n_scans / 2 + (int)((-8.83 - (double)angle) * 2.0 + 0.5);
+    keep[i] = ((double)angle > 2 || (double)angle < -24.33 || scan_id > 50 || scan_id < 0) ? 0 : 1;
+}
+__global__ void decode_velodyne_emit_kernel(const uint8_t* __restrict__ d, int n, int step, int ox, int oy, int oz, int oi, const int32_t* __restrict__ keep_flag,
+                                            const int32_t* __restrict__ pos, float* __restrict__ out, int32_t* __restrict__ n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (keep_flag[i]) {
+        const uint8_t* p = d + (size_t)i * step;
+        float* o = out + (size_t)pos[i] * 5;
+        o[0] = rd_f32(p + ox); o[1] = rd_f32(p + oy); o[2] = rd_f32(p + oz); o[3] = rd_f32(p + oi); o[4] = 0.f;
+    }
+    if (i == n - 1) *n_out = pos[i] + keep_flag[i];
+}
+void launch_decode_livox_count(hipStream_t s, const uint8_t* w, int n, int n_scans, int32_t* counted) {
+    KLAUNCH(decode_livox_count_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, n, n_scans, counted);
+}
+void launch_decode_livox_keep(hipStream_t s, const uint8_t* w, int n, int n_scans, int filter, double blind_sqr, const int32_t* valid_excl, int32_t* keep) {
+    KLAUNCH(decode_livox_keep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, n, n_scans, filter, blind_sqr, valid_excl, keep);
+}
+void launch_decode_livox_emit(hipStream_t s, const uint8_t* w, int n, const int32_t* keep, const int32_t* pos, float* out, int32_t* n_out) {
+    KLAUNCH(decode_livox_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, n, keep, pos, out, n_out);
+}
+void launch_decode_velodyne_keep(hipStream_t s, const uint8_t* d, int n, int step, int ox, int oy, int oz, int n_scans, int32_t* keep) {
+    KLAUNCH(decode_velodyne_keep_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, n, step, ox, oy, oz, n_scans, keep);
+}
+void launch_decode_velodyne_emit(hipStream_t s, const uint8_t* d, int n, int step, int ox, int oy, int oz, int oi, const int32_t* keep, const int32_t* pos, float* out,
+                                 int32_t* n_out) {
+    KLAUNCH(decode_velodyne_emit_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, n, step, ox, oy, oz, oi, keep, pos, out, n_out);
+}
+
 // ---- launchers ------------------------------------------------------------------------------------------------------
 void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm) {
     KLAUNCH(ds_minmax_kernel, dim3(min(1024, (n + 255) / 256)), dim3(256), 0, s, pts, n, stride, inv, mm);

@@ -47,6 +47,12 @@ void launch_ds_index(hipStream_t s, const float* pts, int n, int stride, float i
 void launch_ds_heads(hipStream_t s, const unsigned long long* keys_sorted, int n, int32_t* flags);
 void launch_ds_centroid(hipStream_t s, const float* pts, int n, int stride, const unsigned long long* keys_sorted, const int32_t* idx_sorted, const int32_t* rank,
                         float* out, int32_t* n_out);
+void launch_decode_livox_count(hipStream_t s, const uint8_t* w, int n, int n_scans, int32_t* counted);
+void launch_decode_livox_keep(hipStream_t s, const uint8_t* w, int n, int n_scans, int filter, double blind_sqr, const int32_t* valid_excl, int32_t* keep);
+void launch_decode_livox_emit(hipStream_t s, const uint8_t* w, int n, const int32_t* keep, const int32_t* pos, float* out, int32_t* n_out);
+void launch_decode_velodyne_keep(hipStream_t s, const uint8_t* d, int n, int step, int ox, int oy, int oz, int n_scans, int32_t* keep);
+void launch_decode_velodyne_emit(hipStream_t s, const uint8_t* d, int n, int step, int ox, int oy, int oz, int oi, const int32_t* keep, const int32_t* pos, float* out,
+                                 int32_t* n_out);
 void launch_undistort_keys(hipStream_t s, const float* pts5, int n, uint32_t* key, int32_t* idx);
 void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, int n, const double* poses, int n_poses, const double* fe, float* out_xyzi);
 void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xyzi);

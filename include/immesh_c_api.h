@@ -183,6 +183,22 @@ int immesh_ikd_size(immesh_ctx* ctx, int64_t* n);
 int immesh_ikd_dump(immesh_ctx* ctx, float* xyz, int64_t cap, int64_t* n_out);
 int immesh_ikd_knn(immesh_ctx* ctx, const float* q_xyz, int32_t nq, float* nn_xyz /* nq x 5 x 3 */, float* d2 /* nq x 5 */, int32_t* n_found /* nq */);
 
+/* ---- before the path: sensor decode ----------------------------------------------------------------------------- */
+/* void Preprocess::avia_handler(const livox_ros_driver::CustomMsg::ConstPtr&)   src/preprocess.cpp:139-232, feature_enabled == false (every
+ * shipped config).  wire_points: msg->points as serialised on the wire, n x 19 bytes, little endian
+ * {uint32 offset_time [ns]; float32 x, y, z; uint8 reflectivity, tag, line}.  Points 1 .. n-1 with line < n_scans are counted; every
+ * point_filter_num-th of them is kept when reflectivity > 4 and x^2+y^2+z^2 > blind^2.  out_xyzit: n_out x 5 floats
+ * (x, y, z, intensity = reflectivity, curvature = offset_time / 1e6 [ms]) in arrival order -- the layout immesh_undistort consumes.
+ * out may be a host or a device pointer (capacity n); NULL leaves the cloud in the context (immesh_decode_result). */
+int immesh_decode_livox(immesh_ctx* ctx, const uint8_t* wire_points, int32_t n, int32_t n_scans, int32_t point_filter_num, double blind,
+                        float* out_xyzit, int32_t* n_out);
+/* void Preprocess::velodyne_handler(const sensor_msgs::PointCloud2::ConstPtr&)   src/preprocess.cpp:497-526.  data: msg->data (n points of
+ * point_step bytes); off_*: byte offsets of the float32 fields x, y, z, intensity (msg->fields).  Keeps the points whose elevation
+ * atan(z / sqrt(x^2+y^2)) lies in [-24.33, 2] degrees and whose HDL-64 scan id is in [0, 50]; curvature is 0 (the handler does not set it). */
+int immesh_decode_velodyne(immesh_ctx* ctx, const uint8_t* data, int32_t n, int32_t point_step, int32_t off_x, int32_t off_y, int32_t off_z,
+                           int32_t off_intensity, int32_t n_scans, float* out_xyzit, int32_t* n_out);
+const float* immesh_decode_result(immesh_ctx* ctx);
+
 /* ---- before the path: motion undistortion ---------------------------------------------------------------- */
 typedef struct immesh_imu_sample {   /* sensor_msgs/Imu: header.stamp, angular_velocity, linear_acceleration */
     double t;

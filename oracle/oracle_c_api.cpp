@@ -206,6 +206,21 @@ int orc_ikd_register(void* p, const float* body, int32_t n, const double* state_
     if (normals_pd2) std::memcpy(normals_pd2, r.normals_pd2.data(), r.normals_pd2.size() * sizeof(float));
     return 0;
 }
+int orc_decode_livox(void*, const uint8_t* wire, int32_t n, int32_t n_scans, int32_t point_filter_num, double blind, float* out, int32_t* n_out) {
+    std::vector<float> o;
+    const int k = orc::decode_livox(wire, n, n_scans, point_filter_num, blind, o);
+    if (out) std::memcpy(out, o.data(), o.size() * sizeof(float));
+    if (n_out) *n_out = k;
+    return 0;
+}
+int orc_decode_velodyne(void*, const uint8_t* data, int32_t n, int32_t step, int32_t ox, int32_t oy, int32_t oz, int32_t oi, int32_t n_scans, float* out, int32_t* n_out) {
+    std::vector<float> o;
+    const int k = orc::decode_velodyne(data, n, step, ox, oy, oz, oi, n_scans, o);
+    if (out) std::memcpy(out, o.data(), o.size() * sizeof(float));
+    if (n_out) *n_out = k;
+    return 0;
+}
+const float* orc_decode_result(void*) { return nullptr; }
 int orc_undistort(void* p, const float* pts_xyzit, int32_t n, const immesh_imu_sample* imu, int32_t n_imu, double lidar_beg_time, double* last_update_time,
                   immesh_imu_ctx* ic, double* state_inout, float* out_xyzi) {   // ImuProcess::UndistortPcl, IMU_Processing.cpp:755-958
     (void)p;

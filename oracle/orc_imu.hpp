@@ -151,4 +151,39 @@ inline void undistort_pcl(const float* pts, int n, const immesh_imu_sample* imu,
     }
 }
 
+// Preprocess::avia_handler with feature_enabled == false (src/preprocess.cpp:139-232).  wire: n x 19 bytes {u32 offset_time; f32 x, y, z; u8 reflectivity, tag, line}
+inline int decode_livox(const uint8_t* wire, int n, int n_scans, int point_filter_num, double blind, std::vector<float>& out) {
+    out.clear();
+    unsigned valid_num = 0;
+    const double blind_sqr = blind * blind;
+    for (int i = 1; i < n; i++) {
+        const uint8_t* p = wire + (size_t)i * 19;
+        if (!((int)p[18] < n_scans)) continue;
+        valid_num++;
+        if (valid_num % (unsigned)point_filter_num != 0) continue;
+        float x, y, z; uint32_t ot;
+        std::memcpy(&ot, p, 4); std::memcpy(&x, p + 4, 4); std::memcpy(&y, p + 8, 4); std::memcpy(&z, p + 12, 4);
+        const float inten = (float)p[16];
+        const float curv = (float)ot / float(1000000);
+        if ((inten > 4) && ((double)(x * x + y * y + z * z) > blind_sqr)) { out.push_back(x); out.push_back(y); out.push_back(z); out.push_back(inten); out.push_back(curv); }
+    }
+    return (int)out.size() / 5;
+}
+// Preprocess::velodyne_handler (src/preprocess.cpp:497-526)
+inline int decode_velodyne(const uint8_t* data, int n, int step, int ox, int oy, int oz, int oi, int n_scans, std::vector<float>& out) {
+    out.clear();
+    for (int i = 0; i < n; i++) {
+        const uint8_t* p = data + (size_t)i * step;
+        float x, y, z, inten;
+        std::memcpy(&x, p + ox, 4); std::memcpy(&y, p + oy, 4); std::memcpy(&z, p + oz, 4); std::memcpy(&inten, p + oi, 4);
+        const float angle = (float)((double)(std::atan(z / std::sqrt(x * x + y * y)) * 180) / M_PI);   // float atan / sqrt overloads
+        int scan_id;
+        if (angle >= -8.83) scan_id = int((2 - angle) * 3.0 + 0.5);
+        else scan_id = n_scans / 2 + int((-8.83 - angle) * 2.0 + 0.5);
+        if (angle > 2 || angle < -24.33 || scan_id > 50 || scan_id < 0) continue;
+        out.push_back(x); out.push_back(y); out.push_back(z); out.push_back(inten); out.push_back(0.f);
+    }
+    return (int)out.size() / 5;
+}
+
 }  // namespace orc
