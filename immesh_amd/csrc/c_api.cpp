@@ -81,7 +81,8 @@ static int alloc_all(immesh_ctx* c) {
 #undef A
     HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_out48_host, c->h_out48, 0));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_counters_host, c->h_counters, 0));
     return 0;
 }
 
@@ -320,7 +321,8 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         c->map.upd_seq++;
         c->map.touched = (uint32_t*)c->d_seg_start;
         launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host);
+        return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
         launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, nullptr);

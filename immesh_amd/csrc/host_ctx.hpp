@@ -72,6 +72,7 @@ struct immesh_ctx {
     size_t sort_temp_bytes = 0;
     char* d_raw_stage = nullptr;     // sensor decode: staging for wire-format clouds handed over as host memory (cap_scan x 64 B, first use)
     float *d_und_in = nullptr, *d_und_out = nullptr; double* d_und_tab = nullptr;   // immesh_undistort staging: n x 5 in, n x 4 out, pose table
+    int32_t* d_counters_host = nullptr;   // device view of h_counters
     int32_t* h_counters = nullptr;   // pinned copy of map.counters (8 ints)
     unsigned long long* d_dump_count = nullptr;
 

@@ -714,6 +714,17 @@ __global__ void merge_free_kernel(RegMapDev m) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) m.free_ready[base + i] = m.free_pending[i];
 }
 __global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; m.counters[7] = 0; }
+// Tail of the per-scan map update, one launch: chunks freed by the replay kernel join the free list, the per-update counters reset, and the map
+// counters (node / chunk usage, capacity flag) go straight to pinned host memory -- the next scan's residual passes are queued right behind it.
+__global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32_t* __restrict__ host_counters) {
+    const int np = m.counters[3];
+    const int base = m.counters[2];
+    for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // =====================================================================================================================
 // introspection
@@ -759,10 +770,9 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
     KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats) {
+                         int64_t* stats, int32_t* host_counters) {
     KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats);
-    KLAUNCH(merge_free_kernel, dim3(64), dim3(256), 0, s, m);
-    KLAUNCH(merge_free_finish_kernel, dim3(1), dim3(1), 0, s, m);
+    KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
     (void)hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
