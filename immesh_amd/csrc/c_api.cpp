@@ -76,6 +76,8 @@ static int alloc_all(immesh_ctx* c) {
     A(c->d_slot, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 16); A(c->d_ds_out, ns * 3);
     c->sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns), exclusive_sum_temp_bytes((int)ns)}) + 256;
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
+    A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns);
+    { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     A(c->d_dump_count, 2);
     A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
 #undef A
@@ -112,6 +114,10 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
         g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
     }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
+    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(c->ev_inputs_free, c->stream) != hipSuccess) {
+        g_create_error = "hipStreamCreate/hipEventCreate failed"; immesh_destroy(c); return nullptr;
+    }
     // per-config constants of calcBodyVar: pow(sin(DEG2RAD(deg)),2) with PCL's DEG2RAD(x) = x*0.017453293 and float `degree_inc`
     { const double s = std::sin((double)(float)cfg->beam_err * 0.017453293); c->dvar_beam = s * s; }
     { const double s = std::sin((double)(float)0.01 * 0.017453293); c->dvar_calib = s * s; }
@@ -126,6 +132,8 @@ void immesh_destroy(immesh_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_pre) { (void)hipStreamSynchronize(c->stream_pre); (void)hipStreamDestroy(c->stream_pre); }
+    if (c->ev_inputs_free) (void)hipEventDestroy(c->ev_inputs_free);
     mesh_free(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_out48) (void)hipHostFree(c->h_out48);
@@ -311,7 +319,7 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
 }
 
 // shared by map_build / map_update: per-point var + root slots, sort, per-voxel replay
-static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode) {
+static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr) {
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
@@ -321,6 +329,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         c->map.upd_seq++;
         c->map.touched = (uint32_t*)c->d_seg_start;
         launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
+        if (after_point_var) HIPCHK(c, hipEventRecord(after_point_var, s));   // the scan's input clouds are consumed: the replay works on its own copies
         launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
@@ -392,16 +401,18 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     if ((rc = settle(c, true))) return rc;
     c->ev_par = par;
     (void)hipEventRecord(ev[1], c->stream);
-    if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0))) return rc;
-    (void)hipEventRecord(ev[2], c->stream);
     long job = 0;
     if (mesh_mode) {
         // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own streams + worker thread), as
-        // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417)
+        // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417).  The pose is final, so this goes
+        // ahead of the map growth: the mesher starts a map update earlier, and the input clouds are free for the next scan's pre-processing
+        // as soon as point_var has run.
         float* world = mesh_next_world_buffer(c);
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
+    if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free))) return rc;
+    (void)hipEventRecord(ev[2], c->stream);
     (void)hipEventRecord(ev[3], c->stream);
     c->timing[3] = 0.f;   // (immesh_mesh_wait fills in the mesher's time)
     imh::store_state(st, state_inout);
@@ -415,11 +426,28 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     return 0;
 }
 
+// The stages before the path run on their own stream (they do not read the map) with their own scratch, so they overlap the previous scan's
+// map update when immesh_process_scan was asynchronous.  What they share with that scan are its INPUT clouds: the result buffers below are the
+// down-sampled / raw clouds an asynchronous immesh_process_scan may still be reading (point_var, transform) -- writers wait for ev_inputs_free.
+static int pre_resolve(immesh_ctx* c, const void* p, size_t bytes, void* staging, const void** dev_out) {
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    bool is_dev = false;
+    if (e == hipSuccess) is_dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+    else (void)hipGetLastError();
+    if (is_dev) { *dev_out = p; return 0; }
+    HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_free, 0));   // the staging buffers double as immesh_process_scan's own staging
+    HIPCHK(c, hipMemcpyAsync(staging, p, bytes, hipMemcpyHostToDevice, c->stream_pre));
+    *dev_out = staging;
+    return 0;
+}
+#define PRE_OUTPUT_FENCE(c) HIPCHK(c, hipStreamWaitEvent((c)->stream_pre, (c)->ev_inputs_free, 0))
+
 // ---- sensor decode: flag -> exclusive scan -> compact, in arrival order
 static int decode_finish(immesh_ctx* c, int n, float* out_xyzit, int32_t* n_out) {
     int32_t cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_nseg, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->p_nseg, 4, hipMemcpyDeviceToHost, c->stream_pre));
+    HIPCHK(c, hipStreamSynchronize(c->stream_pre));
     if (out_xyzit && cnt > 0) HIPCHK(c, hipMemcpy(out_xyzit, c->d_und_in, (size_t)cnt * 20, hipMemcpyDefault));
     if (n_out) *n_out = cnt;
     (void)n;
@@ -430,18 +458,18 @@ int immesh_decode_livox(immesh_ctx* c, const uint8_t* wire, int32_t n, int32_t n
     if (!c || !wire || n <= 0 || n > c->cap_scan || n_scans <= 0 || point_filter_num <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
-    if (const int s_rc = settle(c)) return s_rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->stream_pre;
     const void* d_in;
     int rc;
     if (!c->d_raw_stage && (rc = c->dalloc(&c->d_raw_stage, (size_t)c->cap_scan * 64))) return rc;
-    if ((rc = resolve_input(c, wire, (size_t)n * 19, c->d_raw_stage, &d_in))) return rc;
-    int32_t* flag = c->d_idx_a; int32_t* scan = c->d_idx_b; int32_t* keep = c->d_idx_c; int32_t* pos = c->d_seg_start;
+    if ((rc = pre_resolve(c, wire, (size_t)n * 19, c->d_raw_stage, &d_in))) return rc;
+    int32_t* flag = c->p_idx_a; int32_t* scan = c->p_idx_b; int32_t* keep = c->p_idx_c; int32_t* pos = c->p_seg;
     launch_decode_livox_count(s, (const uint8_t*)d_in, n, n_scans, flag);
-    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, flag, scan, n);
+    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, flag, scan, n);
     launch_decode_livox_keep(s, (const uint8_t*)d_in, n, n_scans, point_filter_num, blind * blind, scan, keep);
-    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, keep, pos, n);
-    launch_decode_livox_emit(s, (const uint8_t*)d_in, n, keep, pos, c->d_und_in, c->d_nseg);
+    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, keep, pos, n);
+    PRE_OUTPUT_FENCE(c);
+    launch_decode_livox_emit(s, (const uint8_t*)d_in, n, keep, pos, c->d_und_in, c->p_nseg);
     return decode_finish(c, n, out_xyzit, n_out);
 }
 // Preprocess::velodyne_handler   src/preprocess.cpp:497-526
@@ -454,16 +482,16 @@ int immesh_decode_velodyne(immesh_ctx* c, const uint8_t* data, int32_t n, int32_
     }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
-    if (const int s_rc = settle(c)) return s_rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->stream_pre;
     const void* d_in;
     int rc;
     if (!c->d_raw_stage && (rc = c->dalloc(&c->d_raw_stage, (size_t)c->cap_scan * 64))) return rc;
-    if ((rc = resolve_input(c, data, (size_t)n * point_step, c->d_raw_stage, &d_in))) return rc;
-    int32_t* keep = c->d_idx_c; int32_t* pos = c->d_seg_start;
+    if ((rc = pre_resolve(c, data, (size_t)n * point_step, c->d_raw_stage, &d_in))) return rc;
+    int32_t* keep = c->p_idx_c; int32_t* pos = c->p_seg;
     launch_decode_velodyne_keep(s, (const uint8_t*)d_in, n, point_step, off_x, off_y, off_z, n_scans, keep);
-    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, keep, pos, n);
-    launch_decode_velodyne_emit(s, (const uint8_t*)d_in, n, point_step, off_x, off_y, off_z, off_intensity, keep, pos, c->d_und_in, c->d_nseg);
+    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, keep, pos, n);
+    PRE_OUTPUT_FENCE(c);
+    launch_decode_velodyne_emit(s, (const uint8_t*)d_in, n, point_step, off_x, off_y, off_z, off_intensity, keep, pos, c->d_und_in, c->p_nseg);
     return decode_finish(c, n, out_xyzit, n_out);
 }
 const float* immesh_decode_result(immesh_ctx* c) { return c ? c->d_und_in : nullptr; }
@@ -477,10 +505,9 @@ int immesh_undistort(immesh_ctx* c, const float* pts, int32_t n, const immesh_im
     }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
-    if (const int s_rc = settle(c)) return s_rc;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->stream_pre;
     const void* d_in;
-    int rc = resolve_input(c, pts, (size_t)n * 20, c->d_und_in, &d_in);
+    int rc = pre_resolve(c, pts, (size_t)n * 20, c->d_und_in, &d_in);
     if (rc) return rc;
     float end_curv = 0.f;   // curvature of the package's last point in arrival order (pcl_end_time, :785)
     HIPCHK(c, hipMemcpyAsync(&end_curv, (const float*)d_in + (size_t)(n - 1) * 5 + 4, 4, hipMemcpyDeviceToHost, s));
@@ -495,9 +522,10 @@ int immesh_undistort(immesh_ctx* c, const float* pts, int32_t n, const immesh_im
     double* fe = &tab[poses.size() * 23];
     std::memcpy(fe, st.R, 72); std::memcpy(fe + 9, st.t, 24); std::memcpy(fe + 12, ic->lid_rot_to_imu, 72); std::memcpy(fe + 21, ic->lid_offset_to_imu, 24);
     HIPCHK(c, hipMemcpyAsync(c->d_und_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, s));
-    launch_undistort_keys(s, (const float*)d_in, n, c->d_slot, c->d_idx_a);
-    sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_slot, c->d_slot_s, c->d_idx_a, c->d_idx_c, n, 32);   // stable: equal stamps keep arrival order
-    launch_undistort(s, (const float*)d_in, c->d_idx_c, n, c->d_und_tab, (int)poses.size(), c->d_und_tab + poses.size() * 23, c->d_und_out);
+    launch_undistort_keys(s, (const float*)d_in, n, c->p_slot, c->p_idx_a);
+    sort_pairs_u32(s, c->p_sort_temp, c->sort_temp_bytes, c->p_slot, c->p_slot_s, c->p_idx_a, c->p_idx_c, n, 32);   // stable: equal stamps keep arrival order
+    PRE_OUTPUT_FENCE(c);
+    launch_undistort(s, (const float*)d_in, c->p_idx_c, n, c->d_und_tab, (int)poses.size(), c->d_und_tab + poses.size() * 23, c->d_und_out);
     if (out_xyzi) {
         HIPCHK(c, hipMemcpyAsync(out_xyzi, c->d_und_out, (size_t)n * 16, hipMemcpyDefault, s));
     }
@@ -560,23 +588,35 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0 || !n_out) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
-    hipStream_t s = c->stream;
+    hipStream_t s = c->stream_pre;
     const void* d_pts;
-    int rc = resolve_input(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts);
+    int rc = pre_resolve(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts);
     if (rc) return rc;
     const float inv = (float)(1.0 / leaf);   // np.float32(1.0 / leaf)
-    int32_t* mm = c->d_nseg;                 // 6 ints of scratch: floor(min), floor(max)
+    int32_t* mm = c->p_nseg;                 // 6 ints of scratch: floor(min), floor(max)
     const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     HIPCHK(c, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, s));
     launch_ds_minmax(s, (const float*)d_pts, n, stride, inv, mm);
-    launch_ds_index(s, (const float*)d_pts, n, stride, inv, mm, c->d_key_a, c->d_idx_a);
-    sort_pairs_u64(s, c->d_sort_temp, c->sort_temp_bytes, c->d_key_a, c->d_key_b, c->d_idx_a, c->d_idx_b, n);   // stable: ties keep scan order
-    launch_ds_heads(s, c->d_key_b, n, c->d_idx_c);
-    exclusive_sum_i32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_idx_c, c->d_idx_c, n);
+    launch_ds_index(s, (const float*)d_pts, n, stride, inv, mm, c->p_key_a, c->p_idx_a);
+    // the leaf index is below dx * dy * dz: sorting only its significant bits (typically ~24 of 64) cuts the radix passes from 8 to 3 -- worth the
+    // small read-back of the grid extents
+    int h_mm[6];
+    HIPCHK(c, hipMemcpyAsync(h_mm, mm, sizeof(h_mm), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int key_bits = 1;
+    {
+        const unsigned long long total = (unsigned long long)((long long)h_mm[3] - h_mm[0] + 1) * (unsigned long long)((long long)h_mm[4] - h_mm[1] + 1) *
+                                         (unsigned long long)((long long)h_mm[5] - h_mm[2] + 1);
+        while (key_bits < 64 && (total >> key_bits) != 0) key_bits++;
+    }
+    sort_pairs_u64(s, c->p_sort_temp, c->sort_temp_bytes, c->p_key_a, c->p_key_b, c->p_idx_a, c->p_idx_b, n, key_bits);   // stable: ties keep scan order
+    launch_ds_heads(s, c->p_key_b, n, c->p_idx_c);
+    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, c->p_idx_c, c->p_idx_c, n);
     float* d_out = c->d_ds_out;
-    launch_ds_centroid(s, (const float*)d_pts, n, stride, c->d_key_b, c->d_idx_b, c->d_idx_c, d_out, c->d_nseg + 8);
+    PRE_OUTPUT_FENCE(c);
+    launch_ds_centroid(s, (const float*)d_pts, n, stride, c->p_key_b, c->p_idx_b, c->p_idx_c, d_out, c->p_nseg + 8);
     int32_t cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_nseg + 8, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->p_nseg + 8, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     *n_out = cnt;
     if (out_xyz) {

@@ -30,6 +30,8 @@ struct immesh_ctx {
     immesh_config cfg;
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t stream_pre = nullptr;    // the stages before the path (decode / undistort / down-sample): they do not touch the map, so they run beside the previous scan's map update
+    hipEvent_t ev_inputs_free = nullptr; // recorded on `stream` when the last asynchronous scan has consumed its input clouds (after point_var + transform)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // two sets of four (scan parity)
     int ev_par = 0;
     bool pending = false;            // the last immesh_process_scan returned without waiting for its map update (IMMESH_SCAN_NOWAIT)
@@ -70,6 +72,11 @@ struct immesh_ctx {
     int32_t* d_nseg = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    // scratch of the pre-processing stream (its own copies: the map update uses d_key_a / d_idx_a / d_slot / d_sort_temp concurrently)
+    unsigned long long *p_key_a = nullptr, *p_key_b = nullptr;
+    int32_t *p_idx_a = nullptr, *p_idx_b = nullptr, *p_idx_c = nullptr, *p_seg = nullptr, *p_nseg = nullptr;
+    uint32_t *p_slot = nullptr, *p_slot_s = nullptr;
+    void* p_sort_temp = nullptr;
     char* d_raw_stage = nullptr;     // sensor decode: staging for wire-format clouds handed over as host memory (cap_scan x 64 B, first use)
     float *d_und_in = nullptr, *d_und_out = nullptr; double* d_und_tab = nullptr;   // immesh_undistort staging: n x 5 in, n x 4 out, pose table
     int32_t* d_counters_host = nullptr;   // device view of h_counters
@@ -115,7 +122,7 @@ inline int resolve_input(immesh_ctx* c, const void* p, size_t bytes, void* stagi
 struct ProfBind {  // binds the ctx profiler to the calling thread for the duration of one C-ABI call
     immesh_ctx* c;
     explicit ProfBind(immesh_ctx* ctx) : c(ctx) { g_kprof = &ctx->prof; }
-    ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); c->prof.flush(); } g_kprof = nullptr; }
+    ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre); c->prof.flush(); } g_kprof = nullptr; }
 };
 
 // mesher host orchestration (mesh_host.cpp)

@@ -63,6 +63,6 @@ void exclusive_sum_i32(hipStream_t s, void* temp, size_t temp_bytes, const int32
 size_t sort_pairs_u64_temp_bytes(int n);
 size_t sort_pairs_u32_temp_bytes(int n);
 void sort_pairs_u64(hipStream_t s, void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
-                    const int32_t* vals_in, int32_t* vals_out, int n);
+                    const int32_t* vals_in, int32_t* vals_out, int n, int end_bit = 64);
 void sort_pairs_u32(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in,
                     int32_t* vals_out, int n, int end_bit);

@@ -19,8 +19,8 @@ size_t sort_pairs_u32_temp_bytes(int n) {
     return bytes;
 }
 void sort_pairs_u64(hipStream_t s, void* temp, size_t temp_bytes, const unsigned long long* keys_in, unsigned long long* keys_out,
-                    const int32_t* vals_in, int32_t* vals_out, int n) {
-    KTIMED("radix_sort_pairs_u64", s, (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, s));
+                    const int32_t* vals_in, int32_t* vals_out, int n, int end_bit) {
+    KTIMED("radix_sort_pairs_u64", s, (void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, end_bit, s));
 }
 void sort_pairs_u32(hipStream_t s, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out, const int32_t* vals_in,
                     int32_t* vals_out, int n, int end_bit) {
