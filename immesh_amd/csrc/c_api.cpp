@@ -402,17 +402,26 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     c->ev_par = par;
     (void)hipEventRecord(ev[1], c->stream);
     long job = 0;
+    // IMMESH_SERIAL_ORDER: map growth first, then the hand-over to the mesher -- the order of the reference's map_incremental_grow; the default
+    // hands the scan over first (the pose is final), so the mesher starts a map update earlier and the input clouds are free for the next
+    // scan's pre-processing as soon as point_var has run
+    static const bool serial_order = getenv("IMMESH_SERIAL_ORDER") != nullptr;
+    if (serial_order) {
+        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, nullptr))) return rc;
+        (void)hipEventRecord(ev[2], c->stream);
+    }
     if (mesh_mode) {
         // transformLidar of the full scan on this stream, then hand the scan to the mesher (its own streams + worker thread), as
-        // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417).  The pose is final, so this goes
-        // ahead of the map growth: the mesher starts a map update earlier, and the input clouds are free for the next scan's pre-processing
-        // as soon as point_var has run.
+        // map_incremental_grow hands it to service_reconstruct_mesh (ImMesh_mesh_reconstruction.cpp:413-417)
         float* world = mesh_next_world_buffer(c);
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
-    if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free))) return rc;
-    (void)hipEventRecord(ev[2], c->stream);
+    if (serial_order) (void)hipEventRecord(c->ev_inputs_free, c->stream);
+    else {
+        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free))) return rc;
+        (void)hipEventRecord(ev[2], c->stream);
+    }
     (void)hipEventRecord(ev[3], c->stream);
     c->timing[3] = 0.f;   // (immesh_mesh_wait fills in the mesher's time)
     imh::store_state(st, state_inout);
