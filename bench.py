@@ -394,8 +394,8 @@ def main():
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},
-            "stages_ms_serial": {"gpu_total": round(stage[0] / args.steps, 4), "register": round(stage[1] / args.steps, 4),
-                          "map_update": round(stage[2] / args.steps, 4), "mesh": round(stage[3] / args.steps, 4)},
+            "stages_ms_serial": {"gpu_total": round(stage[0] / max(1, args.steps), 4), "register": round(stage[1] / max(1, args.steps), 4),
+                          "map_update": round(stage[2] / max(1, args.steps), 4), "mesh": round(stage[3] / max(1, args.steps), 4)},
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_new", "v_act", "n_u", "t_add", "t_rem")},
             "pose_err_m": round(pose_err, 4),
             "roofline": roofline, "cpu_baseline": cpu,
@@ -407,6 +407,9 @@ def main():
     if world > 1:
         D.barrier()          # rank 0 may still be in its roofline / CPU-baseline legs: leave together
         dist.destroy_process_group()
+    if prof_note:            # the instrumented child was killed: do not risk the runtime teardown of this process on a possibly disturbed device
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

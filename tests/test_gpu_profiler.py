@@ -1,0 +1,42 @@
+"""In-library HIP-event profiler (immesh_profile_enable / immesh_profile_read) with the mesher on -- the configuration whose bench legs failed at
+the end of round 1 (profiles/README.md).  Opt-in (IMMESH_TEST_PROFILER=1): it is the reproducer to start the next round with, not a gate --
+a hang here must not take the round-end GPU tier with it."""
+import os
+
+import numpy as np
+import pytest
+
+from immesh_amd import capi, synth
+from conftest import make_hip
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.environ.get("IMMESH_TEST_PROFILER"), reason="opt-in reproducer (set IMMESH_TEST_PROFILER=1)")]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_profiled_scans_with_mesher(hip_lib, mode):
+    torch = pytest.importorskip("torch")
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    h = make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(10):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, R, t, n_pts=100000, extT=extT)
+        scans.append((R, t, torch.from_numpy(raw).cuda(), torch.from_numpy(synth.voxel_grid_downsample(raw, 0.4)).cuda()))
+    R0, t0, raw0, _ = scans[0]
+    st = capi.make_state(R=R0, t=t0)
+    h.map_build(np.ascontiguousarray(raw0.cpu().numpy()[:, :3]), st)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    for k in range(1, 10):
+        if k == 5:
+            if mode == 2:
+                h.mesh_wait()
+            h.profile_enable(True)                      # scans 5.. run with HIP events (and the spin prelude) around every launch
+        prior = capi.forward_without_imu_native(hip_lib, st)
+        _, _, raw, down = scans[k]
+        st, info = h.process_scan(down.data_ptr(), raw.data_ptr(), prior, prior, frame_idx=k, do_mesh=1 if k >= 5 else mode, n_ds=len(down), n_raw=len(raw))
+        assert info["n_match"] > 1000
+    ks = h.profile_read()
+    h.profile_enable(False)
+    assert ks["residual_kernel"]["launches"] >= 5 * 3 and ks["mesh_delaunay_kernel<256>"]["launches"] == 5
+    assert 0.005 < ks["mesh_delaunay_kernel<256>"]["total_ms"] / 5 < 5.0
