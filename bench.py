@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     ap.add_argument("--profile-child", type=int, default=0, help="internal: run only the serial stage-timing + HIP-event profile legs and print their JSON (spawned by the parent run)")
     ap.add_argument("--profile-inproc", type=int, default=0, help="1 = run the profile legs inside this process instead of a child process")
-    ap.add_argument("--profile-timeout", type=float, default=240.0, help="seconds the parent waits for the profile child")
+    ap.add_argument("--profile-timeout", type=float, default=120.0, help="seconds the parent waits for the profile child")
     args = ap.parse_args()
 
     import torch
