@@ -357,28 +357,46 @@ def main():
             except Exception:
                 pass
 
-    # ---- CPU baseline leg: the oracle (CPU restatement, "port") on the host cores, bounded sample of the same stream
+    # ---- CPU baseline leg: the oracle (CPU restatement, "port") on the host cores, bounded sample of the same stream.  Two passes over the same
+    # scans, half the budget each: single-threaded, and with the reference's own threading (a 12-thread pool over mesh voxels,
+    # maximum_thread_for_rec_mesh; 4 OpenMP threads in the matcher, MP_PROC_NUM) -- the results are identical, the faster pass is reported.
     cpu = None
     if rank == 0 and args.cpu_seconds > 0:
         orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
         if not os.path.exists(orc_so):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
-        o = capi.HotPath(ctypes.CDLL(orc_so), cfg, "orc_")
-        so = capi.make_state(R=R0, t=t0)
-        o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # (kitti: exactly the GPU leg's map; avia: a local map instead of the 10M-voxel survey)
-        so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
-        if args.mesh:
-            o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
-        tc, nc, kk = 0.0, 0, 1
-        while tc < args.cpu_seconds and kk < len(raws):
-            prior = synth.forward_without_imu(so)
-            a = time.perf_counter()
-            so, _ = o.process_scan(downs[kk], raws[kk], prior, prior, frame_idx=kk, do_mesh=bool(args.mesh))
-            tc += time.perf_counter() - a
-            nc += 1; kk += 1
-        cpu = {"value": round(nc / tc, 4), "unit": "scans/s", "cores": 1, "kind": "port",
-               "sample": f"{nc} scans of the same stream through oracle/liboracle.so (single thread), map = scan 0 + growth (not the 10M-voxel map)",
-               "ms_per_scan": round(1e3 * tc / nc, 3)}
+        orc_lib = ctypes.CDLL(orc_so)
+
+        def cpu_pass(mesher_threads, matcher_threads, budget):
+            o = capi.HotPath(orc_lib, cfg, "orc_")
+            o.set_threads(mesher_threads, matcher_threads)
+            so = capi.make_state(R=R0, t=t0)
+            o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # (kitti: exactly the GPU leg's map; avia: a local map instead of the 10M-voxel survey)
+            so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+            if args.mesh:
+                o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
+            tc, nc, kk = 0.0, 0, 1
+            while tc < budget and kk < len(raws):
+                prior = synth.forward_without_imu(so)
+                a = time.perf_counter()
+                so, _ = o.process_scan(downs[kk], raws[kk], prior, prior, frame_idx=kk, do_mesh=bool(args.mesh))
+                tc += time.perf_counter() - a
+                nc += 1; kk += 1
+            o.close() if hasattr(o, "close") else None
+            return nc, tc
+
+        ncores = os.cpu_count() or 1
+        n1, t1 = cpu_pass(1, 1, args.cpu_seconds / 2)
+        mt = (min(12, ncores), min(4, ncores))
+        n2, t2 = cpu_pass(mt[0], mt[1], args.cpu_seconds / 2) if ncores > 1 else (n1, t1)
+        single, threaded = n1 / t1, n2 / t2
+        use_threads = threaded > single
+        nc, tc = (n2, t2) if use_threads else (n1, t1)
+        cpu = {"value": round(nc / tc, 4), "unit": "scans/s", "cores": mt[0] if use_threads else 1, "kind": "port",
+               "sample": f"{nc} scans of the same stream through oracle/liboracle.so (" +
+                         (f"{mt[0]} threads over mesh voxels, {mt[1]} in the matcher -- the reference's own threading" if use_threads else "single thread") +
+                         "), map = scan 0 + growth (not the 10M-voxel map)",
+               "ms_per_scan": round(1e3 * tc / nc, 3), "single_thread_value": round(single, 4), "reference_threading_value": round(threaded, 4)}
 
     if rank == 0:
         out = {

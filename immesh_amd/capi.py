@@ -427,6 +427,11 @@ class HotPath:
         f = self._f("set_allreduce"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx, self._allreduce_cb, None), "set_allreduce")
 
+    def set_threads(self, mesher_threads, matcher_threads):
+        """oracle only (CPU baseline leg): the reference's own threading -- a 12-thread pool over mesh voxels, 4 OpenMP threads in the matcher"""
+        f = self._f("set_threads"); f.argtypes = [C.c_void_p, C.c_int32, C.c_int32]; f.restype = C.c_int
+        self._check(f(self.ctx, mesher_threads, matcher_threads), "set_threads")
+
     def set_allgather(self, fn):
         """Sharded mesher.  fn(send: uint8 view [nbytes], recv: uint8 view [world * nbytes]) gathers every rank's `send` into `recv` in
         rank order (e.g. torch.distributed.all_gather_into_tensor)."""

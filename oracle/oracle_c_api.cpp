@@ -230,6 +230,13 @@ int orc_undistort(void* p, const float* pts_xyzit, int32_t n, const immesh_imu_s
     return 0;
 }
 const float* orc_undistort_result(void*) { return nullptr; }
+// checker only: worker threads of the voxel-parallel mesher part / the matcher loop (the reference: 12-thread TBB pool, MP_PROC_NUM = 4 OpenMP threads)
+int orc_set_threads(void* p, int32_t mesher_threads, int32_t matcher_threads) {
+    OrcCtx* o = (OrcCtx*)p;
+    o->mesher.threads = mesher_threads > 0 ? mesher_threads : 1;
+    o->vm.threads = matcher_threads > 0 ? matcher_threads : 1;
+    return 0;
+}
 int orc_set_allgather(void*, immesh_allgather_fn, void*) { return 0; }
 int orc_shard_traffic(void*, int64_t* bytes, int64_t* calls) { if (bytes) *bytes = 0; if (calls) *calls = 0; return 0; }
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }

@@ -47,6 +47,7 @@ struct MeshScanOut {
 struct Mesher {
     Config cfg;
     Counters* cnt = nullptr;
+    int threads = 1;   // voxel-parallel neighbourhood search + triangulation (the reference's TBB pool, maximum_thread_for_rec_mesh = 12); results do not depend on it
     std::vector<MeshVertex> verts;                      // m_rgb_pts_vec (index = vertex id)
     std::unordered_map<K3, int, K3Hash> grid;           // m_hashmap_3d_pts : dedupe cell -> vertex id
     std::unordered_map<K3, int, K3Hash> voxel_of;       // m_hashmap_voxels : key -> index in voxels
@@ -208,7 +209,11 @@ struct Mesher {
         std::set<Tri> all_rem;
         std::map<Tri, int> all_add, all_upd, upd_orig;
         std::map<int, std::array<double, 3>> smoothed;
-        std::vector<NN> nn;
+        // The per-voxel work splits into a part that reads only raw vertex positions (20-NN pull, smoothed means, 2-D Delaunay) and a part that
+        // depends on the order of the voxels (smoothed positions seen so far, the live triangle set, which voxel's flip wins).  The first runs
+        // voxel-parallel (the reference's TBB pool), the second strictly in ascending voxel order: same results for any thread count.
+        struct VoxWork { int vi; std::vector<int> ids; std::vector<std::pair<int, std::array<double, 3>>> sm; std::vector<int> tri_ids; long c20 = 0; };
+        std::vector<VoxWork> work;
         for (int vi : recent) {
             MeshVoxel& vox = voxels[vi];
             if (vox.meshing_times >= 1 || vox.new_added < 0) continue;  // :132
@@ -217,11 +222,19 @@ struct Mesher {
             if (vox.pts.size() < 3) continue;  // :147-151
             out.v_act++;
             if (cnt) { cnt->v_act++; cnt->n_v += (long)vox.pts.size(); }
+            VoxWork w; w.vi = vi;
+            work.push_back(std::move(w));
+        }
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads) if (threads > 1)
+        for (long wi = 0; wi < (long)work.size(); wi++) {
+            VoxWork& w = work[(size_t)wi];
+            MeshVoxel& vox = voxels[w.vi];
+            std::vector<NN> nn;
             // a19 retrieve_neighbor_pts_kdtree, mesh_rec_geometry.cpp:336-377
             std::set<long> rel;
             for (int id : vox.pts) {
                 const float q[3] = {(float)verts[id].pos[0], (float)verts[id].pos[1], (float)verts[id].pos[2]};
-                knn(q, 20, accept * 2, nn, cnt ? &cnt->c20 : nullptr);
+                knn(q, 20, accept * 2, nn, &w.c20);
                 double sv[3] = {0, 0, 0};
                 int sc = 0;
                 for (const NN& e : nn) {
@@ -230,14 +243,21 @@ struct Mesher {
                     if (d < accept * 2) { sc++; for (int k = 0; k < 3; k++) sv[k] += verts[e.id].pos[k]; }
                 }
                 for (int k = 0; k < 3; k++) sv[k] /= (double)sc;
-                for (int k = 0; k < 3; k++) verts[id].smooth[k] = sv[k];  // smooth_factor == 1.0
-                smoothed[id] = {sv[0], sv[1], sv[2]};
+                w.sm.push_back({id, {sv[0], sv[1], sv[2]}});
             }
-            std::vector<int> ids(rel.begin(), rel.end());
-            if (cnt) cnt->n_u += (long)ids.size();
-            std::vector<int> tri_ids;
-            delaunay_triangulation(ids, vox.short_axis, tri_ids);
-            if (cnt) cnt->t_v += (long)tri_ids.size() / 3;
+            w.ids.assign(rel.begin(), rel.end());
+            delaunay_triangulation(w.ids, vox.short_axis, w.tri_ids);
+        }
+        for (VoxWork& w : work) {
+            MeshVoxel& vox = voxels[w.vi];
+            for (const auto& e : w.sm) {
+                for (int k = 0; k < 3; k++) verts[e.first].smooth[k] = e.second[k];  // smooth_factor == 1.0
+                smoothed[e.first] = e.second;
+            }
+            const std::vector<int>& ids = w.ids;
+            const std::vector<int>& tri_ids = w.tri_ids;
+            const std::set<long> rel(ids.begin(), ids.end());
+            if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); cnt->t_v += (long)tri_ids.size() / 3; }
             // a21 find_relative_triangulation_combination, triangle.hpp:223-246
             std::set<Tri> old;
             for (int id : ids) {

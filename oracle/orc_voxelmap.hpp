@@ -97,6 +97,7 @@ struct OctoTree {
 
 struct VoxelMap {
     Config cfg;
+    int threads = 1;           // matcher loop (BuildResidualListOMP runs under OpenMP in the reference); results do not depend on it
     std::unordered_map<Key, OctoTree*, KeyHash> map;
     int plane_id = 0;          // g_plane_id, voxel_loc.cpp:43
     int g_max_points = 1000;   // voxel_loc.cpp:45
@@ -329,6 +330,7 @@ inline void build_single_residual(VoxelMap& vm, const PointWithVar& pv, const Oc
     const double* pw = pv.pw;
     if (oct->plane.is_plane) {
         const Plane& pl = oct->plane;
+#pragma omp atomic
         vm.cnt.n_plane_tests++;
         const float dis_to_plane = (float)std::fabs(pl.normal[0] * pw[0] + pl.normal[1] * pw[1] + pl.normal[2] * pw[2] + pl.d);
         const float dis_to_center = (float)((pl.center[0] - pw[0]) * (pl.center[0] - pw[0]) + (pl.center[1] - pw[1]) * (pl.center[1] - pw[1]) +
@@ -371,8 +373,13 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
     const double voxel_size = vm.cfg.voxel_size;  // double in the matcher (:153)
     ptpl_list.clear();
     match_idx.clear();
-    for (size_t i = 0; i < pv_list.size(); i++) {
-        const PointWithVar& pv = pv_list[i];
+    const long n = (long)pv_list.size();
+    std::vector<Ptpl> single(pv_list.size());
+    std::vector<uint8_t> good(pv_list.size(), 0);
+    // the reference runs this loop under OpenMP (MP_PROC_NUM = 4, CMakeLists.txt:21-24); points are independent, the list is compacted in index order
+#pragma omp parallel for schedule(static) num_threads(vm.threads) if (vm.threads > 1)
+    for (long i = 0; i < n; i++) {
+        const PointWithVar& pv = pv_list[(size_t)i];
         const double q[3] = {pv.pw[0] / voxel_size, pv.pw[1] / voxel_size, pv.pw[2] / voxel_size};
         float loc[3];
         for (int j = 0; j < 3; j++) { loc[j] = (float)q[j]; if (loc[j] < 0) loc[j] -= 1.0; }
@@ -380,10 +387,9 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
         auto it = vm.map.find(pos);
         if (it == vm.map.end()) continue;
         OctoTree* cur = it->second;
-        Ptpl single;
         bool ok = false;
         double prob = 0;
-        build_single_residual(vm, pv, cur, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single);
+        build_single_residual(vm, pv, cur, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i]);
         if (!ok) {  // near-voxel retry, literal unit-mismatch quirk, :190-222
             Key nearp = pos;
             int64_t* nk[3] = {&nearp.x, &nearp.y, &nearp.z};
@@ -391,12 +397,15 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
                 if (loc[k] > (cur->voxel_center[k] + cur->quater_length)) *nk[k] = *nk[k] + 1;
                 else if (loc[k] < (cur->voxel_center[k] - cur->quater_length)) *nk[k] = *nk[k] - 1;
             }
+#pragma omp atomic
             vm.cnt.n_extra_probe++;
             auto itn = vm.map.find(nearp);
-            if (itn != vm.map.end()) build_single_residual(vm, pv, itn->second, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single);
+            if (itn != vm.map.end()) build_single_residual(vm, pv, itn->second, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i]);
         }
-        if (ok) { ptpl_list.push_back(single); match_idx.push_back((int)i); }
+        good[(size_t)i] = ok ? 1 : 0;
     }
+    for (long i = 0; i < n; i++)
+        if (good[(size_t)i]) { ptpl_list.push_back(single[(size_t)i]); match_idx.push_back((int)i); }
 }
 
 // ---- StatesGroup boxplus / boxminus, include/common_lib.h:249-271 -----------------------------------------
