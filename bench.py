@@ -265,8 +265,10 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     t_begin = time.perf_counter()
+    t_marks = [t_begin]
     for _ in range(args.steps):
         st, info = run(k, st); k += 1
+        t_marks.append(time.perf_counter())
     if mesh_mode == 2:
         h.mesh_wait()          # drain the mesher: every scan of the timed region is fully meshed before the clock stops
     h.last_timing()            # waits for the last scan's map update (the library's own stream)
@@ -415,6 +417,8 @@ def main():
             "stages_ms_serial": {"gpu_total": round(stage[0] / max(1, args.steps), 4), "register": round(stage[1] / max(1, args.steps), 4),
                           "map_update": round(stage[2] / max(1, args.steps), 4), "mesh": round(stage[3] / max(1, args.steps), 4)},
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_new", "v_act", "n_u", "t_add", "t_rem")},
+            "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
+                               if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
             "pose_err_m": round(pose_err, 4),
             "roofline": roofline, "cpu_baseline": cpu,
             "kernels_ms_per_scan": {n: round(s["total_ms"] / max(1, args.profile_scans), 4) for n, s in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
