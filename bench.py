@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
     ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
-    ap.add_argument("--profile-child", type=int, default=0, help="internal: run only the serial stage-timing + HIP-event profile legs and print their JSON (spawned by the parent run)")
+    ap.add_argument("--profile-child", type=int, default=0, help="internal (spawned by the parent run): 1 = serial stage timing, 2 = HIP-event profile, 3 = both; prints their JSON only")
     ap.add_argument("--profile-inproc", type=int, default=0, help="1 = run the profile legs inside this process instead of a child process")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="seconds the parent waits for the profile child")
     args = ap.parse_args()
@@ -283,23 +283,30 @@ def main():
     # It runs in a CHILD PROCESS of this script (same workload, its own context on the same GPU) with a timeout: the headline number above is
     # complete before it starts, and a failure of the instrumented legs cannot take the bench line with it.  The child uses the serial launch
     # order and unmasked mesher streams (IMMESH_SERIAL_ORDER / IMMESH_MESH_CUS=0): the configuration the per-kernel numbers describe best.
-    def profile_legs(k, st):
-        pstage = np.zeros(4)
-        for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
-            tm = h.last_timing()
-            pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
-        h.counters(reset=True)
-        h.profile_enable(True)
-        for _ in range(args.profile_scans):
-            st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, HIP events around every launch
-        ks = h.profile_read()
-        h.profile_enable(False)
-        pc_ = h.counters(); pc_["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k - args.profile_scans:k]]))
-        return {"stage_per_scan": list(map(float, pstage / max(1, args.profile_scans))), "kstats": ks, "pc": {kk_: float(v) for kk_, v in pc_.items()}}
+    def profile_legs(k, st, what=3):   # bit 0: serial stage timing, bit 1: HIP-event profile
+        res = {}
+        if what & 1:
+            pstage = np.zeros(4)
+            for _ in range(args.profile_scans):
+                st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
+                tm = h.last_timing()
+                pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
+            res["stage_per_scan"] = list(map(float, pstage / max(1, args.profile_scans)))
+        if what & 2:
+            h.counters(reset=True)
+            h.profile_enable(True)
+            k0 = k
+            for _ in range(args.profile_scans):
+                st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, HIP events around every launch
+            ks = h.profile_read()
+            h.profile_enable(False)
+            pc_ = h.counters(); pc_["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k0:k]]))
+            res["kstats"] = ks
+            res["pc"] = {kk_: float(v) for kk_, v in pc_.items()}
+        return res
 
     if args.profile_child:
-        print(json.dumps(profile_legs(k, st)), flush=True)
+        print(json.dumps(profile_legs(k, st, args.profile_child)), flush=True)
         return
 
     roofline = None
@@ -308,29 +315,36 @@ def main():
     prof_note = None
     if (rank == 0 or sharded) and args.profile_scans > 0:   # sharded: every rank takes part in the all-reduces of the extra scans
         if sharded or args.profile_inproc:
-            prof = profile_legs(k, st)
+            prof = profile_legs(k, st, 3)
             k += 2 * args.profile_scans
         else:
-            cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--profile-child", "1", "--gpus", "1", "--steps", "0", "--warmup", str(min(args.warmup, 5)),
-                   "--pts", str(args.pts), "--map-voxels", str(args.map_voxels), "--mesh", str(args.mesh), "--cpu-seconds", "0", "--profile-scans", str(args.profile_scans),
-                   "--config", args.config, "--device-downsample", str(args.device_downsample), "--async-mesh", str(args.async_mesh)]
+            # two children, so that a failure of the profiler leg does not cost the (uninstrumented) stage timing
             env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-            env.update({"IMMESH_SERIAL_ORDER": "1", "IMMESH_MESH_CUS": "0", "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES", str(local)) if world > 1 else os.environ.get("HIP_VISIBLE_DEVICES", "")})
-            if not env["HIP_VISIBLE_DEVICES"]:
-                env.pop("HIP_VISIBLE_DEVICES")
-            try:
-                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
-                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                if r.returncode == 0 and lines:
-                    prof = json.loads(lines[-1])
-                else:
-                    prof_note = f"profile child failed (rc {r.returncode}): {(r.stderr or '').strip().splitlines()[-1][:200] if (r.stderr or '').strip() else 'no output'}"
-            except subprocess.TimeoutExpired:
-                prof_note = f"profile child timed out after {args.profile_timeout:.0f} s"
-            except Exception as e:   # noqa: BLE001
-                prof_note = f"profile child could not run: {e}"
-    if prof:
+            env.update({"IMMESH_SERIAL_ORDER": "1", "IMMESH_MESH_CUS": "0"})
+            if world > 1 and "HIP_VISIBLE_DEVICES" not in env:
+                env["HIP_VISIBLE_DEVICES"] = str(local)
+            prof = {}
+            notes = []
+            for what in (1, 2):
+                cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--profile-child", str(what), "--gpus", "1", "--steps", "0", "--warmup", str(min(args.warmup, 5)),
+                       "--pts", str(args.pts), "--map-voxels", str(args.map_voxels), "--mesh", str(args.mesh), "--cpu-seconds", "0", "--profile-scans", str(args.profile_scans),
+                       "--config", args.config, "--device-downsample", str(args.device_downsample), "--async-mesh", str(args.async_mesh)]
+                label = "stage-timing child" if what == 1 else "profiler child"
+                try:
+                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
+                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    if r.returncode == 0 and lines:
+                        prof.update(json.loads(lines[-1]))
+                    else:
+                        notes.append(f"{label} failed (rc {r.returncode}): {(r.stderr or '').strip().splitlines()[-1][:200] if (r.stderr or '').strip() else 'no output'}")
+                except subprocess.TimeoutExpired:
+                    notes.append(f"{label} timed out after {args.profile_timeout:.0f} s")
+                except Exception as e:   # noqa: BLE001
+                    notes.append(f"{label} could not run: {e}")
+            prof_note = "; ".join(notes) if notes else None
+    if prof and "stage_per_scan" in prof:
         stage = np.array(prof["stage_per_scan"]) * args.steps
+    if prof and "kstats" in prof:
         kstats = prof["kstats"]
         pc = prof["pc"]
         best = None
@@ -348,7 +362,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": best, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
                         "algorithmic_bytes_per_launch": int(by), "source": "HIP events, live (instrumented child run of this script: serial launch order, unmasked mesher streams)"}
-    elif rank == 0 and args.profile_scans > 0:
+    if roofline is None and rank == 0 and args.profile_scans > 0:
         # the live leg is unavailable: fall back to the committed rocprofv3 average of the dominant kernel, with this run's own counters
         roofline = roofline_from_committed_profile("mesh_delaunay_kernel<256>" if args.mesh else "residual_kernel", cnt, args, prof_note)
     if roofline is not None:

@@ -56,6 +56,18 @@ def test_profile_child_failure_falls_back(tmp_path):
     assert "committed rocprofv3" in d["roofline"]["source"] and "rc 3" in d["profile_leg_note"]
 
 
+def test_only_the_profiler_child_fails(tmp_path):
+    # the uninstrumented stage-timing child still delivers; only the roofline falls back
+    bad = tmp_path / "bench_bad_prof.py"
+    bad.write_text(open(SHIM).read().replace('if __name__ == "__main__":\n    bench.main()',
+                   'if __name__ == "__main__":\n    if "--profile-child" in sys.argv and sys.argv[sys.argv.index("--profile-child") + 1] == "2":\n        os._exit(5)\n    bench.main()').replace(
+                   'ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))', f'ROOT = {ROOT!r}'))
+    d = _run(str(bad))
+    _check_line(d)
+    assert "profiler child failed (rc 5)" in d["profile_leg_note"] and "stage-timing" not in d["profile_leg_note"]
+    assert d["stages_ms_serial"]["mesh"] == 0.5 and "committed rocprofv3" in d["roofline"]["source"]
+
+
 def test_profile_child_hang_times_out(tmp_path):
     bad = tmp_path / "bench_hang_child.py"
     bad.write_text(open(SHIM).read().replace('if __name__ == "__main__":\n    bench.main()',
