@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     ap.add_argument("--profile-child", type=int, default=0, help="internal (spawned by the parent run): 1 = serial stage timing, 2 = HIP-event profile, 3 = both; prints their JSON only")
     ap.add_argument("--profile-inproc", type=int, default=0, help="1 = run the profile legs inside this process instead of a child process")
-    ap.add_argument("--profile-timeout", type=float, default=120.0, help="seconds the parent waits for the profile child")
+    ap.add_argument("--profile-timeout", type=float, default=90.0, help="seconds the parent waits for the profile child")
     args = ap.parse_args()
 
     import torch
