@@ -194,7 +194,9 @@ def main():
     if kitti:
         cfg = capi.velodyne_config(device=local, cap_root_voxels=1 << 18, cap_scan_points=400_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
     else:
-        cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3) + (1 << 16), cap_scan_points=2_500_000,
+        # sharded map: a rank keeps its bricks plus the one-voxel halo (~20 % at 32^3-voxel bricks) -> capacity per rank, not per job
+        share = (1.5 / world) if (bool(args.shard) and world > 1) else 1.0
+        cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=2_500_000,
                                cap_vertices=1 << 24, cap_triangles=1 << 25)
     if sharded:
         cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, 5, 1 if args.mesh else 0
