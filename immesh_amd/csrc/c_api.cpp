@@ -161,7 +161,7 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
     if (f) {
         static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 32896 retained points", "extension-table pool exhausted",
                                     "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)",
-                                    "more than 512 points of one scan fall into one root voxel (down-sample the scan, or use immesh_map_build)",
+                                    "(unused)",
                                     "leaf-list pool exhausted (cap_nodes)"};
         c->err = std::string("registration map capacity: ") + why[f < 8 ? f : 0];
         return IMMESH_E_CAPACITY;
@@ -330,7 +330,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         c->map.touched = (uint32_t*)c->d_seg_start;
         launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
         if (after_point_var) HIPCHK(c, hipEventRecord(after_point_var, s));   // the scan's input clouds are consumed: the replay works on its own copies
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
@@ -391,14 +391,20 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     imh::load_state(state_prior, prior); imh::load_state(state_inout, st);
     int mesh_mode = do_mesh & 3;
     if (mesh_mode == IMMESH_MESH_ASYNC && c->mesh.shard_world > 1) mesh_mode = IMMESH_MESH_SYNC;   // sharded mesher: its collectives must not interleave with the next scan's all-reduces
-    const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || (do_mesh & IMMESH_SCAN_NOWAIT);
+    // (sharded mesher: never return before mesh_wait -- the worker's all-gathers must not interleave with the next scan's all-reduces)
+    const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || ((do_mesh & IMMESH_SCAN_NOWAIT) && !(mesh_mode && c->mesh.shard_world > 1));
     const int par = c->ev_par ^ 1;
     hipEvent_t* ev = c->ev + 4 * par;
     (void)hipEventRecord(ev[0], c->stream);
     int n_iter = 0, n_match = 0;
     if ((rc = register_device(c, (const float*)d_down, n_ds, prior, st, &n_iter, &n_match, nullptr))) return rc;
     // the residual passes of this scan ran behind the previous scan's map update on the same stream: that update is complete now
-    if ((rc = settle(c, true))) return rc;
+    if ((rc = settle(c, true))) {   // deferred capacity error of the PREVIOUS scan's map update: this scan's pose is still valid and is handed back
+        imh::store_state(st, state_inout);
+        if (n_iter_out) *n_iter_out = n_iter;
+        if (n_match_out) *n_match_out = n_match;
+        return rc;
+    }
     c->ev_par = par;
     (void)hipEventRecord(ev[1], c->stream);
     long job = 0;

@@ -80,12 +80,14 @@ IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, c
     if ((double)range_dis <= 3.0 * (double)radius && (double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
         best.ok = true;
         const double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
-        if (this_prob > best.prob) { best.prob = this_prob; best.node = node; best.layer = layer; }
+        // strictly greater wins; an exact tie goes to the plane the reference's depth-first recursion reaches first (the flat leaf list is in
+        // insertion order, not DFS order)
+        if (this_prob > best.prob || (!EAGER && this_prob == best.prob && best.node >= 0 && dfs_key(m, node) < dfs_key(m, best.node))) { best.prob = this_prob; best.node = node; best.layer = layer; }
     }
 }
 
 // build_single_residual's recursion over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312): the planes it reaches are the
-// root's flat leaf list.  Equal probabilities keep the reference's "first in depth-first order wins" through dfs_key.
+// root's flat leaf list.  Equal probabilities keep the reference's "first in depth-first order wins" through dfs_key (test_plane).
 IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
     if (m.nodes[root].flags & NF_PLANE) { test_plane<true>(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
     if (m.max_layer <= 0) return;
@@ -183,9 +185,12 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         }
         RDBG(2);
         acc[29] = (double)n_tests; acc[30] = (double)n_extra;
-        o_match[i] = best.ok ? 1 : 0;
+        // is_success with prob still 0 (sigma_l = inf / NaN after a diverged covariance): the reference pushes an uninitialised ptpl there;
+        // here it is no match instead of a read of nodes[-1]
+        const bool matched = best.ok && best.node >= 0;
+        o_match[i] = matched ? 1 : 0;
         o_node[i] = best.node;
-        if (best.ok) {
+        if (matched) {
             const int nd = best.node;
             const double nrm_d[3] = {m.nodes[nd].p_normal[0], m.nodes[nd].p_normal[1], m.nodes[nd].p_normal[2]};
             const double cen[3] = {m.nodes[nd].p_center[0], m.nodes[nd].p_center[1], m.nodes[nd].p_center[2]};
@@ -669,9 +674,9 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
 
 // updateVoxelMap without any global sort: one wavefront per touched root voxel gathers that voxel's points of this scan from its
 // list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them.
-#define RL_CAP 512   /* points of one scan falling into one root voxel */
+#define RL_CAP 512   /* points of one scan falling into one root voxel that are ordered in LDS; longer lists take the global-scratch path */
 __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
-                                                           const double* __restrict__ pt_data, int64_t* stats) {
+                                                           const double* __restrict__ pt_data, int64_t* stats, int32_t* __restrict__ big_idx, int32_t* __restrict__ big_order) {
     __shared__ unsigned long long skey[4][RL_CAP];
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
@@ -690,7 +695,29 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
         if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
         cnt++;
     }
-    if (cnt > RL_CAP) { m.counters[5] = 6; return; }
+    if (cnt > RL_CAP) {
+        // dense or un-down-sampled scans (the reference's updateVoxelMap takes any count): the list is ordered in global scratch instead of
+        // LDS -- a segment of big_idx / big_order (n entries each; the lists of a scan partition its points) claimed with one atomic
+        int base = 0;
+        if (w.lane == 0) base = atomicAdd(&m.counters[9], cnt);
+        base = __shfl(base, 0, 64);
+        if (w.lane == 0) { int k = 0; for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) big_idx[base + k++] = i; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int e = w.lane; e < cnt; e += 64) {
+            const int id = big_idx[base + e];
+            const unsigned long long k = sort_key[id];
+            int rank = 0;
+            for (int f = 0; f < cnt; f++) { const int idf = big_idx[base + f]; const unsigned long long kf = sort_key[idf]; rank += (kf < k || (kf == k && idf < id)) ? 1 : 0; }
+            big_order[base + rank] = id;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        for (int j = 0; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
+        return;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -721,7 +748,7 @@ __global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32
     const int base = m.counters[2];
     for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
     __syncthreads();
-    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; }
+    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; }
     __syncthreads();
     if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -770,8 +797,8 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
     KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters) {
-    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order) {
+    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order);
     KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {

@@ -50,7 +50,7 @@ struct RegMapDev {
     // pools
     double* chunk_data;         // [cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES]
     int32_t* ext_tables;        // [cap_ext * IM_EXT_CHUNKS]
-    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels [7] touched slots of the current update
+    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels [7] touched slots of the current update [8] leaf-list chunks used [9] bump allocator of the long-list scratch (replay_list_kernel)
     int32_t* counters;
     int32_t* free_ready;        // chunk ids available for allocation
     int32_t* free_pending;      // chunk ids freed by the running kernel (merged into ready afterwards)

@@ -1,7 +1,7 @@
 """Multi-GPU plumbing of bench.py (one process per GPU under torch.distributed.run; backend "nccl" = RCCL on ROCm, "gloo"
-in the CPU tests).  Round-1 multi-GPU mode is "replicas only" (DESIGN.md section 6): every rank runs its own scan stream
-against its own map, so the data path has no collective; what is exchanged is the timing barrier and the max-over-ranks
-elapsed time."""
+in the CPU tests).  Two multi-GPU modes: replicas (every rank runs its own scan stream against its own
+map: no data-path collective, only the timing barrier and the max-over-ranks elapsed time) and the sharded map / mesher
+(one stream; the collectives live in the C++ layer -- RCCL -- or behind the host callbacks, see immesh_c_api.h)."""
 import os
 
 

@@ -6,7 +6,7 @@
 //   H / EKF    src/voxel_mapping.cpp:1487-1650 with R_inv = 1 / LASER_POINT_COV
 // The tree itself is not restated -- only what it computes: the exact k nearest points in float arithmetic, and the box-downsample insert
 // (one survivor per downsample_size box: the point nearest to the box centre, a new point winning ties).  Both are checked against the
-// reference's own ikd-Tree (oracle/_ref) in tests/test_oracle_ikdmap.py.  Conventions where the reference is order-dependent or unpinned:
+// reference's own ikd-Tree (oracle/_ref) in tests/test_ikdmap.py.  Conventions where the reference is order-dependent or unpinned:
 //   * "points inside the box" = points with the same floor(x / downsample_size) cell (differs from the float box test only within an ulp of a face)
 //   * equal k-NN distances are ordered by insertion sequence
 //   * Eigen's colPivHouseholderQr is restated from its published algorithm with sequential float sums (Eigen is not in the image: unpinned)

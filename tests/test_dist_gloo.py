@@ -1,5 +1,5 @@
 """The N>1 path of bench.py on CPU: world_size-2 gloo process group, barrier, max-over-ranks timing, per-rank stream assignment,
-whole-job aggregation.  (Round-1 multi-GPU mode is replicas-only: no data-path collective to test beyond this.)"""
+whole-job aggregation.  (The data-path collectives of the sharded mode are exercised by tests/test_gpu_sharded.py and tests/test_bench_plumbing.py.)"""
 import os
 import sys
 
