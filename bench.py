@@ -5,8 +5,10 @@ One "step" = one LiDAR scan through the whole per-scan hot path behind the C ABI
 iterated-EKF point-to-plane registration against the HBM-resident voxel/plane map, map growth, and (``--mesh 1``)
 incremental voxel-wise meshing.  Workload at N=1: the synthetic Livox-Avia-shaped 100k-pt/scan stream of SURVEY.md
 8(d) C2/C3 into a pre-built ~10 M-root-voxel map; scans and the down-sampled clouds are resident in HBM before the
-timed region starts.  N>1 (torchrun, one rank per GPU): every rank runs the same stream against its own map shard
-replica-free -- see DESIGN.md "Multi-GPU" -- weak scaling, max-over-ranks timing.
+timed region starts.  N>1: one rank per GPU (``python bench.py --gpus N`` re-executes itself under torch.distributed.run
+when it was not launched by it).  Headline = N independent scan streams, one per GPU (weak scaling, max-over-ranks timing);
+the ``sharded`` object of the same line is the north-star split measured right after it: ONE stream, registration map and
+mesher sharded by voxel bricks over the ranks (strong scaling) -- see DESIGN.md "Multi-GPU".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -16,6 +18,7 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -122,109 +125,69 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
         return n_ds * 96 + (c["n_refit_pts"] * 96 + c["n_refits"] * 229) / n_scans
     if kname == "mesh_knn_kernel":      # per scan: C20 inspected vertices x 12 B + query 12 B + 20 ids out
         return (c["c20"] * 12 + c["n_v"] * (12 + 80 + 24)) / n_scans
-    if kname == "mesh_delaunay_kernel":  # per scan: n_u x (12 B pos + 6 x 12 B incident triangles) + T_v x 12 B
+    if kname in ("mesh_delaunay_kernel", "mesh_delaunay64_kernel"):  # per scan: n_u x (12 B pos + 6 x 12 B incident triangles) + T_v x 12 B
         return (c["n_u"] * 84 + c["t_v"] * 12) / n_scans
     if kname == "mesh_transform_kernel":
         return n_raw * 32
     return None
 
 
-def roofline_from_committed_profile(kernel, cnt, args, note):
-    """Fallback when the live HIP-event leg could not run: average launch time of `kernel` from profiles/r01_full_kernel_stats.csv (rocprofv3
-    --kernel-trace --stats of this script), algorithmic bytes from THIS run's counters.  Clearly labelled in `source`."""
+COMMITTED_STATS = "r02_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
+COMMITTED_TRAFFIC = "traffic_r02.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+
+
+def roofline_from_committed_profile(mesh, cnt, n_scans, n_raw, note):
+    """Fallback when the live HIP-event leg could not run: the kernel with the largest total time in the committed rocprofv3 --kernel-trace --stats
+    summary of this script (among those with an algorithmic-bytes model), its average launch time from there, algorithmic bytes from THIS
+    run's counters.  Clearly labelled in `source`."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_full_kernel_stats.csv")
-    try:
-        avg_ns = None
-        for r in csv.DictReader(open(path)):
-            n = r["Name"].strip('"')
-            n = n[5:] if n.startswith("void ") else n
-            if n.startswith(kernel + "("):
-                avg_ns = float(r["AverageNs"])
-                break
-        if avg_ns is None:
-            return None
-        c = dict(cnt)
-        by = algorithmic_bytes(kernel, c, args.steps, args.pts)
-        if by is None:
-            return None
-        avg_ms = avg_ns * 1e-6
-        ach = by / (avg_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
-                "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(by),
-                "source": "profiles/r01_full_kernel_stats.csv (committed rocprofv3 average) -- live HIP-event leg unavailable: " + (note or "unknown")}
-    except Exception:   # noqa: BLE001
-        return None
+    for name in (COMMITTED_STATS, "r01_full_kernel_stats.csv"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            for r in csv.DictReader(open(path)):   # rows are sorted by total duration
+                n = r["Name"].strip('"')
+                n = n[5:] if n.startswith("void ") else n
+                kernel = n.split("(")[0]
+                if (not mesh) and kernel.startswith("mesh_"):
+                    continue
+                by = algorithmic_bytes(kernel, dict(cnt), n_scans, n_raw)
+                if by is None or kernel.split("<")[0] in ("point_var_kernel", "replay_kernel"):   # (their rows include the map pre-build launches)
+                    continue
+                avg_ms = float(r["AverageNs"]) * 1e-6
+                ach = by / (avg_ms * 1e-3) / 1e9
+                return {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 5), "algorithmic_bytes_per_launch": int(by),
+                        "source": f"profiles/{name} (committed rocprofv3 average) -- live HIP-event leg unavailable: " + (note or "unknown")}
+        except Exception:   # noqa: BLE001
+            continue
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pts", type=int, default=100000, help="raw points per scan")
-    ap.add_argument("--map-voxels", type=float, default=10e6, help="root voxels of the pre-built registration map")
-    ap.add_argument("--mesh", type=int, default=1, help="1 = full pipeline (configs[2]); 0 = registration + map update only (configs[1])")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU budget of the oracle baseline leg (0 = skip)")
-    ap.add_argument("--profile-scans", type=int, default=5)
-    ap.add_argument("--config", choices=["avia", "velodyne"], default="avia", help="avia = BASELINE configs[1]/[2] (the metric's workload); velodyne = configs[3], KITTI-shaped HDL-64 scans with velodyne.yaml parameters")
-    ap.add_argument("--shard", type=int, default=0, help="N>1 only. 0 = replicas (every rank its own stream + map, weak scaling); 1 = ONE stream, registration map sharded by "
-                    "root-voxel bricks over the ranks, 46-double all-reduce per EKF iteration, meshing on rank 0 (strong scaling; the capacity mode of configs[4])")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
-    ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
-    ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
-    ap.add_argument("--profile-child", type=int, default=0, help="internal (spawned by the parent run): 1 = serial stage timing, 2 = HIP-event profile, 3 = both; prints their JSON only")
-    ap.add_argument("--profile-inproc", type=int, default=0, help="1 = run the profile legs inside this process instead of a child process")
-    ap.add_argument("--profile-timeout", type=float, default=90.0, help="seconds the parent waits for the profile child")
-    args = ap.parse_args()
+COUNTER_KEYS = ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_app", "n_new", "c1", "v_act", "n_v", "c20", "n_u", "t_v", "t_add", "t_rem")
 
-    import torch
-    rank, world, local = D.env_rank()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    local = local % torch.cuda.device_count()   # one GPU per rank on a real node; functional tests may stack ranks on one device (gloo)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = D.init(args.backend, dev if args.backend == "nccl" else None) if world > 1 else None
-    sharded = bool(args.shard) and world > 1
 
-    hip = capi.load_hip_library()
-    side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0     # ~8.8 root voxels per m^2 of this world (ground + walls)
+def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
+    """One measured pass of the stream: context + map, warm-up, the timed region (barrier / synchronize on both sides, max over ranks) and -- on the
+    rank(s) that report, when `full` -- the instrumented legs on the SAME context, continuing the SAME stream."""
     kitti = args.config == "velodyne"
+    side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0     # ~8.8 root voxels per m^2 of this world (ground + walls)
     if kitti:
         cfg = capi.velodyne_config(device=local, cap_root_voxels=1 << 18, cap_scan_points=400_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
     else:
         # sharded map: a rank keeps its bricks plus the one-voxel halo (~20 % at 32^3-voxel bricks) -> capacity per rank, not per job
-        share = (1.5 / world) if (bool(args.shard) and world > 1) else 1.0
+        share = (1.5 / world) if sharded else 1.0
         cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=2_500_000,
                                cap_vertices=1 << 24, cap_triangles=1 << 25)
     if sharded:
         cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, 5, 1 if args.mesh else 0
     h = capi.HotPath(hip, cfg, "immesh_")
+    comm = "none"
     if sharded:
-        if args.backend == "nccl":
-            red = torch.zeros(46, dtype=torch.float64, device=dev)
-
-            def _allreduce(buf):                      # 46 doubles: H^T R^-1 H, H^T R^-1 z, counters -- RCCL all-reduce over xGMI
-                red.copy_(torch.from_numpy(buf)); dist.all_reduce(red); buf[:] = red.cpu().numpy()
-        else:
-            def _allreduce(buf):
-                dist.all_reduce(torch.from_numpy(buf))
-        h.set_allreduce(_allreduce)
-        if args.mesh:   # sharded mesher: all-gather of this scan's smoothed vertices and triangle marks (two exchanges per scan)
-            def _allgather(send, recv):
-                if args.backend == "nccl":
-                    src = torch.from_numpy(send).to(dev)
-                    dst = torch.empty(len(send) * world, dtype=torch.uint8, device=dev)
-                    dist.all_gather_into_tensor(dst, src)
-                    recv[:] = dst.cpu().numpy()
-                else:
-                    parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
-                    dist.all_gather(parts, torch.from_numpy(send))
-                    for r_ in range(world):
-                        recv[r_ * len(send):(r_ + 1) * len(send)] = parts[r_].numpy()
-            h.set_allgather(_allgather)
-    n_total = args.warmup + args.steps + 2 * args.profile_scans
+        comm = D.attach_collectives(h, hip, dist, args.backend, dev, world, bool(args.mesh))
+    n_extra = 2 * args.profile_scans if full else 0
+    n_total = args.warmup + args.steps + n_extra
     raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
     if kitti:   # SURVEY 8(d) C4: the map grows from the stream itself (3 m root voxels, max_layer 4)
         R0_, t0_ = synth.trajectory_pose(0)
@@ -246,8 +209,7 @@ def main():
     mesh_mode = (2 if (args.async_mesh and not sharded) else 1) if args.mesh else (NOWAIT if args.async_mesh else 0)   # sharded mesher: serial per scan (its collectives must not interleave)
     if mesh_mode & 3:
         # mesh map is seeded by scan 0 (the registration map is the pre-built survey); sharded: every rank takes part in the scan's all-reduces
-        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1 if (mesh_mode & 3) else 0, n_ds=len(downs[0]), n_raw=len(raws[0]))
-
+        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1, n_ds=len(downs[0]), n_raw=len(raws[0]))
 
     def run(k, state, mode=None):
         prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
@@ -255,15 +217,12 @@ def main():
         if args.device_downsample:
             _, n_ds = h.downsample(d_raw[k].data_ptr(), 0.5 if kitti else 0.4, n=len(raws[k]), stride=4, to_host=False)
             down_ptr = h.downsample_result_ptr()
-        out, info = h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode,
-                                   n_ds=n_ds, n_raw=len(raws[k]))
-        return out, info
+        return h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode, n_ds=n_ds, n_raw=len(raws[k]))
 
     k = 1
     for _ in range(args.warmup):
         st, _ = run(k, st); k += 1
     h.counters(reset=True)
-    stage = np.zeros(4)
     torch.cuda.synchronize()
     D.barrier()
     t_begin = time.perf_counter()
@@ -278,178 +237,269 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()
-    cnt["_n_ds_mean"] = n_ds_mean
-    pose_err = float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1]))
+    res = {"elapsed": elapsed, "cnt": cnt, "n_ds_mean": n_ds_mean, "n_map": int(n_map), "mesh_mode": mesh_mode, "n_raw": int(np.mean([len(r) for r in raws])), "comm": comm,
+           "pose_err": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1])),
+           "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
+                              if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
+           "cpu_inputs": (cfg, raws, downs, R0, t0)}
+    if sharded:
+        res["shard_traffic"] = h.shard_traffic()
 
-    # ---- roofline leg: serial per-stage times + per-kernel HIP-event timing (events recorded on the library's own streams) over extra scans.
-    # It runs in a CHILD PROCESS of this script (same workload, its own context on the same GPU) with a timeout: the headline number above is
-    # complete before it starts, and a failure of the instrumented legs cannot take the bench line with it.  The child uses the serial launch
-    # order and unmasked mesher streams (IMMESH_SERIAL_ORDER / IMMESH_MESH_CUS=0): the configuration the per-kernel numbers describe best.
-    def profile_legs(k, st, what=3):   # bit 0: serial stage timing, bit 1: HIP-event profile
-        res = {}
-        if what & 1:
-            pstage = np.zeros(4)
-            for _ in range(args.profile_scans):
-                st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, profiler off: per-stage times of one scan
-                tm = h.last_timing()
-                pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
-            res["stage_per_scan"] = list(map(float, pstage / max(1, args.profile_scans)))
-        if what & 2:
-            h.counters(reset=True)
-            h.profile_enable(True)
-            k0 = k
-            for _ in range(args.profile_scans):
-                st, _ = run(k, st, mode=1 if (mesh_mode & 3) else 0); k += 1    # serial mode, HIP events around every launch
-            ks = h.profile_read()
-            h.profile_enable(False)
-            pc_ = h.counters(); pc_["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k0:k]]))
-            res["kstats"] = ks
-            res["pc"] = {kk_: float(v) for kk_, v in pc_.items()}
-        return res
+    # ---- instrumented legs (roofline): the SAME context continues the SAME stream -- same map, same mesh map, scans right after the timed
+    # ones.  (a) serial per-stage times, profiler off; (b) HIP events around every launch on the library's own streams.  Run by main() under a
+    # watchdog: the headline number is complete at this point and must not be lost if they hang.
+    def legs():
+        nonlocal st, k
+        stage_, kstats_, pc_out, note = None, None, None, None
+        try:
+            if full and args.profile_scans > 0 and (rank == 0 or sharded):
+                serial = 1 if (mesh_mode & 3) else 0
+                pstage = np.zeros(4)
+                for _ in range(args.profile_scans):
+                    st, _ = run(k, st, mode=serial); k += 1
+                    tm = h.last_timing()
+                    pstage += [tm["total"], tm["register"], tm["map_update"], tm["mesh"]]
+                stage_ = list(map(float, pstage / args.profile_scans))
+                if not sharded or args.profile_inproc:
+                    h.counters(reset=True)
+                    h.profile_enable(True)
+                    k0 = k
+                    for _ in range(args.profile_scans):
+                        st, _ = run(k, st, mode=serial); k += 1
+                    kstats_ = h.profile_read()
+                    h.profile_enable(False)
+                    pc_ = h.counters(); pc_["_n_ds_mean"] = float(np.mean([len(d) for d in downs[k0:k]]))
+                    pc_out = {kk_: float(v) for kk_, v in pc_.items()}
+        except Exception as e:   # noqa: BLE001
+            note = f"instrumented leg failed: {str(e)[:200]}"
+        h.close()
+        return stage_, kstats_, pc_out, note
+    res["legs"] = legs
+    return res
 
-    if args.profile_child:
-        print(json.dumps(profile_legs(k, st, args.profile_child)), flush=True)
-        return
 
-    roofline = None
-    kstats = {}
-    prof = None
-    prof_note = None
-    if (rank == 0 or sharded) and args.profile_scans > 0:   # sharded: every rank takes part in the all-reduces of the extra scans
-        if sharded or args.profile_inproc:
-            # sharded: every rank takes part in the extra scans' collectives, so they run in-process -- uninstrumented stage timing only unless
-            # --profile-inproc asks for the HIP-event leg too (open issue)
-            prof = profile_legs(k, st, 3 if args.profile_inproc else 1)
-            k += 2 * args.profile_scans
-        else:
-            # two children, so that a failure of the profiler leg does not cost the (uninstrumented) stage timing
-            env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-            env.update({"IMMESH_SERIAL_ORDER": "1", "IMMESH_MESH_CUS": "0"})
-            if world > 1 and "HIP_VISIBLE_DEVICES" not in env:
-                env["HIP_VISIBLE_DEVICES"] = str(local)
-            prof = {}
-            notes = []
-            for what in (1, 2):
-                cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--profile-child", str(what), "--gpus", "1", "--steps", "0", "--warmup", str(min(args.warmup, 5)),
-                       "--pts", str(args.pts), "--map-voxels", str(args.map_voxels), "--mesh", str(args.mesh), "--cpu-seconds", "0", "--profile-scans", str(args.profile_scans),
-                       "--config", args.config, "--device-downsample", str(args.device_downsample), "--async-mesh", str(args.async_mesh)]
-                label = "stage-timing child" if what == 1 else "profiler child"
-                try:
-                    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
-                    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    if r.returncode == 0 and lines:
-                        prof.update(json.loads(lines[-1]))
-                    else:
-                        notes.append(f"{label} failed (rc {r.returncode}): {(r.stderr or '').strip().splitlines()[-1][:200] if (r.stderr or '').strip() else 'no output'}")
-                except subprocess.TimeoutExpired:
-                    notes.append(f"{label} timed out after {args.profile_timeout:.0f} s")
-                except Exception as e:   # noqa: BLE001
-                    notes.append(f"{label} could not run: {e}")
-            prof_note = "; ".join(notes) if notes else None
-    if prof and "stage_per_scan" in prof:
-        stage = np.array(prof["stage_per_scan"]) * args.steps
-    if prof and "kstats" in prof:
-        kstats = prof["kstats"]
-        pc = prof["pc"]
-        best = None
-        for name, s_ in kstats.items():
-            if s_["launches"] and algorithmic_bytes(name, pc, args.profile_scans, args.pts) is not None:
-                if best is None or s_["total_ms"] > kstats[best]["total_ms"]:
-                    best = name
-        if best:
-            per_scan_launches = kstats[best]["launches"] / args.profile_scans
-            by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
-            if best.split("<")[0] not in ("residual_kernel",):
-                by = by / max(1.0, per_scan_launches)
-            avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]
-            ach = by / (avg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": best, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
-                        "algorithmic_bytes_per_launch": int(by), "source": "HIP events, live (instrumented child run of this script: serial launch order, unmasked mesher streams)"}
-    if roofline is None and rank == 0 and args.profile_scans > 0:
-        # the live leg is unavailable: fall back to the committed rocprofv3 average of the dominant kernel, with this run's own counters
-        roofline = roofline_from_committed_profile("mesh_delaunay_kernel<256>" if args.mesh else "residual_kernel", cnt, args, prof_note)
-    if roofline is not None:
-        tr = os.path.join(ROOT, "profiles", "traffic_r01.json")   # PMC-derived HBM bytes/launch from the committed rocprofv3 --pmc passes
-        if os.path.exists(tr):
+def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
+    """The oracle (CPU restatement, kind "port") on the host cores: a bounded sample of the same stream.  Two variants per SURVEY 8(d): (i) the
+    reference's own threading (12-thread pool over mesh voxels, maximum_thread_for_rec_mesh; 4 OpenMP threads in the matcher, MP_PROC_NUM) and
+    (ii) every parallelisable loop on all cores; per-stage p50 / p95 after warm-up.  Results of the variants are identical."""
+    cfg, raws, downs, R0, t0 = hip_cfg_inputs
+    orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(orc_so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    orc_lib = ctypes.CDLL(orc_so)
+    ncores = os.cpu_count() or 1
+
+    def cpu_pass(mesher_threads, matcher_threads, budget, warm):
+        o = capi.HotPath(orc_lib, cfg, "orc_")
+        o.set_threads(mesher_threads, matcher_threads)
+        so = capi.make_state(R=R0, t=t0)
+        o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # (kitti: exactly the GPU leg's map; avia: a local map instead of the 10M-voxel survey)
+        so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+        if args.mesh:
+            o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
+        tc, kk, per, stages = 0.0, 1, [], []
+        while (tc < budget or len(per) < 3) and kk < len(raws):
+            prior = synth.forward_without_imu(so)
+            a = time.perf_counter()
+            so, _ = o.process_scan(downs[kk], raws[kk], prior, prior, frame_idx=kk, do_mesh=bool(args.mesh))
+            dt = time.perf_counter() - a
+            if kk > warm:
+                tc += dt; per.append(dt)
+                tm = o.last_timing(); stages.append([tm["register"], tm["map_update"], tm["mesh"]])
+            kk += 1
+        o.close()
+        per = np.array(per) * 1e3; stages = np.array(stages)
+        return {"scans": int(len(per)), "scans_per_s": round(len(per) / tc, 4), "ms_p50": round(float(np.percentile(per, 50)), 3), "ms_p95": round(float(np.percentile(per, 95)), 3),
+                "stages_ms_p50": {"register": round(float(np.percentile(stages[:, 0], 50)), 3), "map_update": round(float(np.percentile(stages[:, 1], 50)), 3),
+                                  "mesh": round(float(np.percentile(stages[:, 2], 50)), 3)},
+                "threads": {"mesher": mesher_threads, "matcher": matcher_threads}}
+
+    warm = 2 if budget_s < 5 else 5
+    ref_thr = (min(12, ncores), min(4, ncores))
+    v_ref = cpu_pass(ref_thr[0], ref_thr[1], budget_s / 2, warm)
+    v_all = cpu_pass(ncores, ncores, budget_s / 2, warm) if ncores > 1 else v_ref
+    best, cores = (v_all, ncores) if v_all["scans_per_s"] > v_ref["scans_per_s"] else (v_ref, ref_thr[0])
+    return {"value": best["scans_per_s"], "unit": "scans/s", "cores": cores, "kind": "port",
+            "sample": f"{best['scans']} scans of the same stream (after {warm} warm-up scans) through oracle/liboracle.so; map = scan 0 + growth (a local map, not the 10M-voxel survey: "
+                      "the oracle needs minutes to build that one); the faster of the two variants is `value`",
+            "ms_per_scan": best["ms_p50"], "reference_threading": v_ref, "all_cores": v_all, "host_cores": ncores}
+
+
+def build_roofline(res, args):
+    kstats, pc = res["kstats"], res["pc"]
+    best = None
+    for name, s_ in kstats.items():
+        if s_["launches"] and algorithmic_bytes(name, pc, args.profile_scans, args.pts) is not None:
+            if best is None or s_["total_ms"] > kstats[best]["total_ms"]:
+                best = name
+    if not best:
+        return None
+    per_scan_launches = kstats[best]["launches"] / args.profile_scans
+    by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
+    if best.split("<")[0] not in ("residual_kernel",):
+        by = by / max(1.0, per_scan_launches)
+    avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]
+    ach = by / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": best, "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+            "algorithmic_bytes_per_launch": int(by), "launches": int(kstats[best]["launches"]),
+            "counters_of_the_profiled_scans": {kk_: round(pc[kk_] / args.profile_scans, 1) for kk_ in COUNTER_KEYS if kk_ in pc},
+            "source": f"HIP events, live: {args.profile_scans} scans of the same stream on the same context, right after the timed region (serial per scan, events on the library's own streams)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pts", type=int, default=100000, help="raw points per scan")
+    ap.add_argument("--map-voxels", type=float, default=10e6, help="root voxels of the pre-built registration map")
+    ap.add_argument("--mesh", type=int, default=1, help="1 = full pipeline (configs[2]); 0 = registration + map update only (configs[1])")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="CPU budget of the oracle baseline leg (0 = skip)")
+    ap.add_argument("--profile-scans", type=int, default=5)
+    ap.add_argument("--config", choices=["avia", "velodyne"], default="avia", help="avia = BASELINE configs[1]/[2] (the metric's workload); velodyne = configs[3], KITTI-shaped HDL-64 scans with velodyne.yaml parameters")
+    ap.add_argument("--shard", type=int, default=0, help="N>1 only. 0 = headline is N replicas (every rank its own stream + map, weak scaling) with the sharded split as a second leg; "
+                    "1 = only the sharded split: ONE stream, registration map and mesher sharded by voxel bricks over the ranks (strong scaling; the capacity mode of configs[4])")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
+    ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
+    ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
+    ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
+    ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
+    ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
+    ap.add_argument("--extra-configs", type=int, default=-1, help="1 = also run BASELINE configs[1] (--mesh 0) and configs[3] (--config velodyne) as short child runs and report them under "
+                    "`extra`; default: on for the plain N=1 headline run")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched as `python bench.py --gpus N`: become the launcher of N ranks (one per GPU) of this very command line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(sys.argv[0])] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
+    import torch
+    rank, world, local = D.env_rank()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    local = local % torch.cuda.device_count()   # one GPU per rank on a real node; functional tests may stack ranks on one device (gloo)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = D.init(args.backend, dev if args.backend == "nccl" else None) if world > 1 else None
+    only_sharded = bool(args.shard) and world > 1
+    kitti = args.config == "velodyne"
+    hip = capi.load_hip_library()
+
+    res = measure(args, torch, D, dist, hip, rank, world, local, dev, sharded=only_sharded, full=True)
+    value = D.aggregate_throughput(args.steps, 1 if only_sharded else world, res["elapsed"])
+    mesh_mode, cnt = res["mesh_mode"], res["cnt"]
+    cnt["_n_ds_mean"] = res["n_ds_mean"]
+    NOWAIT = 0x10
+
+    # The line as it stands after the timed region; the legs below fill it in.  A watchdog prints it -- with whatever has been filled in -- if one
+    # of them hangs: the headline number must not be lost.
+    out = None
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and out is not None and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    def watchdog():
+        if not printed.wait(2.0 * args.profile_timeout + args.cpu_seconds + 30.0):
+            out["profile_leg_note"] = ((out.get("profile_leg_note") or "") + " watchdog: a leg after the timed region did not finish; the line was printed without it").strip()
+            emit()
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+
+    def add_traffic(rf):
+        tr = os.path.join(ROOT, "profiles", COMMITTED_TRAFFIC)   # PMC-derived HBM bytes/launch from the committed rocprofv3 --pmc passes
+        if rf is not None and os.path.exists(tr):
             try:
-                roofline["traffic"] = json.load(open(tr)).get(roofline["kernel"])
-            except Exception:
+                rf["traffic"] = json.load(open(tr)).get(rf["kernel"])
+                rf["traffic_source"] = f"profiles/{COMMITTED_TRAFFIC}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC counters cannot be read in-process); not measured in this run"
+            except Exception:   # noqa: BLE001
                 pass
-
-    # ---- CPU baseline leg: the oracle (CPU restatement, "port") on the host cores, bounded sample of the same stream.  Two passes over the same
-    # scans, half the budget each: single-threaded, and with the reference's own threading (a 12-thread pool over mesh voxels,
-    # maximum_thread_for_rec_mesh; 4 OpenMP threads in the matcher, MP_PROC_NUM) -- the results are identical, the faster pass is reported.
-    cpu = None
-    if rank == 0 and args.cpu_seconds > 0:
-        orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
-        if not os.path.exists(orc_so):
-            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
-        orc_lib = ctypes.CDLL(orc_so)
-
-        def cpu_pass(mesher_threads, matcher_threads, budget):
-            o = capi.HotPath(orc_lib, cfg, "orc_")
-            o.set_threads(mesher_threads, matcher_threads)
-            so = capi.make_state(R=R0, t=t0)
-            o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # (kitti: exactly the GPU leg's map; avia: a local map instead of the 10M-voxel survey)
-            so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
-            if args.mesh:
-                o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
-            tc, nc, kk = 0.0, 0, 1
-            while tc < budget and kk < len(raws):
-                prior = synth.forward_without_imu(so)
-                a = time.perf_counter()
-                so, _ = o.process_scan(downs[kk], raws[kk], prior, prior, frame_idx=kk, do_mesh=bool(args.mesh))
-                tc += time.perf_counter() - a
-                nc += 1; kk += 1
-            o.close() if hasattr(o, "close") else None
-            return nc, tc
-
-        ncores = os.cpu_count() or 1
-        n1, t1 = cpu_pass(1, 1, args.cpu_seconds / 2)
-        mt = (min(12, ncores), min(4, ncores))
-        n2, t2 = cpu_pass(mt[0], mt[1], args.cpu_seconds / 2) if ncores > 1 else (n1, t1)
-        single, threaded = n1 / t1, n2 / t2
-        use_threads = threaded > single
-        nc, tc = (n2, t2) if use_threads else (n1, t1)
-        cpu = {"value": round(nc / tc, 4), "unit": "scans/s", "cores": mt[0] if use_threads else 1, "kind": "port",
-               "sample": f"{nc} scans of the same stream through oracle/liboracle.so (" +
-                         (f"{mt[0]} threads over mesh voxels, {mt[1]} in the matcher -- the reference's own threading" if use_threads else "single thread") +
-                         "), map = scan 0 + growth (not the 10M-voxel map)",
-               "ms_per_scan": round(1e3 * tc / nc, 3), "single_thread_value": round(single, 4), "reference_threading_value": round(threaded, 4)}
+        return rf
 
     if rank == 0:
         out = {
             "metric": ("scans/sec (reg+mesh), KITTI-shaped 130k-ray scans" if kitti else "scans/sec (reg+mesh), 100k-pt scan into 10M-voxel map") if args.mesh else
                       "scans/sec (registration + map update, meshing off), 100k-pt scan into 10M-voxel map",
-            "value": round(D.aggregate_throughput(args.steps, 1 if sharded else world, elapsed), 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "value": round(value, 4), "unit": "scans/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * res["elapsed"] / args.steps, 4), "higher_is_better": True, "scaling": "strong" if only_sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (("synthetic KITTI-shaped HDL-64 scan stream (velodyne.yaml), " if kitti else "synthetic Livox-Avia 100k-pt/scan stream, ") +
                                     ("full pipeline (registration + map update + voxel meshing)" if args.mesh else "registration + map update, meshing off")),
-                       "n_raw": int(np.mean([len(r) for r in raws])), "n_ds_mean": round(n_ds_mean, 1), "map_root_voxels": int(n_map), "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
-                       "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks)" if sharded
+                       "n_raw": res["n_raw"], "n_ds_mean": round(res["n_ds_mean"], 1), "map_root_voxels": res["n_map"], "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
+                       "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},
-            "stages_ms_serial": {"gpu_total": round(stage[0] / max(1, args.steps), 4), "register": round(stage[1] / max(1, args.steps), 4),
-                          "map_update": round(stage[2] / max(1, args.steps), 4), "mesh": round(stage[3] / max(1, args.steps), 4)},
-            "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in ("n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_new", "v_act", "n_u", "t_add", "t_rem")},
-            "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
-                               if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
-            "pose_err_m": round(pose_err, 4),
-            "roofline": roofline, "cpu_baseline": cpu,
-            "kernels_ms_per_scan": {n: round(s["total_ms"] / max(1, args.profile_scans), 4) for n, s in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])},
+            "stages_ms_serial": None,
+            "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},
+            "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
+            "roofline": None, "cpu_baseline": None, "kernels_ms_per_scan": {},
         }
+        if args.profile_scans > 0:   # until the live leg has delivered: the committed rocprofv3 average of the dominant kernel with this run's own counters
+            out["roofline"] = add_traffic(roofline_from_committed_profile(args.mesh, cnt, args.steps, args.pts, "not run yet"))
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    stage, kstats, pc, prof_note = res["legs"]()
+    if rank == 0:
+        if stage:
+            out["stages_ms_serial"] = {"gpu_total": round(stage[0], 4), "register": round(stage[1], 4), "map_update": round(stage[2], 4), "mesh": round(stage[3], 4)}
+        if kstats:
+            res["kstats"], res["pc"] = kstats, pc
+            out["kernels_ms_per_scan"] = {n: round(s_["total_ms"] / max(1, args.profile_scans), 4) for n, s_ in sorted(kstats.items(), key=lambda kv: -kv[1]["total_ms"])}
+            live = build_roofline(res, args)
+            if live is not None:
+                out["roofline"] = add_traffic(live)
+        elif args.profile_scans > 0:
+            out["roofline"] = add_traffic(roofline_from_committed_profile(args.mesh, cnt, args.steps, args.pts, prof_note or "the HIP-event leg did not run"))
         if prof_note:
             out["profile_leg_note"] = prof_note
-        print(json.dumps(out), flush=True)
+
+    # ---- N > 1: the north-star split as a second leg -- ONE stream, voxel bricks sharded over the ranks (every rank takes part)
+    if world > 1 and not only_sharded and args.sharded_leg:
+        rs = measure(args, torch, D, dist, hip, rank, world, local, dev, sharded=True, full=False)
+        rs["legs"]()   # (nothing to run for this leg: closes its context)
+        if rank == 0:
+            out["sharded"] = {"value": round(D.aggregate_throughput(args.steps, 1, rs["elapsed"]), 4), "unit": "scans/s", "scaling": "strong", "ms_per_step": round(1e3 * rs["elapsed"] / args.steps, 4),
+                              "parallelism": f"ONE stream; registration map + mesher sharded by voxel bricks over {world} GPUs", "collectives": rs["comm"], "map_root_voxels_rank0": rs["n_map"],
+                              "exchange_bytes_per_scan_rank0": round(rs["shard_traffic"]["bytes"] / max(1, args.steps + args.warmup + 1), 1) if rs.get("shard_traffic") else None,
+                              "pose_err_m": round(rs["pose_err"], 4)}
+
+    # ---- CPU baseline leg (rank 0, N = 1 semantics: the oracle on this box's host cores)
+    if rank == 0 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline_leg(args, res["cpu_inputs"], args.cpu_seconds)
+
+    # ---- BASELINE configs[1] and configs[3] as short child runs of this script (N = 1 headline runs only)
+    want_extra = args.extra_configs if args.extra_configs >= 0 else int(world == 1 and args.mesh == 1 and args.config == "avia" and not args.device_downsample and args.pts == 100000 and args.map_voxels >= 10e6)
+    if rank == 0 and want_extra:
+        extra = {}
+        env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20))])):
+            cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
+                lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and lines:
+                    d = json.loads(lines[-1])
+                    extra[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "metric": d["metric"], "n_ds_mean": d["config"]["n_ds_mean"],
+                                    "map_root_voxels": d["config"]["map_root_voxels"], "scan_thread_ms": d["scan_thread_ms"]}
+                else:
+                    extra[label] = {"error": f"rc {r.returncode}"}
+            except Exception as e:   # noqa: BLE001
+                extra[label] = {"error": str(e)[:120]}
+        out["extra"] = extra
+
+    emit()
     if world > 1:
-        D.barrier()          # rank 0 may still be in its roofline / CPU-baseline legs: leave together
+        D.barrier()          # rank 0 may still be in its CPU-baseline leg: leave together
         dist.destroy_process_group()
-    if prof_note:            # the instrumented child was killed: do not risk the runtime teardown of this process on a possibly disturbed device
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -79,10 +79,15 @@ static int alloc_all(immesh_ctx* c) {
     A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns);
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     A(c->d_dump_count, 2);
+    A(c->d_regstate, 1);
+    HIPCHK(c, hipMemsetAsync(c->d_regstate, 0, sizeof(RegState), c->stream));
     A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
 #undef A
     HIPCHK(c, hipHostMalloc((void**)&c->h_out48, RES_NV_HOST * sizeof(double), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_out48_host, c->h_out48, 0));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_reg_out, REG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_reg_out_host, c->h_reg_out, 0));
+    std::memset(c->h_reg_out, 0, REG_OUT_DOUBLES * sizeof(double));
     HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_counters_host, c->h_counters, 0));
     return 0;
@@ -137,6 +142,7 @@ void immesh_destroy(immesh_ctx* c) {
     mesh_free(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_out48) (void)hipHostFree(c->h_out48);
+    if (c->h_reg_out) (void)hipHostFree(c->h_reg_out);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -188,7 +194,10 @@ static int run_residual_pass(immesh_ctx* c, const float* d_pts, int n, const imh
     // the last block of the launch writes the 48 sums straight into pinned host memory: one launch + one stream sync per EKF iteration
     // and a completion ticket after them; the host polls the ticket (a few microseconds) instead of paying a stream synchronisation
     const double ticket = (double)(++c->res_ticket);
-    launch_residual(c->stream, c->map, sp, d_pts, n, c->d_partials, c->d_done, c->d_out48_host, ticket, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
+    RegIterArgs& a = c->reg_args;
+    a.mode = REG_MODE_HOST; a.it = 0; a.max_iter = c->cfg.max_iter; a.sp = sp;
+    launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n, c->d_partials, c->d_done, c->d_out48_host, c->d_reg_out_host, ticket, c->d_match, c->d_mnode, c->d_dis,
+                    c->d_rinv, c->d_normal);
     {
         volatile double* flag = c->h_out48 + (RES_NV_HOST - 1);
         const auto t0 = std::chrono::steady_clock::now();
@@ -218,8 +227,71 @@ static int fetch_matches(immesh_ctx* c, int n, std::vector<int8_t>& mt) {
     return 0;
 }
 
+// The iterated update with the 18-state step on the device (reg_kernels.hip: ekf_step_wave in the last block of every residual pass): all
+// passes of the scan are enqueued up front, a pass that finds the loop already stopped returns at once.  The posterior stays on the device
+// (RegState::sp) for the map update / full-scan transform queued behind it; the host only collects it.
+static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, const imh::State& st) {
+    const int max_iter = c->cfg.max_iter;
+    RegIterArgs& a = c->reg_args;
+    make_scan_params(c, st, st.cov, a.sp);
+    a.max_iter = max_iter; a.pad = 0;
+    std::memcpy(a.st, st.R, 72); std::memcpy(a.st + 9, st.t, 24); std::memcpy(a.st + 12, st.vel, 24); std::memcpy(a.st + 15, st.bg, 24); std::memcpy(a.st + 18, st.ba, 24); std::memcpy(a.st + 21, st.g, 24);
+    std::memcpy(a.prior, prior.R, 72); std::memcpy(a.prior + 9, prior.t, 24); std::memcpy(a.prior + 12, prior.vel, 24); std::memcpy(a.prior + 15, prior.bg, 24);
+    std::memcpy(a.prior + 18, prior.ba, 24); std::memcpy(a.prior + 21, prior.g, 24);
+    c->reg_ticket = (double)(++c->res_ticket);
+    for (int it = 0; it < max_iter; it++) {
+        a.it = it;
+        if (it == 0) {
+            a.mode = REG_MODE_FIRST;
+            double p11[36];
+            for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) p11[r * 6 + q] = st.cov[r * 18 + q];
+            if (!imh::invert(p11, a.mat, 6)) { c->err = "singular prior covariance"; return IMMESH_E_INVAL; }
+            for (int i = 0; i < 12; i++)
+                for (int q = 0; q < 6; q++) { double sacc = 0; for (int k = 0; k < 6; k++) sacc += st.cov[(6 + i) * 18 + k] * a.mat[k * 6 + q]; a.mat[36 + i * 6 + q] = sacc; }
+        }
+        else { a.mode = REG_MODE_NEXT; if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat)); }
+        launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, c->d_out48, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
+                        c->d_dis, c->d_rinv, c->d_normal);
+    }
+    return 0;
+}
+static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
+    volatile double* flag = c->h_reg_out + (REG_OUT_DOUBLES - 1);
+    const double ticket = c->reg_ticket;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*flag != ticket) {
+        if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) break;   // never spin unbounded: fall back to the stream
+    }
+    if (*flag != ticket || c->prof.on) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (*flag != ticket) { c->err = "registration kernels did not complete"; return IMMESH_E_HIP; }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const double* o = c->h_reg_out;
+    imh::load_state(o, st);
+    const int iters = (int)o[348];
+    if (n_iter) *n_iter = iters;
+    if (n_match) *n_match = (int)o[349];
+    if (res_mean) *res_mean = o[349] > 0 ? o[350] / o[349] : 0.0;
+    c->cnt.n_match += (int64_t)o[353];
+    c->cnt.n_plane_tests += (int64_t)o[351];
+    c->cnt.n_extra_probe += (int64_t)o[352];
+    c->cnt.n_iter += iters;
+    c->cnt.n_ds = n_ds;
+    c->last_n_ds = n_ds;
+    return 0;
+}
+static bool use_fused_ekf(const immesh_ctx* c) {
+    static const bool host_ekf = getenv("IMMESH_HOST_EKF") != nullptr;   // debugging: the round-1 host loop (one round trip per pass)
+    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && !c->reg_dbg;
+}
+
 // the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
 static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
+    if (use_fused_ekf(c)) {
+        const int rc = register_enqueue_fused(c, d_pts, n_ds, prior, st);
+        if (rc) return rc;
+        return register_collect_fused(c, n_ds, st, n_iter, n_match, res_mean);
+    }
     imh::EkfLoop ekf;
     const int max_iter = c->cfg.max_iter;
     int iters = 0;
@@ -319,7 +391,10 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
 }
 
 // shared by map_build / map_update: per-point var + root slots, sort, per-voxel replay
-static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr) {
+// spd != nullptr: pose + covariance blocks come from device memory (the posterior the in-kernel EKF left in RegState::sp); `st` then only
+// supplies the per-configuration constants
+static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr,
+                             const ScanParams* spd = nullptr) {
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
@@ -328,13 +403,13 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
         c->map.upd_seq++;
         c->map.touched = (uint32_t*)c->d_seg_start;
-        launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
+        launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
         if (after_point_var) HIPCHK(c, hipEventRecord(after_point_var, s));   // the scan's input clouds are consumed: the replay works on its own copies
         launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
-        launch_point_var(s, c->map, sp, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, nullptr);
+        launch_point_var(s, c->map, sp, nullptr, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, nullptr);
         launch_iota(s, c->d_idx_a, (int)n);
         sort_pairs_u32(s, c->d_sort_temp, c->sort_temp_bytes, c->d_slot, c->d_slot_s, c->d_idx_a, c->d_idx_c, (int)n, 32);  // 0xFFFFFFFF "no slot" sorts last
         launch_segment_heads(s, c->d_slot_s, (int)n, c->d_seg_start, c->d_nseg);
@@ -397,6 +472,39 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     hipEvent_t* ev = c->ev + 4 * par;
     (void)hipEventRecord(ev[0], c->stream);
     int n_iter = 0, n_match = 0;
+    if (use_fused_ekf(c)) {
+        // Everything of the scan is enqueued before the host looks at a single result: the residual passes with the in-kernel 18-state update,
+        // the full-scan transform and the map update (both read the posterior from RegState::sp on the device).  The host then collects the
+        // pose -- by then the device is already growing the map -- and hands the scan to the mesher.
+        if ((rc = register_enqueue_fused(c, (const float*)d_down, n_ds, prior, st))) return rc;
+        (void)hipEventRecord(ev[1], c->stream);
+        float* world = nullptr;
+        if (mesh_mode) {
+            world = mesh_next_world_buffer(c);
+            launch_mesh_transform(c->stream, (const float*)d_raw, world, n_raw, nullptr, nullptr, c->cfg.extR, c->cfg.extT, (const double*)&c->d_regstate->sp);
+            mesh_record_ready(c);
+        }
+        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp))) return rc;
+        (void)hipEventRecord(ev[2], c->stream);
+        (void)hipEventRecord(ev[3], c->stream);
+        rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
+        imh::store_state(st, state_inout);
+        if (n_iter_out) *n_iter_out = n_iter;
+        if (n_match_out) *n_match_out = n_match;
+        if (rc) return rc;
+        // this scan's passes ran behind the previous scan's map update on the same stream: that update is complete now
+        if ((rc = settle(c, true))) return rc;   // (deferred capacity error of the previous update; this scan's pose has been handed back)
+        c->ev_par = par;
+        long job = 0;
+        if (mesh_mode) job = mesh_submit(c, world, n_raw, st.t, frame_idx, true);
+        c->timing[3] = 0.f;
+        c->pending = true;
+        if (nowait) return 0;
+        if ((rc = settle(c))) return rc;
+        if (mesh_mode == IMMESH_MESH_SYNC && (rc = mesh_wait(c, job))) return rc;
+        c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
+        return 0;
+    }
     if ((rc = register_device(c, (const float*)d_down, n_ds, prior, st, &n_iter, &n_match, nullptr))) return rc;
     // the residual passes of this scan ran behind the previous scan's map update on the same stream: that update is complete now
     if ((rc = settle(c, true))) {   // deferred capacity error of the PREVIOUS scan's map update: this scan's pose is still valid and is handed back

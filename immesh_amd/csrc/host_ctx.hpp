@@ -55,6 +55,11 @@ struct immesh_ctx {
     double* h_out48 = nullptr;       // pinned, device-mapped
     double* d_out48_host = nullptr;  // device view of h_out48
     unsigned int* d_done = nullptr;  // residual_kernel's "blocks finished" counter
+    RegState* d_regstate = nullptr;  // device-resident iterate of the scan being registered (in-kernel EKF)
+    RegIterArgs reg_args;            // argument block of the residual passes (host staging)
+    double* h_reg_out = nullptr;     // pinned, device-mapped: posterior state + counters + ticket written by the pass that stops the loop
+    double* d_reg_out_host = nullptr;
+    double reg_ticket = 0;
     immesh_allreduce_fn allreduce = nullptr;   // sharded map: sums the per-rank partial normal equations
     void* allreduce_user = nullptr;
     unsigned long long* reg_dbg = nullptr;  // phase timers of residual_kernel (IMMESH_DEBUG)
@@ -128,7 +133,8 @@ struct ProfBind {  // binds the ctx profiler to the calling thread for the durat
 // mesher host orchestration (mesh_host.cpp)
 int mesh_alloc(immesh_ctx* c);
 void mesh_free(immesh_ctx* c);
-long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx);
+long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded = false);
+void mesh_record_ready(immesh_ctx* c);   // record the NEXT job's "scan is in its world buffer" event on the registration stream now (before more work is queued behind it)
 float* mesh_next_world_buffer(immesh_ctx* c);
 int mesh_wait(immesh_ctx* c, long id);
 void mesh_wait_all(immesh_ctx* c);

@@ -28,9 +28,37 @@ struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
 #define RES_NV_HOST 48
 #define RES_NR_HOST 32
 
-void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
-                     double* out48, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
-void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
+// ---- device-resident iterated EKF (Voxel_mapping::lio_state_estimation, src/voxel_mapping.cpp:1585-1650) ---------------------
+// The state of the scan being registered stays on the device between the residual passes: the last block of a pass runs the 18-state
+// update in-kernel and leaves the next pass's parameters behind, so a whole scan is enqueued without a host round trip.
+struct RegState {
+    ScanParams sp;            // what the per-point kernels of the NEXT pass (and the map update / full-scan transform) read
+    double st[24];            // current iterate: R[9] t[3] vel[3] bias_g[3] bias_a[3] gravity[3]
+    double prior[24];         // state_propagat
+    double p11inv[36];        // inverse of the pose block P11 of the prior covariance (state.cov is the prior for every iteration of a scan)
+    double tmat[72];          // P21 P11^-1 (12 x 6): with X = (H^T R^-1 H + P11^-1)^-1 the gain's six columns are [X; tmat X]
+    double tot[4];            // cumulative over the passes: n_plane_tests, n_extra_probe, passes run, n_match
+    int rematch, done, pad0, pad1;
+};
+// argument block of one residual pass (kernel arguments are limited to 4 KB: RegMapDev + this + a dozen pointers stay below)
+#define REG_MODE_HOST 0       /* legacy: parameters by value, the 48 sums + ticket go to pinned host memory, the host runs the EKF step */
+#define REG_MODE_FIRST 1      /* fused, first pass of a scan: parameters, iterate, prior and the gain constants arrive by value */
+#define REG_MODE_NEXT 2       /* fused, later pass: parameters from RegState; mat = the prior covariance (needed when the loop stops) */
+#define REG_MODE_SUMS 3       /* parameters from RegState (it > 0) or by value (it == 0); the 48 sums go to device memory for an in-stream all-reduce, ekf_step_kernel follows */
+struct RegIterArgs {
+    int mode, it, max_iter, pad;
+    ScanParams sp;
+    double st[24], prior[24];
+    double mat[324];          // first pass: [0,36) P11^-1, [36,108) P21 P11^-1; later passes: the prior covariance
+};
+#define REG_OUT_DOUBLES 360   /* pinned result block: [0,348) posterior state, 348 passes run, 349 n_match (last pass), 350 sum|dis| (last pass), 351 plane tests, 352 extra probes, 353 n_match summed over the passes, 359 ticket */
+
+void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
+                     double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+// the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
+void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
+// spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`
+void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const ScanParams* spd, const float* pts, int n, int stride, int mode, double* pt_data,
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next);
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
                          int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order);

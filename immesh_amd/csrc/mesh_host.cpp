@@ -83,7 +83,7 @@ int mesh_alloc(immesh_ctx* c) {
     const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
     m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
     m.dbg = nullptr;
-    if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 16))) return rc; m.dbg = t; (void)hipMemset(t, 0, 128); }
+    if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 32))) return rc; m.dbg = t; (void)hipMemset(t, 0, 256); }
     hipStream_t s = c->stream;
     launch_fill_u64(s, m.g_keys, ~0ull, (size_t)gcap);
     launch_fill_u64(s, m.x_keys, ~0ull, (size_t)xcap);
@@ -135,13 +135,12 @@ int mesh_alloc(immesh_ctx* c) {
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (getenv("IMMESH_NO_PRIORITY")) prio_least = 0;
     {
-        // The registration stream is the pose chain and keeps the whole device; the mesher's two streams are confined to 5/8 of the CUs.
-        // Its kernels are swarms of lone, issue-bound wavefronts: sharing every SIMD with them slowed the pose chain's kernels by up to 2x
-        // (replay_list 73 -> 150 us), while the mesher loses ~2 % from the narrower device (measured: 3000 -> 3480 scans/s at 160 of 256 CUs;
-        // 128: 3320, 192: 3430, 224: 3130).  IMMESH_MESH_CUS=n overrides, 0 = no mask (lowest-priority streams instead).
-        hipDeviceProp_t prop;
+        // The mesher's two streams are plain non-blocking streams of the lowest priority.  IMMESH_MESH_CUS=n confines them to n CUs instead
+        // (hipExtStreamCreateWithCUMask).  Round 1 ran with 160 of 256 CUs by default (+16 % when the mesher's lone wavefronts slowed the pose
+        // chain's kernels); with the round-2 kernels the gain is within noise (3280 vs 3220 scans/s), and CU-masked streams are BLOCKING streams
+        // on which event-timed launches failed intermittently (garbage counters / memory faults / hangs with the in-library profiler on,
+        // tools/debug_profiler.sh) -- so the mask is opt-in.
         int ncu = 0;
-        if (hipGetDeviceProperties(&prop, g.device) == hipSuccess) ncu = (prop.multiProcessorCount * 5 / 8) & ~7;
         if (const char* e = getenv("IMMESH_MESH_CUS")) ncu = atoi(e);
         if (ncu >= 8 && ncu < 1024) {
             uint32_t mask[32];
@@ -394,8 +393,11 @@ static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes
     h.n_live += n_add - n_rem;
     h.cum[SC_MAXNU] = std::max<int64_t>(h.cum[SC_MAXNU], h.h_sc[SC_MAXNU]); h.cum[SC_PASS2] += h.h_sc[SC_PASS2];
     if (m.dbg) {
-        unsigned long long t[16];
-        (void)hipMemcpy(t, m.dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 128);
+        unsigned long long t[32];
+        (void)hipMemcpy(t, m.dbg, 256, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 256);
+        fprintf(stderr, "[delaunay64 cycles/voxel] cavity %llu edges %llu extras %llu inplace %llu filter+emit %llu | sums %llu jacobi %llu proj %llu | points %llu bails %llu\n", t[16] / std::max(1, n_active),
+                t[17] / std::max(1, n_active), t[18] / std::max(1, n_active), t[19] / std::max(1, n_active), t[20] / std::max(1, n_active), t[24] / std::max(1, n_active), t[25] / std::max(1, n_active),
+                t[26] / std::max(1, n_active), t[15], t[7]);
         fprintf(stderr, "[slowest voxel] knn %llu cycles (nq %llu)  delaunay %llu cycles (n_u %llu)\n", t[13] >> 16, t[13] & 0xFFFF, t[14] >> 16, t[14] & 0xFFFF);
         fprintf(stderr, "[knn cycles/voxel] stage0 %llu query0 %llu stage1 %llu query1 %llu final %llu\n", t[8] / std::max(1, n_active), t[9] / std::max(1, n_active), t[10] / std::max(1, n_active),
                 t[11] / std::max(1, n_active), t[12] / std::max(1, n_active));
@@ -471,7 +473,13 @@ static void mesh_worker_main(immesh_ctx* c) {
 
 // Called on the scan thread.  d_pts = world-frame xyzI already (being) produced on c->stream; returns the job id.
 // At most two jobs are outstanding (their scans live in the two world buffers), so this blocks while job id-2 is still running.
-long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx) {
+void mesh_record_ready(immesh_ctx* c) {
+    MeshHost& h = c->mesh_host;
+    long next;
+    { std::unique_lock<std::mutex> lk(h.mu); next = h.submitted + 1; }
+    (void)hipEventRecord(h.ev_ready[next & 1], c->stream);
+}
+long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded) {
     MeshHost& h = c->mesh_host;
     MeshJob job;
     {
@@ -481,7 +489,7 @@ long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sen
     job.d_pts = d_pts; job.n_raw = n_raw; job.frame_idx = frame_idx;
     job.cam[0] = sensor_pos[0]; job.cam[1] = sensor_pos[1]; job.cam[2] = sensor_pos[2];
     job.ready = h.ev_ready[job.id & 1];
-    (void)hipEventRecord(job.ready, c->stream);
+    if (!ready_recorded) (void)hipEventRecord(job.ready, c->stream);
     {
         std::lock_guard<std::mutex> lk(h.mu);
         h.q.push_back(job);

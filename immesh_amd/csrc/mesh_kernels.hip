@@ -6,7 +6,7 @@
 //   mesh_knn_kernel              retrieve_neighbor_pts_kdtree (mesh_rec_geometry.cpp:336-377): one workgroup per active mesh
 //                                voxel, the surrounding voxel block staged through LDS, exact 20-NN per vertex (float
 //                                distances as KD_TREE::calc_dist, ikd_Tree.cpp:1722), smoothing, neighbourhood union
-//   mesh_delaunay_kernel         delaunay_triangulation + triangle_compare + correct_triangle_index
+//   mesh_delaunay64_kernel       delaunay_triangulation + triangle_compare + correct_triangle_index
 //                                (mesh_rec_geometry.cpp:174-295, 137-172, 399-433): one wavefront per voxel; PCA, 2-D
 //                                projection, wave-parallel Bowyer-Watson with the plain-double Simple_cartesian predicates,
 //                                skinny-face filter, diff against the live triangles found through the min-vertex lists
@@ -92,9 +92,16 @@ IMD void list_push(const MeshDev& m, int32_t* list, int counter, int v) {
 // transformLidar of the full scan
 // =====================================================================================================================
 struct XformParams { double R[9], t[3], extR[9], extT[3]; };
-__global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __restrict__ in, float4* __restrict__ out, int n, XformParams xp) {
+// rt_dev != nullptr: R (9 doubles) and t (3) of the pose are read from device memory -- the head of RegState::sp, left there by the in-kernel EKF
+__global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __restrict__ in, float4* __restrict__ out, int n, XformParams xp, const double* __restrict__ rt_dev) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (rt_dev) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) xp.R[k] = rt_dev[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) xp.t[k] = rt_dev[9 + k];
+    }
     const float4 v = in[i];
     const double p[3] = {(double)v.x, (double)v.y, (double)v.z};
     double pi[3], pw[3];
@@ -744,9 +751,9 @@ IMD int tri_find_or_insert(const MeshDev& m, int a, int b, int c, int* spare) {
 }
 
 #define DBG_T(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
+// The general per-voxel triangulation (any neighbourhood size up to CAP): triangle table in LDS.  One wavefront; r = rank of the active voxel.
 template <int CAP>
-__global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_lo, int n_hi) {
-    MESH_DYN(m_in);
+__device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const MeshScanParams& sp, const int r) {
     constexpr int TCAP = 2 * CAP + 8;
     __shared__ int ids[CAP];
     __shared__ float pf[CAP * 3];
@@ -763,11 +770,7 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     __shared__ unsigned short old_i[2 * CAP];
 
     const int lane = threadIdx.x;
-    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
-    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     const int n = m.rel_n[r];
-    if (n < n_lo || n > n_hi) continue;  // size class of the other instantiation
-    if (n == 0) { if (threadIdx.x == 0) m.vox_ntris[r] = 0; continue; }   // sharded mesher: a voxel another rank triangulates (its marks arrive by all-gather)
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
     const unsigned long long tvox0 = tprev;
     const int vi = m.act_vox_s[r];
@@ -1045,8 +1048,17 @@ __global__ __launch_bounds__(64) void mesh_delaunay_kernel(MeshDev m_in, int n_l
     __syncthreads();
     DBG_T(6);
     if (m.dbg && lane == 0) atomicMax(&m.dbg[14], ((__builtin_readcyclecounter() - tvox0) << 16) | (unsigned long long)n);
-    }
+    __syncthreads();
 }
+// neighbourhoods above 256 vertices (space-filling clouds; never with the shipped configurations): the big-LDS instantiation
+__global__ __launch_bounds__(64) void mesh_delaunay_big_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x)
+        if (m.rel_n[r] > 256) mesh_delaunay_voxel<MV_REL_CAP>(m, sp, r);
+}
+
+#include "mesh_delaunay64.inc"
 
 // cross-voxel resolution: the voxel with the highest rank that touched a triangle owns its flip (later voxel wins, as the
 // sequential loop); it also queues the triangle for insertion / reports a changed flip.  Then this scan's smoothed positions commit.
@@ -1364,11 +1376,11 @@ __global__ void mesh_commit_add_kernel(MeshDev m_in, const int32_t* __restrict__
 static inline dim3 g1(int n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
-                           const double* extT) {
+                           const double* extT, const double* rt_dev) {
     XformParams xp;
-    for (int i = 0; i < 9; i++) { xp.R[i] = R[i]; xp.extR[i] = extR[i]; }
-    for (int i = 0; i < 3; i++) { xp.t[i] = t[i]; xp.extT[i] = extT[i]; }
-    KLAUNCH(mesh_transform_kernel, g1(n), dim3(256), 0, s, (const float4*)raw_xyzi, (float4*)world_xyzi, n, xp);
+    for (int i = 0; i < 9; i++) { xp.R[i] = R ? R[i] : 0.0; xp.extR[i] = extR[i]; }
+    for (int i = 0; i < 3; i++) { xp.t[i] = t ? t[i] : 0.0; xp.extT[i] = extT[i]; }
+    KLAUNCH(mesh_transform_kernel, g1(n), dim3(256), 0, s, (const float4*)raw_xyzi, (float4*)world_xyzi, n, xp, rt_dev);
 }
 // n_cand only sizes the grids here; the kernels take every per-scan value from MeshDev::dyn
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts) {
@@ -1413,8 +1425,8 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 }
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
-    KLAUNCH(mesh_delaunay_kernel<256>, dim3(4096), dim3(64), 0, s, m, 0, 256);
-    KLAUNCH(mesh_delaunay_kernel<MV_REL_CAP>, dim3(512), dim3(64), 0, s, m, 257, MV_REL_CAP);
+    KLAUNCH(mesh_delaunay64_kernel, dim3(4096), dim3(64), 0, s, m);          // n_u <= 256 (register fast path up to 64)
+    KLAUNCH(mesh_delaunay_big_kernel, dim3(256), dim3(64), 0, s, m);         // n_u > 256
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }

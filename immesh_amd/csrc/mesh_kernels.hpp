@@ -157,7 +157,7 @@ struct MeshHost {
 };
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
-                           const double* extT);
+                           const double* extT, const double* rt_dev = nullptr);
 void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m);
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter);

@@ -102,6 +102,187 @@ IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double
     }
 }
 
+
+// =====================================================================================================================
+// the 18-state iterated-EKF update on one wavefront (imh::EkfLoop::step, ekf_host.hpp -- the same operations in the same order:
+// Gauss-Jordan with partial pivoting on [H^T R^-1 H + P^-1 | e_0..e_5], G = K1 H^T R^-1 H, solution, boxplus, stop rule, (I - G) P)
+// =====================================================================================================================
+IMD double rl_d(double x, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
+    return __hiloint2double(hi, lo);
+}
+IMD void dev_so3_exp(double v1, double v2, double v3, double* R) {  // include/so3_math.h:71-89
+    const double norm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    if (norm > 0.00001) {
+        const double r[3] = {v1 / norm, v2 / norm, v3 / norm};
+        const double K[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
+        double KK[9];
+        m3_mul(K, K, KK);
+        const double sn = sin(norm), c1 = 1.0 - cos(norm);
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (R[i] + sn * K[i]) + c1 * KK[i];
+    }
+}
+IMD void dev_so3_log(const double* R, double* out) {  // include/so3_math.h:92-98
+    const double tr = R[0] + R[4] + R[8];
+    const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+    const double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    if (fabs(theta) < 0.001) { out[0] = 0.5 * K[0]; out[1] = 0.5 * K[1]; out[2] = 0.5 * K[2]; }
+    else { const double f = 0.5 * theta / sin(theta); out[0] = f * K[0]; out[1] = f * K[1]; out[2] = f * K[2]; }
+}
+// hth: 6x6 row-major, htz: 6 (LDS).  W: >= 260 doubles of LDS scratch.  cov: the prior covariance (only read when the loop stops).
+// Returns true when the loop stops with this pass (rs->done set, posterior written to reg_out).
+// The gain: K1 = (H^T R^-1 H + P^-1)^-1 restricted to its first six columns (H only has the six pose columns).  With P = [P11 P12; P21 P22]
+// those columns are [X; P21 P11^-1 X], X = (H^T R^-1 H + P11^-1)^-1 (block inverse + Schur complement) -- a 6x6 inverse per pass instead of the
+// 18x18 one of ekf_host.hpp / Eigen; P11^-1 and P21 P11^-1 are per-scan constants the host supplies.  Same result up to rounding (~1e-14 rel.).
+// C (LDS): the staged inputs -- [0,36) P11^-1, [36,108) P21 P11^-1, [108,132) iterate, [132,156) prior, [156,160) cumulative counters (this pass
+// included), [160] rematch count.
+#define EKF_C_DOUBLES 164
+__device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const double* C, const double* __restrict__ cov, const double* hth, const double* htz, const double n_match,
+                                              const double res_sum, double* W, const int lane, const int it, const int max_iter, const double* __restrict__ extR,
+                                              double* __restrict__ reg_out, const double ticket) {
+    // ---- X = (H + P11^-1)^-1: lane j < 12 holds column j of [S | I] in registers; Gauss-Jordan without pivoting (S is symmetric positive definite)
+    double a[6];
+    {
+        const int j = lane < 12 ? lane : 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) a[r] = j < 6 ? hth[r * 6 + j] + C[r * 6 + j] : ((r == j - 6) ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int col = 0; col < 6; col++) {
+        const double d = rl_d(a[col], col);
+        double f[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) f[r] = rl_d(a[r], col);
+        a[col] = a[col] / d;
+#pragma unroll
+        for (int r = 0; r < 6; r++) if (r != col) a[r] -= f[r] * a[col];
+    }
+    // K1 rows 0..5 = X -> W[0,36); rows 6..17 = (P21 P11^-1) X -> W[36,108)
+    if (lane >= 6 && lane < 12) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) W[r * 6 + (lane - 6)] = a[r];
+    }
+    __syncthreads();
+    for (int e = lane; e < 72; e += 64) {
+        const int i = e / 6, k = e % 6;
+        double sacc = 0;
+#pragma unroll
+        for (int mm = 0; mm < 6; mm++) sacc += C[36 + i * 6 + mm] * W[mm * 6 + k];
+        W[36 + e] = sacc;
+    }
+    __syncthreads();
+    // G = K1 * HTH (18 x 6) -> W[108,216)
+    for (int e = lane; e < 108; e += 64) {
+        const int r = e / 6, c = e % 6;
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sacc += W[r * 6 + k] * hth[k * 6 + c];
+        W[108 + e] = sacc;
+    }
+    // vec = prior [-] state  (every lane computes the same 18 values)
+    double st[24], vec[18];
+#pragma unroll
+    for (int k = 0; k < 24; k++) st[k] = C[108 + k];
+    {
+        double Rt[9], rotd[9], pR[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) pR[k] = C[132 + k];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j2 = 0; j2 < 3; j2++) Rt[i * 3 + j2] = st[j2 * 3 + i];
+        m3_mul(Rt, pR, rotd);
+        dev_so3_log(rotd, vec);
+#pragma unroll
+        for (int k = 0; k < 15; k++) vec[3 + k] = C[132 + 9 + k] - st[9 + k];
+    }
+    __syncthreads();
+    // solution: (K1 HTz + vec) - G vec    (G and vec only act on the first 6 states)
+    double my_sol = 0;
+    if (lane < 18) {
+        double s1 = 0, s2 = 0;
+        double vr = 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++) if (lane == k) vr = vec[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { s1 += W[lane * 6 + k] * htz[k]; s2 += W[108 + lane * 6 + k] * vec[k]; }
+        my_sol = (s1 + vr) - s2;
+    }
+    double sol[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) sol[k] = rl_d(my_sol, k);
+    // state += solution
+    {
+        double E[9], Rn[9];
+        dev_so3_exp(sol[0], sol[1], sol[2], E);
+        m3_mul(st, E, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; k++) st[k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 15; k++) st[9 + k] += sol[3 + k];
+    }
+    const double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    const double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    const bool converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+    int rematch = (int)C[160];
+    if (converged || ((rematch == 0) && (it == (max_iter - 2)))) rematch++;
+    const bool stop = rematch >= 2 || (it == max_iter - 1);
+    // next pass / map update parameters
+    if (lane < 24) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
+        rs->st[lane] = v;
+    }
+    {
+        double RextR[9];
+        m3_mul(st, extR, RextR);
+        if (lane < 9) { double v = 0, w = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) if (lane == k) { v = st[k]; w = RextR[k]; }
+            rs->sp.R[lane] = v; rs->sp.RextR[lane] = w; }
+        if (lane < 3) { double v = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) if (lane == k) v = st[9 + k];
+            rs->sp.t[lane] = v; }
+    }
+    const double passes = C[158] + 1.0;
+    if (lane == 0) { rs->rematch = rematch; rs->done = stop ? 1 : 0; rs->tot[0] = C[156]; rs->tot[1] = C[157]; rs->tot[2] = passes; rs->tot[3] = C[159]; }
+    if (stop) {
+        // cov = (I - G) * cov ; G is zero outside its first 6 columns:  cov[r][c] - sum_{k<6} G[r][k] cov[k][c]
+        for (int e = lane; e < 324; e += 64) {
+            const int r = e / 18, c = e % 18;
+            double g6[6], c6[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { g6[k] = W[108 + r * 6 + k]; c6[k] = cov[k * 18 + c]; }
+            double sub = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) sub += g6[k] * c6[k];
+            const double sacc = cov[e] - sub;
+            __hip_atomic_store((unsigned long long*)&reg_out[24 + e], (unsigned long long)__double_as_longlong(sacc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (r < 3 && c < 3) rs->sp.rot_var[r * 3 + c] = sacc;                       // the map update propagates the POSTERIOR covariance blocks
+            if (r >= 3 && r < 6 && c >= 3 && c < 6) rs->sp.t_var[(r - 3) * 3 + (c - 3)] = sacc;
+        }
+        if (lane < 24) {
+            double v = 0;
+#pragma unroll
+            for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
+            __hip_atomic_store((unsigned long long*)&reg_out[lane], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (lane == 0) {
+            const double o[6] = {passes, n_match, res_sum, C[156], C[157], C[159]};
+            for (int k = 0; k < 6; k++) __hip_atomic_store((unsigned long long*)&reg_out[348 + k], (unsigned long long)__double_as_longlong(o[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(&reg_out[REG_OUT_DOUBLES - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return stop;
+}
+
 #define RES_NV 48   // host layout: 36 HTH + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe + 2 spare
 #define RES_NR 32   // reduced per block: 21 (upper triangle of HTH) + 6 HTz + 4 counters + 1 spare
 
@@ -109,11 +290,21 @@ IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double
 // One wavefront per block (n/64 blocks: a down-sampled scan is only ~8k points, so small blocks are what spreads it over the CUs).
 // Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
 // finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
-__global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n,
-                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48, double ticket,
+__global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
+                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
+                                                       double* __restrict__ reg_out, double ticket,
                                                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                        float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
     __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
+    const bool from_dev = a.mode == REG_MODE_NEXT || (a.mode == REG_MODE_SUMS && a.it > 0);
+    if (from_dev && rs->done) return;   // the iterated update stopped with an earlier pass (the passes of a scan are enqueued up front)
+    ScanParams sp = a.sp;               // constants always by value; the iterate-dependent part from the device when this is a later pass
+    if (from_dev) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sp.R[k] = rs->sp.R[k]; sp.RextR[k] = rs->sp.RextR[k]; sp.rot_var[k] = rs->sp.rot_var[k]; sp.t_var[k] = rs->sp.t_var[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) sp.t[k] = rs->sp.t[k];
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
@@ -252,6 +443,16 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
     __syncthreads();
     RDBG(4);
     if (!s_last) return;
+    if (a.mode == REG_MODE_FIRST || a.mode == REG_MODE_NEXT) {
+        // stage what the 18-state update needs (first pass: from the kernel arguments, later: from RegState) -- issued ahead of the final sum's loads
+        double* Cst = &red[0][0] + 400;
+        for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
+            double v;
+            if (a.mode == REG_MODE_FIRST) v = e < 108 ? a.mat[e] : (e < 132 ? a.st[e - 108] : (e < 156 ? a.prior[e - 132] : 0.0));
+            else v = e < 36 ? rs->p11inv[e] : (e < 108 ? rs->tmat[e - 36] : (e < 132 ? rs->st[e - 108] : (e < 156 ? rs->prior[e - 132] : (e < 160 ? rs->tot[e - 156] : (double)rs->rematch))));
+            Cst[e] = v;
+        }
+    }
     // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 8 independent (L2-served) loads in flight per
     // lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
     {
@@ -272,17 +473,61 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
         red[0][lane] = tot;
     }
     __syncthreads();
-    if (lane < RES_NV - 1) {  // expand to the host layout (pinned, device-mapped host memory)
-        double v = 0;
-        if (lane < 36) { const int r = lane / 6, c = lane % 6; v = red[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
-        else if (lane < 42) v = red[0][21 + (lane - 36)];
-        else if (lane < 46) v = red[0][27 + (lane - 42)];
-        __hip_atomic_store((unsigned long long*)&out48[lane], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    double v48 = 0;   // host layout of the sums: 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
+    if (lane < 36) { const int r = lane / 6, c = lane % 6; v48 = red[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
+    else if (lane < 42) v48 = red[0][21 + (lane - 36)];
+    else if (lane < 46) v48 = red[0][27 + (lane - 42)];
+    if (lane == 0) *done_counter = 0;
+    if (a.mode == REG_MODE_HOST || a.mode == REG_MODE_SUMS) {
+        // pinned, device-mapped host memory (HOST) / device memory ahead of an in-stream all-reduce (SUMS)
+        if (lane < RES_NV - 1) __hip_atomic_store((unsigned long long*)&out48[lane], (unsigned long long)__double_as_longlong(v48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // slot 47 is the completion ticket the host polls: a release store, issued after the 47 value stores of this (single) wavefront drained
+        RDBG(5);
+        if (lane == 0 && a.mode == REG_MODE_HOST) __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // slot 47 is the completion ticket the host polls: a release store, issued after the 47 value stores of this (single) wavefront drained
+    // ---- fused: the 18-state update runs right here, in the last block of the pass (its inputs were staged in LDS while the partials were summed)
+    double* L = &red[0][0];
+    __syncthreads();
+    if (lane < 46) L[64 + lane] = v48;
+    if (a.mode == REG_MODE_FIRST) {   // the later passes find the scan's constants in RegState (fire-and-forget stores: the next launch is the fence)
+        for (int e = lane; e < 108; e += 64) { if (e < 36) rs->p11inv[e] = a.mat[e]; else rs->tmat[e - 36] = a.mat[e]; }
+        if (lane < 24) rs->prior[lane] = a.prior[lane];
+        const unsigned long long* src = (const unsigned long long*)&a.sp;
+        unsigned long long* dst = (unsigned long long*)&rs->sp;
+        for (int e = lane; e < (int)(sizeof(ScanParams) / 8); e += 64) dst[e] = src[e];
+    }
+    __syncthreads();
+    if (lane == 0) { L[400 + 156] += L[64 + 44]; L[400 + 157] += L[64 + 45]; L[400 + 159] += L[64 + 42]; }
+    __syncthreads();
+    ekf_step_wave(rs, L + 400, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, a.it, a.max_iter, a.sp.extR, reg_out, ticket);
     RDBG(5);
-    if (lane == 0) { *done_counter = 0; __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+}
+
+// the same update as its own launch: sums48 = the (all-reduced) 48 sums of the pass in device memory
+__global__ __launch_bounds__(64) void ekf_step_kernel(RegIterArgs a, RegState* rs, const double* __restrict__ sums48, double* __restrict__ reg_out, double ticket) {
+    __shared__ double L[800];
+    const int lane = threadIdx.x;
+    if (a.it > 0 && rs->done) return;
+    if (lane < 46) L[64 + lane] = sums48[lane];
+    for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
+        double v;
+        if (a.it == 0) v = e < 108 ? a.mat[e] : (e < 132 ? a.st[e - 108] : (e < 156 ? a.prior[e - 132] : 0.0));
+        else v = e < 36 ? rs->p11inv[e] : (e < 108 ? rs->tmat[e - 36] : (e < 132 ? rs->st[e - 108] : (e < 156 ? rs->prior[e - 132] : (e < 160 ? rs->tot[e - 156] : (double)rs->rematch))));
+        L[400 + e] = v;
+    }
+    if (a.it == 0) {
+        for (int e = lane; e < 108; e += 64) { if (e < 36) rs->p11inv[e] = a.mat[e]; else rs->tmat[e - 36] = a.mat[e]; }
+        if (lane < 24) rs->prior[lane] = a.prior[lane];
+        const unsigned long long* src = (const unsigned long long*)&a.sp;
+        unsigned long long* dst = (unsigned long long*)&rs->sp;
+        for (int e = lane; e < (int)(sizeof(ScanParams) / 8); e += 64) dst[e] = src[e];
+    }
+    __syncthreads();
+    if (lane == 0) { L[400 + 156] += L[64 + 44]; L[400 + 157] += L[64 + 45]; L[400 + 159] += L[64 + 42]; }
+    __syncthreads();
+    ekf_step_wave(rs, L + 400, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, a.it, a.max_iter, a.sp.extR, reg_out, ticket);
 }
 
 // =====================================================================================================================
@@ -290,11 +535,17 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, ScanParams sp
 // =====================================================================================================================
 // mode 0: map_incremental_grow  (var = (R extR) bcov (R extR)^T + (-[p_imu]x) Srot (-[p_imu]x)^T + St, p_imu with the z==0 -> 1e-3 quirk)
 // mode 1: voxel_map_init        (var = R bcov R^T + (-[p_lidar]x) Srot (..)^T + St, p_lidar after calcBodyVar's z==0 -> 1e-4 quirk)
-__global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const float* __restrict__ pts, int n, int stride, int mode,
+__global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const ScanParams* __restrict__ spd, const float* __restrict__ pts, int n, int stride, int mode,
                                                          double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out,
                                                          int32_t* __restrict__ pt_next) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (spd) {   // posterior of the scan just registered, left on the device by the in-kernel EKF update
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sp.R[k] = spd->R[k]; sp.RextR[k] = spd->RextR[k]; sp.rot_var[k] = spd->rot_var[k]; sp.t_var[k] = spd->t_var[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) sp.t[k] = spd->t[k];
+    }
     const double p[3] = {(double)pts[(size_t)i * stride + 0], (double)pts[(size_t)i * stride + 1], (double)pts[(size_t)i * stride + 2]};
     double pimu[3], pwd[3];
     m3_vec(sp.extR, p, pimu);
@@ -787,14 +1038,17 @@ __global__ void iota_kernel(int32_t* p, int n) {
 }
 
 // ---- launchers (called from the host layer) -------------------------------------------------------------------------
-void launch_residual(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, double* partials, unsigned int* done_counter,
-                     double* out48, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
+                     double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = (n + 63) / 64;
-    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, sp, pts, n, partials, done_counter, out48, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
-void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const float* pts, int n, int stride, int mode, double* pt_data,
+void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
+    KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);
+}
+void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const ScanParams* spd, const float* pts, int n, int stride, int mode, double* pt_data,
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next) {
-    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
+    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, spd, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
                          int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order) {

@@ -46,3 +46,40 @@ def stream_of_rank(rank, n_scans):
 def aggregate_throughput(steps_per_rank, world, elapsed_max_s):
     """whole-job scans/s: all ranks' scans over the slowest rank's time"""
     return steps_per_rank * world / elapsed_max_s
+
+
+def attach_collectives(h, hip, dist, backend, device, world, mesh):
+    """Data-path collectives of a sharded context.  backend "nccl": the library calls RCCL itself on its own streams
+    (immesh_rccl_init: ncclAllReduce of the 46 sums between a residual pass and the 18-state update, ncclAllGather of the mesher's exchange
+    records); the unique id travels through torch.distributed.  Any other backend (gloo, functional tests): host callbacks.
+    Returns a short description for the bench line."""
+    import numpy as np
+    import torch
+    if backend == "nccl" and hasattr(h, "rccl_init"):
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        if dist.get_rank() == 0:
+            uid.copy_(torch.from_numpy(h.rccl_unique_id()))
+        dist.broadcast(uid, src=0)
+        h.rccl_init(uid.cpu().numpy())
+        return "RCCL inside the library (ncclAllReduce / ncclAllGather on its own streams)"
+
+    def _allreduce(buf):                      # 46 doubles: H^T R^-1 H, H^T R^-1 z, counters
+        if backend == "nccl":
+            t = torch.from_numpy(buf).to(device); dist.all_reduce(t); buf[:] = t.cpu().numpy()
+        else:
+            dist.all_reduce(torch.from_numpy(buf))
+    h.set_allreduce(_allreduce)
+    if mesh:   # sharded mesher: all-gather of this scan's smoothed vertices and triangle marks (two exchanges per scan)
+        def _allgather(send, recv):
+            if backend == "nccl":
+                src = torch.from_numpy(send).to(device)
+                dst = torch.empty(len(send) * world, dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(dst, src)
+                recv[:] = dst.cpu().numpy()
+            else:
+                parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(send))
+                for r_ in range(world):
+                    recv[r_ * len(send):(r_ + 1) * len(send)] = parts[r_].numpy()
+        h.set_allgather(_allgather)
+    return f"host callbacks through torch.distributed ({backend})"
