@@ -35,18 +35,15 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924):
-    """Pre-build the registration map by streaming a dense survey of the procedural world (synth.py geometry) through
-    immesh_map_update, strip by strip, generated on the GPU (harness only; the product never sees torch)."""
+def survey_strips(cfg, torch, dev, side_m, seed=20260924):
+    """Dense survey of the procedural world (synth.py geometry), strip by strip, generated on the GPU: yields (n, 3) float32 device tensors of
+    body-frame points for the identity pose (harness only; the product never sees torch)."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
-    extT = torch.tensor(list(cfg.extT), device=dev, dtype=torch.float32)
-    st = capi.make_state()  # identity pose: p_world = extR p + extT  ->  p_body = p_world - extT
+    extT = torch.tensor(list(cfg.extT), device=dev, dtype=torch.float32)   # identity pose: p_world = extR p + extT  ->  p_body = p_world - extT
     L = synth.LATTICE
     x0 = -side_m / 2 + 50.0
     nstrip = int(np.ceil(side_m / L))
     gs, ws = 1.0 / 6.0, 1.0 / 8.0   # survey lattice spacing: ground 36 pts/m^2, walls 64 pts/m^2
-    t0 = time.time()
-    nv = 0
     for si in range(nstrip):
         xs0 = (np.floor(x0 / L) + si) * L
         # ground
@@ -81,10 +78,22 @@ def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924):
                 parts.append(torch.stack([xs0 + u, by + w, z], dim=1))
         P = (torch.cat(parts, dim=0) - extT[None, :]).contiguous()
         torch.cuda.synchronize()
-        cap = int(cfg.cap_scan_points)
+        yield P
+
+
+def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924, also=None):
+    """Pre-build the registration map by streaming the survey through immesh_map_update.  `also`: a second context (the CPU oracle in the
+    full-size parity tests) that is fed the very same chunks from host copies."""
+    st = capi.make_state()
+    t0 = time.time()
+    nv, si = 0, 0
+    cap = int(cfg.cap_scan_points)
+    for si, P in enumerate(survey_strips(cfg, torch, dev, side_m, seed)):
         for a in range(0, P.shape[0], cap):
             chunk = P[a:a + cap]
             h.map_update(chunk.data_ptr(), st, n=chunk.shape[0])
+            if also is not None:
+                also.map_update(np.ascontiguousarray(chunk.cpu().numpy()), st)
         nv = h.counters()["n_root_voxels"]
         if nv >= target_voxels:
             break

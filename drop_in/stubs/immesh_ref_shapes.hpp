@@ -1,0 +1,101 @@
+// drop_in/stubs -- the SHAPES of the reference types the five replaced bodies touch, so that drop_in/immesh_shim.cpp is compiled (and run, on a
+// GPU box) without Eigen / PCL / ROS: every declaration below mirrors one of the reference (file:line cited), reduced to the members the shim
+// uses.  In the reference build the shim includes the real headers instead (-DIMMESH_SHIM_REAL_HEADERS: "voxel_mapping.hpp", which pulls in
+// Eigen, PCL, common_lib.h, triangle.hpp, pointcloud_rgbd.hpp).  Nothing here is linked into libimmesh_hip.so.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace Eigen {   // element access only: the shim marshals through operator() and never relies on the storage order
+struct Vector3d { double v[3] = {0, 0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
+struct Matrix3d { double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; double& operator()(int r, int c) { return m[c * 3 + r]; } double operator()(int r, int c) const { return m[c * 3 + r]; } };
+struct Quaterniond { double w = 1, x = 0, y = 0, z = 0; };
+template <int N> struct MatrixNd { std::vector<double> m = std::vector<double>(N * N, 0.0); double& operator()(int r, int c) { return m[c * N + r]; } double operator()(int r, int c) const { return m[c * N + r]; } };
+}  // namespace Eigen
+typedef Eigen::Vector3d V3D;   // include/common_lib.h:60-70
+typedef Eigen::Matrix3d M3D;
+
+namespace pcl {
+struct alignas(16) PointXYZINormal { float x = 0, y = 0, z = 0, _w = 1; float normal_x = 0, normal_y = 0, normal_z = 0, _n = 0; float intensity = 0, curvature = 0, _p[2] = {0, 0}; };   // 48 B, EIGEN_ALIGN16
+struct alignas(16) PointXYZI { float x = 0, y = 0, z = 0, _w = 1; float intensity = 0, _p[3] = {0, 0, 0}; };                                                                       // 32 B
+template <typename T> struct PointCloud {
+    typedef std::shared_ptr<PointCloud<T>> Ptr;
+    std::vector<T> points;
+    size_t size() const { return points.size(); }
+    void resize(size_t n) { points.resize(n); }
+    void clear() { points.clear(); }
+};
+}  // namespace pcl
+typedef pcl::PointXYZINormal PointType;               // include/common_lib.h:58
+typedef pcl::PointCloud<PointType> PointCloudXYZI;
+
+struct StatesGroup {   // include/common_lib.h:199-288
+    M3D rot_end; V3D pos_end, vel_end, bias_g, bias_a, gravity;
+    Eigen::MatrixNd<18> cov;
+};
+
+// ---- src/meshing/r3live/pointcloud_rgbd.hpp:77-140, 234-298 and triangle.hpp:9-34, 115-395 (the host mirrors the renderer / PLY export read) --------
+struct vec_3 { double v[3]; vec_3(double x = 0, double y = 0, double z = 0) : v{x, y, z} {} double operator()(int i) const { return v[i]; } };
+class RGB_pts {
+  public:
+    double m_pos[3] = {0, 0, 0}, m_pos_aft_smooth[3] = {0, 0, 0};
+    int m_pt_index = 0;
+    bool m_smoothed = false;
+    void set_pos(const vec_3& p) { for (int i = 0; i < 3; i++) m_pos[i] = p(i); }
+    void set_smooth_pos(const vec_3& p) { for (int i = 0; i < 3; i++) m_pos_aft_smooth[i] = p(i); m_smoothed = true; }
+};
+class Global_map { public: std::vector<std::shared_ptr<RGB_pts>> m_rgb_pts_vec; };
+class Triangle { public: int m_tri_pts_id[3] = {0, 0, 0}; int m_index_flip = 0; Triangle(int a, int b, int c) : m_tri_pts_id{a, b, c} { std::sort(m_tri_pts_id, m_tri_pts_id + 3); } };
+using Triangle_ptr = std::shared_ptr<Triangle>;
+using Triangle_set = std::set<Triangle_ptr>;
+class Triangle_manager {   // same three entry points and semantics as triangle.hpp:212 (remove_triangle_list), :311 (find_triangle), :330 (insert_triangle)
+  public:
+    std::map<std::vector<int>, Triangle_ptr> m_triangle_hash;   // entries persist after erase, like m_triangle_hash
+    Triangle_set m_live;
+    Triangle_ptr find_triangle(int a, int b, int c) { int k[3] = {a, b, c}; std::sort(k, k + 3); auto it = m_triangle_hash.find({k[0], k[1], k[2]}); return it == m_triangle_hash.end() ? nullptr : it->second; }
+    void remove_triangle_list(const Triangle_set& s, const int = 0) { for (auto& t : s) if (t) m_live.erase(t); }
+    Triangle_ptr insert_triangle(int a, int b, int c, int = 0, const int& = 0) {
+        Triangle_ptr t = find_triangle(a, b, c);
+        if (!t) { t = std::make_shared<Triangle>(a, b, c); m_triangle_hash[{t->m_tri_pts_id[0], t->m_tri_pts_id[1], t->m_tri_pts_id[2]}] = t; }
+        m_live.insert(t);
+        return t;
+    }
+};
+extern Global_map g_map_rgb_pts_mesh;           // src/ImMesh_mesh_reconstruction.cpp:40
+extern Triangle_manager g_triangles_manager;    // :41
+
+struct Preprocess_shape { int calib_laser = 0; };   // src/preprocess.h:170
+
+struct immesh_ctx;
+class Voxel_mapping {   // src/voxel_mapping.hpp:132-420 -- only what the replaced bodies read or write
+  public:
+    V3D m_extT; M3D m_extR;                                   // :149-150
+    int NUM_MAX_ITERATIONS = 4;                               // :153
+    int m_effct_feat_num = 0;                                 // :157
+    double m_res_mean_last = 0.05;                            // :159
+    double m_max_voxel_size = 0.5, m_min_eigen_value = 0.01;  // :176
+    double m_beam_err = 0.05, m_dept_err = 0.02;              // :177
+    int m_max_points_size = 100, m_max_layer = 2;             // :190-191
+    std::vector<int> m_layer_init_size = {5, 5, 5, 5, 5};     // :192
+    PointCloudXYZI::Ptr m_feats_undistort = std::make_shared<PointCloudXYZI>();   // :226
+    PointCloudXYZI::Ptr m_feats_down_body = std::make_shared<PointCloudXYZI>();   // :227
+    PointCloudXYZI::Ptr m_laserCloudOri = std::make_shared<PointCloudXYZI>();     // :230
+    PointCloudXYZI::Ptr m_corr_normvect = std::make_shared<PointCloudXYZI>();     // :231
+    StatesGroup state;                                        // :264
+    double m_meshing_distance_scale = 1.0, m_meshing_points_minimum_scale = 0.1, m_meshing_voxel_resolution = 0.4, m_meshing_region_size = 10.0;   // :279-282
+    int m_meshing_number_of_pts_append_to_map = 10000;        // :286
+    std::shared_ptr<Preprocess_shape> m_p_pre = std::make_shared<Preprocess_shape>();
+    immesh_ctx* m_hip = nullptr;                              // the one member the drop-in adds
+    void immesh_shim_init();                                  // end of init_ros_node() (src/voxel_mapping.cpp:1654)
+    void map_incremental_grow();                              // :365  (src/ImMesh_mesh_reconstruction.cpp:377)
+    bool voxel_map_init();                                    // :409  (src/voxel_mapping.cpp:1243)
+    void lio_state_estimation(StatesGroup& state_propagat);   // :412  (src/voxel_mapping.cpp:1284)
+};
+void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, Eigen::Quaterniond pose_q, Eigen::Vector3d pose_t, int frame_idx);   // src/ImMesh_mesh_reconstruction.cpp:92
+void reconstruct_mesh_from_pointcloud(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, double minimum_pts_distance = 0.01);                               // :328, src/voxel_mapping.hpp:131
+void save_to_ply_file(std::string ply_file, double smooth_factor = 0.1, double knn = 20);                                                               // src/meshing/mesh_rec_geometry.hpp:40

@@ -56,6 +56,28 @@ def ref_ikd_lib():
 
 
 @pytest.fixture(scope="session")
+def ref_tri_lib():
+    """The reference's own Triangle_manager (triangle.hpp / triangle.cpp / tools_kd_hash.hpp) compiled from /root/reference (oracle/_ref).
+    On the GPU box only the prebuilt .so exists (oracle/_ref travels with the snapshot)."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_triangle.so")
+    if not os.path.exists(so):
+        if os.path.exists("/root/reference/src/meshing/r3live/triangle.hpp"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+        else:
+            pytest.skip("oracle/_ref/libref_triangle.so not built and /root/reference absent")
+    lib = C.CDLL(so)
+    lib.rt_create.restype = C.c_void_p; lib.rt_create.argtypes = [C.c_double]
+    lib.rt_destroy.argtypes = [C.c_void_p]
+    lib.rt_append_vertices.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.rt_commit.restype = C.c_int64; lib.rt_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.rt_set_flips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.rt_live.restype = C.c_int64; lib.rt_live.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.rt_live_size.restype = C.c_int64; lib.rt_live_size.argtypes = [C.c_void_p]
+    lib.rt_find_relative.restype = C.c_int64; lib.rt_find_relative.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    return lib
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     return capi.load_hip_library()
 

@@ -1,0 +1,19 @@
+"""The drop-in shim's marshalling, call order and host-mirror update on a machine without a GPU: drop_in/immesh_shim.cpp + shim_main.cpp linked
+against the CPU oracle (entry points renamed by macros, drop_in/Makefile target shim_main_oracle) must reproduce, bit for bit, the same calls
+issued directly -- and `make -C drop_in shim_main` (the product link against libimmesh_hip.so) must build."""
+import os
+import subprocess
+
+from conftest import make_oracle, ROOT
+from test_gpu_dropin import run_drop_in
+
+
+def test_shim_against_the_oracle_build(oracle_lib, tmp_path):
+    run_drop_in(oracle_lib, lambda cfg: make_oracle(oracle_lib, cfg), "shim_main_oracle", tmp_path, expect_ply=False)
+
+
+def test_shim_links_against_the_product_library():
+    if not os.path.exists(os.path.join(ROOT, "immesh_amd", "csrc", "libimmesh_hip.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "immesh_amd", "csrc"), "-j8"])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "shim_main"])
+    assert os.path.exists(os.path.join(ROOT, "drop_in", "shim_main"))

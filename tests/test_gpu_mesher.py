@@ -257,3 +257,26 @@ def test_reconstruct_mesh_from_pointcloud(oracle_lib, hip_lib):
     mh = h.reconstruct_mesh_from_pointcloud(pts, 0.01)
     _compare_scan(mo, mh, "offline cloud")
     assert len(mo["new_vtx"]) > 8000 and len(mo["tri_add"]) > 15000
+
+
+def test_hip_diff_lists_on_the_reference_triangle_manager(hip_lib, ref_tri_lib):
+    """Rows a21 / a22 / a24 against reference code: the HIP path's per-scan lists applied to the reference's OWN Triangle_manager (prebuilt
+    oracle/_ref/libref_triangle.so, compiled from /root/reference/src/meshing/r3live/triangle.{hpp,cpp}) in the reference's commit order leave it
+    with exactly the live set -- triplets and m_index_flip -- that the device-side map exports."""
+    from ref_triangle_mirror import RefTriangleMirror
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    h = make_hip(hip_lib, cfg)
+    mirror = RefTriangleMirror(ref_tri_lib, cfg.mesh_region)
+    n_rem = 0
+    for k in range(8):
+        pts, cam = _world_scan(k, 40000, cfg)
+        m = h.mesh_scan(pts, cam, frame_idx=k)
+        assert mirror.apply(m, k) == 0          # every removal named a triangle the real manager holds
+        n_rem += len(m["tri_rem"])
+    live = mirror.live()
+    vtx, faces = h.mesh_export(smooth_factor=0.0)
+    # save_to_ply_file winding: (v0, v1, v2) when m_index_flip != 0, else (v0, v2, v1)
+    dev = {tuple(sorted(map(int, f))): (1 if (f[1] < f[2]) else 0) for f in faces}
+    assert n_rem > 1000 and len(live) == len(dev) == h.counters()["n_triangles_live"]
+    assert dev == {t: (1 if fl else 0) for t, fl in live.items()}
+    mirror.close()

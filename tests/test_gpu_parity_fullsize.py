@@ -1,0 +1,160 @@
+"""HIP path vs the CPU oracle AT BASELINE.json's sizes -- not properties, the checker itself:
+  (i)   configs[1]/[2]: >= 10 scans of the 100 000-pt Livox-Avia stream, mesher on, against a >= 1 M-root-voxel map that BOTH sides build
+        from the same survey strips (the trajectory corridor of the bench's 10 M-voxel survey, so that the oracle finishes in seconds);
+  (ii)  configs[3]: full-width HDL-64 scans (2032 azimuth steps x 64 rings = 130 048 rays, velodyne.yaml, max_layer 4, 3 m roots);
+  (iii) configs[4]'s scan size: one 500 000-pt scan.
+Bars (north_star): match-index sets identical, plane tables / pose within 1e-5, vertex ids + positions and every triangle list bit-exact.
+Pose-dependent f32 roundings: the full pipeline's world-frame scan is f32(f64 transform) with poses that agree to ~1e-12, so single
+vertices may round differently; the mesher is therefore ALSO compared on bit-identical world-frame inputs (the oracle's poses), where
+every list must be equal for every scan, and the full-pipeline run reports how many scans stayed exactly equal."""
+import numpy as np
+import pytest
+
+from immesh_amd import capi, synth
+from conftest import make_oracle, make_hip
+from parity_utils import compare_plane_tables_fast
+from test_gpu_mesher import _compare_scan
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+TOL = 1e-5
+
+
+def _world(raw, st, cfg):
+    """transformLidar of the full scan with pose `st` (f64 compute, f32 store) -- the SAME array is handed to both meshers"""
+    R = np.asarray(st[0:9]).reshape(3, 3); t = np.asarray(st[9:12])
+    extR = np.array(list(cfg.extR)).reshape(3, 3); extT = np.array(list(cfg.extT))
+    p = raw[:, :3].astype(np.float64) @ extR.T + extT
+    out = raw.copy()
+    out[:, :3] = (p @ R.T + t).astype(np.float32)
+    return np.ascontiguousarray(out)
+
+
+def _exact(mo, mh):
+    return all(np.array_equal(mh[k], mo[k]) for k in ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "flip_upd", "smooth_ids")) and mh["vtx_base"] == mo["vtx_base"]
+
+
+def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property):
+    torch = pytest.importorskip("torch")
+    import bench
+    dev = torch.device("cuda", 0)
+    n_vox = 1.0e6
+    caps = dict(cap_root_voxels=int(n_vox * 1.6), cap_scan_points=2_500_000, cap_vertices=1 << 22, cap_triangles=1 << 24)
+    cfg = capi.avia_config(**caps)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    o2, h2 = make_oracle(oracle_lib, capi.avia_config(cap_root_voxels=1 << 12, **{k: v for k, v in caps.items() if k != "cap_root_voxels"})), \
+        make_hip(hip_lib, capi.avia_config(cap_root_voxels=1 << 12, **{k: v for k, v in caps.items() if k != "cap_root_voxels"}))   # mesher-only pair
+    nv = bench.build_big_map(h, cfg, torch, dev, n_vox, float(np.sqrt(n_vox / 8.8)) + 40.0, also=o)
+    assert nv >= 1_000_000 and o.counters()["n_root_voxels"] == nv
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+    n_planar = compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL)
+    assert n_planar > 800_000
+    record_property("planar_nodes_compared", n_planar)
+
+    extT = np.array(list(cfg.extT))
+    R0, t0 = synth.trajectory_pose(0)
+    so = capi.make_state(R=R0, t=t0)
+    so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    n_exact, still_exact = 0, True
+    for k in range(0, 11):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, Rk, tk, n_pts=100000, extT=extT)
+        down = synth.voxel_grid_downsample(raw, 0.4)
+        po, ph = (synth.forward_without_imu(so), synth.forward_without_imu(sh)) if k else (so, sh)
+        if k == 3:   # one matcher pass at a fixed state: match index sets / normals / residuals at full size
+            ro, rh = o.residuals(down, po), h.residuals(down, po)
+            assert np.array_equal(rh["match_idx"], ro["match_idx"]) and len(ro["match_idx"]) > 5000
+            np.testing.assert_allclose(rh["HTH"], ro["HTH"], rtol=1e-7, atol=1e-6)
+            np.testing.assert_allclose(rh["HTz"], ro["HTz"], rtol=1e-7, atol=1e-6)
+            np.testing.assert_array_equal(rh["dis"], ro["dis"])
+        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=True)
+        d_down, d_raw = torch.from_numpy(down).cuda(), torch.from_numpy(raw).cuda()
+        sh, ih = h.process_scan(d_down.data_ptr(), d_raw.data_ptr(), ph, ph, frame_idx=k, do_mesh=1, n_ds=len(down), n_raw=len(raw))
+        assert ih == io, (k, ih, io)
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+        np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)      # posterior covariance
+        mo, mh = o.mesh_fetch(), h.mesh_fetch()
+        still_exact = still_exact and _exact(mo, mh)
+        n_exact += int(still_exact)
+        if not still_exact:   # a world point rounded differently somewhere: the maps have diverged by single vertices, nothing more
+            assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50, k
+        # the mesher on bit-identical inputs (the oracle's pose): every list of every scan
+        w = _world(raw, so, cfg)
+        _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"scan {k} (identical world-frame input)")
+    record_property("full_pipeline_scans_bit_exact", f"{n_exact} of 11")
+    print(f"[parity] full pipeline: {n_exact} of 11 scans bit-exact (vertices + all triangle lists); mesher on identical inputs: 11 of 11")
+    assert n_exact >= 1
+    co, ch = o.counters(), h.counters()
+    for key in ("n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_root_voxels"):   # (n_iter per scan is compared above; the oracle also counts the stand-alone matcher pass)
+        assert ch[key] == co[key], key
+    c2o, c2h = o2.counters(), h2.counters()
+    for key in ("n_app", "n_new", "v_act", "n_v", "n_u", "t_v", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
+        assert c2h[key] == c2o[key], key
+    assert c2o["n_vertices"] > 20000
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) >= n_planar   # the grown map, again in full
+
+
+def test_hdl64_full_width_scans(oracle_lib, hip_lib):
+    """configs[3] at its real width: 64 rings x 2032 azimuth steps, velodyne.yaml (3 m root voxels, max_layer 4, 3 EKF iterations, mesh scale 1.5)"""
+    caps = dict(cap_root_voxels=1 << 16, cap_scan_points=400_000, cap_vertices=1 << 21, cap_triangles=1 << 23)
+    cfg = capi.velodyne_config(**caps)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    o2, h2 = make_oracle(oracle_lib, capi.velodyne_config(**caps)), make_hip(hip_lib, capi.velodyne_config(**caps))
+    R0, t0 = synth.trajectory_pose(0)
+    raw0 = synth.hdl64_scan(0, R0, t0, n_az=2032)
+    assert len(raw0) > 100_000
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st); h.map_build(p0, st)
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
+    so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    for k in range(1, 5):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.hdl64_scan(k, Rk, tk, n_az=2032)
+        down = synth.voxel_grid_downsample(raw, 0.5)
+        po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
+        if k == 2:
+            ro, rh = o.residuals(down, po), h.residuals(down, po)
+            assert np.array_equal(rh["match_idx"], ro["match_idx"]) and len(ro["match_idx"]) > 3000
+            np.testing.assert_allclose(rh["HTH"], ro["HTH"], rtol=1e-7, atol=1e-6)
+        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=False)
+        sh, ih = h.process_scan(down, raw, ph, ph, frame_idx=k, do_mesh=0)
+        assert ih == io, (k, ih, io)
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+        w = _world(raw, so, cfg)
+        _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"hdl64 scan {k}")
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
+    assert o2.counters()["n_vertices"] > 5000
+
+
+def test_one_500k_point_scan(oracle_lib, hip_lib):
+    """configs[4]'s scan size on one GPU: a 500 000-pt scan registered against the map of a first 500 000-pt scan, then meshed"""
+    caps = dict(cap_root_voxels=1 << 18, cap_scan_points=600_000, cap_vertices=1 << 21, cap_triangles=1 << 23)
+    cfg = capi.avia_config(**caps)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    R0, t0 = synth.trajectory_pose(0)
+    raw0 = synth.livox_scan(0, R0, t0, n_pts=500000, extT=extT)
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    o.map_build(p0, st); h.map_build(p0, st)
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 2000
+    R1, t1 = synth.trajectory_pose(1)
+    raw = synth.livox_scan(1, R1, t1, n_pts=500000, extT=extT)
+    down = synth.voxel_grid_downsample(raw, 0.4)
+    prior = capi.make_state(R=R1, t=t1 + np.array([0.02, -0.01, 0.01]), cov_diag=1e-5)
+    ro, rh = o.residuals(down, prior), h.residuals(down, prior)
+    assert np.array_equal(rh["match_idx"], ro["match_idx"]) and len(ro["match_idx"]) > 5000
+    np.testing.assert_allclose(rh["HTH"], ro["HTH"], rtol=1e-7, atol=1e-6)
+    so, io = o.process_scan(down, raw, prior, prior, frame_idx=1, do_mesh=True)
+    sh, ih = h.process_scan(down, raw, prior, prior, frame_idx=1, do_mesh=1)
+    assert ih == io
+    np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+    # the mesher on the identical 500k-pt world-frame scan (step = round(500000 / 10000) = 50 -> 10 000 candidates), two scans so that the second diffs
+    o2, h2 = make_oracle(oracle_lib, capi.avia_config(**caps)), make_hip(hip_lib, capi.avia_config(**caps))
+    for k, (r_, s_) in enumerate(((raw0, st), (raw, so))):
+        w = _world(r_, s_, cfg)
+        _compare_scan(o2.mesh_scan(w, s_[9:12], frame_idx=k), h2.mesh_scan(w, s_[9:12], frame_idx=k), f"500k scan {k}")
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 2000
