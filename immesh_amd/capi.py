@@ -427,6 +427,20 @@ class HotPath:
         f = self._f("set_allreduce"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx, self._allreduce_cb, None), "set_allreduce")
 
+    # -- RCCL inside the library (sharded contexts) ----------------------------------------------------------------
+    def rccl_unique_id(self):
+        f = self._f("rccl_unique_id"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        uid = np.zeros(128, np.uint8)
+        rc = f(_ptr(uid))
+        if rc != 0:
+            e = self._f("rccl_error"); e.restype = C.c_char_p
+            raise RuntimeError(f"immesh_rccl_unique_id failed rc={rc}: {e().decode()}")
+        return uid
+
+    def rccl_init(self, uid):
+        f = self._f("rccl_init"); f.argtypes = [C.c_void_p, C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx, _ptr(np.ascontiguousarray(uid, np.uint8))), "rccl_init")
+
     def set_threads(self, mesher_threads, matcher_threads):
         """oracle only (CPU baseline leg): the reference's own threading -- a 12-thread pool over mesh voxels, 4 OpenMP threads in the matcher"""
         f = self._f("set_threads"); f.argtypes = [C.c_void_p, C.c_int32, C.c_int32]; f.restype = C.c_int

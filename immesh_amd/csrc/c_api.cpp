@@ -62,7 +62,7 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
     m.upd_seq = 0;
     A(c->d_stats, 8);
-    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 8); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 64, c->stream)); }
+    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 16); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 128, c->stream)); }
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
@@ -140,6 +140,7 @@ void immesh_destroy(immesh_ctx* c) {
     if (c->stream_pre) { (void)hipStreamSynchronize(c->stream_pre); (void)hipStreamDestroy(c->stream_pre); }
     if (c->ev_inputs_free) (void)hipEventDestroy(c->ev_inputs_free);
     mesh_free(c);
+    rccl_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_out48) (void)hipHostFree(c->h_out48);
     if (c->h_reg_out) (void)hipHostFree(c->h_reg_out);
@@ -239,19 +240,25 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
     std::memcpy(a.prior, prior.R, 72); std::memcpy(a.prior + 9, prior.t, 24); std::memcpy(a.prior + 12, prior.vel, 24); std::memcpy(a.prior + 15, prior.bg, 24);
     std::memcpy(a.prior + 18, prior.ba, 24); std::memcpy(a.prior + 21, prior.g, 24);
     c->reg_ticket = (double)(++c->res_ticket);
+    const bool rccl = c->rccl_comm != nullptr;   // sharded map: the 46 sums are all-reduced in-stream between pass and update
     for (int it = 0; it < max_iter; it++) {
         a.it = it;
         if (it == 0) {
-            a.mode = REG_MODE_FIRST;
+            a.mode = rccl ? REG_MODE_SUMS : REG_MODE_FIRST;
             double p11[36];
             for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) p11[r * 6 + q] = st.cov[r * 18 + q];
             if (!imh::invert(p11, a.mat, 6)) { c->err = "singular prior covariance"; return IMMESH_E_INVAL; }
             for (int i = 0; i < 12; i++)
                 for (int q = 0; q < 6; q++) { double sacc = 0; for (int k = 0; k < 6; k++) sacc += st.cov[(6 + i) * 18 + k] * a.mat[k * 6 + q]; a.mat[36 + i * 6 + q] = sacc; }
         }
-        else { a.mode = REG_MODE_NEXT; if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat)); }
+        else { a.mode = rccl ? REG_MODE_SUMS : REG_MODE_NEXT; if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat)); }
         launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, c->d_out48, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
                         c->d_dis, c->d_rinv, c->d_normal);
+        if (rccl) {   // ncclAllReduce on the device-resident sums, then the 18-state update as its own (one-wavefront) launch; no host involvement
+            int rc = rccl_allreduce_f64(c, c->d_out48, RES_NV_HOST - 2, c->stream);
+            if (rc) return rc;
+            launch_ekf_step(c->stream, a, c->d_regstate, c->d_out48, c->d_reg_out_host, c->reg_ticket);
+        }
     }
     return 0;
 }
@@ -282,7 +289,7 @@ static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* 
 }
 static bool use_fused_ekf(const immesh_ctx* c) {
     static const bool host_ekf = getenv("IMMESH_HOST_EKF") != nullptr;   // debugging: the round-1 host loop (one round trip per pass)
-    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && !c->reg_dbg;
+    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && !c->reg_dbg && (c->cfg.shard_world <= 1 || c->rccl_comm != nullptr);
 }
 
 // the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
@@ -305,8 +312,10 @@ static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const im
         if (ekf.step(o, o + 36, prior, st, it, max_iter)) break;
     }
     if (c->reg_dbg) {
-        unsigned long long t[8];
-        (void)hipMemcpy(t, c->reg_dbg, 64, hipMemcpyDeviceToHost); (void)hipMemset(c->reg_dbg, 0, 64);
+        unsigned long long t[16];
+        (void)hipMemcpy(t, c->reg_dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(c->reg_dbg, 0, 128);
+        fprintf(stderr, "[replay (previous scan)] slowest fast-path voxel %llu cycles (%llu pts), slowest general voxel %llu cycles (%llu pts); mean replay cycles fast %llu (%llu voxels) general %llu (%llu voxels); list gather + sort %llu per voxel\n",
+                t[8] >> 16, t[8] & 0xFFFF, t[9] >> 16, t[9] & 0xFFFF, t[10] / std::max(1ull, t[12]), t[12], t[11] / std::max(1ull, t[13]), t[13], t[14] / std::max(1ull, t[12] + t[13]));
         const unsigned long long nw = (unsigned long long)iters * ((n_ds + 63) / 64);
         fprintf(stderr, "[residual cycles/wave] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block final %llu\n", t[0] / nw, t[1] / nw, t[2] / nw, t[3] / nw, t[4] / nw, t[5] / (unsigned long long)iters);
     }
@@ -405,7 +414,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         c->map.touched = (uint32_t*)c->d_seg_start;
         launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
         if (after_point_var) HIPCHK(c, hipEventRecord(after_point_var, s));   // the scan's input clouds are consumed: the replay works on its own copies
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->d_key_b, c->reg_dbg);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel

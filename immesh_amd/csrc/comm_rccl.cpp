@@ -1,0 +1,101 @@
+// RCCL inside the library: the data-path collectives of a sharded context are issued by the C++ layer itself on the
+// context's own HIP streams, on device-resident buffers -- no host staging, no callback into the application:
+//   * registration map sharded by root-voxel bricks: ncclAllReduce(sum) of the 46 doubles of a residual pass (H^T R^-1 H, H^T R^-1 z,
+//     counters) between the pass and the in-kernel 18-state update (ekf_step_kernel); the whole scan is enqueued without a host round trip;
+//   * sharded mesher: ncclAllGather of the exchange records (smoothed boundary-band vertices, triangle marks).
+// librccl.so is opened at immesh_rccl_init: a single-GPU process never loads it.  xGMI note: every message here is <= a few hundred KB, so
+// the collectives are latency-bound (one ring step per peer over point-to-point links), never link-bound.
+#include "host_ctx.hpp"
+#include <dlfcn.h>
+
+namespace {
+// the handful of RCCL entry points used (signatures of rccl/rccl.h; ncclDataType_t / ncclRedOp_t passed as their integer values)
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef int (*fn_get_unique_id)(rcclUniqueId*);
+typedef int (*fn_comm_init_rank)(void**, int, rcclUniqueId, int);
+typedef int (*fn_comm_destroy)(void*);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*fn_error_string)(int);
+struct RcclApi {
+    void* lib = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_all_reduce all_reduce = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_error_string error_string = nullptr;
+    std::string err;
+};
+RcclApi g_rccl;
+enum { RCCL_INT8 = 0, RCCL_INT32 = 2, RCCL_FLOAT64 = 8, RCCL_SUM = 0 };   // ncclInt8 / ncclInt32 / ncclFloat64, ncclSum
+
+bool rccl_load() {
+    if (g_rccl.lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { g_rccl.err = std::string("dlopen(librccl.so): ") + dlerror(); return false; }
+    g_rccl.get_unique_id = (fn_get_unique_id)dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.all_reduce = (fn_all_reduce)dlsym(g_rccl.lib, "ncclAllReduce");
+    g_rccl.all_gather = (fn_all_gather)dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.error_string = (fn_error_string)dlsym(g_rccl.lib, "ncclGetErrorString");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather) {
+        g_rccl.err = "librccl.so lacks an expected entry point"; dlclose(g_rccl.lib); g_rccl.lib = nullptr; return false;
+    }
+    return true;
+}
+std::string rccl_why(int rc) { return g_rccl.error_string ? std::string(g_rccl.error_string(rc)) : std::to_string(rc); }
+}  // namespace
+
+int rccl_allreduce_f64(immesh_ctx* c, double* dev_buf, size_t n, hipStream_t s) {
+    const int rc = g_rccl.all_reduce(dev_buf, dev_buf, n, RCCL_FLOAT64, RCCL_SUM, c->rccl_comm, s);
+    if (rc) { c->err = "ncclAllReduce: " + rccl_why(rc); return IMMESH_E_HIP; }
+    c->rccl_calls++;
+    return 0;
+}
+int rccl_allgather_bytes(immesh_ctx* c, const void* dev_send, void* dev_recv, size_t bytes_per_rank, hipStream_t s, std::string* err) {
+    const int rc = g_rccl.all_gather(dev_send, dev_recv, bytes_per_rank, RCCL_INT8, c->rccl_comm, s);
+    if (rc) { *err = "ncclAllGather: " + rccl_why(rc); return IMMESH_E_HIP; }
+    c->rccl_calls++;
+    return 0;
+}
+void rccl_release(immesh_ctx* c) {
+    if (c->rccl_comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->rccl_comm);
+    c->rccl_comm = nullptr;
+}
+
+extern "C" {
+
+int immesh_rccl_unique_id(uint8_t id_out[128]) {
+    if (!id_out) return IMMESH_E_INVAL;
+    if (!rccl_load()) return IMMESH_E_NODEV;
+    rcclUniqueId id;
+    const int rc = g_rccl.get_unique_id(&id);
+    if (rc) { g_rccl.err = "ncclGetUniqueId: " + rccl_why(rc); return IMMESH_E_HIP; }
+    std::memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+int immesh_rccl_init(immesh_ctx* c, const uint8_t id_in[128]) {
+    if (!c || !id_in) return IMMESH_E_INVAL;
+    if (c->cfg.shard_world < 1) { c->err = "immesh_rccl_init: the context is not sharded (shard_world)"; return IMMESH_E_INVAL; }
+    if (!rccl_load()) { c->err = g_rccl.err; return IMMESH_E_NODEV; }
+    (void)hipSetDevice(c->cfg.device);
+    mesh_wait_all(c);
+    rccl_release(c);
+    rcclUniqueId id;
+    std::memcpy(id.internal, id_in, 128);
+    const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1, rank = c->cfg.shard_world > 1 ? c->cfg.shard_rank : 0;
+    const int rc = g_rccl.comm_init_rank(&c->rccl_comm, world, id, rank);
+    if (rc) { c->rccl_comm = nullptr; c->err = "ncclCommInitRank: " + rccl_why(rc); return IMMESH_E_HIP; }
+    c->allreduce = nullptr; c->mesh_host.allgather = nullptr;   // the library's own collectives replace the host callbacks
+    return 0;
+}
+
+const char* immesh_rccl_error(void) { return g_rccl.err.c_str(); }
+
+}  // extern "C"

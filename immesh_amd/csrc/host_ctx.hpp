@@ -89,6 +89,8 @@ struct immesh_ctx {
     unsigned long long* d_dump_count = nullptr;
 
     KProf prof;
+    void* rccl_comm = nullptr;       // ncclComm_t of a sharded context after immesh_rccl_init (comm_rccl.cpp); null: host callbacks
+    int64_t rccl_calls = 0;
 
     // cumulative counters (host side)
     immesh_counters_t cnt;
@@ -129,6 +131,11 @@ struct ProfBind {  // binds the ctx profiler to the calling thread for the durat
     explicit ProfBind(immesh_ctx* ctx) : c(ctx) { g_kprof = &ctx->prof; }
     ~ProfBind() { if (c->prof.on && c->stream) { (void)hipStreamSynchronize(c->stream); if (c->stream_pre) (void)hipStreamSynchronize(c->stream_pre); c->prof.flush(); } g_kprof = nullptr; }
 };
+
+// RCCL inside the library (comm_rccl.cpp)
+int rccl_allreduce_f64(immesh_ctx* c, double* dev_buf, size_t n, hipStream_t s);
+int rccl_allgather_bytes(immesh_ctx* c, const void* dev_send, void* dev_recv, size_t bytes_per_rank, hipStream_t s, std::string* err);
+void rccl_release(immesh_ctx* c);
 
 // mesher host orchestration (mesh_host.cpp)
 int mesh_alloc(immesh_ctx* c);

@@ -103,7 +103,8 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m1.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
     for (int k = 0; k < 2; k++) {
         MeshDyn* t; if ((rc = c->dalloc(&t, 1))) return rc; h.d_dyn[k] = t;
-        HIPCHK(c, hipHostMalloc((void**)&h.h_dyn[k], sizeof(MeshDyn)));
+        HIPCHK(c, hipHostMalloc((void**)&h.h_dyn[k], sizeof(MeshDyn), hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&h.h_dyn_dev[k], h.h_dyn[k], 0));
         std::memset(h.h_dyn[k], 0, sizeof(MeshDyn));
         HIPCHK(c, hipHostMalloc((void**)&h.h_sc2[k], SC_COUNT * 4));
         std::memset(h.h_sc2[k], 0, SC_COUNT * 4);
@@ -178,6 +179,8 @@ void mesh_free(immesh_ctx* c) {
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
+    if (h.d_xall) (void)hipFree(h.d_xall);
+    h.d_xall = nullptr; h.xall_bytes = 0;
     h.exp_vtx = h.exp_work = h.exp_tmp = nullptr;
     for (int k = 0; k < 2; k++) {
         if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
@@ -213,23 +216,24 @@ static int mesh_overflow(immesh_ctx* c) {
 static int mesh_enqueue_a(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s, const float* d_pts, int n_cand, int64_t ccap, bool resolve) {
     MeshHost& h = c->mesh_host;
     if (resolve) {
-        MHIPCHK(c, hipMemcpyAsync(h.d_dyn[par], h.h_dyn[par], sizeof(MeshDyn), hipMemcpyHostToDevice, s));
-        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, s));
-        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, s));
-        launch_mesh_begin_scan(s, m);
+        launch_mesh_begin_scan(s, m, h.h_dyn_dev[par], (unsigned long long)ccap);
         launch_mesh_append_prepare(s, m, n_cand, d_pts);
         // every block of the launch is resident (<= 256 blocks), so the lowest undecided candidate can always decide: the loop terminates;
         // the iteration bound only guards against a hung device and is checked by the caller
         launch_mesh_append_resolve(s, m, n_cand, d_pts, 1 << 16);
     }
-    launch_mesh_append_flags(s, m, n_cand);
-    exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, n_cand);
-    launch_mesh_append_commit(s, m, n_cand, d_pts);
-    launch_mesh_select_active(s, m, n_cand);
-    // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
-    // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
-    launch_mesh_sort_emit(s, m, 0, h.d_sort_recs_a, nullptr);   // sorted active list + ranks
+    if (n_cand <= 16384) {
+        // per-scan sized candidate sets: ids, commit, voxel selection and the active voxels' order in ONE single-workgroup launch
+        launch_mesh_append_finish(s, m, d_pts);
+    } else {
+        launch_mesh_append_flags(s, m, n_cand);
+        exclusive_sum_i32(s, h.d_sort_temp, h.sort_temp_bytes, m.cand_rank, m.cand_rank, n_cand);
+        launch_mesh_append_commit(s, m, n_cand, d_pts);
+        launch_mesh_select_active(s, m, n_cand);
+        // ascending (x,y,z) voxel order defines "earlier / later voxel" for the order-dependent parts (smoothed positions seen by
+        // correct_triangle_index, which voxel's flip wins): the deterministic sequential order of the CPU checker
+        launch_mesh_sort_emit(s, m, 0, h.d_sort_recs_a, nullptr);   // sorted active list + ranks
+    }
     launch_mesh_knn(s, m);                                      // a18-a19
     return 0;
 }
@@ -239,8 +243,7 @@ static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
     MeshHost& h = c->mesh_host;
     if (part != 2) launch_mesh_delaunay(s, m);                // a20-a23
     if (part == 1) return 0;
-    launch_mesh_finalize(s, m);
-    launch_mesh_commit_rem(s, m, m.list_rem);
+    launch_mesh_finalize(s, m);                               // (+ the removals: Triangle_manager::remove_triangle_list)
     launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
     launch_mesh_commit_add(s, m, h.p_a);
     MHIPCHK(c, hipMemcpyAsync(h.h_sc2[par], m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
@@ -253,7 +256,35 @@ static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
 static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::function<void(const void*, int)>& unpack) {
     MeshHost& h = c->mesh_host;
     const int world = c->cfg.shard_world, me = c->cfg.shard_rank;
-    if (!h.allgather) { h.err = "sharded mesher: no all-gather callback registered (immesh_set_allgather)"; return IMMESH_E_INVAL; }
+    if (c->rccl_comm) {
+        // RCCL on device buffers: all-gather the record counts (the host needs the largest one to size the payload gather), then the payload padded
+        // to it; every other rank's records are unpacked straight from the gathered buffer -- no host staging, one small read-back
+        int rc;
+        if (!h.d_xcounts && (rc = c->dalloc(&h.d_xcounts, 64))) { h.err = c->err; return rc; }
+        if ((rc = rccl_allgather_bytes(c, h.d_xcount, h.d_xcounts, 4, s, &h.err))) return rc;
+        int32_t counts32[64];
+        if (world > 64) { h.err = "sharded mesher: more than 64 ranks"; return IMMESH_E_INVAL; }
+        MHIPCHK(c, hipMemcpyAsync(counts32, h.d_xcounts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
+        int64_t maxc = 0;
+        for (int r = 0; r < world; r++) maxc = std::max<int64_t>(maxc, counts32[r]);
+        h.xcalls++;
+        if (maxc == 0) return 0;
+        if ((size_t)maxc * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
+        const size_t need = (size_t)world * maxc * rec;
+        if (need > h.xall_bytes) {
+            if (h.d_xall) (void)hipFree(h.d_xall);
+            h.d_xall = nullptr; h.xall_bytes = 0;
+            if (hipMalloc(&h.d_xall, need + need / 4) != hipSuccess) { h.err = "hipMalloc(exchange buffer)"; return IMMESH_E_NOMEM; }
+            h.xall_bytes = need + need / 4;
+        }
+        if ((rc = rccl_allgather_bytes(c, h.d_xsend, h.d_xall, (size_t)maxc * rec, s, &h.err))) return rc;
+        h.xcalls++; h.xbytes_sent += (int64_t)counts32[me] * (int64_t)rec;
+        for (int r = 0; r < world; r++)
+            if (r != me && counts32[r] > 0) unpack((const char*)h.d_xall + (size_t)r * maxc * rec, counts32[r]);
+        return 0;
+    }
+    if (!h.allgather) { h.err = "sharded mesher: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
     int32_t cnt32 = 0;
     MHIPCHK(c, hipMemcpyAsync(&cnt32, h.d_xcount, 4, hipMemcpyDeviceToHost, s));
     MHIPCHK(c, hipStreamSynchronize(s));
@@ -320,11 +351,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     int rc = 0;
     if (sp.n_cand > 65536) {
         // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
-        MHIPCHK(c, hipMemcpyAsync(h.d_dyn[par], h.h_dyn[par], sizeof(MeshDyn), hipMemcpyHostToDevice, sa));
-        MHIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, sa));
-        MHIPCHK(c, hipMemsetAsync(m.ch_keys, 0xFF, (size_t)ccap * 8, sa));
-        MHIPCHK(c, hipMemsetAsync(m.ch_head, 0xFF, (size_t)ccap * 4, sa));
-        launch_mesh_begin_scan(sa, m);
+        launch_mesh_begin_scan(sa, m, h.h_dyn_dev[par], (unsigned long long)ccap);
         launch_mesh_append_prepare(sa, m, sp.n_cand, d_pts);
         for (int round = 0; round < 100000; round++) {
             if (round > 0) MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, sa));

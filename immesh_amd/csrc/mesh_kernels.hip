@@ -114,14 +114,24 @@ __global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __res
 // =====================================================================================================================
 // append_points_to_global_map
 // =====================================================================================================================
-// first kernel of a scan (after the copy of the host's parameters and the clear of the per-scan counters): the id of the scan's first new
-// vertex is the device's own vertex count, so the host can enqueue a scan before the previous one has reported its size
-__global__ void mesh_begin_scan_kernel(MeshDev m) {
-    const int base = m.pc[PC_VERTS];
-    m.dyn->sp.vtx_base = base;
-    m.sc[SC_VTXBASE] = base;
+// first kernel of a scan: takes the scan's parameters from pinned host memory (no separate copy node), clears the per-scan counters and the
+// candidate-cell table (no separate fill nodes: each of those ran as a ~5 us kernel of its own), and snapshots the vertex count -- the id of the
+// scan's first new vertex is the device's own count, so the host can enqueue a scan before the previous one has reported its size
+__global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const MeshDyn* __restrict__ h_dyn, unsigned long long ccap) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < ccap; k += stride) { m.ch_keys[k] = MKEY_EMPTY; m.ch_head[k] = -1; }
+    if (i == 0) {
+        MeshDyn d = *h_dyn;
+        const int base = m.pc[PC_VERTS];
+        d.sp.vtx_base = base;
+        *m.dyn = d;
+        for (int k = 0; k < SC_COUNT; k++) m.sc[k] = 0;
+        m.sc[SC_VTXBASE] = base;
+    }
 }
-void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_begin_scan_kernel, dim3(1), dim3(1), 0, s, m); }
+void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dyn_dev, unsigned long long ccap) {
+    KLAUNCH(mesh_begin_scan_kernel, dim3(128), dim3(256), 0, s, m, h_dyn_dev, ccap);
+}
 
 __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts) {
     MESH_DYN(m_in);
@@ -313,6 +323,109 @@ __global__ void mesh_select_active_kernel(MeshDev m_in) {
     m.act_vox[a] = vi;
 }
 
+// The tail of vertex admission for per-scan sized candidate sets (<= MV_FIN_CAND), ONE launch of one 1024-thread workgroup instead of seven
+// (flags, 2 x device scan, commit, select, 2 x sort): new vertex ids by a block-wide prefix sum over the accept flags (ids grow in scan order as in
+// the reference), the commit of mesh_append_commit_kernel, the voxel selection of mesh_select_active_kernel, and the ascending-(x, y, z) order of
+// the active voxels (bitonic network in LDS) that defines "earlier / later voxel" for the order-dependent parts.  Every one of those launches
+// was a few microseconds of work behind ~5 us of launch latency on the mesher's phase-A chain.
+IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+#define MV_FIN_CAND 16384
+#define MV_FIN_ACT 8192        /* >= MV_FIN_CAND / 3: an active voxel holds at least three vertices */
+__global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts) {
+    MESH_DYN(m_in);
+    __shared__ unsigned long long skey[MV_FIN_ACT];
+    __shared__ int svox[MV_FIN_ACT];
+    __shared__ int sscan[1024];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int n = sp.n_cand;
+    const int per = (n + 1023) / 1024;            // <= 16 consecutive candidates per thread: ids stay in scan order
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    int local = 0;
+    for (int i = i0; i < i1; i++) local += (m.cand_status[i] == ST_ACCEPT) ? 1 : 0;
+    sscan[tid] = local;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const int v = tid >= off ? sscan[tid - off] : 0;
+        __syncthreads();
+        sscan[tid] += v;
+        __syncthreads();
+    }
+    const int total = sscan[1023];
+    int rank = sscan[tid] - local;
+    if (tid == 0) { m.sc[SC_ACCEPTED] = total; m.pc[PC_VERTS] = sp.vtx_base + total; }
+    // the accepted candidates, compacted in scan order (accepted candidates cluster: a thread's own 11 may hold several, and each commit is a chain
+    // of dependent global round trips -- so the commits are dealt out one per thread from the compacted list)
+    int* clist = (int*)skey;   // MV_FIN_CAND ints == the key array's bytes; the keys are not in use yet
+    for (int i = i0; i < i1; i++)
+        if (m.cand_status[i] == ST_ACCEPT) clist[rank++] = i;
+    __syncthreads();
+    for (int e = tid; e < total; e += 1024) {
+        const int i = clist[e];
+        const int id = sp.vtx_base + e;
+        if (id >= m.cap_verts) { m.sc[SC_OVERFLOW] = 4; continue; }
+        const float* p = pts + 4 * (size_t)i * sp.step;
+        const float px = p[0], py = p[1], pz = p[2];
+        m.v_pos[(size_t)id * 3 + 0] = px; m.v_pos[(size_t)id * 3 + 1] = py; m.v_pos[(size_t)id * 3 + 2] = pz;
+        m.v_smooth[(size_t)id * 3 + 0] = (double)px; m.v_smooth[(size_t)id * 3 + 1] = (double)py; m.v_smooth[(size_t)id * 3 + 2] = (double)pz;
+        int vi = m.cand_vox[i];
+        if (vi < 0) {
+            const long long vs = h_find(m.x_keys, m.x_mask, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
+            vi = vs >= 0 ? m.x_vals[vs] : -1;
+        }
+        if (vi < 0) { m.sc[SC_OVERFLOW] = 5; continue; }
+        m.v_voxel[id] = vi;
+        bool created;
+        const long long gs = h_find_or_insert(m.g_keys, m.g_mask, m.cand_cell[i], &created);
+        if (gs < 0) { m.sc[SC_OVERFLOW] = 6; continue; }
+        ((float4*)m.g_rec)[gs] = make_float4(px, py, pz, __int_as_float(id));
+        const int pos = atomicAdd(&m.vx_npts[vi], 1);
+        if (pos >= MV_VOX_CAP) { m.sc[SC_OVERFLOW] = 7; atomicSub(&m.vx_npts[vi], 1); continue; }
+        m.vx_pts[(size_t)vi * MV_VOX_CAP + pos] = id;
+        atomicAdd(&m.vx_new_added[vi], 1);
+        st_agent(&m.vx_meshing_times[vi], 0);
+    }
+    __threadfence();
+    __syncthreads();
+    // ---- voxels to (re)mesh this scan: visited, m_meshing_times < 1, m_new_added_pts_count >= 0, >= 3 vertices (ImMesh_mesh_reconstruction.cpp:132-151)
+    const int n_recent = m.sc[SC_RECENT];
+    for (int r = tid; r < n_recent; r += 1024) {
+        const int vi = m.recent[r];
+        if (ld_agent(&m.vx_meshing_times[vi]) >= 1 || ld_agent(&m.vx_new_added[vi]) < 0) continue;
+        st_agent(&m.vx_meshing_times[vi], ld_agent(&m.vx_meshing_times[vi]) + 1);
+        st_agent(&m.vx_new_added[vi], 0);
+        if (ld_agent(&m.vx_npts[vi]) < 3) continue;
+        const int a = atomicAdd(&s_n, 1);
+        if (a >= MV_FIN_ACT) { m.sc[SC_OVERFLOW] = 8; continue; }
+        skey[a] = m.vx_key[vi];
+        svox[a] = vi;
+    }
+    __syncthreads();
+    const int na = min(s_n, MV_FIN_ACT);
+    const int np2 = next_pow2_i(max(na, 1));
+    for (int k = na + tid; k < np2; k += 1024) { skey[k] = ~0ull; svox[k] = -1; }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)            // ascending packed key == ascending (x, y, z); keys are unique (one entry per voxel)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < (np2 >> 1); p += 1024) {
+                const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
+                const bool up = ((i & k) == 0);
+                const unsigned long long x = skey[i], y = skey[ixj];
+                if ((x > y) == up) { skey[i] = y; skey[ixj] = x; const int t = svox[i]; svox[i] = svox[ixj]; svox[ixj] = t; }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < na; r += 1024) {
+        const int vi = svox[r];
+        m.act_vox_s[r] = vi;
+        m.vx_rank[vi] = r;
+        m.vx_rank_seq[vi] = m.seq;
+    }
+    if (tid == 0) m.sc[SC_ACTIVE] = na;
+}
+void launch_mesh_append_finish(hipStream_t s, const MeshDev& m, const float* pts) { KLAUNCH(mesh_append_finish_kernel, dim3(1), dim3(1024), 0, s, m, pts); }
+
 // =====================================================================================================================
 // LDS helpers
 // =====================================================================================================================
@@ -331,7 +444,6 @@ IMD void lds_bitonic_sort(T* a, int N, int tid) {  // N power of two; ascending;
             __syncthreads();
         }
 }
-IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 IMD int lds_bsearch_i32(const int* a, int n, int key) {
     int lo = 0, hi = n - 1;
     while (lo <= hi) { const int mid = (lo + hi) >> 1; const int v = a[mid]; if (v == key) return mid; if (v < key) lo = mid + 1; else hi = mid - 1; }
@@ -372,7 +484,8 @@ IMD double wave_max_d(double x) {
 // =====================================================================================================================
 // 20-NN neighbourhood pull + smoothing: one workgroup (4 wavefronts) per active voxel
 // =====================================================================================================================
-#define KC 1000                 /* candidates staged per batch */
+#define KC 500                  /* candidates staged per batch (a 20-NN pull of the shipped configurations inspects ~200 per query); with the per-wave work
+                                   lists this sets the kernel's LDS footprint: 56 KB -> two workgroups per CU still leave room for the other chains' kernels */
 #define WL (KC + MV_KNN + 4)    /* per-wave work list */
 #define HSET 4096
 
@@ -1057,13 +1170,37 @@ __global__ __launch_bounds__(64) void mesh_delaunay_big_kernel(MeshDev m_in) {
     for (int r = blockIdx.x; r < n_active; r += gridDim.x)
         if (m.rel_n[r] > 256) mesh_delaunay_voxel<MV_REL_CAP>(m, sp, r);
 }
+// neighbourhoods of 65..256 vertices, and the voxels the register fast path (mesh_delaunay64_kernel, launched before) handed over
+__global__ __launch_bounds__(64) void mesh_delaunay_general_kernel(MeshDev m_in) {
+    MESH_DYN(m_in);
+    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
+    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
+        const int n = m.rel_n[r];
+        if ((n > 64 && n <= 256) || (n > 0 && n <= 64 && m.vox_ntris[r] < 0)) mesh_delaunay_voxel<256>(m, sp, r);
+    }
+}
 
 #include "mesh_delaunay64.inc"
 
 // cross-voxel resolution: the voxel with the highest rank that touched a triangle owns its flip (later voxel wins, as the
 // sequential loop); it also queues the triangle for insertion / reports a changed flip.  Then this scan's smoothed positions commit.
+// Triangle_manager::remove_triangle_list (triangle.hpp:212-221): drop from the live set and from its smallest vertex's list.  Runs inside the
+// finalize launch (the two touch disjoint data: live flags + adjacency here, flip words + result lists there).
+IMD void mesh_commit_rem_slice(const MeshDev& m, const int32_t* __restrict__ tris, int first, int stride) {
+    const int n = min(m.sc[SC_REM], m.cap_list);
+    for (int i = first; i < n; i += stride) {
+        const int t = tris[i];
+        m.t_live[t] = 0;
+        const int v0 = m.t_v[(size_t)t * 3 + 0];
+        bool done = false;
+        for (int ch = m.a_head[v0]; ch >= 0 && !done; ch = m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + MV_ADJ_STRIDE - 1])
+            for (int s = 0; s < MV_ADJ_SLOTS; s++)
+                if (m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] == t) { m.a_chunks[(size_t)ch * MV_ADJ_STRIDE + s * 3] = -1; done = true; break; }
+    }
+}
 __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
     MESH_DYN(m_in);
+    mesh_commit_rem_slice(m, m.list_rem, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);   // Triangle_manager::remove_triangle_list rides along (independent data)
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
@@ -1425,7 +1562,8 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 }
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
-    KLAUNCH(mesh_delaunay64_kernel, dim3(4096), dim3(64), 0, s, m);          // n_u <= 256 (register fast path up to 64)
+    KLAUNCH(mesh_delaunay64_kernel, dim3(2048), dim3(64), 0, s, m);          // n_u <= 64: register fast path
+    KLAUNCH(mesh_delaunay_general_kernel, dim3(512), dim3(64), 0, s, m);     // 64 < n_u <= 256, and what the fast path handed over
     KLAUNCH(mesh_delaunay_big_kernel, dim3(256), dim3(64), 0, s, m);         // n_u > 256
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }

@@ -134,7 +134,8 @@ struct MeshHost {
     bool stop = false;
     // per-scan parameters + graph replay
     MeshDyn* d_dyn[2] = {nullptr, nullptr};  // device copies read by the kernels (job parity)
-    MeshDyn* h_dyn[2] = {nullptr, nullptr};  // pinned host copies (source of the copy node at the head of the graph)
+    MeshDyn* h_dyn[2] = {nullptr, nullptr};  // pinned, device-mapped host copies (read by the first kernel of a scan)
+    MeshDyn* h_dyn_dev[2] = {nullptr, nullptr};   // their device-side addresses
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // phase A, one per job parity (world buffer / result set pointers differ)
     hipGraphExec_t graph_exec_b[2] = {nullptr, nullptr}; // phase B
     int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
@@ -149,6 +150,7 @@ struct MeshHost {
     immesh_allgather_fn allgather = nullptr;
     void* allgather_user = nullptr;
     void* d_xsend = nullptr; void* d_xrecv = nullptr; int32_t* d_xcount = nullptr;   // device staging (cap_list records each) + record counter
+    int32_t* d_xcounts = nullptr; void* d_xall = nullptr; size_t xall_bytes = 0;     // RCCL path: every rank's record count / records (grow-only)
     size_t xcap_bytes = 0;
     std::vector<char> h_xsend, h_xrecv;
     int64_t xbytes_sent = 0, xcalls = 0;     // cumulative exchange volume of this rank (payload bytes, collective calls)
@@ -158,12 +160,13 @@ struct MeshHost {
 
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
                            const double* extT, const double* rt_dev = nullptr);
-void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m);
+void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dyn_dev, unsigned long long ccap);
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter);
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
+void launch_mesh_append_finish(hipStream_t s, const MeshDev& m, const float* pts);   // flags + scan + commit + select + active-voxel order in one launch (n_cand <= 16384)
 void launch_mesh_knn(hipStream_t s, const MeshDev& m);
 void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor);
 void launch_mesh_export_faces(hipStream_t s, const MeshDev& m, int32_t* tri_idx, int32_t* count);

@@ -9,6 +9,7 @@
 //                        plane fits (OctoTree::init_plane, :47-139) are wave-parallel: lanes stride the retained points,
 //                        64-lane butterfly reductions for the moment sums and the 21-entry plane covariance.
 // Bound: HBM/latency (dependent gathers through hash -> node -> plane); no GEMM-shaped work, MFMA is not used.
+#include <algorithm>
 #include "regmap.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
@@ -453,21 +454,21 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
             Cst[e] = v;
         }
     }
-    // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 8 independent (L2-served) loads in flight per
-    // lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
+    // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 32 independent (L2-served, ~900-cycle) loads in
+    // flight per lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
     {
         const int k = lane & 31;
         const unsigned int nb = gridDim.x;
         double tot = 0;
-        for (unsigned int b0 = (unsigned int)(lane >> 5); b0 < nb; b0 += 16) {
-            double v[8];
+        for (unsigned int b0 = (unsigned int)(lane >> 5); b0 < nb; b0 += 64) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 32; u++) {
                 const unsigned int b = b0 + 2u * u;
                 v[u] = b < nb ? __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)&partials[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) tot += v[u];
+            for (int u = 0; u < 32; u++) tot += v[u];
         }
         tot += __shfl_xor(tot, 32, 64);
         red[0][lane] = tot;
@@ -894,6 +895,114 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
     }
 }
 
+// Fast path of the per-voxel replay for the common state of a settled map: the root is an initialised, planar, update-enabled node whose
+// retained points fit the inline chunk table.  Same state machine as wave_update_point (OctoTree::UpdateOctoTree, voxel_loc.cpp:240-262), but
+//   * the node header lives in registers for the whole batch (the general path re-reads flags / counts / chunk ids from HBM for every point:
+//     three to four dependent round trips per point);
+//   * a refit that falls due in the middle of the batch is DEFERRED when its outcome is certain: the smallest eigenvalue of the covariance is
+//     at most its smallest diagonal entry, so "min_k var_k < min_eigen_value" (with a rounding margin) proves the node stays planar without the
+//     eigen-decomposition; only the plane of the LAST refit is observable after the update (the matcher reads the map between scans), and
+//     it is fitted once, at the end, over exactly the points the reference's last refit saw (the first n_at_refit retained points).
+//     When the bound does not decide, the fit runs on the spot as in the general path.
+// Returns the number of points consumed; the node header in memory is current again on return (the general path may continue from it).
+__device__ int wave_replay_planar_root(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w) {
+    NodeRec& nd = m.nodes[root];
+    int flags = nd.flags;
+    const int layer = nd.layer;
+    int npts = nd.npts, newp = nd.newpts;
+    const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
+    if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) return cnt;   // a full planar root (m_update_enable_ == false) drops every point
+    if ((flags & want) != want || layer != 0 || npts + cnt > IM_INLINE_CHUNKS * IM_CHUNK_PTS) return 0;
+    int chunks[IM_INLINE_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
+    auto chunk_of = [&](int ci) { int c = chunks[0];
+#pragma unroll
+        for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
+        return c; };
+    // running per-axis sums of the retained points: only needed when a refit falls due inside this batch
+    double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    const bool will_refit = newp + cnt > 5;
+    if (will_refit) {
+        for (int i = w.lane; i < npts; i += 64) {
+            const double* q = m.chunk_data + ((size_t)chunk_of(i / IM_CHUNK_PTS) * IM_CHUNK_PTS + (i % IM_CHUNK_PTS)) * IM_PT_DOUBLES;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double v = q[a]; s1[a] += v; s2[a] += v * v; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
+    }
+    WaveCtx wq = w; wq.stats = nullptr;   // refits are counted here (deferred ones included), not by wave_init_plane
+    int last_refit_n = 0, n_ref = 0, j = 0;
+    long long n_ref_pts = 0;
+    bool header_dirty = false;
+    auto write_header = [&]() {
+        if (w.lane == 0) {
+            nd.flags = flags; nd.npts = npts; nd.newpts = newp;
+#pragma unroll
+            for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        header_dirty = false;
+    };
+    for (; j < cnt; j++) {
+        const double* src = pt_data + (size_t)order[j] * IM_PT_DOUBLES;
+        const int ci = npts / IM_CHUNK_PTS;
+        if ((npts % IM_CHUNK_PTS) == 0 && chunk_of(ci) < 0) {
+            int c = -1;
+            if (w.lane == 0) c = alloc_chunk(m);
+            c = __shfl(c, 0, 64);
+            if (c < 0) { write_header(); return j; }   // pool exhausted (flag set by alloc_chunk): stop here, the caller's loop sees the flag path
+#pragma unroll
+            for (int k = 0; k < IM_INLINE_CHUNKS; k++) if (ci == k) chunks[k] = c;
+        }
+        const double pv = w.lane < IM_PT_DOUBLES ? src[w.lane] : 0.0;
+        if (w.lane < IM_PT_DOUBLES) m.chunk_data[((size_t)chunk_of(ci) * IM_CHUNK_PTS + (npts % IM_CHUNK_PTS)) * IM_PT_DOUBLES + w.lane] = pv;
+        if (will_refit) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double v = __shfl(pv, a, 64); s1[a] += v; s2[a] += v * v; }
+        }
+        npts++; newp++; header_dirty = true;
+        if (newp > 5) {   // m_update_size_threshold_: the refit over all retained points falls due
+            n_ref++; n_ref_pts += npts;
+            const double dn = (double)npts;
+            double vmin = 1e300, mag = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double mu = s1[a] / dn; const double v = s2[a] / dn - mu * mu; vmin = fmin(vmin, v); mag += s2[a] / dn; }
+            const double err = 1e-7 + 1e-12 * mag;   // rounding of the one-pass variance (and of the exact fit's own eigenvalue), generously
+            newp = 0;
+            if (vmin + err < (double)m.planer_threshold) last_refit_n = npts;   // certainly still planar: fit later, over these npts points
+            else {
+                write_header();   // (wave_init_plane finds the points through the chunk ids in the node record)
+                last_refit_n = 0;
+                const bool planar = wave_init_plane(m, root, npts, wq);
+                if (!planar) {   // the node turns non-planar: later points take the general route (children)
+                    if (w.lane == 0) node_set_flags(m, w.root, root, flags, flags & ~NF_PLANE);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    flags &= ~NF_PLANE;
+                    j++;
+                    break;
+                }
+            }
+        }
+        if (npts >= m.max_points_size) {   // the node is full: last fit (if one is pending), then it stops updating and drops its points
+            if (last_refit_n) { write_header(); (void)wave_init_plane(m, root, last_refit_n, wq); last_refit_n = 0; }
+            flags &= ~NF_UPDATE_EN;
+            write_header();
+            if (w.lane == 0) { node_free_points(m, root); nd.newpts = 0; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            npts = 0; newp = 0;
+            j++;
+            break;
+        }
+    }
+    if (header_dirty) write_header();
+    if (last_refit_n) (void)wave_init_plane(m, root, last_refit_n, wq);
+    if (w.lane == 0 && w.stats && n_ref) { atomicAdd((unsigned long long*)&w.stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n_ref_pts); }
+    return j;
+}
+
 // one wavefront per touched root voxel.  mode 0 = updateVoxelMap (sequential replay), mode 1 = buildVoxelMap (bucket all, then init)
 __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t* __restrict__ sorted_slot, const int32_t* __restrict__ sorted_idx,
                                                       const double* __restrict__ pt_data, int n, const int32_t* __restrict__ seg_start,
@@ -923,11 +1032,133 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
     }
 }
 
+#define RL_CAP 64    /* points of one scan falling into one root voxel that are ordered in LDS (a down-sampled scan puts <= ~8 into a voxel); longer lists take the
+                        global-scratch path.  Kept small on purpose: LDS is what limits how many workgroups of the three concurrent chains fit a CU */
+// ---- the map update in three launches (LDS / register footprints decide how much of it runs beside the mesher's kernels) ---------------
+//   replay_light_kernel   one wavefront per touched root voxel, ~64 registers: list gather + ordering + the settled-planar-root state machine
+//                         with every refit DEFERRED (see wave_replay_planar_root).  Whatever it cannot finish without an eigen-decomposition in
+//                         the middle of the batch -- or any other node state -- is handed over untouched;
+//   replay_list_kernel    (work list = the handed-over voxels, a few dozen per scan) the general state machine, fits inline;
+//   replay_refit_kernel   one wavefront per deferred refit: OctoTree::init_plane over the first n retained points.
+// The fit's ~300 registers per lane (one wavefront per SIMD) are thereby spent on ~1.3 k wavefronts per scan instead of on every touched voxel.
+__global__ __launch_bounds__(256) void replay_light_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
+                                                            const double* __restrict__ pt_data, int64_t* stats, uint32_t* __restrict__ general_list, int2* __restrict__ refit_list) {
+    __shared__ unsigned long long skey[4][RL_CAP];
+    __shared__ int sidx[4][RL_CAP];
+    __shared__ int order[4][RL_CAP];
+    __builtin_amdgcn_s_setprio(3);
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wv;
+    if (t >= m.counters[7]) return;
+    const uint32_t slot = m.touched[t];
+    const int root = m.htab[slot].root;
+    if (root < 0) return;
+    NodeRec& nd = m.nodes[root];
+    // node header and the head of the point list: independent loads, one latency
+    const int flags = nd.flags, layer = nd.layer;
+    int npts = nd.npts, newp = nd.newpts;
+    int chunks[IM_INLINE_CHUNKS];
+#pragma unroll
+    for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
+    int cnt = 0;
+    for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
+        if (cnt < RL_CAP && lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
+        cnt++;
+    }
+    const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
+    if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) return;   // a full planar root (m_update_enable_ == false) drops every point
+    bool hand_over = cnt > RL_CAP || (flags & want) != want || layer != 0 || npts + cnt > IM_INLINE_CHUNKS * IM_CHUNK_PTS || npts + cnt >= m.max_points_size;
+    if (!hand_over) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int e = lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique
+            const unsigned long long k = skey[wv][e];
+            const int id = sidx[wv][e];
+            int rank = 0;
+            for (int f = 0; f < cnt; f++) { const unsigned long long kf = skey[wv][f]; rank += (kf < k || (kf == k && sidx[wv][f] < id)) ? 1 : 0; }
+            order[wv][rank] = id;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        auto chunk_of = [&](int ci) { int c = chunks[0];
+#pragma unroll
+            for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
+            return c; };
+        // ---- pass 1 (nothing is written): would every refit of this batch be decided by the diagonal bound ?
+        int last_refit_n = 0, n_ref = 0;
+        long long n_ref_pts = 0;
+        if (newp + cnt > 5) {
+            double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+            for (int i = lane; i < npts; i += 64) {
+                const double* q = m.chunk_data + ((size_t)chunk_of(i / IM_CHUNK_PTS) * IM_CHUNK_PTS + (i % IM_CHUNK_PTS)) * IM_PT_DOUBLES;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const double v = q[a]; s1[a] += v; s2[a] += v * v; }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
+            int np = npts, nw = newp;
+            for (int j = 0; j < cnt && !hand_over; j++) {
+                const double* src = pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const double v = src[a]; s1[a] += v; s2[a] += v * v; }
+                np++; nw++;
+                if (nw > 5) {
+                    const double dn = (double)np;
+                    double vmin = 1e300, mag = 0;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { const double mu = s1[a] / dn; const double v = s2[a] / dn - mu * mu; vmin = fmin(vmin, v); mag += s2[a] / dn; }
+                    if (vmin + (1e-7 + 1e-12 * mag) < (double)m.planer_threshold) { last_refit_n = np; n_ref++; n_ref_pts += np; nw = 0; }
+                    else hand_over = true;   // the exact fit must run in the middle of the batch: the general kernel's job
+                }
+            }
+        }
+        if (!hand_over) {
+            // ---- pass 2: append the points, write the header back, queue the (single) fit
+            for (int j = 0; j < cnt; j++) {
+                const double* src = pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES;
+                const int ci = npts / IM_CHUNK_PTS;
+                if ((npts % IM_CHUNK_PTS) == 0 && chunk_of(ci) < 0) {
+                    int c = -1;
+                    if (lane == 0) c = alloc_chunk(m);
+                    c = __shfl(c, 0, 64);
+                    if (c < 0) return;   // pool exhausted: alloc_chunk has raised the capacity flag, the update fails as a whole
+#pragma unroll
+                    for (int k = 0; k < IM_INLINE_CHUNKS; k++) if (ci == k) chunks[k] = c;
+                }
+                if (lane < IM_PT_DOUBLES) m.chunk_data[((size_t)chunk_of(ci) * IM_CHUNK_PTS + (npts % IM_CHUNK_PTS)) * IM_PT_DOUBLES + lane] = src[lane];
+                npts++; newp++;
+                if (newp > 5) newp = 0;
+            }
+            if (lane == 0) {
+                nd.npts = npts; nd.newpts = newp;
+#pragma unroll
+                for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
+                if (last_refit_n) refit_list[atomicAdd(&m.counters[11], 1)] = make_int2(root, last_refit_n);
+                if (n_ref) { atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_ref_pts); }
+            }
+            return;
+        }
+    }
+    if (lane == 0) general_list[atomicAdd(&m.counters[10], 1)] = slot;
+}
+__global__ __launch_bounds__(64) void replay_refit_kernel(RegMapDev m, const int2* __restrict__ refit_list) {
+    __builtin_amdgcn_s_setprio(3);
+    const int n = m.counters[11];
+    WaveCtx w; w.lane = threadIdx.x; w.stats = nullptr; w.root = -1;
+    for (int t = blockIdx.x; t < n; t += gridDim.x) {
+        const int2 rq = refit_list[t];
+        w.root = rq.x;
+        (void)wave_init_plane(m, rq.x, rq.y, w);   // certainly planar (the light kernel's bound): flags stay as they are
+    }
+}
+
 // updateVoxelMap without any global sort: one wavefront per touched root voxel gathers that voxel's points of this scan from its
 // list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them.
-#define RL_CAP 512   /* points of one scan falling into one root voxel that are ordered in LDS; longer lists take the global-scratch path */
 __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
-                                                           const double* __restrict__ pt_data, int64_t* stats, int32_t* __restrict__ big_idx, int32_t* __restrict__ big_order) {
+                                                           const double* __restrict__ pt_data, int64_t* stats, int32_t* __restrict__ big_idx, int32_t* __restrict__ big_order,
+                                                           unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ work, const int32_t* __restrict__ n_work) {
     __shared__ unsigned long long skey[4][RL_CAP];
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
@@ -935,12 +1166,13 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __builtin_amdgcn_s_setprio(3);   // map growth is on the pose chain too (the next scan's registration waits for it)
     const int wv = threadIdx.x >> 6;
     const int t = blockIdx.x * 4 + wv;
-    if (t >= m.counters[7]) return;
+    if (t >= (n_work ? *n_work : m.counters[7])) return;
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
-    const uint32_t slot = m.touched[t];
+    const uint32_t slot = work ? work[t] : m.touched[t];   // work: the voxels the light kernel handed over (replay_light_kernel)
     const int root = m.htab[slot].root;
     if (root < 0) return;
     w.root = root;
+    const unsigned long long tdbg0 = dbg ? __builtin_readcyclecounter() : 0;
     int cnt = 0;
     for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
         if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
@@ -966,7 +1198,7 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (int j = 0; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
+        for (int j = wave_replay_planar_root(m, root, big_order + base, cnt, pt_data, w); j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
         return;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -982,7 +1214,17 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int j = 0; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
+    // settled planar roots take the register-resident fast path; whatever it does not consume goes through the general state machine
+    const unsigned long long tdbg1 = dbg ? __builtin_readcyclecounter() : 0;
+    const int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
+    for (int j = jf; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
+    if (dbg && w.lane == 0) {   // IMMESH_DEBUG: slowest voxel of each kind (cycles << 16 | points), totals
+        const unsigned long long t2 = __builtin_readcyclecounter();
+        atomicMax(&dbg[jf == cnt ? 8 : 9], ((t2 - tdbg0) << 16) | (unsigned long long)cnt);
+        atomicAdd(&dbg[jf == cnt ? 10 : 11], t2 - tdbg1);
+        atomicAdd(&dbg[jf == cnt ? 12 : 13], 1ull);
+        atomicAdd(&dbg[14], tdbg1 - tdbg0);
+    }
 }
 
 // merge chunk ids freed by the previous kernel into the ready stack
@@ -999,7 +1241,7 @@ __global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32
     const int base = m.counters[2];
     for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
     __syncthreads();
-    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; }
+    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; m.counters[10] = 0; m.counters[11] = 0; }
     __syncthreads();
     if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1051,8 +1293,11 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
     KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, spd, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order) {
-    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, void* refit_list, unsigned long long* dbg) {
+    KLAUNCH(replay_light_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, (int2*)refit_list);
+    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
+            (const int32_t*)(m.counters + 10));
+    KLAUNCH(replay_refit_kernel, dim3(std::min(n, 2048)), dim3(64), 0, s, m, (const int2*)refit_list);
     KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {

@@ -245,6 +245,14 @@ int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
  * cb gathers `bytes` bytes from every rank into recv (world x bytes, rank order); equal `bytes` on all ranks.  RCCL: ncclAllGather. */
 typedef int (*immesh_allgather_fn)(const void* send, int64_t bytes, void* recv, void* user);
 int immesh_set_allgather(immesh_ctx* ctx, immesh_allgather_fn cb, void* user);
+/* RCCL inside the library: after immesh_rccl_init the sharded paths issue their collectives themselves, on the context's own HIP streams and on
+ * device-resident buffers (ncclAllReduce of the 46 sums between a residual pass and the in-kernel EKF update: the scan is enqueued without a host
+ * round trip; ncclAllGather of the mesher's exchange records) -- the callbacks above are then unused.  librccl.so is opened on first use.
+ *   immesh_rccl_unique_id: ncclGetUniqueId, called by ONE rank; the 128 bytes travel to the others by whatever launcher the application uses
+ *   (MPI, torch.distributed, a file).   immesh_rccl_init: ncclCommInitRank(world = shard_world, rank = shard_rank) -- collective over the ranks. */
+int immesh_rccl_unique_id(uint8_t id_out[128]);
+int immesh_rccl_init(immesh_ctx* ctx, const uint8_t id[128]);
+const char* immesh_rccl_error(void);
 /* payload bytes this rank has contributed to the mesher's all-gathers, and the number of collective calls, since create */
 int immesh_shard_traffic(immesh_ctx* ctx, int64_t* bytes, int64_t* calls);
 

@@ -38,7 +38,8 @@ def test_library_exports_every_declared_symbol():
 def test_oracle_mirrors_the_boundary(oracle_lib):
     """The checker exports the same entry points under the orc_ prefix (so parity tests drive both with identical calls)."""
     for f in _declared_functions():
-        if f in ("immesh_default_config", "immesh_create_error", "immesh_last_error", "immesh_profile_enable", "immesh_profile_read"):
+        if f in ("immesh_default_config", "immesh_create_error", "immesh_last_error", "immesh_profile_enable", "immesh_profile_read",
+                 "immesh_rccl_unique_id", "immesh_rccl_init", "immesh_rccl_error"):   # (the checker is single-process: no collectives)
             continue
         assert hasattr(oracle_lib, f.replace("immesh_", "orc_", 1)), f
 

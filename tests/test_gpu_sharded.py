@@ -176,3 +176,31 @@ def test_two_rank_sharded_mesher_matches_unsharded():
     assert nv0 == nv1 and nl0 == nl1
     assert nu0 > 0 and nu1 > 0 and nu0 + nu1 == nu_ref            # each rank searched / triangulated only its own voxels; together: all of them
     assert out[(0, "traffic")]["bytes"] > 0 and out[(1, "traffic")]["bytes"] > 0 and out[(0, "traffic")]["calls"] == 4 * 4
+
+
+def test_rccl_inside_the_library_world_size_one(hip_lib):
+    """RCCL called by the C++ layer itself (immesh_rccl_init: librccl.so opened at run time, ncclCommInitRank, then per residual pass
+    residual_kernel -> ncclAllReduce on the device-resident 46 sums -> ekf_step_kernel, all enqueued on the context's stream without a host round
+    trip).  One rank is all a one-GPU box can run: the collective degenerates to a copy, so the result must equal the unsharded fused path bit for
+    bit -- what this exercises is the RCCL symbols, the communicator life cycle and the in-stream pass / reduce / update chain."""
+    scans = _scans(4)
+    cfg1 = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 16, cap_triangles=1 << 18, shard_rank=0, shard_world=1)
+    h, ref = make_hip(hip_lib, cfg1), make_hip(hip_lib, _cfg())
+    h.rccl_init(h.rccl_unique_id())
+    R0, t0, raw0, _ = scans[0]
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raw0[:, :3])
+    h.map_build(p0, st); ref.map_build(p0, st)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    sr = st.copy()
+    for k in range(1, 4):
+        down, raw = scans[k][3], scans[k][2]
+        prior, pr = synth.forward_without_imu(st), synth.forward_without_imu(sr)
+        st, info = h.process_scan(down, raw, prior, prior, frame_idx=k, do_mesh=1)
+        sr, ir = ref.process_scan(down, raw, pr, pr, frame_idx=k, do_mesh=1)
+        assert info == ir
+        np.testing.assert_array_equal(st, sr)
+        mh, mr = h.mesh_fetch(), ref.mesh_fetch()
+        for key in ("new_vtx", "tri_add", "tri_rem"):
+            np.testing.assert_array_equal(mh[key], mr[key])
+    h.close(); ref.close()

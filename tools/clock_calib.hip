@@ -93,7 +93,43 @@ __global__ void calib(unsigned long long* out, double* sink, double seed, int la
       T1(12) } acc += x;
     sink[lane] = acc;
 }
+// dependent random 64-byte-line reads over buffers of growing size (lone wavefront): cache / TLB reach of the gather-bound kernels
+__global__ void fill_lines(unsigned long long* buf, size_t nlines) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nlines; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long k = i * 0x9E3779B97F4A7C15ull; k ^= k >> 29; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 32;
+        buf[i * 8] = k;
+    }
+}
+__global__ void chase(const unsigned long long* buf, size_t nlines, int steps, unsigned long long* out) {
+    unsigned long long idx = threadIdx.x * 7919ull + 12345ull;
+    double x = 0;
+    const unsigned long long t0 = tick(x);
+    for (int i = 0; i < steps; i++) { const unsigned long long v = buf[(idx % nlines) * 8]; idx = idx * 6364136223846793005ull + v; }
+    x += (double)(idx & 1);
+    const unsigned long long t1 = tick(x);
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = idx; }
+}
 int main() {
+    {
+        unsigned long long* d; unsigned long long h[2];
+        hipMalloc(&d, 16);
+        const size_t sizes_mb[6] = {4, 64, 1024, 8192, 32768, 98304};
+        for (int k = 0; k < 6; k++) {
+            unsigned long long* buf = nullptr;
+            const size_t bytes = sizes_mb[k] << 20;
+            if (hipMalloc(&buf, bytes) != hipSuccess) { printf("hipMalloc %zu MB failed\n", sizes_mb[k]); continue; }
+            const size_t nlines = bytes / 64;
+            hipLaunchKernelGGL(fill_lines, dim3(4096), dim3(256), 0, 0, buf, nlines);
+            for (int lanes = 1; lanes <= 64; lanes *= 64) {
+                hipLaunchKernelGGL(chase, dim3(1), dim3(lanes), 0, 0, buf, nlines, 512, d);
+                hipDeviceSynchronize();
+                hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+                printf("dependent random line reads over %6zu MB, %2d lanes (distinct lines): %8.1f ticks = %6.1f ns per step\n", sizes_mb[k], lanes, (double)h[0] / 512, (double)h[0] / 512 / 2.4);
+            }
+            hipFree(buf);
+        }
+        hipFree(d);
+    }
     unsigned long long* d; unsigned long long h[16]; double* s;
     hipMalloc(&d, 128); hipMalloc(&s, 512);
     const char* names[13] = {"f64 add", "f64 mul", "f64 fma", "f64 div (1/(x+1.5)) incl. add", "f64 sqrt incl. add", "f64 add, 8 independent chains (per op)", "LDS write+read round trip",
