@@ -223,6 +223,8 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     def run(k, state, mode=None):
         prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
         down_ptr, n_ds = d_down[k].data_ptr(), len(downs[k])
+        if args.host_inputs:
+            return h.process_scan(downs[k], raws[k], prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode)
         if args.device_downsample:
             _, n_ds = h.downsample(d_raw[k].data_ptr(), 0.5 if kitti else 0.4, n=len(raws[k]), stride=4, to_host=False)
             down_ptr = h.downsample_result_ptr()
@@ -371,6 +373,7 @@ def main():
                     "1 = only the sharded split: ONE stream, registration map and mesher sharded by voxel bricks over the ranks (strong scaling; the capacity mode of configs[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
     ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
+    ap.add_argument("--host-inputs", type=int, default=0, help="1 = every scan is handed over as HOST buffers (the library stages them over PCIe inside the timed region): the PCIe-inclusive rate")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
@@ -446,7 +449,8 @@ def main():
                        "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
-                       "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)"},
+                       "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
+                       "inputs": "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region"},
             "stages_ms_serial": None,
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},
             "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
@@ -490,7 +494,9 @@ def main():
     if rank == 0 and want_extra:
         extra = {}
         env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20))])):
+        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20))]),
+                             ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
+                             ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)

@@ -120,7 +120,7 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
     if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) != hipSuccess ||
-        hipEventRecord(c->ev_inputs_free, c->stream) != hipSuccess) {
+        hipEventRecord(c->ev_inputs_free, c->stream) != hipSuccess || !(c->ev_inputs_cur = c->ev_inputs_free)) {
         g_create_error = "hipStreamCreate/hipEventCreate failed"; immesh_destroy(c); return nullptr;
     }
     // per-config constants of calcBodyVar: pow(sin(DEG2RAD(deg)),2) with PCL's DEG2RAD(x) = x*0.017453293 and float `degree_inc`
@@ -183,8 +183,11 @@ static int settle(immesh_ctx* c, bool synced = false) {
     if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
     hipEvent_t* e = c->ev + 4 * c->ev_par;
-    (void)hipEventElapsedTime(&c->timing[1], e[0], e[1]);
-    (void)hipEventElapsedTime(&c->timing[2], e[1], e[2]);
+    c->timing[1] = c->timing[2] = 0.f;
+    if (c->timing_valid) {
+        (void)hipEventElapsedTime(&c->timing[1], e[0], e[1]);
+        (void)hipEventElapsedTime(&c->timing[2], e[1], e[2]);
+    }
     c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
     return check_overflow(c);
 }
@@ -403,7 +406,7 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
 // spd != nullptr: pose + covariance blocks come from device memory (the posterior the in-kernel EKF left in RegState::sp); `st` then only
 // supplies the per-configuration constants
 static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr,
-                             const ScanParams* spd = nullptr) {
+                             const ScanParams* spd = nullptr, const float* d_raw = nullptr, float* world = nullptr, int n_raw = 0) {
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
@@ -412,8 +415,11 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
         c->map.upd_seq++;
         c->map.touched = (uint32_t*)c->d_seg_start;
-        launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a);
-        if (after_point_var) HIPCHK(c, hipEventRecord(after_point_var, s));   // the scan's input clouds are consumed: the replay works on its own copies
+        launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a, d_raw, world, n_raw);
+        // the scan's input clouds are consumed here (the replay works on its own copies) and the mesher's scan is in its world buffer: ONE event
+        // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
+        if (world) c->ev_inputs_cur = mesh_record_ready(c);
+        else if (after_point_var) { HIPCHK(c, hipEventRecord(after_point_var, s)); c->ev_inputs_cur = after_point_var; }
         launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->d_key_b, c->reg_dbg);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
@@ -479,23 +485,24 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     const bool nowait = mesh_mode == IMMESH_MESH_ASYNC || ((do_mesh & IMMESH_SCAN_NOWAIT) && !(mesh_mode && c->mesh.shard_world > 1));
     const int par = c->ev_par ^ 1;
     hipEvent_t* ev = c->ev + 4 * par;
-    (void)hipEventRecord(ev[0], c->stream);
+    // stage timings (immesh_last_timing [1], [2]) are taken for synchronous calls only: an asynchronous call keeps event records -- barrier packets,
+    // each a few microseconds of bubble between two kernels of the pose chain -- out of the queue and reports zeros
+    const bool fused = use_fused_ekf(c);
+    const bool timed = !(fused && nowait) || c->prof.on;
+    if (timed) (void)hipEventRecord(ev[0], c->stream);
     int n_iter = 0, n_match = 0;
-    if (use_fused_ekf(c)) {
+    if (fused) {
         // Everything of the scan is enqueued before the host looks at a single result: the residual passes with the in-kernel 18-state update,
         // the full-scan transform and the map update (both read the posterior from RegState::sp on the device).  The host then collects the
         // pose -- by then the device is already growing the map -- and hands the scan to the mesher.
         if ((rc = register_enqueue_fused(c, (const float*)d_down, n_ds, prior, st))) return rc;
-        (void)hipEventRecord(ev[1], c->stream);
+        if (timed) (void)hipEventRecord(ev[1], c->stream);
         float* world = nullptr;
-        if (mesh_mode) {
-            world = mesh_next_world_buffer(c);
-            launch_mesh_transform(c->stream, (const float*)d_raw, world, n_raw, nullptr, nullptr, c->cfg.extR, c->cfg.extT, (const double*)&c->d_regstate->sp);
-            mesh_record_ready(c);
-        }
-        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp))) return rc;
-        (void)hipEventRecord(ev[2], c->stream);
-        (void)hipEventRecord(ev[3], c->stream);
+        if (mesh_mode) world = mesh_next_world_buffer(c);
+        // (the transform of the full scan for the mesher rides in the first launch of the map update)
+        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw))) return rc;
+        if (timed) (void)hipEventRecord(ev[2], c->stream);
+        c->timing_valid = timed;
         rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
         imh::store_state(st, state_inout);
         if (n_iter_out) *n_iter_out = n_iter;
@@ -523,6 +530,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         return rc;
     }
     c->ev_par = par;
+    c->timing_valid = true;
     (void)hipEventRecord(ev[1], c->stream);
     long job = 0;
     // IMMESH_SERIAL_ORDER: map growth first, then the hand-over to the mesher -- the order of the reference's map_incremental_grow; the default
@@ -540,7 +548,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
-    if (serial_order) (void)hipEventRecord(c->ev_inputs_free, c->stream);
+    if (serial_order) { (void)hipEventRecord(c->ev_inputs_free, c->stream); c->ev_inputs_cur = c->ev_inputs_free; }
     else {
         if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free))) return rc;
         (void)hipEventRecord(ev[2], c->stream);
@@ -568,12 +576,12 @@ static int pre_resolve(immesh_ctx* c, const void* p, size_t bytes, void* staging
     if (e == hipSuccess) is_dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
     else (void)hipGetLastError();
     if (is_dev) { *dev_out = p; return 0; }
-    HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_free, 0));   // the staging buffers double as immesh_process_scan's own staging
+    HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_cur, 0));   // the staging buffers double as immesh_process_scan's own staging
     HIPCHK(c, hipMemcpyAsync(staging, p, bytes, hipMemcpyHostToDevice, c->stream_pre));
     *dev_out = staging;
     return 0;
 }
-#define PRE_OUTPUT_FENCE(c) HIPCHK(c, hipStreamWaitEvent((c)->stream_pre, (c)->ev_inputs_free, 0))
+#define PRE_OUTPUT_FENCE(c) HIPCHK(c, hipStreamWaitEvent((c)->stream_pre, (c)->ev_inputs_cur, 0))
 
 // ---- sensor decode: flag -> exclusive scan -> compact, in arrival order
 static int decode_finish(immesh_ctx* c, int n, float* out_xyzit, int32_t* n_out) {

@@ -32,6 +32,8 @@ struct immesh_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_pre = nullptr;    // the stages before the path (decode / undistort / down-sample): they do not touch the map, so they run beside the previous scan's map update
     hipEvent_t ev_inputs_free = nullptr; // recorded on `stream` when the last asynchronous scan has consumed its input clouds (after point_var + transform)
+    hipEvent_t ev_inputs_cur = nullptr;  // the event that currently carries that meaning (the mesher's "scan is in its world buffer" event when one was recorded)
+    bool timing_valid = true;            // the last immesh_process_scan recorded its stage events (synchronous calls only)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // two sets of four (scan parity)
     int ev_par = 0;
     bool pending = false;            // the last immesh_process_scan returned without waiting for its map update (IMMESH_SCAN_NOWAIT)
@@ -141,7 +143,7 @@ void rccl_release(immesh_ctx* c);
 int mesh_alloc(immesh_ctx* c);
 void mesh_free(immesh_ctx* c);
 long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded = false);
-void mesh_record_ready(immesh_ctx* c);   // record the NEXT job's "scan is in its world buffer" event on the registration stream now (before more work is queued behind it)
+hipEvent_t mesh_record_ready(immesh_ctx* c);   // record the NEXT job's "scan is in its world buffer" event on the registration stream now (before more work is queued behind it)
 float* mesh_next_world_buffer(immesh_ctx* c);
 int mesh_wait(immesh_ctx* c, long id);
 void mesh_wait_all(immesh_ctx* c);

@@ -59,7 +59,8 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const ScanParams* spd, const float* pts, int n, int stride, int mode, double* pt_data,
-                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next);
+                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next, const float* raw_xyzi = nullptr, float* world_xyzi = nullptr, int n_raw = 0);
+// (raw_xyzi != nullptr: the same launch also transforms the full xyzI scan into the world frame for the mesher)
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
                          int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, void* refit_list, unsigned long long* dbg = nullptr);
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);

@@ -500,11 +500,12 @@ static void mesh_worker_main(immesh_ctx* c) {
 
 // Called on the scan thread.  d_pts = world-frame xyzI already (being) produced on c->stream; returns the job id.
 // At most two jobs are outstanding (their scans live in the two world buffers), so this blocks while job id-2 is still running.
-void mesh_record_ready(immesh_ctx* c) {
+hipEvent_t mesh_record_ready(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     long next;
     { std::unique_lock<std::mutex> lk(h.mu); next = h.submitted + 1; }
     (void)hipEventRecord(h.ev_ready[next & 1], c->stream);
+    return h.ev_ready[next & 1];
 }
 long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded) {
     MeshHost& h = c->mesh_host;

@@ -1531,7 +1531,10 @@ void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, cons
 }
 void launch_mesh_append_flags(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_append_flags_kernel, g1(n_cand), dim3(256), 0, s, m); }
 void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KLAUNCH(mesh_select_active_kernel, g1(n_cand), dim3(256), 0, s, m); }
-void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(1024), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
+// IMMESH_MESH_GRID_DIV (experiments): divides the grids of the two big per-voxel kernels -- fewer resident mesher wavefronts per SIMD leave register
+// room for the registration chain's kernels
+static int mesh_grid_div() { static const int v = getenv("IMMESH_MESH_GRID_DIV") ? std::max(1, atoi(getenv("IMMESH_MESH_GRID_DIV"))) : 1; return v; }
+void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(1024 / mesh_grid_div()), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
 void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor) {
     KLAUNCH(mesh_knn_kernel<true>, dim3(2048), dim3(256), 0, s, m, export_vtx, smooth_factor);
 }
@@ -1562,7 +1565,7 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 }
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
-    KLAUNCH(mesh_delaunay64_kernel, dim3(2048), dim3(64), 0, s, m);          // n_u <= 64: register fast path
+    KLAUNCH(mesh_delaunay64_kernel, dim3(2048 / mesh_grid_div()), dim3(64), 0, s, m);          // n_u <= 64: register fast path
     KLAUNCH(mesh_delaunay_general_kernel, dim3(512), dim3(64), 0, s, m);     // 64 < n_u <= 256, and what the fast path handed over
     KLAUNCH(mesh_delaunay_big_kernel, dim3(256), dim3(64), 0, s, m);         // n_u > 256
 }

@@ -538,7 +538,27 @@ __global__ __launch_bounds__(64) void ekf_step_kernel(RegIterArgs a, RegState* r
 // mode 1: voxel_map_init        (var = R bcov R^T + (-[p_lidar]x) Srot (..)^T + St, p_lidar after calcBodyVar's z==0 -> 1e-4 quirk)
 __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const ScanParams* __restrict__ spd, const float* __restrict__ pts, int n, int stride, int mode,
                                                          double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out,
-                                                         int32_t* __restrict__ pt_next) {
+                                                         int32_t* __restrict__ pt_next, const float4* __restrict__ raw, float4* __restrict__ world, int n_raw, int nb_pv) {
+    if ((int)blockIdx.x >= nb_pv) {
+        // transformLidar of the FULL scan for the mesher (voxel_mapping_common.cpp:709-726) rides in the same launch: it was a launch of its own
+        // on the pose chain, between the last residual pass and this kernel
+        const int i = ((int)blockIdx.x - nb_pv) * 256 + threadIdx.x;
+        if (i >= n_raw) return;
+        const ScanParams* q = spd ? spd : &sp;
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = q->R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] = q->t[k];
+        const float4 v = raw[i];
+        const double p[3] = {(double)v.x, (double)v.y, (double)v.z};
+        double pi[3], pw[3];
+        m3_vec(sp.extR, p, pi);
+        pi[0] += sp.extT[0]; pi[1] += sp.extT[1]; pi[2] += sp.extT[2];
+        m3_vec(R, pi, pw);
+        world[i] = make_float4((float)(pw[0] + t[0]), (float)(pw[1] + t[1]), (float)(pw[2] + t[2]), v.w);
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (spd) {   // posterior of the scan just registered, left on the device by the in-kernel EKF update
@@ -1289,8 +1309,10 @@ void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const do
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);
 }
 void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, const ScanParams* spd, const float* pts, int n, int stride, int mode, double* pt_data,
-                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next) {
-    KLAUNCH(point_var_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, sp, spd, pts, n, stride, mode, pt_data, sort_key, slot, pt_next);
+                      unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next, const float* raw_xyzi, float* world_xyzi, int n_raw) {
+    const int nb_pv = (n + 255) / 256, nb_x = raw_xyzi ? (n_raw + 255) / 256 : 0;
+    KLAUNCH(point_var_kernel, dim3(nb_pv + nb_x), dim3(256), 0, s, m, sp, spd, pts, n, stride, mode, pt_data, sort_key, slot, pt_next, (const float4*)raw_xyzi,
+            (float4*)world_xyzi, n_raw, nb_pv);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
                          int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, void* refit_list, unsigned long long* dbg) {

@@ -295,7 +295,9 @@ typedef struct immesh_counters_t {  /* cumulative since create / last reset; SUR
 int immesh_counters(immesh_ctx* ctx, immesh_counters_t* out, int32_t reset);
 
 /* timing of the last immesh_process_scan, milliseconds from HIP events on the ctx stream:
- * [0] total  [1] register  [2] map update  [3] mesh  */
+ * [0] total  [1] register  [2] map update  [3] mesh
+ * [1] and [2] are taken for synchronous calls only: an asynchronous call (IMMESH_MESH_ASYNC or IMMESH_SCAN_NOWAIT) keeps the stage events out of
+ * the stream -- every event record is a barrier packet between two kernels of the pose chain -- and reports zeros for them. */
 int immesh_last_timing(immesh_ctx* ctx, float ms[4]);
 
 /* per-kernel timing (HIP events on the ctx stream around every launch); off by default.  bench.py's roofline leg. */

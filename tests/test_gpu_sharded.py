@@ -204,3 +204,17 @@ def test_rccl_inside_the_library_world_size_one(hip_lib):
         for key in ("new_vtx", "tri_add", "tri_rem"):
             np.testing.assert_array_equal(mh[key], mr[key])
     h.close(); ref.close()
+
+
+def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo` as ONE command (not under torch.distributed.run): it re-executes itself as two ranks -- both on
+    cuda:0 here, the pool has one GPU per box -- and the line carries the replica headline (n_gpus 2, weak) and the sharded leg (strong)."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--map-voxels", "150000",
+                        "--pts", "30000", "--profile-scans", "0", "--cpu-seconds", "0", "--extra-configs", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["sharded"]["scaling"] == "strong" and d["sharded"]["value"] > 0 and "gloo" in d["sharded"]["collectives"] and d["sharded"]["pose_err_m"] < 0.1
