@@ -17,6 +17,12 @@ def _clouds():
     yield (rng.normal(0, 3, (5000, 4))).astype(np.float32), 0.25                       # negative coordinates, dense leaves
     yield np.array([[0.1, 0.2, 0.3, 1.0]], np.float32), 0.4                           # single point
     yield np.repeat(np.array([[1.0, -2.0, 0.5, 0.0]], np.float32), 50, axis=0), 0.4   # all in one leaf
+    # leaves with hundreds of points (the float32 sums must be formed in scan order whatever the device does in between) and a cloud with far
+    # more leaves than points per leaf
+    blob = (rng.uniform(0.02, 0.38, (300, 4)) + np.array([2.0, 0.4, -0.8, 0.0])).astype(np.float32)
+    yield np.concatenate([rng.normal(0, 4, (3000, 4)).astype(np.float32), blob, rng.normal(0, 4, (3000, 4)).astype(np.float32)]), 0.4
+    yield np.concatenate([rng.normal(0, 2, (500, 4)).astype(np.float32), (rng.uniform(0.05, 0.35, (700, 4)) + np.array([0.4, 0.4, 0.4, 0.0])).astype(np.float32)]), 0.4
+    yield rng.uniform(-150, 150, (40000, 4)).astype(np.float32), 0.5
 
 
 def test_oracle_downsample_matches_harness(oracle_lib):
