@@ -420,8 +420,11 @@ def main():
             print(json.dumps(out), flush=True)
 
     def watchdog():
-        if not printed.wait(2.0 * args.profile_timeout + args.cpu_seconds + 30.0):
-            out["profile_leg_note"] = ((out.get("profile_leg_note") or "") + " watchdog: a leg after the timed region did not finish; the line was printed without it").strip()
+        # every rank runs one: when a leg after the timed region hangs (a collective of the sharded leg with a dead peer, say), rank 0 prints the line
+        # as it stands and every rank leaves -- the launcher must not be left waiting for the others
+        if not printed.wait(2.0 * args.profile_timeout + args.cpu_seconds + (30.0 if rank == 0 else 40.0)):
+            if out is not None:
+                out["profile_leg_note"] = ((out.get("profile_leg_note") or "") + " watchdog: a leg after the timed region did not finish; the line was printed without it").strip()
             emit()
             sys.stdout.flush(); sys.stderr.flush()
             os._exit(0)
@@ -458,7 +461,7 @@ def main():
         }
         if args.profile_scans > 0:   # until the live leg has delivered: the committed rocprofv3 average of the dominant kernel with this run's own counters
             out["roofline"] = add_traffic(roofline_from_committed_profile(args.mesh, cnt, args.steps, args.pts, "not run yet"))
-        threading.Thread(target=watchdog, daemon=True).start()
+    threading.Thread(target=watchdog, daemon=True).start()
 
     stage, kstats, pc, prof_note = res["legs"]()
     if rank == 0:
