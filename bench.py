@@ -459,6 +459,8 @@ def main():
             "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
             "roofline": None, "cpu_baseline": None, "kernels_ms_per_scan": {},
         }
+        if res.get("shard_traffic"):
+            out["exchange_bytes_per_scan_rank0"] = round(res["shard_traffic"]["bytes"] / max(1, args.steps + args.warmup + 1), 1)
         if args.profile_scans > 0:   # until the live leg has delivered: the committed rocprofv3 average of the dominant kernel with this run's own counters
             out["roofline"] = add_traffic(roofline_from_committed_profile(args.mesh, cnt, args.steps, args.pts, "not run yet"))
     threading.Thread(target=watchdog, daemon=True).start()
@@ -478,15 +480,33 @@ def main():
         if prof_note:
             out["profile_leg_note"] = prof_note
 
-    # ---- N > 1: the north-star split as a second leg -- ONE stream, voxel bricks sharded over the ranks (every rank takes part)
+    # ---- N > 1: the north-star split as a second leg -- ONE stream, voxel bricks sharded over the ranks.  It runs as a CHILD job (this script with
+    # --shard 1, the same N ranks) that rank 0 launches after every rank of this job has finished the replica headline and the other ranks have
+    # left: a crash or a hung collective in the sharded path (RCCL issued by the library on its own streams) must not take the headline with it.
+    if world > 1:
+        D.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     if world > 1 and not only_sharded and args.sharded_leg:
-        rs = measure(args, torch, D, dist, hip, rank, world, local, dev, sharded=True, full=False)
-        rs["legs"]()   # (nothing to run for this leg: closes its context)
-        if rank == 0:
-            out["sharded"] = {"value": round(D.aggregate_throughput(args.steps, 1, rs["elapsed"]), 4), "unit": "scans/s", "scaling": "strong", "ms_per_step": round(1e3 * rs["elapsed"] / args.steps, 4),
-                              "parallelism": f"ONE stream; registration map + mesher sharded by voxel bricks over {world} GPUs", "collectives": rs["comm"], "map_root_voxels_rank0": rs["n_map"],
-                              "exchange_bytes_per_scan_rank0": round(rs["shard_traffic"]["bytes"] / max(1, args.steps + args.warmup + 1), 1) if rs.get("shard_traffic") else None,
-                              "pose_err_m": round(rs["pose_err"], 4)}
+        env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE",
+                                                                       "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT",
+                                                                       "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
+        cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", str(world), "--shard", "1", "--backend", args.backend, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--pts", str(args.pts), "--map-voxels", str(args.map_voxels), "--mesh", str(args.mesh), "--config", args.config, "--cpu-seconds", "0", "--profile-scans", "0",
+               "--extra-configs", "0"]
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1.5 * args.profile_timeout, text=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and lines:
+                d = json.loads(lines[-1])
+                out["sharded"] = {"value": d["value"], "unit": d["unit"], "scaling": d["scaling"], "ms_per_step": d["ms_per_step"], "parallelism": d["config"]["parallelism"],
+                                  "map_root_voxels_rank0": d["config"]["map_root_voxels"], "exchange_bytes_per_scan_rank0": d.get("exchange_bytes_per_scan_rank0"),
+                                  "pose_err_m": d["pose_err_m"], "how": "child job of the same N ranks, launched by rank 0 after the replica headline"}
+            else:
+                out["sharded"] = {"error": f"rc {r.returncode}: " + (r.stderr or "")[-300:]}
+        except Exception as e:   # noqa: BLE001
+            out["sharded"] = {"error": str(e)[:200]}
 
     # ---- CPU baseline leg (rank 0, N = 1 semantics: the oracle on this box's host cores)
     if rank == 0 and args.cpu_seconds > 0:
@@ -515,9 +535,6 @@ def main():
         out["extra"] = extra
 
     emit()
-    if world > 1:
-        D.barrier()          # rank 0 may still be in its CPU-baseline leg: leave together
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
