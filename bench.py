@@ -459,6 +459,8 @@ def main():
             "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
             "roofline": None, "cpu_baseline": None, "kernels_ms_per_scan": {},
         }
+        if only_sharded:
+            out["collectives"] = res["comm"]
         if res.get("shard_traffic"):
             out["exchange_bytes_per_scan_rank0"] = round(res["shard_traffic"]["bytes"] / max(1, args.steps + args.warmup + 1), 1)
         if args.profile_scans > 0:   # until the live leg has delivered: the committed rocprofv3 average of the dominant kernel with this run's own counters
@@ -501,7 +503,7 @@ def main():
             if r.returncode == 0 and lines:
                 d = json.loads(lines[-1])
                 out["sharded"] = {"value": d["value"], "unit": d["unit"], "scaling": d["scaling"], "ms_per_step": d["ms_per_step"], "parallelism": d["config"]["parallelism"],
-                                  "map_root_voxels_rank0": d["config"]["map_root_voxels"], "exchange_bytes_per_scan_rank0": d.get("exchange_bytes_per_scan_rank0"),
+                                  "collectives": d.get("collectives"), "map_root_voxels_rank0": d["config"]["map_root_voxels"], "exchange_bytes_per_scan_rank0": d.get("exchange_bytes_per_scan_rank0"),
                                   "pose_err_m": d["pose_err_m"], "how": "child job of the same N ranks, launched by rank 0 after the replica headline"}
             else:
                 out["sharded"] = {"error": f"rc {r.returncode}: " + (r.stderr or "")[-300:]}
