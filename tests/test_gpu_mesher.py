@@ -119,7 +119,7 @@ def test_process_scan_full_pipeline(oracle_lib, hip_lib, mesh_mode):
     o.map_build(p0, st); h.map_build(p0, st)
     so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
     sh = so.copy()
-    exact = True
+    exact, n_exact = True, 0
     for k in range(1, 5):
         Rk, tk = synth.trajectory_pose(k)
         raw = synth.livox_scan(k, Rk, tk, n_pts=30000, extT=extT)
@@ -138,10 +138,15 @@ def test_process_scan_full_pipeline(oracle_lib, hip_lib, mesh_mode):
         exact = exact and np.array_equal(mh["new_vtx"], mo["new_vtx"])
         if exact:
             _compare_scan(mo, mh, f"scan {k}")
+            n_exact += 1
         else:
             assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50
         tm = h.last_timing()
         assert tm["total"] > 0 and tm["mesh"] > 0
+    # how many of the four scans stayed bit-exact through the FULL pipeline (vertices and every triangle list); the strict all-scans version of this
+    # comparison, on bit-identical world-frame inputs and at BASELINE's sizes, is tests/test_gpu_parity_fullsize.py
+    print(f"[full pipeline, mesh_mode {mesh_mode}] {n_exact} of 4 scans bit-exact")
+    assert n_exact >= 1
 
 
 def test_async_pipeline_matches_serial(hip_lib):
