@@ -62,7 +62,7 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
     m.upd_seq = 0;
     A(c->d_stats, 8);
-    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 16); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 128, c->stream)); }
+    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 64); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 512, c->stream)); }
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
@@ -244,24 +244,31 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
     std::memcpy(a.prior + 18, prior.ba, 24); std::memcpy(a.prior + 21, prior.g, 24);
     c->reg_ticket = (double)(++c->res_ticket);
     const bool rccl = c->rccl_comm != nullptr;   // sharded map: the 46 sums are all-reduced in-stream between pass and update
+    if (!rccl) {
+        // ONE launch for the scan: a resident grid runs every pass and the 18-state update (residual_persistent_kernel); a.mat = the prior covariance
+        a.mode = REG_MODE_FUSED; a.it = 0;
+        std::memcpy(a.mat, st.cov, sizeof(a.mat));
+        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, (unsigned int)(c->res_ticket & 0x3FFFFFFull) * 64u, c->d_reg_out_host,
+                                   c->reg_ticket, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
+        return 0;
+    }
     for (int it = 0; it < max_iter; it++) {
-        a.it = it;
+        // sharded map: residual pass (sums to device memory) -> ncclAllReduce on the device-resident sums -> the 18-state update as its own
+        // (one-wavefront) launch; all passes enqueued up front, no host involvement
+        a.it = it; a.mode = REG_MODE_SUMS;
         if (it == 0) {
-            a.mode = rccl ? REG_MODE_SUMS : REG_MODE_FIRST;
             double p11[36];
             for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) p11[r * 6 + q] = st.cov[r * 18 + q];
             if (!imh::invert(p11, a.mat, 6)) { c->err = "singular prior covariance"; return IMMESH_E_INVAL; }
             for (int i = 0; i < 12; i++)
                 for (int q = 0; q < 6; q++) { double sacc = 0; for (int k = 0; k < 6; k++) sacc += st.cov[(6 + i) * 18 + k] * a.mat[k * 6 + q]; a.mat[36 + i * 6 + q] = sacc; }
         }
-        else { a.mode = rccl ? REG_MODE_SUMS : REG_MODE_NEXT; if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat)); }
+        else if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat));
         launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, c->d_out48, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
                         c->d_dis, c->d_rinv, c->d_normal);
-        if (rccl) {   // ncclAllReduce on the device-resident sums, then the 18-state update as its own (one-wavefront) launch; no host involvement
-            int rc = rccl_allreduce_f64(c, c->d_out48, RES_NV_HOST - 2, c->stream);
-            if (rc) return rc;
-            launch_ekf_step(c->stream, a, c->d_regstate, c->d_out48, c->d_reg_out_host, c->reg_ticket);
-        }
+        int rc = rccl_allreduce_f64(c, c->d_out48, RES_NV_HOST - 2, c->stream);
+        if (rc) return rc;
+        launch_ekf_step(c->stream, a, c->d_regstate, c->d_out48, c->d_reg_out_host, c->reg_ticket);
     }
     return 0;
 }
@@ -292,7 +299,7 @@ static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* 
 }
 static bool use_fused_ekf(const immesh_ctx* c) {
     static const bool host_ekf = getenv("IMMESH_HOST_EKF") != nullptr;   // debugging: the round-1 host loop (one round trip per pass)
-    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && !c->reg_dbg && (c->cfg.shard_world <= 1 || c->rccl_comm != nullptr);
+    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && c->cfg.max_iter < 64 && (c->cfg.shard_world <= 1 || c->rccl_comm != nullptr);
 }
 
 // the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
@@ -313,14 +320,6 @@ static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const im
         if (n_match) *n_match = (int)o[42];
         if (res_mean) *res_mean = o[42] > 0 ? o[43] / o[42] : 0.0;
         if (ekf.step(o, o + 36, prior, st, it, max_iter)) break;
-    }
-    if (c->reg_dbg) {
-        unsigned long long t[16];
-        (void)hipMemcpy(t, c->reg_dbg, 128, hipMemcpyDeviceToHost); (void)hipMemset(c->reg_dbg, 0, 128);
-        fprintf(stderr, "[replay (previous scan)] slowest fast-path voxel %llu cycles (%llu pts), slowest general voxel %llu cycles (%llu pts); mean replay cycles fast %llu (%llu voxels) general %llu (%llu voxels); list gather + sort %llu per voxel\n",
-                t[8] >> 16, t[8] & 0xFFFF, t[9] >> 16, t[9] & 0xFFFF, t[10] / std::max(1ull, t[12]), t[12], t[11] / std::max(1ull, t[13]), t[13], t[14] / std::max(1ull, t[12] + t[13]));
-        const unsigned long long nw = (unsigned long long)iters * ((n_ds + 63) / 64);
-        fprintf(stderr, "[residual cycles/wave] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block final %llu\n", t[0] / nw, t[1] / nw, t[2] / nw, t[3] / nw, t[4] / nw, t[5] / (unsigned long long)iters);
     }
     c->cnt.n_iter += iters;
     c->cnt.n_ds = n_ds;
@@ -420,7 +419,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
         if (world) c->ev_inputs_cur = mesh_record_ready(c);
         else if (after_point_var) { HIPCHK(c, hipEventRecord(after_point_var, s)); c->ev_inputs_cur = after_point_var; }
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->d_key_b, c->reg_dbg);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->reg_dbg);
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
@@ -715,6 +714,19 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     out->n_refits = stats[0]; out->n_refit_pts = stats[1];
     out->n_root_voxels = c->h_counters[6]; out->n_nodes = c->h_counters[0];
     mesh_counters(c, out);
+    if (c->reg_dbg) {   // IMMESH_DEBUG: in-kernel phase timers since the last call (cycles of the shader clock; see the FDBG / RDBG markers in reg_kernels.hip)
+        unsigned long long t[64];
+        HIPCHK(c, hipMemcpy(t, c->reg_dbg, sizeof(t), hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemset(c->reg_dbg, 0, sizeof(t)));
+        const unsigned long long nv = std::max(1ull, t[25]);
+        fprintf(stderr, "[replay_fused cycles/voxel, %llu voxels (%llu with a fit)] header+list %llu sort %llu load %llu decide %llu commit %llu plane %llu | slowest %llu cycles (%llu pts)\n", t[25], t[26],
+                t[16] / nv, t[17] / nv, t[18] / nv, t[19] / nv, t[20] / nv, t[21] / std::max(1ull, t[26]), t[24] >> 16, t[24] & 0xFFFF);
+        fprintf(stderr, "[replay_list] slowest fast-path voxel %llu cycles (%llu pts), slowest general voxel %llu cycles (%llu pts); mean cycles fast %llu (%llu voxels) general %llu (%llu voxels); list gather + sort %llu per voxel\n",
+                t[8] >> 16, t[8] & 0xFFFF, t[9] >> 16, t[9] & 0xFFFF, t[10] / std::max(1ull, t[12]), t[12], t[11] / std::max(1ull, t[13]), t[13], t[14] / std::max(1ull, t[12] + t[13]));
+        const unsigned long long nwv = std::max(1ull, t[6]), npass = std::max(1ull, t[7]);
+        fprintf(stderr, "[residual cycles/wave, %llu waves in %llu passes] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block tail %llu per pass\n", t[6], t[7], t[0] / nwv, t[1] / nwv,
+                t[2] / nwv, t[3] / nwv, t[4] / nwv, t[5] / npass);
+    }
     if (reset) {
         mesh_counters_reset(c);
         std::memset(&c->cnt, 0, sizeof(c->cnt));

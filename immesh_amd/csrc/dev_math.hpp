@@ -155,6 +155,70 @@ IMD void sym3_eigen_jacobi(const double* Ain, double* evals, double* V) {
     for (int i = 0; i < 9; i++) V[i] = v[i];
 }
 
+// ---- the same cyclic Jacobi for OctoTree::init_plane on the device (reg_kernels.hip: the plane fit is the unit of the map update) ----------
+// Same sweep order, same rotation per step, same convergence tests as sym3_eigen_jacobi -- so the eigenvalue that ends up at each diagonal
+// position and the sign of every eigenvector column are the checker's -- but the three IEEE divides and two IEEE square roots of a rotation
+// (~430 cycles of a lone wavefront's dependent chain, 11 k cycles per decomposition) become one reciprocal and two reciprocal square roots by
+// v_rcp_f64 / v_rsq_f64 + two Newton steps (no scaling / fix-up: the operands are covariances, far from the ends of the exponent range):
+//   theta = (aqq - app) / (2 apq),  t = sgn(theta) / (|theta| + sqrt(theta^2 + 1))   ==   t = s |apq| / (|h| + sqrt(h^2 + apq^2)),  h = (aqq - app) / 2
+// Differences to the IEEE version are a few ulp per rotation (parity bar: 1e-5); NOT for the mesher's PCA, whose axes feed bit-exact predicates.
+IMD double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+IMD double fast_rsqrt(double x) {   // x > 0
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = __builtin_fma(__builtin_fma(-hx * y, y, 0.5), y, y);
+    y = __builtin_fma(__builtin_fma(-hx * y, y, 0.5), y, y);
+    return y;
+}
+IMD void sym3_eigen_jacobi_fast(const double* Ain, double* evals, double* V) {
+    double a00 = Ain[0], a01 = Ain[1], a02 = Ain[2], a11 = Ain[4], a12 = Ain[5], a22 = Ain[8];
+    double v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            double app, aqq, apq, arp, arq;
+            if (e == 0) { app = a00; aqq = a11; apq = a01; arp = a02; arq = a12; }
+            else if (e == 1) { app = a00; aqq = a22; apq = a02; arp = a01; arq = a12; }
+            else { app = a11; aqq = a22; apq = a12; arp = a01; arq = a02; }
+            if (apq == 0.0) continue;
+            double napp = app, naqq = aqq, nrp = arp, nrq = arq;
+            if (!(fabs(apq) <= 1e-300 || (fabs(app) + fabs(apq) == fabs(app) && fabs(aqq) + fabs(apq) == fabs(aqq)))) {
+                rotated = true;
+                const double h = 0.5 * (aqq - app);
+                const double ah = fabs(h), aq = fabs(apq);
+                const double r2 = __builtin_fma(h, h, apq * apq);
+                const double root = r2 * fast_rsqrt(r2);                      // sqrt(h^2 + apq^2) > 0
+                double t = aq * fast_rcp(ah + root);
+                if (h != 0.0 && ((h < 0.0) != (apq < 0.0))) t = -t;           // sign of theta; theta == +-0 counts as >= 0
+                const double c = fast_rsqrt(__builtin_fma(t, t, 1.0));
+                const double s = t * c;
+                napp = app - t * apq; naqq = aqq + t * apq;
+                nrp = c * arp - s * arq; nrq = s * arp + c * arq;
+                const int p = (e == 2) ? 1 : 0, q = (e == 0) ? 1 : 2;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const double vip = v[i * 3 + p], viq = v[i * 3 + q];
+                    v[i * 3 + p] = c * vip - s * viq;
+                    v[i * 3 + q] = s * vip + c * viq;
+                }
+            }
+            if (e == 0) { a00 = napp; a11 = naqq; a01 = 0.0; a02 = nrp; a12 = nrq; }
+            else if (e == 1) { a00 = napp; a22 = naqq; a02 = 0.0; a01 = nrp; a12 = nrq; }
+            else { a11 = napp; a22 = naqq; a12 = 0.0; a01 = nrp; a02 = nrq; }
+        }
+        if (!rotated) break;
+    }
+    evals[0] = a00; evals[1] = a11; evals[2] = a22;
+#pragma unroll
+    for (int i = 0; i < 9; i++) V[i] = v[i];
+}
+
 // wave64 all-reduce (sum) of a double via xor shuffles; every lane gets the total.  Fixed butterfly order => deterministic.
 IMD double wave_sum(double x) {
 #pragma unroll

@@ -42,8 +42,7 @@ struct RegState {
 };
 // argument block of one residual pass (kernel arguments are limited to 4 KB: RegMapDev + this + a dozen pointers stay below)
 #define REG_MODE_HOST 0       /* legacy: parameters by value, the 48 sums + ticket go to pinned host memory, the host runs the EKF step */
-#define REG_MODE_FIRST 1      /* fused, first pass of a scan: parameters, iterate, prior and the gain constants arrive by value */
-#define REG_MODE_NEXT 2       /* fused, later pass: parameters from RegState; mat = the prior covariance (needed when the loop stops) */
+#define REG_MODE_FUSED 1      /* residual_persistent_kernel: every pass of the scan + the 18-state update in one launch; mat = the prior covariance */
 #define REG_MODE_SUMS 3       /* parameters from RegState (it > 0) or by value (it == 0); the 48 sums go to device memory for an in-stream all-reduce, ekf_step_kernel follows */
 struct RegIterArgs {
     int mode, it, max_iter, pad;
@@ -55,6 +54,9 @@ struct RegIterArgs {
 
 void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
                      double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+// all passes of a scan + the in-kernel 18-state update as one resident grid; a.mat = the prior covariance, sync = {arrive counter, epoch word}
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* sync,
+                                unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`
@@ -62,7 +64,7 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next, const float* raw_xyzi = nullptr, float* world_xyzi = nullptr, int n_raw = 0);
 // (raw_xyzi != nullptr: the same launch also transforms the full xyzI scan into the world frame for the mesher)
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, void* refit_list, unsigned long long* dbg = nullptr);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg = nullptr);
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);
 void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
                    const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats);

@@ -112,6 +112,9 @@ IMD double rl_d(double x, int k) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), k), hi = __builtin_amdgcn_readlane(__double2hiint(x), k);
     return __hiloint2double(hi, lo);
 }
+// write-through store / coherent load of a double other wavefronts of the same launch read (the L2 of another XCD may hold a stale line)
+IMD void dev_publish(double* p, const double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+IMD double dev_observe(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 IMD void dev_so3_exp(double v1, double v2, double v3, double* R) {  // include/so3_math.h:71-89
     const double norm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
 #pragma unroll
@@ -236,7 +239,7 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
         double v = 0;
 #pragma unroll
         for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
-        rs->st[lane] = v;
+        dev_publish(&rs->st[lane], v);
     }
     {
         double RextR[9];
@@ -251,7 +254,11 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
             rs->sp.t[lane] = v; }
     }
     const double passes = C[158] + 1.0;
-    if (lane == 0) { rs->rematch = rematch; rs->done = stop ? 1 : 0; rs->tot[0] = C[156]; rs->tot[1] = C[157]; rs->tot[2] = passes; rs->tot[3] = C[159]; }
+    if (lane == 0) {
+        dev_publish(&rs->tot[0], C[156]); dev_publish(&rs->tot[1], C[157]); dev_publish(&rs->tot[2], passes); dev_publish(&rs->tot[3], C[159]);
+        __hip_atomic_store(&rs->rematch, rematch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&rs->done, stop ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (stop) {
         // cov = (I - G) * cov ; G is zero outside its first 6 columns:  cov[r][c] - sum_{k<6} G[r][k] cov[k][c]
         for (int e = lane; e < 324; e += 64) {
@@ -288,31 +295,12 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
 #define RES_NR 32   // reduced per block: 21 (upper triangle of HTH) + 6 HTz + 4 counters + 1 spare
 
 
-// One wavefront per block (n/64 blocks: a down-sampled scan is only ~8k points, so small blocks are what spreads it over the CUs).
-// Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
-// finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
-__global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
-                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
-                                                       double* __restrict__ reg_out, double ticket,
-                                                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
-                                                       float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
-    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
-    const bool from_dev = a.mode == REG_MODE_NEXT || (a.mode == REG_MODE_SUMS && a.it > 0);
-    if (from_dev && rs->done) return;   // the iterated update stopped with an earlier pass (the passes of a scan are enqueued up front)
-    ScanParams sp = a.sp;               // constants always by value; the iterate-dependent part from the device when this is a later pass
-    if (from_dev) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) { sp.R[k] = rs->sp.R[k]; sp.RextR[k] = rs->sp.RextR[k]; sp.rot_var[k] = rs->sp.rot_var[k]; sp.t_var[k] = rs->sp.t_var[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) sp.t[k] = rs->sp.t[k];
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+// One point of one residual pass: transformLidar + covariance propagation (lio_state_estimation :1302-1359), BuildResidualListOMP with the
+// near-voxel retry (:171-222), residual (:1372-1392), H / R^-1 (:1493-1575); adds the point's terms of H^T R^-1 H / H^T R^-1 z and the counters
+// to acc[RES_NR] and writes the per-point match outputs.  Shared by the single-pass kernel and the persistent one.
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
-    double acc[RES_NR];
-#pragma unroll
-    for (int k = 0; k < RES_NR; k++) acc[k] = 0;
-    if (i < n) {
+IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, double* acc, unsigned long long& tprev,
+                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
         const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
         // --- per-scan part of lio_state_estimation (:1302-1316): body covariance + cross matrix of the IMU-frame point
         double pz[3] = {p[0], p[1], p[2]};
@@ -376,7 +364,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
             }
         }
         RDBG(2);
-        acc[29] = (double)n_tests; acc[30] = (double)n_extra;
+        acc[29] += (double)n_tests; acc[30] += (double)n_extra;
         // is_success with prob still 0 (sigma_l = inf / NaN after a diverged covariance): the reference pushes an uninitialised ptpl there;
         // here it is no match instead of a read of nodes[-1]
         const bool matched = best.ok && best.node >= 0;
@@ -417,13 +405,39 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
             for (int r = 0; r < 6; r++) {
                 const double hr = H[r] * ri;
 #pragma unroll
-                for (int c = r; c < 6; c++) acc[k++] = hr * H[c];   // (H^T R^-1) H is symmetric up to rounding of hr*H[c] vs hc*H[r]; see below
-                acc[21 + r] = hr * meas;
+                for (int c = r; c < 6; c++) acc[k++] += hr * H[c];   // (H^T R^-1) H is symmetric up to rounding of hr*H[c] vs hc*H[r]
+                acc[21 + r] += hr * meas;
             }
-            acc[27] = 1.0;
-            acc[28] = fabs((double)dis);
+            acc[27] += 1.0;
+            acc[28] += fabs((double)dis);
         }
+}
+
+// One wavefront per block (n/64 blocks: a down-sampled scan is only ~8k points, so small blocks are what spreads it over the CUs).
+// Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
+// finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
+__global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
+                                                       double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
+                                                       double* __restrict__ reg_out, double ticket,
+                                                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
+                                                       float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
+    const bool from_dev = a.mode == REG_MODE_SUMS && a.it > 0;   // (modes: HOST = one pass, sums to the host; SUMS = sharded map, sums to device memory for the in-stream all-reduce)
+    if (from_dev && rs->done) return;   // the iterated update stopped with an earlier pass (the passes of a scan are enqueued up front)
+    ScanParams sp = a.sp;               // constants always by value; the iterate-dependent part from the device when this is a later pass
+    if (from_dev) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sp.R[k] = rs->sp.R[k]; sp.RextR[k] = rs->sp.RextR[k]; sp.rot_var[k] = rs->sp.rot_var[k]; sp.t_var[k] = rs->sp.t_var[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) sp.t[k] = rs->sp.t[k];
     }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+    if (sp.dbg && threadIdx.x == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
+    double acc[RES_NR];
+#pragma unroll
+    for (int k = 0; k < RES_NR; k++) acc[k] = 0;
+    if (i < n) residual_point(m, sp, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
     RDBG(3);
     __shared__ double red[RES_NR][65];
     __shared__ int s_last;
@@ -444,16 +458,6 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
     __syncthreads();
     RDBG(4);
     if (!s_last) return;
-    if (a.mode == REG_MODE_FIRST || a.mode == REG_MODE_NEXT) {
-        // stage what the 18-state update needs (first pass: from the kernel arguments, later: from RegState) -- issued ahead of the final sum's loads
-        double* Cst = &red[0][0] + 400;
-        for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
-            double v;
-            if (a.mode == REG_MODE_FIRST) v = e < 108 ? a.mat[e] : (e < 132 ? a.st[e - 108] : (e < 156 ? a.prior[e - 132] : 0.0));
-            else v = e < 36 ? rs->p11inv[e] : (e < 108 ? rs->tmat[e - 36] : (e < 132 ? rs->st[e - 108] : (e < 156 ? rs->prior[e - 132] : (e < 160 ? rs->tot[e - 156] : (double)rs->rematch))));
-            Cst[e] = v;
-        }
-    }
     // final sum over blocks: 64 lanes = 32 values x 2 interleaved halves of the block list, 32 independent (L2-served, ~900-cycle) loads in
     // flight per lane; each half is added in ascending block order and the halves are combined last -- a fixed order, so the result is deterministic
     {
@@ -479,31 +483,159 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
     else if (lane < 42) v48 = red[0][21 + (lane - 36)];
     else if (lane < 46) v48 = red[0][27 + (lane - 42)];
     if (lane == 0) *done_counter = 0;
-    if (a.mode == REG_MODE_HOST || a.mode == REG_MODE_SUMS) {
-        // pinned, device-mapped host memory (HOST) / device memory ahead of an in-stream all-reduce (SUMS)
-        if (lane < RES_NV - 1) __hip_atomic_store((unsigned long long*)&out48[lane], (unsigned long long)__double_as_longlong(v48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // slot 47 is the completion ticket the host polls: a release store, issued after the 47 value stores of this (single) wavefront drained
-        RDBG(5);
-        if (lane == 0 && a.mode == REG_MODE_HOST) __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    // ---- fused: the 18-state update runs right here, in the last block of the pass (its inputs were staged in LDS while the partials were summed)
-    double* L = &red[0][0];
-    __syncthreads();
-    if (lane < 46) L[64 + lane] = v48;
-    if (a.mode == REG_MODE_FIRST) {   // the later passes find the scan's constants in RegState (fire-and-forget stores: the next launch is the fence)
-        for (int e = lane; e < 108; e += 64) { if (e < 36) rs->p11inv[e] = a.mat[e]; else rs->tmat[e - 36] = a.mat[e]; }
-        if (lane < 24) rs->prior[lane] = a.prior[lane];
-        const unsigned long long* src = (const unsigned long long*)&a.sp;
-        unsigned long long* dst = (unsigned long long*)&rs->sp;
-        for (int e = lane; e < (int)(sizeof(ScanParams) / 8); e += 64) dst[e] = src[e];
-    }
-    __syncthreads();
-    if (lane == 0) { L[400 + 156] += L[64 + 44]; L[400 + 157] += L[64 + 45]; L[400 + 159] += L[64 + 42]; }
-    __syncthreads();
-    ekf_step_wave(rs, L + 400, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, a.it, a.max_iter, a.sp.extR, reg_out, ticket);
+    // pinned, device-mapped host memory (HOST) / device memory ahead of an in-stream all-reduce (SUMS)
+    if (lane < RES_NV - 1) __hip_atomic_store((unsigned long long*)&out48[lane], (unsigned long long)__double_as_longlong(v48), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // slot 47 is the completion ticket the host polls: a release store, issued after the 47 value stores of this (single) wavefront drained
     RDBG(5);
+    if (lane == 0 && a.mode == REG_MODE_HOST) __hip_atomic_store(&out48[RES_NV - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The whole iterated update of a scan as ONE launch (Voxel_mapping::lio_state_estimation, src/voxel_mapping.cpp:1284-1652).
+// Round 2 enqueued one residual_kernel per EKF iteration: four dispatches in a row, each paying the launch / drain of a kernel boundary
+// (~6-8 us of a ~27 us pass) and re-reading its arguments.  Here the grid stays resident: every wavefront owns the point tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... for all passes; a pass ends in a grid-wide hand-over --
+//   block partials -> write-through stores;  arrive counter (one returning atomic);  the LAST wavefront to arrive adds the partials in block
+//   order, runs the 18-state update (ekf_step_wave) and publishes the new iterate;  epoch word = pass number, the others poll it --
+// and the next pass starts from the published pose.  No deadlock: the grid is capped (launch_residual_persistent) far below what the chip
+// holds resident, and nothing the grid waits for is queued behind it.  Values that cross wavefronts inside the launch (partials, iterate, loop
+// state, epoch) are write-through stores / coherent loads: the eight XCDs do not share an L2.
+// The gain constants P11^-1 and P21 P11^-1 (kernel arguments in round 2: they no longer fit beside the prior covariance) are computed by every
+// wavefront at launch into LDS: a 6x6 Gauss-Jordan in registers, ~1 k cycles off the critical tail.
+// ---------------------------------------------------------------------------------------------------------------------
+#define RP_MAX_BLOCKS 512
+__global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
+                                                                  double* __restrict__ partials, unsigned int* __restrict__ sync, unsigned int epoch_base,
+                                                                  double* __restrict__ reg_out, double ticket,
+                                                                  int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
+                                                                  float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+    __shared__ double red[RES_NR][65];
+    __shared__ double pc[108];       // [0,36) P11^-1, [36,108) P21 P11^-1
+    __shared__ int s_last;
+    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
+    const int lane = threadIdx.x;
+    ScanParams sp = a.sp;
+    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+    // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
+    {
+        double c6[6];
+        const int j = lane < 12 ? lane : 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) c6[r] = j < 6 ? a.mat[r * 18 + j] : ((r == j - 6) ? 1.0 : 0.0);
+#pragma unroll
+        for (int col = 0; col < 6; col++) {
+            const double d = rl_d(c6[col], col);
+            double f[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) f[r] = rl_d(c6[r], col);
+            c6[col] = c6[col] / d;
+#pragma unroll
+            for (int r = 0; r < 6; r++) if (r != col) c6[r] -= f[r] * c6[col];
+        }
+        if (lane >= 6 && lane < 12) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) pc[r * 6 + (lane - 6)] = c6[r];
+        }
+        __syncthreads();
+        for (int e = lane; e < 72; e += 64) {
+            const int i = e / 6, q = e % 6;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) sacc += a.mat[(6 + i) * 18 + k] * pc[k * 6 + q];
+            pc[36 + e] = sacc;
+        }
+        __syncthreads();
+    }
+    const int ntiles = (n + 63) / 64;
+    for (int it = 0; it < a.max_iter; it++) {
+        if (it > 0) {
+            // the update of pass it - 1 has been published when the epoch word says so
+            __builtin_amdgcn_s_setprio(0);
+            while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch_base + (unsigned int)it) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_setprio(3);
+            if (__hip_atomic_load(&rs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // the loop stopped with that pass
+#pragma unroll
+            for (int k = 0; k < 9; k++) sp.R[k] = dev_observe(&rs->st[k]);
+#pragma unroll
+            for (int k = 0; k < 3; k++) sp.t[k] = dev_observe(&rs->st[9 + k]);
+            m3_mul(sp.R, sp.extR, sp.RextR);
+            if (sp.dbg) tprev = __builtin_readcyclecounter();
+        }
+        if (sp.dbg && lane == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
+        double acc[RES_NR];
+#pragma unroll
+        for (int k = 0; k < RES_NR; k++) acc[k] = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int i = tile * 64 + lane;
+            if (i < n) residual_point(m, sp, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+        }
+        RDBG(3);
+        // ---- block sums (LDS transpose: lane k adds column k in lane order -- fixed order) -> write-through partials -> arrive
+        __syncthreads();   // (the previous pass's readers of `red` are done)
+#pragma unroll
+        for (int k = 0; k < RES_NR; k++) red[k][lane] = acc[k];
+        __syncthreads();
+        {
+            const int k = lane & 31, half = lane >> 5;
+            double ssum = 0;
+            for (int j = 0; j < 32; j++) ssum += red[k][half * 32 + j];
+            ssum += __shfl_xor(ssum, 32, 64);
+            if (lane < RES_NR) dev_publish(&partials[(size_t)blockIdx.x * RES_NR + lane], ssum);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) s_last = (atomicAdd(&sync[0], 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        RDBG(4);
+        if (!s_last) continue;
+        // ---- last wavefront of the pass: stage what the 18-state update needs (LDS, beside the running sums), add the partials, update
+        double* L = &red[0][0];
+        double* Cst = L + 400;
+        __syncthreads();
+        for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
+            double v;
+            if (e < 108) v = pc[e];
+            else if (e < 132) v = it == 0 ? a.st[e - 108] : dev_observe(&rs->st[e - 108]);
+            else if (e < 156) v = a.prior[e - 132];
+            else if (e < 160) v = it == 0 ? 0.0 : dev_observe(&rs->tot[e - 156]);
+            else v = it == 0 ? 0.0 : (double)__hip_atomic_load(&rs->rematch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Cst[e] = v;
+        }
+        double tot = 0;
+        {
+            const int k = lane & 31;
+            const unsigned int nb = gridDim.x;
+            for (unsigned int b0 = (unsigned int)(lane >> 5); b0 < nb; b0 += 64) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) {
+                    const unsigned int b = b0 + 2u * u;
+                    v[u] = b < nb ? dev_observe(&partials[(size_t)b * RES_NR + k]) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 32; u++) tot += v[u];
+            }
+            tot += __shfl_xor(tot, 32, 64);
+        }
+        if (lane == 0) __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L[lane] = tot;
+        __syncthreads();
+        double v48 = 0;   // 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
+        if (lane < 36) { const int r = lane / 6, c = lane % 6; v48 = L[r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
+        else if (lane < 42) v48 = L[21 + (lane - 36)];
+        else if (lane < 46) v48 = L[27 + (lane - 42)];
+        __syncthreads();
+        if (lane < 46) L[64 + lane] = v48;
+        __syncthreads();
+        if (lane == 0) { Cst[156] += L[64 + 44]; Cst[157] += L[64 + 45]; Cst[159] += L[64 + 42]; }
+        __syncthreads();
+        const bool stop = ekf_step_wave(rs, Cst, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, it, a.max_iter, a.sp.extR, reg_out, ticket);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(&sync[1], epoch_base + (unsigned int)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        RDBG(5);
+        if (stop) break;
+    }
 }
 
 // the same update as its own launch: sums48 = the (all-reduced) 48 sums of the pass in device memory
@@ -641,99 +773,179 @@ __global__ void segment_heads_kernel(const uint32_t* __restrict__ sorted_slot, i
 // =====================================================================================================================
 struct WaveCtx { int lane; int64_t* stats; int root; };  // stats[0] refits, stats[1] refit points
 
-// OctoTree::init_plane (src/voxel_loc.cpp:47-139) for node `nd` holding `n` points; returns planar?  All lanes get the result.
-__device__ bool wave_init_plane(const RegMapDev& m, int nd, int n, const WaveCtx& w) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+// ---------------------------------------------------------------------------------------------------------------------
+// OctoTree::init_plane (src/voxel_loc.cpp:47-139) on one wavefront.  The fit is the unit of the map update (one fit used to be 44 k cycles =
+// 18 us of a lone wavefront, and the update was three of them in a row), so it is built for latency:
+//   * the points are visited through a functor: register-resident (lane i holds points i and i + 64: the settled-root path and every node
+//     of <= 128 points) or strided from the chunk pool (larger nodes);
+//   * moments -> covariance exactly as the reference (sum / n - c c^T), eigen-decomposition by the checker's own cyclic Jacobi with cheap
+//     reciprocals (sym3_eigen_jacobi_fast: same rotations, same eigenvalue positions and eigenvector signs, ~1/4 of the cycles);
+//   * the plane covariance sum_i J_i V_i J_i^T (voxel_loc.cpp:80-105) in closed form.  With U = [u_0 u_1 u_2], m1, m2 the two indices other
+//     than imin, alpha_k = 1 / (n (ev_min - ev_mk)), dp = p_i - c:  J_i = [A_i; I/n],  A_i = sum_k alpha_k u_mk g_k^T,
+//     g_k = (dp . u_min) u_mk + (dp . u_mk) u_min   (this is evecs * F of the reference, F row m = dp^T (u_m u_min^T + u_min u_m^T) / denom_m).
+//     Hence with h_k = V_i g_k:   top-left  = sum_kl alpha_k alpha_l (sum_i g_k . h_l) u_mk u_ml^T,
+//                                 top-right = (1/n) sum_k alpha_k u_mk (sum_i h_k)^T,      bottom-right = (sum_i V_i) / n^2
+//     -- 15 wave sums instead of 21, ~90 flops per point instead of ~350 and no divide inside the loop.  Same value up to rounding.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlaneFit { double c[3], ev[3], U[9]; int imin, imax; bool planar; };
+// by-value select (a conditional expression on lvalues is a select of ADDRESSES: it would pin the struct to scratch memory)
+IMD double sel3(const int i, const double a, const double b, const double c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+template <class FE>
+IMD void fit_eigen(FE&& for_each_point, const int n, const float planer_threshold, PlaneFit& f) {
     double s[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) s[k] = 0;
-    for (int i = w.lane; i < n; i += 64) {
-        const double* q = node_point_ptr(m, nd, i);
+    for_each_point([&](const double* q) __attribute__((always_inline)) {
         const double x = q[0], y = q[1], z = q[2];
         s[0] += x; s[1] += y; s[2] += z;
         s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
-    }
+    });
 #pragma unroll
     for (int k = 0; k < 9; k++) s[k] = wave_sum(s[k]);
     const double dn = (double)n;
-    const double c[3] = {s[0] / dn, s[1] / dn, s[2] / dn};
+    f.c[0] = s[0] / dn; f.c[1] = s[1] / dn; f.c[2] = s[2] / dn;
     double cov[9];
-    cov[0] = s[3] / dn - c[0] * c[0]; cov[1] = s[4] / dn - c[0] * c[1]; cov[2] = s[5] / dn - c[0] * c[2];
-    cov[3] = cov[1];                  cov[4] = s[6] / dn - c[1] * c[1]; cov[5] = s[7] / dn - c[1] * c[2];
-    cov[6] = cov[2];                  cov[7] = cov[5];                  cov[8] = s[8] / dn - c[2] * c[2];
-    double ev[3], U[9];
-    sym3_eigen_jacobi(cov, ev, U);
+    cov[0] = s[3] / dn - f.c[0] * f.c[0]; cov[1] = s[4] / dn - f.c[0] * f.c[1]; cov[2] = s[5] / dn - f.c[0] * f.c[2];
+    cov[3] = cov[1];                      cov[4] = s[6] / dn - f.c[1] * f.c[1]; cov[5] = s[7] / dn - f.c[1] * f.c[2];
+    cov[6] = cov[2];                      cov[7] = cov[5];                      cov[8] = s[8] / dn - f.c[2] * f.c[2];
+    sym3_eigen_jacobi_fast(cov, f.ev, f.U);
+    // minCoeff / maxCoeff: the first extremal index (voxel_loc.cpp:68-69); selects, not indexed reads -- the struct has to stay in registers
+    const double e0 = f.ev[0], e1 = f.ev[1], e2 = f.ev[2];
     int imin = 0, imax = 0;
-    if (ev[1] < ev[imin]) imin = 1;
-    if (ev[2] < ev[imin]) imin = 2;
-    if (ev[1] > ev[imax]) imax = 1;
-    if (ev[2] > ev[imax]) imax = 2;
-    const bool planar = ev[imin] < (double)m.planer_threshold;
-    if (w.lane == 0 && w.stats) { atomicAdd((unsigned long long*)&w.stats[0], 1ull); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n); }
-    if (planar) {
-        const double Umin[3] = {U[0 * 3 + imin], U[1 * 3 + imin], U[2 * 3 + imin]};
-        double pv[21];
+    double emin = e0, emax = e0;
+    if (e1 < emin) { imin = 1; emin = e1; }
+    if (e2 < emin) { imin = 2; emin = e2; }
+    if (e1 > emax) { imax = 1; emax = e1; }
+    if (e2 > emax) { imax = 2; emax = e2; }
+    f.imin = imin; f.imax = imax;
+    f.planar = emin < (double)planer_threshold;
+}
+
+template <class FE>
+IMD void fit_plane_var(FE&& for_each_point, const int n, const PlaneFit& f, double* pv) {
+#pragma clang fp contract(fast)
+    const int imin = f.imin, m1 = imin == 0 ? 1 : 0, m2 = imin == 2 ? 1 : 2;
+    double um1[3], um2[3], umin[3];
 #pragma unroll
-        for (int k = 0; k < 21; k++) pv[k] = 0;
-        for (int i = w.lane; i < n; i += 64) {
-            const double* q = node_point_ptr(m, nd, i);
-            const double dp[3] = {q[0] - c[0], q[1] - c[1], q[2] - c[2]};
-            const double V[9] = {q[3], q[4], q[5], q[4], q[6], q[7], q[5], q[7], q[8]};
-            double F[9];
+    for (int r = 0; r < 3; r++) {
+        const double u0 = f.U[r * 3 + 0], u1 = f.U[r * 3 + 1], u2 = f.U[r * 3 + 2];
+        um1[r] = sel3(m1, u0, u1, u2);
+        um2[r] = sel3(m2, u0, u1, u2);
+        umin[r] = sel3(imin, u0, u1, u2);
+    }
+    double acc[15];
 #pragma unroll
-            for (int mm = 0; mm < 3; mm++) {
-                if (mm != imin) {
-                    const double denom = dn * (ev[imin] - ev[mm]);
-                    const double row[3] = {dp[0] / denom, dp[1] / denom, dp[2] / denom};
-                    const double Um[3] = {U[0 * 3 + mm], U[1 * 3 + mm], U[2 * 3 + mm]};
+    for (int k = 0; k < 15; k++) acc[k] = 0;
+    for_each_point([&](const double* q) __attribute__((always_inline)) {
+#pragma clang fp contract(fast)
+        const double dp[3] = {q[0] - f.c[0], q[1] - f.c[1], q[2] - f.c[2]};
+        const double a1 = dp[0] * um1[0] + dp[1] * um1[1] + dp[2] * um1[2];
+        const double a2 = dp[0] * um2[0] + dp[1] * um2[1] + dp[2] * um2[2];
+        const double b = dp[0] * umin[0] + dp[1] * umin[1] + dp[2] * umin[2];
+        double g1[3], g2[3], h1[3], h2[3];
 #pragma unroll
-                    for (int cc = 0; cc < 3; cc++) {
-                        const double S0 = Um[0] * Umin[cc] + Umin[0] * Um[cc];
-                        const double S1 = Um[1] * Umin[cc] + Umin[1] * Um[cc];
-                        const double S2 = Um[2] * Umin[cc] + Umin[2] * Um[cc];
-                        F[mm * 3 + cc] = row[0] * S0 + row[1] * S1 + row[2] * S2;
-                    }
-                } else { F[mm * 3 + 0] = 0; F[mm * 3 + 1] = 0; F[mm * 3 + 2] = 0; }
-            }
-            double J[18];
-            m3_mul(U, F, J);
+        for (int r = 0; r < 3; r++) { g1[r] = b * um1[r] + a1 * umin[r]; g2[r] = b * um2[r] + a2 * umin[r]; }
+        const double V[9] = {q[3], q[4], q[5], q[4], q[6], q[7], q[5], q[7], q[8]};
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int cc = 0; cc < 3; cc++) J[(3 + r) * 3 + cc] = (r == cc) ? 1.0 / dn : 0.0;
-            double JV[18];
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int cc = 0; cc < 3; cc++) JV[r * 3 + cc] = J[r * 3 + 0] * V[0 * 3 + cc] + J[r * 3 + 1] * V[1 * 3 + cc] + J[r * 3 + 2] * V[2 * 3 + cc];
-            int k = 0;
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int cc = r; cc < 6; cc++) { pv[k] += JV[r * 3 + 0] * J[cc * 3 + 0] + JV[r * 3 + 1] * J[cc * 3 + 1] + JV[r * 3 + 2] * J[cc * 3 + 2]; k++; }
+        for (int r = 0; r < 3; r++) {
+            h1[r] = V[r * 3 + 0] * g1[0] + V[r * 3 + 1] * g1[1] + V[r * 3 + 2] * g1[2];
+            h2[r] = V[r * 3 + 0] * g2[0] + V[r * 3 + 1] * g2[1] + V[r * 3 + 2] * g2[2];
         }
+        acc[0] += g1[0] * h1[0] + g1[1] * h1[1] + g1[2] * h1[2];
+        acc[1] += g1[0] * h2[0] + g1[1] * h2[1] + g1[2] * h2[2];
+        acc[2] += g2[0] * h2[0] + g2[1] * h2[1] + g2[2] * h2[2];
 #pragma unroll
-        for (int k = 0; k < 21; k++) pv[k] = wave_sum(pv[k]);
-        if (w.lane < 21) {
+        for (int r = 0; r < 3; r++) { acc[3 + r] += h1[r]; acc[6 + r] += h2[r]; }
+#pragma unroll
+        for (int r = 0; r < 6; r++) acc[9 + r] += q[3 + r];
+    });
+#pragma unroll
+    for (int k = 0; k < 15; k++) acc[k] = wave_sum(acc[k]);
+    const double dn = (double)n;
+    const double e0 = f.ev[0], e1 = f.ev[1], e2 = f.ev[2];
+    const double evmin = sel3(imin, e0, e1, e2);
+    const double al1 = 1.0 / (dn * (evmin - sel3(m1, e0, e1, e2)));
+    const double al2 = 1.0 / (dn * (evmin - sel3(m2, e0, e1, e2)));
+    const double w11 = al1 * al1 * acc[0], w12 = al1 * al2 * acc[1], w22 = al2 * al2 * acc[2];
+    const double inv_n = 1.0 / dn, inv_n2 = inv_n * inv_n;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = r; c < 6; c++) {
+            double v;
+            if (c < 3) v = w11 * um1[r] * um1[c] + w12 * (um1[r] * um2[c] + um2[r] * um1[c]) + w22 * um2[r] * um2[c];
+            else if (r < 3) v = inv_n * (al1 * um1[r] * acc[3 + (c - 3)] + al2 * um2[r] * acc[6 + (c - 3)]);
+            else { const int a = r - 3, b2 = c - 3; v = inv_n2 * acc[9 + (a == 0 ? b2 : (a == 1 ? 2 + b2 : 5))]; }   // V upper triangle: 00 01 02 11 12 22
+            pv[k++] = v;
+        }
+}
+
+// write the fitted plane (or, for a non-planar node, what the reference leaves behind) into the node record; every lane holds the same values
+IMD void fit_store(NodeRec& nr, const PlaneFit& f, const double* pv, const int lane) {
+    if (f.planar) {
+        const int imin = f.imin;
+        const double Umin[3] = {sel3(imin, f.U[0], f.U[1], f.U[2]), sel3(imin, f.U[3], f.U[4], f.U[5]), sel3(imin, f.U[6], f.U[7], f.U[8])};
+        if (lane < 21) {
             double v = 0;
 #pragma unroll
-            for (int k = 0; k < 21; k++) if (w.lane == k) v = pv[k];
-            m.nodes[nd].p_var[w.lane] = v;
+            for (int k = 0; k < 21; k++) if (lane == k) v = pv[k];
+            nr.p_var[lane] = v;
         }
-        if (w.lane == 0) {
+        if (lane == 0) {
+            const double evmin = sel3(imin, f.ev[0], f.ev[1], f.ev[2]);
+            const double evmax = sel3(f.imax, f.ev[0], f.ev[1], f.ev[2]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) { m.nodes[nd].p_center[k] = c[k]; m.nodes[nd].p_normal[k] = Umin[k]; }
-            m.nodes[nd].min_eig = (float)ev[imin];
-            m.nodes[nd].radius = (float)sqrt(ev[imax]);
-            m.nodes[nd].d = (float)(-(Umin[0] * c[0] + Umin[1] * c[1] + Umin[2] * c[2]));
+            for (int k = 0; k < 3; k++) { nr.p_center[k] = f.c[k]; nr.p_normal[k] = Umin[k]; }
+            nr.min_eig = (float)evmin;
+            nr.radius = (float)sqrt(evmax);
+            nr.d = (float)(-(Umin[0] * f.c[0] + Umin[1] * f.c[1] + Umin[2] * f.c[2]));
         }
-    } else if (w.lane == 0) {
+    } else if (lane == 0) {
         // reference zeroes centre/normal/plane_var before the test and leaves them zero when not planar; only the centre is observable (dump)
 #pragma unroll
-        for (int k = 0; k < 3; k++) { m.nodes[nd].p_center[k] = c[k]; m.nodes[nd].p_normal[k] = 0.0; }
-        m.nodes[nd].radius = 0.f;
+        for (int k = 0; k < 3; k++) { nr.p_center[k] = f.c[k]; nr.p_normal[k] = 0.0; }
+        nr.radius = 0.f;
     }
-    return planar;
+}
+
+// OctoTree::init_plane for node `nd` holding `n` points in the chunk pool; returns planar?  All lanes get the result.
+__device__ __noinline__ bool wave_init_plane(const RegMapDev& m, int nd, int n, const WaveCtx& w) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (w.lane == 0 && w.stats) { atomicAdd((unsigned long long*)&w.stats[0], 1ull); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n); }
+    PlaneFit f;
+    double pv[21];
+    const int lane = w.lane;
+    if (n <= 128) {
+        // one gather: every lane pulls its (up to) two points into registers; both passes of the fit run from there
+        double P0[9], P1[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { P0[k] = 0; P1[k] = 0; }
+        if (lane < n) { const double* q = node_point_ptr(m, nd, lane);
+#pragma unroll
+            for (int k = 0; k < 9; k++) P0[k] = q[k]; }
+        if (lane + 64 < n) { const double* q = node_point_ptr(m, nd, lane + 64);
+#pragma unroll
+            for (int k = 0; k < 9; k++) P1[k] = q[k]; }
+        auto fe = [&](auto&& fn) __attribute__((always_inline)) { if (lane < n) fn(P0); if (lane + 64 < n) fn(P1); };
+        fit_eigen(fe, n, m.planer_threshold, f);
+        if (f.planar) fit_plane_var(fe, n, f, pv);
+    } else {
+        auto fe = [&](auto&& fn) __attribute__((always_inline)) {
+            for (int i = lane; i < n; i += 64) {
+                const double* q = node_point_ptr(m, nd, i);
+                double P[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) P[k] = q[k];
+                fn(P);
+            }
+        };
+        fit_eigen(fe, n, m.planer_threshold, f);
+        if (f.planar) fit_plane_var(fe, n, f, pv);
+    }
+    fit_store(m.nodes[nd], f, pv, lane);
+    return f.planar;
 }
 
 // append one point (9 doubles at src) to node `nd` currently holding `n` points; lanes 0..8 copy.  Returns false on pool exhaustion.
@@ -1054,15 +1266,20 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
 
 #define RL_CAP 64    /* points of one scan falling into one root voxel that are ordered in LDS (a down-sampled scan puts <= ~8 into a voxel); longer lists take the
                         global-scratch path.  Kept small on purpose: LDS is what limits how many workgroups of the three concurrent chains fit a CU */
-// ---- the map update in three launches (LDS / register footprints decide how much of it runs beside the mesher's kernels) ---------------
-//   replay_light_kernel   one wavefront per touched root voxel, ~64 registers: list gather + ordering + the settled-planar-root state machine
-//                         with every refit DEFERRED (see wave_replay_planar_root).  Whatever it cannot finish without an eigen-decomposition in
-//                         the middle of the batch -- or any other node state -- is handed over untouched;
-//   replay_list_kernel    (work list = the handed-over voxels, a few dozen per scan) the general state machine, fits inline;
-//   replay_refit_kernel   one wavefront per deferred refit: OctoTree::init_plane over the first n retained points.
-// The fit's ~300 registers per lane (one wavefront per SIMD) are thereby spent on ~1.3 k wavefronts per scan instead of on every touched voxel.
-__global__ __launch_bounds__(256) void replay_light_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
-                                                            const double* __restrict__ pt_data, int64_t* stats, uint32_t* __restrict__ general_list, int2* __restrict__ refit_list) {
+#define RF_PTS 128   /* a settled root's retained points + this scan's points live in registers (two per lane) */
+// ---- the map update in two launches ---------------------------------------------------------------------------------------------------------
+//   replay_fused_kernel   one wavefront per touched root voxel.  The common state of a settled map -- an initialised, planar, update-enabled root
+//                         whose points fit two per lane -- is handled completely: list gather + ordering, the OctoTree::UpdateOctoTree state
+//                         machine of the batch (voxel_loc.cpp:240-262) evaluated in registers, the append, and the ONE observable plane fit
+//                         (only the last refit of a batch survives: the matcher reads the map between scans) with the points still in registers.
+//                         Refits that fall due earlier in the batch only decide "still planar?" -- by the diagonal bound (lambda_min <= smallest
+//                         diagonal entry of the covariance) or, when that does not decide, by the exact eigenvalues.  Nothing is written before
+//                         every decision of the batch is known, so whatever this path cannot finish is handed over untouched;
+//   replay_list_kernel    the work list of handed-over voxels (new / subdivided / filling-up roots, a few dozen per scan): the general state machine.
+// Round 2 ran this as three launches (light -> list -> refit: three plane-fit latencies in a row, 40 + 57 + 18 us).
+__global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
+                                                            const double* __restrict__ pt_data, int64_t* stats, uint32_t* __restrict__ general_list,
+                                                            unsigned long long* __restrict__ dbg) {
     __shared__ unsigned long long skey[4][RL_CAP];
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
@@ -1070,13 +1287,16 @@ __global__ __launch_bounds__(256) void replay_light_kernel(RegMapDev m, const in
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wv;
     if (t >= m.counters[7]) return;
+    unsigned long long tprev = dbg ? __builtin_readcyclecounter() : 0;
+    const unsigned long long tstart = tprev;
+#define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&dbg[16 + (k)], _t - tprev); tprev = _t; } } while (0)
     const uint32_t slot = m.touched[t];
     const int root = m.htab[slot].root;
     if (root < 0) return;
     NodeRec& nd = m.nodes[root];
     // node header and the head of the point list: independent loads, one latency
     const int flags = nd.flags, layer = nd.layer;
-    int npts = nd.npts, newp = nd.newpts;
+    const int npts = nd.npts, newp = nd.newpts;
     int chunks[IM_INLINE_CHUNKS];
 #pragma unroll
     for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
@@ -1085,14 +1305,16 @@ __global__ __launch_bounds__(256) void replay_light_kernel(RegMapDev m, const in
         if (cnt < RL_CAP && lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
         cnt++;
     }
+    FDBG(0);
     const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
     if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) return;   // a full planar root (m_update_enable_ == false) drops every point
-    bool hand_over = cnt > RL_CAP || (flags & want) != want || layer != 0 || npts + cnt > IM_INLINE_CHUNKS * IM_CHUNK_PTS || npts + cnt >= m.max_points_size;
+    const int ntot = npts + cnt;
+    bool hand_over = cnt > RL_CAP || (flags & want) != want || layer != 0 || newp > 5 || ntot > RF_PTS || ntot >= m.max_points_size;
     if (!hand_over) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int e = lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique
+        for (int e = lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique -- std::sort(pv_list, var_contrast) restricted to this voxel, ties by scan index
             const unsigned long long k = skey[wv][e];
             const int id = sidx[wv][e];
             int rank = 0;
@@ -1102,80 +1324,104 @@ __global__ __launch_bounds__(256) void replay_light_kernel(RegMapDev m, const in
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        FDBG(1);
         auto chunk_of = [&](int ci) { int c = chunks[0];
 #pragma unroll
             for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
             return c; };
-        // ---- pass 1 (nothing is written): would every refit of this batch be decided by the diagonal bound ?
-        int last_refit_n = 0, n_ref = 0;
-        long long n_ref_pts = 0;
-        if (newp + cnt > 5) {
-            double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-            for (int i = lane; i < npts; i += 64) {
-                const double* q = m.chunk_data + ((size_t)chunk_of(i / IM_CHUNK_PTS) * IM_CHUNK_PTS + (i % IM_CHUNK_PTS)) * IM_PT_DOUBLES;
+        // point q of the voxel AFTER the append: q < npts retained, else this scan's point order[q - npts].  Lane i holds q = i and q = i + 64.
+        const int n_ref = (newp + cnt) / 6;   // refits falling due inside the batch: new_points counts 0..5 between refits (m_update_size_threshold_ = 5)
+        double P0[9], P1[9];
 #pragma unroll
-                for (int a = 0; a < 3; a++) { const double v = q[a]; s1[a] += v; s2[a] += v * v; }
-            }
+        for (int k = 0; k < 9; k++) { P0[k] = 0; P1[k] = 0; }
+        {
+            const int q0 = lane, q1 = lane + 64;
+            const double* s0 = nullptr; const double* s1 = nullptr;
+            if (q0 < ntot && (q0 >= npts || n_ref > 0))
+                s0 = q0 < npts ? m.chunk_data + ((size_t)chunk_of(q0 >> 4) * IM_CHUNK_PTS + (q0 & 15)) * IM_PT_DOUBLES : pt_data + (size_t)order[wv][q0 - npts] * IM_PT_DOUBLES;
+            if (q1 < ntot && (q1 >= npts || n_ref > 0))
+                s1 = q1 < npts ? m.chunk_data + ((size_t)chunk_of(q1 >> 4) * IM_CHUNK_PTS + (q1 & 15)) * IM_PT_DOUBLES : pt_data + (size_t)order[wv][q1 - npts] * IM_PT_DOUBLES;
+            if (s0) {
 #pragma unroll
-            for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
-            int np = npts, nw = newp;
-            for (int j = 0; j < cnt && !hand_over; j++) {
-                const double* src = pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES;
+                for (int k = 0; k < 9; k++) P0[k] = s0[k]; }
+            if (s1) {
 #pragma unroll
-                for (int a = 0; a < 3; a++) { const double v = src[a]; s1[a] += v; s2[a] += v * v; }
-                np++; nw++;
-                if (nw > 5) {
-                    const double dn = (double)np;
-                    double vmin = 1e300, mag = 0;
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { const double mu = s1[a] / dn; const double v = s2[a] / dn - mu * mu; vmin = fmin(vmin, v); mag += s2[a] / dn; }
-                    if (vmin + (1e-7 + 1e-12 * mag) < (double)m.planer_threshold) { last_refit_n = np; n_ref++; n_ref_pts += np; nw = 0; }
-                    else hand_over = true;   // the exact fit must run in the middle of the batch: the general kernel's job
-                }
-            }
+                for (int k = 0; k < 9; k++) P1[k] = s1[k]; }
         }
-        if (!hand_over) {
-            // ---- pass 2: append the points, write the header back, queue the (single) fit
-            for (int j = 0; j < cnt; j++) {
-                const double* src = pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES;
-                const int ci = npts / IM_CHUNK_PTS;
-                if ((npts % IM_CHUNK_PTS) == 0 && chunk_of(ci) < 0) {
-                    int c = -1;
-                    if (lane == 0) c = alloc_chunk(m);
-                    c = __shfl(c, 0, 64);
-                    if (c < 0) return;   // pool exhausted: alloc_chunk has raised the capacity flag, the update fails as a whole
+        FDBG(2);
+        // ---- decisions (nothing is written yet)
+        PlaneFit fit;
+        long long n_ref_pts = 0;
+        int n_last = 0;
+        for (int r = 0; r < n_ref && !hand_over; r++) {
+            const int nr = npts + 6 * (r + 1) - newp;      // points the node holds when the r-th refit of the batch runs
+            n_ref_pts += nr;
+            auto fe = [&](auto&& fn) __attribute__((always_inline)) { if (lane < nr) fn(P0); if (lane + 64 < nr) fn(P1); };
+            if (r + 1 < n_ref) {
+                // an intermediate refit: only its verdict matters.  lambda_min <= smallest diagonal entry of the covariance decides most of them
+                double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+                fe([&](const double* q) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int k = 0; k < IM_INLINE_CHUNKS; k++) if (ci == k) chunks[k] = c;
-                }
-                if (lane < IM_PT_DOUBLES) m.chunk_data[((size_t)chunk_of(ci) * IM_CHUNK_PTS + (npts % IM_CHUNK_PTS)) * IM_PT_DOUBLES + lane] = src[lane];
-                npts++; newp++;
-                if (newp > 5) newp = 0;
+                    for (int a = 0; a < 3; a++) { s1[a] += q[a]; s2[a] += q[a] * q[a]; } });
+#pragma unroll
+                for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
+                const double dn = (double)nr;
+                double vmin = 1e300, mag = 0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const double mu = s1[a] / dn; const double v = s2[a] / dn - mu * mu; vmin = fmin(vmin, v); mag += s2[a] / dn; }
+                if (vmin + (1e-7 + 1e-12 * mag) < (double)m.planer_threshold) continue;   // certainly still planar
+            }
+            fit_eigen(fe, nr, m.planer_threshold, fit);
+            if (!fit.planar) hand_over = true;   // the root turns non-planar in the middle of the batch: the general kernel's job (children)
+            n_last = nr;
+        }
+        FDBG(3);
+        if (!hand_over) {
+            // ---- commit: chunks for the new points, the points, the header, the plane
+            const int c_first = (npts + IM_CHUNK_PTS - 1) >> 4, c_last = (ntot - 1) >> 4;   // chunk slots first touched by this batch
+            if (cnt > 0 && c_first <= c_last) {
+                int c = 0;
+                const bool need = lane >= c_first && lane <= c_last && lane < IM_INLINE_CHUNKS && chunk_of(lane) < 0;
+                if (need) c = alloc_chunk(m);
+                if (__ballot(need && c < 0)) return;   // pool exhausted: alloc_chunk has raised the capacity flag, the update fails as a whole
+#pragma unroll
+                for (int k = 0; k < IM_INLINE_CHUNKS; k++) { const int ck = __shfl(c, k, 64); const int nk = __shfl(need ? 1 : 0, k, 64); if (nk) chunks[k] = ck; }
+            }
+            {
+                const int q0 = lane, q1 = lane + 64;
+                if (q0 >= npts && q0 < ntot) { double* d = m.chunk_data + ((size_t)chunk_of(q0 >> 4) * IM_CHUNK_PTS + (q0 & 15)) * IM_PT_DOUBLES;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) d[k] = P0[k]; }
+                if (q1 >= npts && q1 < ntot) { double* d = m.chunk_data + ((size_t)chunk_of(q1 >> 4) * IM_CHUNK_PTS + (q1 & 15)) * IM_PT_DOUBLES;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) d[k] = P1[k]; }
             }
             if (lane == 0) {
-                nd.npts = npts; nd.newpts = newp;
+                nd.npts = ntot; nd.newpts = (newp + cnt) % 6;
 #pragma unroll
                 for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
-                if (last_refit_n) refit_list[atomicAdd(&m.counters[11], 1)] = make_int2(root, last_refit_n);
                 if (n_ref) { atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_ref_pts); }
             }
+            FDBG(4);
+            if (n_ref > 0) {   // (n_last is the last refit's point count: fit holds its eigen-decomposition)
+                double pv[21];
+                auto fe = [&](auto&& fn) __attribute__((always_inline)) { if (lane < n_last) fn(P0); if (lane + 64 < n_last) fn(P1); };
+                fit_plane_var(fe, n_last, fit, pv);
+                fit_store(nd, fit, pv, lane);
+            }
+            FDBG(5);
+            if (dbg && lane == 0) { atomicMax(&dbg[24], ((__builtin_readcyclecounter() - tstart) << 16) | (unsigned long long)cnt); atomicAdd(&dbg[25], 1ull); if (n_ref) atomicAdd(&dbg[26], 1ull); }
             return;
         }
     }
     if (lane == 0) general_list[atomicAdd(&m.counters[10], 1)] = slot;
-}
-__global__ __launch_bounds__(64) void replay_refit_kernel(RegMapDev m, const int2* __restrict__ refit_list) {
-    __builtin_amdgcn_s_setprio(3);
-    const int n = m.counters[11];
-    WaveCtx w; w.lane = threadIdx.x; w.stats = nullptr; w.root = -1;
-    for (int t = blockIdx.x; t < n; t += gridDim.x) {
-        const int2 rq = refit_list[t];
-        w.root = rq.x;
-        (void)wave_init_plane(m, rq.x, rq.y, w);   // certainly planar (the light kernel's bound): flags stay as they are
-    }
+#undef FDBG
 }
 
-// updateVoxelMap without any global sort: one wavefront per touched root voxel gathers that voxel's points of this scan from its
-// list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them.
+// updateVoxelMap without any global sort: one wavefront per root voxel of the work list gathers that voxel's points of this scan from its
+// list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them through the
+// general state machine.  The grid is FIXED and strides over the list (a few dozen voxels per scan on a settled map, every touched voxel while
+// a map is being surveyed): round 2 launched one wavefront per down-sampled point to find ~80 work items.
 __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
                                                            const double* __restrict__ pt_data, int64_t* stats, int32_t* __restrict__ big_idx, int32_t* __restrict__ big_order,
                                                            unsigned long long* __restrict__ dbg, const uint32_t* __restrict__ work, const int32_t* __restrict__ n_work) {
@@ -1185,65 +1431,67 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __shared__ int stacks[4][48];
     __builtin_amdgcn_s_setprio(3);   // map growth is on the pose chain too (the next scan's registration waits for it)
     const int wv = threadIdx.x >> 6;
-    const int t = blockIdx.x * 4 + wv;
-    if (t >= (n_work ? *n_work : m.counters[7])) return;
+    const int nw = *n_work;
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
-    const uint32_t slot = work ? work[t] : m.touched[t];   // work: the voxels the light kernel handed over (replay_light_kernel)
-    const int root = m.htab[slot].root;
-    if (root < 0) return;
-    w.root = root;
-    const unsigned long long tdbg0 = dbg ? __builtin_readcyclecounter() : 0;
-    int cnt = 0;
-    for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
-        if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
-        cnt++;
-    }
-    if (cnt > RL_CAP) {
-        // dense or un-down-sampled scans (the reference's updateVoxelMap takes any count): the list is ordered in global scratch instead of
-        // LDS -- a segment of big_idx / big_order (n entries each; the lists of a scan partition its points) claimed with one atomic
-        int base = 0;
-        if (w.lane == 0) base = atomicAdd(&m.counters[9], cnt);
-        base = __shfl(base, 0, 64);
-        if (w.lane == 0) { int k = 0; for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) big_idx[base + k++] = i; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (int e = w.lane; e < cnt; e += 64) {
-            const int id = big_idx[base + e];
-            const unsigned long long k = sort_key[id];
-            int rank = 0;
-            for (int f = 0; f < cnt; f++) { const int idf = big_idx[base + f]; const unsigned long long kf = sort_key[idf]; rank += (kf < k || (kf == k && idf < id)) ? 1 : 0; }
-            big_order[base + rank] = id;
+    for (int t = blockIdx.x * 4 + wv; t < nw; t += gridDim.x * 4) {
+        const uint32_t slot = work[t];   // the voxels the fused kernel handed over (replay_fused_kernel)
+        const int root = m.htab[slot].root;
+        if (root < 0) continue;
+        w.root = root;
+        const unsigned long long tdbg0 = dbg ? __builtin_readcyclecounter() : 0;
+        __builtin_amdgcn_wave_barrier();   // (the previous voxel's reads of the per-wave LDS lists are done)
+        int cnt = 0;
+        for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
+            if (cnt < RL_CAP && w.lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
+            cnt++;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (cnt > RL_CAP) {
+            // dense or un-down-sampled scans (the reference's updateVoxelMap takes any count): the list is ordered in global scratch instead of
+            // LDS -- a segment of big_idx / big_order (n entries each; the lists of a scan partition its points) claimed with one atomic
+            int base = 0;
+            if (w.lane == 0) base = atomicAdd(&m.counters[9], cnt);
+            base = __shfl(base, 0, 64);
+            if (w.lane == 0) { int k = 0; for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) big_idx[base + k++] = i; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int e = w.lane; e < cnt; e += 64) {
+                const int id = big_idx[base + e];
+                const unsigned long long k = sort_key[id];
+                int rank = 0;
+                for (int f = 0; f < cnt; f++) { const int idf = big_idx[base + f]; const unsigned long long kf = sort_key[idf]; rank += (kf < k || (kf == k && idf < id)) ? 1 : 0; }
+                big_order[base + rank] = id;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int j = wave_replay_planar_root(m, root, big_order + base, cnt, pt_data, w); j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        for (int j = wave_replay_planar_root(m, root, big_order + base, cnt, pt_data, w); j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
-        return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (int e = w.lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique
-        const unsigned long long k = skey[wv][e];
-        const int id = sidx[wv][e];
-        int rank = 0;
-        for (int f = 0; f < cnt; f++) { const unsigned long long kf = skey[wv][f]; rank += (kf < k || (kf == k && sidx[wv][f] < id)) ? 1 : 0; }
-        order[wv][rank] = id;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // settled planar roots take the register-resident fast path; whatever it does not consume goes through the general state machine
-    const unsigned long long tdbg1 = dbg ? __builtin_readcyclecounter() : 0;
-    const int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
-    for (int j = jf; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
-    if (dbg && w.lane == 0) {   // IMMESH_DEBUG: slowest voxel of each kind (cycles << 16 | points), totals
-        const unsigned long long t2 = __builtin_readcyclecounter();
-        atomicMax(&dbg[jf == cnt ? 8 : 9], ((t2 - tdbg0) << 16) | (unsigned long long)cnt);
-        atomicAdd(&dbg[jf == cnt ? 10 : 11], t2 - tdbg1);
-        atomicAdd(&dbg[jf == cnt ? 12 : 13], 1ull);
-        atomicAdd(&dbg[14], tdbg1 - tdbg0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int e = w.lane; e < cnt; e += 64) {  // rank sort: (key, index) pairs are unique
+            const unsigned long long k = skey[wv][e];
+            const int id = sidx[wv][e];
+            int rank = 0;
+            for (int f = 0; f < cnt; f++) { const unsigned long long kf = skey[wv][f]; rank += (kf < k || (kf == k && sidx[wv][f] < id)) ? 1 : 0; }
+            order[wv][rank] = id;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // settled planar roots take the register-resident fast path; whatever it does not consume goes through the general state machine
+        const unsigned long long tdbg1 = dbg ? __builtin_readcyclecounter() : 0;
+        const int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
+        for (int j = jf; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
+        if (dbg && w.lane == 0) {   // IMMESH_DEBUG: slowest voxel of each kind (cycles << 16 | points), totals
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            atomicMax(&dbg[jf == cnt ? 8 : 9], ((t2 - tdbg0) << 16) | (unsigned long long)cnt);
+            atomicAdd(&dbg[jf == cnt ? 10 : 11], t2 - tdbg1);
+            atomicAdd(&dbg[jf == cnt ? 12 : 13], 1ull);
+            atomicAdd(&dbg[14], tdbg1 - tdbg0);
+        }
     }
 }
 
@@ -1305,6 +1553,11 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
     const int nb = (n + 63) / 64;
     KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* sync,
+                                unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+    const int nb = std::min((n + 63) / 64, RP_MAX_BLOCKS);   // resident grid: 512 single-wavefront blocks at 2 per SIMD are a quarter of the chip
+    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, sync, epoch_base, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+}
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);
 }
@@ -1315,11 +1568,12 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
             (float4*)world_xyzi, n_raw, nb_pv);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, void* refit_list, unsigned long long* dbg) {
-    KLAUNCH(replay_light_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, (int2*)refit_list);
-    KLAUNCH(replay_list_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg) {
+    KLAUNCH(replay_fused_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg);
+    // the work list's length is only known on the device: a fixed grid strides over it (sized for the map-building case, where every touched voxel is on it)
+    const int nb_list = std::min(std::max((n + 127) / 128, 32), 4096);
+    KLAUNCH(replay_list_kernel, dim3(nb_list), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
             (const int32_t*)(m.counters + 10));
-    KLAUNCH(replay_refit_kernel, dim3(std::min(n, 2048)), dim3(64), 0, s, m, (const int2*)refit_list);
     KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
