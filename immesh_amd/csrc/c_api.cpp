@@ -62,7 +62,7 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
     m.upd_seq = 0;
     A(c->d_stats, 8);
-    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, 64); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, 512, c->stream)); }
+    if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, REG_DBG_WORDS); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, (size_t)REG_DBG_WORDS * 8, c->stream)); }
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
@@ -80,6 +80,7 @@ static int alloc_all(immesh_ctx* c) {
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     A(c->d_dump_count, 2);
     A(c->d_regstate, 1);
+    A(c->d_rp_partials, RP_PARTIALS_DOUBLES); A(c->d_rp_hist, RP_HIST_TOTAL);
     HIPCHK(c, hipMemsetAsync(c->d_regstate, 0, sizeof(RegState), c->stream));
     A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
 #undef A
@@ -248,7 +249,7 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
         // ONE launch for the scan: a resident grid runs every pass and the 18-state update (residual_persistent_kernel); a.mat = the prior covariance
         a.mode = REG_MODE_FUSED; a.it = 0;
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
-        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, (unsigned int)(c->res_ticket & 0x3FFFFFFull) * 64u, c->d_reg_out_host,
+        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_partials, c->d_rp_hist, c->d_done, (unsigned int)(c->res_ticket & 0x3FFFFFFull) * 64u, c->d_reg_out_host,
                                    c->reg_ticket, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
         return 0;
     }
@@ -717,10 +718,12 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     if (c->reg_dbg) {   // IMMESH_DEBUG: in-kernel phase timers since the last call (cycles of the shader clock; see the FDBG / RDBG markers in reg_kernels.hip)
         unsigned long long t[64];
         HIPCHK(c, hipMemcpy(t, c->reg_dbg, sizeof(t), hipMemcpyDeviceToHost));
+        if (const char* tf = getenv("IMMESH_TRACE_FILE")) {   // the per-wavefront trace records of the LAST launches (tools/trace_report.py reads them)
+            std::vector<unsigned long long> all(REG_DBG_WORDS);
+            HIPCHK(c, hipMemcpy(all.data(), c->reg_dbg, all.size() * 8, hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(tf, "wb")) { fwrite(all.data(), 8, all.size(), f); fclose(f); }
+        }
         HIPCHK(c, hipMemset(c->reg_dbg, 0, sizeof(t)));
-        const unsigned long long nv = std::max(1ull, t[25]);
-        fprintf(stderr, "[replay_fused cycles/voxel, %llu voxels (%llu with a fit)] header+list %llu sort %llu load %llu decide %llu commit %llu plane %llu | slowest %llu cycles (%llu pts)\n", t[25], t[26],
-                t[16] / nv, t[17] / nv, t[18] / nv, t[19] / nv, t[20] / nv, t[21] / std::max(1ull, t[26]), t[24] >> 16, t[24] & 0xFFFF);
         fprintf(stderr, "[replay_list] slowest fast-path voxel %llu cycles (%llu pts), slowest general voxel %llu cycles (%llu pts); mean cycles fast %llu (%llu voxels) general %llu (%llu voxels); list gather + sort %llu per voxel\n",
                 t[8] >> 16, t[8] & 0xFFFF, t[9] >> 16, t[9] & 0xFFFF, t[10] / std::max(1ull, t[12]), t[12], t[11] / std::max(1ull, t[13]), t[13], t[14] / std::max(1ull, t[12] + t[13]));
         const unsigned long long nwv = std::max(1ull, t[6]), npass = std::max(1ull, t[7]);

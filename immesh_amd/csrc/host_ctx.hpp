@@ -53,6 +53,7 @@ struct immesh_ctx {
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     double* d_partials = nullptr;    // residual block partials
+    double *d_rp_partials = nullptr, *d_rp_hist = nullptr;   // residual_persistent_kernel: block partials and the iterate's record, one set per pass
     double* d_out48 = nullptr;
     double* h_out48 = nullptr;       // pinned, device-mapped
     double* d_out48_host = nullptr;  // device view of h_out48

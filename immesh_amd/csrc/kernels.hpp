@@ -25,6 +25,7 @@ struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
     double center[3], normal[3], plane_var[36];
 };
 
+#define REG_DBG_WORDS (64 + 16384 * 8 + 8 * 512 * 8)   /* IMMESH_DEBUG buffer (reg_kernels.hip DBG_*): counters + per-wavefront trace records */
 #define RES_NV_HOST 48
 #define RES_NR_HOST 32
 
@@ -55,7 +56,10 @@ struct RegIterArgs {
 void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
                      double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 // all passes of a scan + the in-kernel 18-state update as one resident grid; a.mat = the prior covariance, sync = {arrive counter, epoch word}
-void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* sync,
+// partials: RP_PARTIALS_DOUBLES doubles (per pass x block), hist: RP_HIST_TOTAL doubles (per-pass record of the iterate)
+#define RP_PARTIALS_DOUBLES (64 * 512 * 32)
+#define RP_HIST_TOTAL (64 * 32)
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, double* hist, unsigned int* sync,
                                 unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);

@@ -115,6 +115,9 @@ IMD double rl_d(double x, int k) {
 // write-through store / coherent load of a double other wavefronts of the same launch read (the L2 of another XCD may hold a stale line)
 IMD void dev_publish(double* p, const double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IMD double dev_observe(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+IMD double uni_d(const double x) {   // a wave-uniform value into scalar registers
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
 IMD void dev_so3_exp(double v1, double v2, double v3, double* R) {  // include/so3_math.h:71-89
     const double norm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
 #pragma unroll
@@ -146,7 +149,9 @@ IMD void dev_so3_log(const double* R, double* out) {  // include/so3_math.h:92-9
 #define EKF_C_DOUBLES 164
 __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const double* C, const double* __restrict__ cov, const double* hth, const double* htz, const double n_match,
                                               const double res_sum, double* W, const int lane, const int it, const int max_iter, const double* __restrict__ extR,
-                                              double* __restrict__ reg_out, const double ticket) {
+                                              double* __restrict__ reg_out, const double ticket, unsigned long long* __restrict__ dbg = nullptr, double* __restrict__ hist = nullptr) {
+    unsigned long long tk = dbg ? __builtin_readcyclecounter() : 0;
+#define EDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) dbg[40 + (k)] += _t - tk; tk = _t; } } while (0)
     // ---- X = (H + P11^-1)^-1: lane j < 12 holds column j of [S | I] in registers; Gauss-Jordan without pivoting (S is symmetric positive definite)
     double a[6];
     {
@@ -164,6 +169,7 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
 #pragma unroll
         for (int r = 0; r < 6; r++) if (r != col) a[r] -= f[r] * a[col];
     }
+    EDBG(0);
     // K1 rows 0..5 = X -> W[0,36); rows 6..17 = (P21 P11^-1) X -> W[36,108)
     if (lane >= 6 && lane < 12) {
 #pragma unroll
@@ -186,6 +192,7 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
         for (int k = 0; k < 6; k++) sacc += W[r * 6 + k] * hth[k * 6 + c];
         W[108 + e] = sacc;
     }
+    EDBG(1);
     // vec = prior [-] state  (every lane computes the same 18 values)
     double st[24], vec[18];
 #pragma unroll
@@ -218,6 +225,7 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
     double sol[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) sol[k] = rl_d(my_sol, k);
+    EDBG(2);
     // state += solution
     {
         double E[9], Rn[9];
@@ -234,12 +242,14 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
     int rematch = (int)C[160];
     if (converged || ((rematch == 0) && (it == (max_iter - 2)))) rematch++;
     const bool stop = rematch >= 2 || (it == max_iter - 1);
+    EDBG(3);
     // next pass / map update parameters
     if (lane < 24) {
         double v = 0;
 #pragma unroll
         for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
         dev_publish(&rs->st[lane], v);
+        if (hist) dev_publish(&hist[lane], v);
     }
     {
         double RextR[9];
@@ -258,6 +268,7 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
         dev_publish(&rs->tot[0], C[156]); dev_publish(&rs->tot[1], C[157]); dev_publish(&rs->tot[2], passes); dev_publish(&rs->tot[3], C[159]);
         __hip_atomic_store(&rs->rematch, rematch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&rs->done, stop ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hist) { dev_publish(&hist[24], C[156]); dev_publish(&hist[25], C[157]); dev_publish(&hist[26], passes); dev_publish(&hist[27], C[159]); dev_publish(&hist[28], (double)rematch); dev_publish(&hist[29], stop ? 1.0 : 0.0); }
     }
     if (stop) {
         // cov = (I - G) * cov ; G is zero outside its first 6 columns:  cov[r][c] - sum_{k<6} G[r][k] cov[k][c]
@@ -288,6 +299,9 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
         __syncthreads();
         if (lane == 0) __hip_atomic_store(&reg_out[REG_OUT_DOUBLES - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    EDBG(4);
+    if (dbg && lane == 0) dbg[47] += 1;
+#undef EDBG
     return stop;
 }
 
@@ -299,7 +313,8 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
 // near-voxel retry (:171-222), residual (:1372-1392), H / R^-1 (:1493-1575); adds the point's terms of H^T R^-1 H / H^T R^-1 z and the counters
 // to acc[RES_NR] and writes the per-point match outputs.  Shared by the single-pass kernel and the persistent one.
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
-IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, double* acc, unsigned long long& tprev,
+// sp: the per-scan constants (kernel arguments: scalar loads); Rm / tv / RextR: the iterate of this pass (wave-uniform)
+IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const double* Rm, const double* tv, const double* RextR, const float* __restrict__ pts, const int i, double* acc, unsigned long long& tprev,
                         int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
         const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
         // --- per-scan part of lio_state_estimation (:1302-1316): body covariance + cross matrix of the IMU-frame point
@@ -314,14 +329,14 @@ IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const float* _
         double pimu[3], pwd[3];
         m3_vec(sp.extR, p, pimu);
         pimu[0] += sp.extT[0]; pimu[1] += sp.extT[1]; pimu[2] += sp.extT[2];
-        m3_vec(sp.R, pimu, pwd);
-        pwd[0] += sp.t[0]; pwd[1] += sp.t[1]; pwd[2] += sp.t[2];
+        m3_vec(Rm, pimu, pwd);
+        pwd[0] += tv[0]; pwd[1] += tv[1]; pwd[2] += tv[2];
         const double pw[3] = {(double)(float)pwd[0], (double)(float)pwd[1], (double)(float)pwd[2]};
         // --- covariance propagation (:1346-1359)
         double var[9];
         {
             double a[9], cm[9], nc[9], nct[9], tmp[9], b[9];
-            m3_sandwich(sp.R, bcov, a);
+            m3_sandwich(Rm, bcov, a);
             skew(pimu_z, cm);
 #pragma unroll
             for (int k = 0; k < 9; k++) nc[k] = -cm[k];
@@ -386,7 +401,7 @@ IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const float* _
             double pthis[3] = {pimu[0], pimu[1], pimu[2]};
             double bv[9], varw[9];
             calc_body_var(pthis, sp.dept_err, sp.calib_laser ? sp.dvar_calib : sp.dvar_beam, bv);
-            m3_sandwich(sp.RextR, bv, varw);
+            m3_sandwich(RextR, bv, varw);
             const double J[6] = {pwd[0] - cen[0], pwd[1] - cen[1], pwd[2] - cen[2], -nrm_d[0], -nrm_d[1], -nrm_d[2]};
             double sigma_l;
             plane_sigma(m, nd, J, &sigma_l);
@@ -396,7 +411,7 @@ IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const float* _
             const double ri = 1.0 / (sigma_l + nvn);
             o_rinv[i] = ri;
             double T1[9], A[3];
-            m3_mul_bt(cm, sp.R, T1);  // crossmat * R^T
+            m3_mul_bt(cm, Rm, T1);  // crossmat * R^T
             m3_vec(T1, nv, A);
             const double H[6] = {A[0], A[1], A[2], nv[0], nv[1], nv[2]};
             const double meas = -(double)dis;
@@ -437,7 +452,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
     double acc[RES_NR];
 #pragma unroll
     for (int k = 0; k < RES_NR; k++) acc[k] = 0;
-    if (i < n) residual_point(m, sp, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+    if (i < n) residual_point(m, sp, sp.R, sp.t, sp.RextR, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
     RDBG(3);
     __shared__ double red[RES_NR][65];
     __shared__ int s_last;
@@ -505,8 +520,9 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
 // wavefront at launch into LDS: a 6x6 Gauss-Jordan in registers, ~1 k cycles off the critical tail.
 // ---------------------------------------------------------------------------------------------------------------------
 #define RP_MAX_BLOCKS 512
+#define RP_HIST_DOUBLES 32     /* per-pass record of the iterate: st[24], tot[4], rematch, done */
 __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
-                                                                  double* __restrict__ partials, unsigned int* __restrict__ sync, unsigned int epoch_base,
+                                                                  double* __restrict__ partials_all, double* __restrict__ hist_all, unsigned int* __restrict__ sync, unsigned int epoch_base,
                                                                   double* __restrict__ reg_out, double ticket,
                                                                   int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                                   float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
@@ -515,7 +531,12 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
     __shared__ int s_last;
     __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
     const int lane = threadIdx.x;
-    ScanParams sp = a.sp;
+    const ScanParams& sp = a.sp;     // per-scan constants stay kernel arguments (scalar loads); only the iterate below changes between passes
+    double Rm[9], tv[3], RextR[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { Rm[k] = a.sp.R[k]; RextR[k] = a.sp.RextR[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) tv[k] = a.sp.t[k];
     unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
     // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
     {
@@ -549,28 +570,42 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
     }
     const int ntiles = (n + 63) / 64;
     for (int it = 0; it < a.max_iter; it++) {
+        // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] points done [2] arrived [3] partials summed [4] update done [5] published [6] last?
+        unsigned long long* const tr = (sp.dbg && lane == 0 && it < 8) ? sp.dbg + (64 + 16384 * 8) + ((size_t)it * 512 + blockIdx.x) * 8 : nullptr;
+        // everything that crosses wavefronts inside the launch has its own address per pass (block partials, the iterate + loop state): a line
+        // is written once and read after that, never re-read from an XCD's L2 that may have kept an earlier pass's copy
+        double* const partials = partials_all + (size_t)it * gridDim.x * RES_NR;
+        const double* const hprev = hist_all + (size_t)(it > 0 ? it - 1 : 0) * RP_HIST_DOUBLES;
         if (it > 0) {
             // the update of pass it - 1 has been published when the epoch word says so
             __builtin_amdgcn_s_setprio(0);
             while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch_base + (unsigned int)it) __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_s_setprio(3);
-            if (__hip_atomic_load(&rs->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;   // the loop stopped with that pass
+            if (dev_observe(&hprev[29]) != 0.0) break;   // the loop stopped with that pass
+            // (wave-uniform: through readfirstlane into scalar registers -- 21 doubles in vector registers for the whole pass otherwise)
 #pragma unroll
-            for (int k = 0; k < 9; k++) sp.R[k] = dev_observe(&rs->st[k]);
+            for (int k = 0; k < 9; k++) Rm[k] = uni_d(dev_observe(&hprev[k]));
 #pragma unroll
-            for (int k = 0; k < 3; k++) sp.t[k] = dev_observe(&rs->st[9 + k]);
-            m3_mul(sp.R, sp.extR, sp.RextR);
+            for (int k = 0; k < 3; k++) tv[k] = uni_d(dev_observe(&hprev[9 + k]));
+            {
+                double t9[9];
+                m3_mul(Rm, sp.extR, t9);
+#pragma unroll
+                for (int k = 0; k < 9; k++) RextR[k] = uni_d(t9[k]);
+            }
             if (sp.dbg) tprev = __builtin_readcyclecounter();
         }
         if (sp.dbg && lane == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
+        if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[6] = 0; }
         double acc[RES_NR];
 #pragma unroll
         for (int k = 0; k < RES_NR; k++) acc[k] = 0;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const int i = tile * 64 + lane;
-            if (i < n) residual_point(m, sp, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+            if (i < n) residual_point(m, sp, Rm, tv, RextR, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
         }
         RDBG(3);
+        if (tr) tr[1] = __builtin_amdgcn_s_memrealtime();
         // ---- block sums (LDS transpose: lane k adds column k in lane order -- fixed order) -> write-through partials -> arrive
         __syncthreads();   // (the previous pass's readers of `red` are done)
 #pragma unroll
@@ -587,6 +622,7 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
         if (lane == 0) s_last = (atomicAdd(&sync[0], 1u) == gridDim.x - 1) ? 1 : 0;
         __syncthreads();
         RDBG(4);
+        if (tr) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[6] = (unsigned long long)s_last; }
         if (!s_last) continue;
         // ---- last wavefront of the pass: stage what the 18-state update needs (LDS, beside the running sums), add the partials, update
         double* L = &red[0][0];
@@ -595,10 +631,10 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
         for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
             double v;
             if (e < 108) v = pc[e];
-            else if (e < 132) v = it == 0 ? a.st[e - 108] : dev_observe(&rs->st[e - 108]);
+            else if (e < 132) v = it == 0 ? a.st[e - 108] : dev_observe(&hprev[e - 108]);
             else if (e < 156) v = a.prior[e - 132];
-            else if (e < 160) v = it == 0 ? 0.0 : dev_observe(&rs->tot[e - 156]);
-            else v = it == 0 ? 0.0 : (double)__hip_atomic_load(&rs->rematch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (e < 160) v = it == 0 ? 0.0 : dev_observe(&hprev[24 + (e - 156)]);
+            else v = it == 0 ? 0.0 : dev_observe(&hprev[28]);
             Cst[e] = v;
         }
         double tot = 0;
@@ -618,6 +654,7 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
             tot += __shfl_xor(tot, 32, 64);
         }
         if (lane == 0) __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
         L[lane] = tot;
         __syncthreads();
         double v48 = 0;   // 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
@@ -629,10 +666,12 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
         __syncthreads();
         if (lane == 0) { Cst[156] += L[64 + 44]; Cst[157] += L[64 + 45]; Cst[159] += L[64 + 42]; }
         __syncthreads();
-        const bool stop = ekf_step_wave(rs, Cst, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, it, a.max_iter, a.sp.extR, reg_out, ticket);
+        const bool stop = ekf_step_wave(rs, Cst, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, it, a.max_iter, a.sp.extR, reg_out, ticket, sp.dbg, hist_all + (size_t)it * RP_HIST_DOUBLES);
+        if (tr) tr[4] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (lane == 0) __hip_atomic_store(&sync[1], epoch_base + (unsigned int)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tr) tr[5] = __builtin_amdgcn_s_memrealtime();
         RDBG(5);
         if (stop) break;
     }
@@ -1266,6 +1305,10 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
 
 #define RL_CAP 64    /* points of one scan falling into one root voxel that are ordered in LDS (a down-sampled scan puts <= ~8 into a voxel); longer lists take the
                         global-scratch path.  Kept small on purpose: LDS is what limits how many workgroups of the three concurrent chains fit a CU */
+#define DBG_FUSED_OFF 64          /* IMMESH_DEBUG buffer: [0,64) counters, then 16384 x 8 trace words of replay_fused_kernel, then 8 x 512 x 8 of the residual passes */
+#define DBG_FUSED_RECS 16384
+#define DBG_RES_OFF (DBG_FUSED_OFF + DBG_FUSED_RECS * 8)
+#define DBG_TOTAL_WORDS (DBG_RES_OFF + 8 * 512 * 8)
 #define RF_PTS 128   /* a settled root's retained points + this scan's points live in registers (two per lane) */
 // ---- the map update in two launches ---------------------------------------------------------------------------------------------------------
 //   replay_fused_kernel   one wavefront per touched root voxel.  The common state of a settled map -- an initialised, planar, update-enabled root
@@ -1286,13 +1329,18 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     __builtin_amdgcn_s_setprio(3);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wv;
-    if (t >= m.counters[7]) return;
+    // IMMESH_DEBUG: one trace record per wavefront of the launch (plain stores, no contention): [0] start, [1] end (s_memrealtime, 100 MHz),
+    // [2..5] eight 32-bit cycle counts (root known, header, list, sort, load, decide, commit, plane), [6] cnt | n_ref << 8 | state << 16
+    unsigned long long* const tr = (dbg && lane == 0 && t < DBG_FUSED_RECS) ? dbg + DBG_FUSED_OFF + (size_t)t * 8 : nullptr;
     unsigned long long tprev = dbg ? __builtin_readcyclecounter() : 0;
-    const unsigned long long tstart = tprev;
-#define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&dbg[16 + (k)], _t - tprev); tprev = _t; } } while (0)
+    if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = tr[3] = tr[4] = tr[5] = tr[6] = 0; }
+#define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tr) ((unsigned int*)tr)[4 + (k)] = (unsigned int)(_t - tprev); tprev = _t; } } while (0)
+#define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[6] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
+    if (t >= m.counters[7]) { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); } return; }
     const uint32_t slot = m.touched[t];
     const int root = m.htab[slot].root;
     if (root < 0) return;
+    FDBG(0);
     NodeRec& nd = m.nodes[root];
     // node header and the head of the point list: independent loads, one latency
     const int flags = nd.flags, layer = nd.layer;
@@ -1301,13 +1349,15 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
 #pragma unroll
     for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
     int cnt = 0;
-    for (int i = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull); i >= 0; i = pt_next[i]) {
+    int ihead = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FDBG(1); }
+    for (int i = ihead; i >= 0; i = pt_next[i]) {
         if (cnt < RL_CAP && lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
         cnt++;
     }
-    FDBG(0);
+    FDBG(2);
     const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
-    if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) return;   // a full planar root (m_update_enable_ == false) drops every point
+    if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) { FEND(1, 0); return; }   // a full planar root (m_update_enable_ == false) drops every point
     const int ntot = npts + cnt;
     bool hand_over = cnt > RL_CAP || (flags & want) != want || layer != 0 || newp > 5 || ntot > RF_PTS || ntot >= m.max_points_size;
     if (!hand_over) {
@@ -1324,7 +1374,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        FDBG(1);
+        FDBG(3);
         auto chunk_of = [&](int ci) { int c = chunks[0];
 #pragma unroll
             for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
@@ -1348,7 +1398,8 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
 #pragma unroll
                 for (int k = 0; k < 9; k++) P1[k] = s1[k]; }
         }
-        FDBG(2);
+        if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FDBG(4);
         // ---- decisions (nothing is written yet)
         PlaneFit fit;
         long long n_ref_pts = 0;
@@ -1375,7 +1426,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
             if (!fit.planar) hand_over = true;   // the root turns non-planar in the middle of the batch: the general kernel's job (children)
             n_last = nr;
         }
-        FDBG(3);
+        FDBG(5);
         if (!hand_over) {
             // ---- commit: chunks for the new points, the points, the header, the plane
             const int c_first = (npts + IM_CHUNK_PTS - 1) >> 4, c_last = (ntot - 1) >> 4;   // chunk slots first touched by this batch
@@ -1402,20 +1453,22 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
                 for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
                 if (n_ref) { atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_ref_pts); }
             }
-            FDBG(4);
+            FDBG(6);
             if (n_ref > 0) {   // (n_last is the last refit's point count: fit holds its eigen-decomposition)
                 double pv[21];
                 auto fe = [&](auto&& fn) __attribute__((always_inline)) { if (lane < n_last) fn(P0); if (lane + 64 < n_last) fn(P1); };
                 fit_plane_var(fe, n_last, fit, pv);
                 fit_store(nd, fit, pv, lane);
             }
-            FDBG(5);
-            if (dbg && lane == 0) { atomicMax(&dbg[24], ((__builtin_readcyclecounter() - tstart) << 16) | (unsigned long long)cnt); atomicAdd(&dbg[25], 1ull); if (n_ref) atomicAdd(&dbg[26], 1ull); }
+            FDBG(7);
+            FEND(2, n_ref);
             return;
         }
     }
     if (lane == 0) general_list[atomicAdd(&m.counters[10], 1)] = slot;
+    FEND(3, 0);
 #undef FDBG
+#undef FEND
 }
 
 // updateVoxelMap without any global sort: one wavefront per root voxel of the work list gathers that voxel's points of this scan from its
@@ -1553,10 +1606,10 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
     const int nb = (n + 63) / 64;
     KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
-void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* sync,
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, double* hist, unsigned int* sync,
                                 unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = std::min((n + 63) / 64, RP_MAX_BLOCKS);   // resident grid: 512 single-wavefront blocks at 2 per SIMD are a quarter of the chip
-    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, sync, epoch_base, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, hist, sync, epoch_base, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);
