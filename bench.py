@@ -129,6 +129,8 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     if kname == "residual_kernel":      # per EKF iteration: point 12 B + key/slot 12 B per point, 12 B per extra probe, 229 B per plane test
         launches = c["n_iter"]
         return (n_ds * 24 * launches + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / launches
+    if kname == "residual_persistent_kernel":   # ONE launch per scan runs every EKF iteration: the same per-iteration bytes, summed over the scan's iterations
+        return (n_ds * 24 * c["n_iter"] + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / n_scans
     if kname == "point_var_kernel":     # point 12 B in, Point_with_var 96 B + sort key 8 + slot 12 out
         return n_ds * (12 + 96 + 8 + 12)
     if kname == "replay_kernel":        # per scan: every point record once (96 B) + every refit re-reads its retained points (96 B each) and writes a plane (229 B)
@@ -374,7 +376,7 @@ def build_roofline(res, args):
         return None
     per_scan_launches = kstats[best]["launches"] / args.profile_scans
     by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
-    if best.split("<")[0] not in ("residual_kernel",):
+    if best.split("<")[0] not in ("residual_kernel", "residual_persistent_kernel"):
         by = by / max(1.0, per_scan_launches)
     avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]
     ach = by / (avg_ms * 1e-3) / 1e9

@@ -80,7 +80,7 @@ static int alloc_all(immesh_ctx* c) {
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     A(c->d_dump_count, 2);
     A(c->d_regstate, 1);
-    A(c->d_rp_partials, RP_PARTIALS_DOUBLES); A(c->d_rp_hist, RP_HIST_TOTAL);
+    for (int q = 0; q < 2; q++) { A(c->d_rp_slots[q], RP_SLOT_DOUBLES); launch_fill_u64(c->stream, (unsigned long long*)c->d_rp_slots[q], RP_SLOT_SENTINEL, RP_SLOT_DOUBLES); }
     HIPCHK(c, hipMemsetAsync(c->d_regstate, 0, sizeof(RegState), c->stream));
     A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
 #undef A
@@ -249,8 +249,9 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
         // ONE launch for the scan: a resident grid runs every pass and the 18-state update (residual_persistent_kernel); a.mat = the prior covariance
         a.mode = REG_MODE_FUSED; a.it = 0;
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
-        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_partials, c->d_rp_hist, c->d_done, (unsigned int)(c->res_ticket & 0x3FFFFFFull) * 64u, c->d_reg_out_host,
-                                   c->reg_ticket, c->d_match, c->d_mnode, c->d_dis, c->d_rinv, c->d_normal);
+        const int par = (c->rp_parity ^= 1);   // this scan's slot buffer; the launch re-arms the other one for the next scan
+        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_slots[par], c->d_rp_slots[par ^ 1], c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
+                                   c->d_dis, c->d_rinv, c->d_normal);
         return 0;
     }
     for (int it = 0; it < max_iter; it++) {

@@ -225,6 +225,26 @@ IMD double wave_sum(double x) {
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
 }
+// The same all-reduce without the LDS crossbar: ds_bpermute steps are ~100-cycle round trips, and a plane fit chains 24 of these reductions
+// (9 moments, 15 plane-covariance terms) -- two thirds of its time.  Within a row of 16 lanes the butterfly runs on DPP moves (quad_perm
+// xor 1 / xor 2, row_half_mirror, row_mirror: VALU latency only); the four row sums are read with v_readlane and added in row order.
+template <int CTRL>
+IMD double dpp_d(const double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+IMD double wave_sum_fast(double x) {
+    x += dpp_d<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_d<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_d<0x141>(x);   // row_half_mirror
+    x += dpp_d<0x140>(x);   // row_mirror
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 0), __builtin_amdgcn_readlane(__double2loint(x), 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 16), __builtin_amdgcn_readlane(__double2loint(x), 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 32), __builtin_amdgcn_readlane(__double2loint(x), 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 48), __builtin_amdgcn_readlane(__double2loint(x), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 IMD int wave_sum_i(int x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);

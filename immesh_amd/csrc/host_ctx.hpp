@@ -53,7 +53,8 @@ struct immesh_ctx {
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     double* d_partials = nullptr;    // residual block partials
-    double *d_rp_partials = nullptr, *d_rp_hist = nullptr;   // residual_persistent_kernel: block partials and the iterate's record, one set per pass
+    int rp_parity = 0;
+    double* d_rp_slots[2] = {nullptr, nullptr};   // residual_persistent_kernel: block-partial slots (per pass x block), one buffer per scan parity
     double* d_out48 = nullptr;
     double* h_out48 = nullptr;       // pinned, device-mapped
     double* d_out48_host = nullptr;  // device view of h_out48

@@ -55,12 +55,12 @@ struct RegIterArgs {
 
 void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
                      double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
-// all passes of a scan + the in-kernel 18-state update as one resident grid; a.mat = the prior covariance, sync = {arrive counter, epoch word}
-// partials: RP_PARTIALS_DOUBLES doubles (per pass x block), hist: RP_HIST_TOTAL doubles (per-pass record of the iterate)
-#define RP_PARTIALS_DOUBLES (64 * 512 * 32)
-#define RP_HIST_TOTAL (64 * 32)
-void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, double* hist, unsigned int* sync,
-                                unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+// all passes of a scan + the 18-state update as one resident grid (residual_persistent_kernel); a.mat = the prior covariance.
+// slots / slots_next: the two parities of the block-partial buffer, RP_SLOT_DOUBLES each, filled with RP_SLOT_SENTINEL before first use
+#define RP_SLOT_DOUBLES (64 * 128 * 32)
+#define RP_SLOT_SENTINEL 0x7FF8DEADBEEF0001ull
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
+                                double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`

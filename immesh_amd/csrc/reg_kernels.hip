@@ -19,10 +19,11 @@ using namespace imd;
 // =====================================================================================================================
 // matcher + H build
 // =====================================================================================================================
-struct BestMatch { int node; int layer; double prob; bool ok; };
+// what a point-to-plane test reads of a node record: kept in registers from the matcher to the H build (no second gather)
+struct PlaneRegs { double n[3], c[3], pv[21]; float d, radius; };
+struct BestMatch { int node; int layer; double prob; bool ok; PlaneRegs P; };
 
-IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigma_out) {  // J * plane_var * J^T, plane_var symmetric (21)
-    const double* pv = m.nodes[node].p_var;
+IMD double plane_sigma(const double* pv, const double* J) {  // J * plane_var * J^T, plane_var symmetric (21)
     double tmp[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) {
@@ -34,71 +35,78 @@ IMD void plane_sigma(const RegMapDev& m, int node, const double* J, double* sigm
     double sig = 0;
 #pragma unroll
     for (int c = 0; c < 6; c++) sig += tmp[c] * J[c];
-    *sigma_out = sig;
+    return sig;
+}
+IMD void load_plane_geometry(const NodeRec& nr, PlaneRegs& P) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { P.n[k] = nr.p_normal[k]; P.c[k] = nr.p_center[k]; }
+    P.d = nr.d; P.radius = nr.radius;
+}
+IMD void load_plane_var(const NodeRec& nr, PlaneRegs& P) {
+#pragma unroll
+    for (int k = 0; k < 21; k++) P.pv[k] = nr.p_var[k];
 }
 
-// build_single_residual on one plane node (voxel_mapping.cpp:252-290).  The whole plane record (normal, centre, d, radius, 21-entry
-// covariance) is fetched up front -- one gather latency -- and both gates are evaluated from registers; computing sigma_l before
-// knowing that the range gate passed has no side effect, so the accept set is the reference's.
-// EAGER (planar root voxel, the common avia case): everything in one gather.  !EAGER (leaves of a subdivided voxel, where most of the many
-// candidates fail the range gate): the covariance is fetched only for the survivors.
-template <bool EAGER>
-IMD void test_plane(const RegMapDev& m, int node, int layer, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
-    n_tests++;
-    const NodeRec& nr = m.nodes[node];
-    double pv[21];
-    if (EAGER) {
-#pragma unroll
-        for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
-    }
-    const double nx = nr.p_normal[0], ny = nr.p_normal[1], nz = nr.p_normal[2];
-    const double cx = nr.p_center[0], cy = nr.p_center[1], cz = nr.p_center[2];
-    const float pd = nr.d, radius = nr.radius;
-    const float dis_to_plane = (float)fabs(nx * pw[0] + ny * pw[1] + nz * pw[2] + (double)pd);
-    const float dis_to_center = (float)((cx - pw[0]) * (cx - pw[0]) + (cy - pw[1]) * (cy - pw[1]) + (cz - pw[2]) * (cz - pw[2]));
-    const float range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);  // NaN compares false below
-    if (!EAGER) {
-        if (!((double)range_dis <= 3.0 * (double)radius)) return;
-#pragma unroll
-        for (int k = 0; k < 21; k++) pv[k] = nr.p_var[k];
-    }
-    const double J[6] = {pw[0] - cx, pw[1] - cy, pw[2] - cz, -nx, -ny, -nz};
-    double tmp[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-        double sacc = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++) sacc += J[r] * pv[(r <= c) ? sym21_index(r, c) : sym21_index(c, r)];
-        tmp[c] = sacc;
-    }
-    double sigma_l = 0;
-#pragma unroll
-    for (int c = 0; c < 6; c++) sigma_l += tmp[c] * J[c];
+// build_single_residual on one plane node (voxel_mapping.cpp:252-290) with the plane record P already in registers: both gates are evaluated
+// from there; computing sigma_l before knowing that the range gate passed has no side effect, so the accept set is the reference's.
+// TIE: an exact tie of probabilities goes to the plane the reference's depth-first recursion reaches first (leaf lists are in insertion order).
+template <bool TIE>
+IMD void test_plane(const RegMapDev& m, const PlaneRegs& P, int node, int layer, const double* pw, const double* var, double sigma_num, float dis_to_plane, float range_dis,
+                    BestMatch& best) {
+    const double nx = P.n[0], ny = P.n[1], nz = P.n[2];
+    const double J[6] = {pw[0] - P.c[0], pw[1] - P.c[1], pw[2] - P.c[2], -nx, -ny, -nz};
+    double sigma_l = plane_sigma(P.pv, J);
     const double nrm[3] = {nx, ny, nz};
     double vn[3];
     m3t_vec(var, nrm, vn);
     sigma_l += vn[0] * nx + vn[1] * ny + vn[2] * nz;
-    if ((double)range_dis <= 3.0 * (double)radius && (double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
+    if ((double)range_dis <= 3.0 * (double)P.radius && (double)dis_to_plane < sigma_num * sqrt(sigma_l)) {
         best.ok = true;
         const double this_prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dis_to_plane * (double)dis_to_plane / sigma_l);
-        // strictly greater wins; an exact tie goes to the plane the reference's depth-first recursion reaches first (the flat leaf list is in
-        // insertion order, not DFS order)
-        if (this_prob > best.prob || (!EAGER && this_prob == best.prob && best.node >= 0 && dfs_key(m, node) < dfs_key(m, best.node))) { best.prob = this_prob; best.node = node; best.layer = layer; }
+        if (this_prob > best.prob || (TIE && this_prob == best.prob && best.node >= 0 && dfs_key(m, node) < dfs_key(m, best.node))) {
+            best.prob = this_prob; best.node = node; best.layer = layer; best.P = P;
+        }
     }
+}
+IMD void plane_gates(const PlaneRegs& P, const double* pw, float& dis_to_plane, float& range_dis) {
+    dis_to_plane = (float)fabs(P.n[0] * pw[0] + P.n[1] * pw[1] + P.n[2] * pw[2] + (double)P.d);
+    const float dis_to_center = (float)((P.c[0] - pw[0]) * (P.c[0] - pw[0]) + (P.c[1] - pw[1]) * (P.c[1] - pw[1]) + (P.c[2] - pw[2]) * (P.c[2] - pw[2]));
+    range_dis = sqrtf(dis_to_center - dis_to_plane * dis_to_plane);  // NaN compares false in the gate
 }
 
 // build_single_residual's recursion over ALL existing children of non-plane nodes (voxel_mapping.cpp:299-312): the planes it reaches are the
-// root's flat leaf list.  Equal probabilities keep the reference's "first in depth-first order wins" through dfs_key (test_plane).
+// root's flat leaf list.  The root's own plane record is gathered together with its flags -- ONE dependent access for the common case of a
+// planar root voxel (a subdivided root pays three wasted lines); leaves fetch their covariance only when they survive the range gate.
 IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double* var, double sigma_num, BestMatch& best, int& n_tests) {
-    if (m.nodes[root].flags & NF_PLANE) { test_plane<true>(m, root, 0, pw, var, sigma_num, best, n_tests); return; }
+    const NodeRec& nr = m.nodes[root];
+    const int flags = nr.flags, leaf_head = nr.leaf_head;
+    PlaneRegs P;
+    load_plane_geometry(nr, P);
+    load_plane_var(nr, P);
+    if (flags & NF_PLANE) {
+        n_tests++;
+        float dp, rd;
+        plane_gates(P, pw, dp, rd);
+        test_plane<false>(m, P, root, 0, pw, var, sigma_num, dp, rd, best);
+        return;
+    }
     if (m.max_layer <= 0) return;
-    for (int ch = m.nodes[root].leaf_head; ch >= 0;) {
+    for (int ch = leaf_head; ch >= 0;) {
         int e[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) e[k] = m.leaf_chunks[(size_t)ch * 16 + k];   // one 64-byte line: 15 node ids + next
 #pragma unroll
         for (int s2 = 0; s2 < IM_LEAF_SLOTS; s2++)
-            if (e[s2] >= 0) test_plane<false>(m, e[s2], 1, pw, var, sigma_num, best, n_tests);
+            if (e[s2] >= 0) {
+                n_tests++;
+                const NodeRec& lr = m.nodes[e[s2]];
+                load_plane_geometry(lr, P);
+                float dp, rd;
+                plane_gates(P, pw, dp, rd);
+                if (!((double)rd <= 3.0 * (double)P.radius)) continue;
+                load_plane_var(lr, P);
+                test_plane<true>(m, P, e[s2], 1, pw, var, sigma_num, dp, rd, best);
+            }
         ch = e[15];
     }
 }
@@ -118,6 +126,26 @@ IMD double dev_observe(const double* p) { return __longlong_as_double((long long
 IMD double uni_d(const double x) {   // a wave-uniform value into scalar registers
     return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
 }
+// The rotation increments of the iterated update are far below a radian, and the generic double-precision sin / cos / acos cost ~1.7 us EACH on
+// the single wavefront that runs the update (4 k cycles for Exp, 4 k for Log, measured): below 0.5 rad (Exp) / 0.05 (Log) the functions are summed
+// from their Taylor series to below 1e-17 relative -- at least as close to the true value as libm -- and libm serves the rest.
+IMD void sin_1mcos(const double x, double* sn, double* c1) {
+    if (fabs(x) < 0.5) {
+        const double x2 = x * x;
+        double a = 1.0 - x2 * (1.0 / 272.0);
+        a = 1.0 - x2 * (1.0 / 210.0) * a; a = 1.0 - x2 * (1.0 / 156.0) * a; a = 1.0 - x2 * (1.0 / 110.0) * a; a = 1.0 - x2 * (1.0 / 72.0) * a;
+        a = 1.0 - x2 * (1.0 / 42.0) * a; a = 1.0 - x2 * (1.0 / 20.0) * a; a = 1.0 - x2 * (1.0 / 6.0) * a;
+        *sn = x * a;
+        double b = 1.0 - x2 * (1.0 / 306.0);
+        b = 1.0 - x2 * (1.0 / 240.0) * b; b = 1.0 - x2 * (1.0 / 182.0) * b; b = 1.0 - x2 * (1.0 / 132.0) * b; b = 1.0 - x2 * (1.0 / 90.0) * b;
+        b = 1.0 - x2 * (1.0 / 56.0) * b; b = 1.0 - x2 * (1.0 / 30.0) * b; b = 1.0 - x2 * (1.0 / 12.0) * b;
+        *c1 = 0.5 * x2 * b;
+    } else {
+        double cs;
+        sincos(x, sn, &cs);
+        *c1 = 1.0 - cs;
+    }
+}
 IMD void dev_so3_exp(double v1, double v2, double v3, double* R) {  // include/so3_math.h:71-89
     const double norm = sqrt(v1 * v1 + v2 * v2 + v3 * v3);
 #pragma unroll
@@ -127,17 +155,29 @@ IMD void dev_so3_exp(double v1, double v2, double v3, double* R) {  // include/s
         const double K[9] = {0.0, -r[2], r[1], r[2], 0.0, -r[0], -r[1], r[0], 0.0};
         double KK[9];
         m3_mul(K, K, KK);
-        const double sn = sin(norm), c1 = 1.0 - cos(norm);
+        double sn, c1;
+        sin_1mcos(norm, &sn, &c1);
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = (R[i] + sn * K[i]) + c1 * KK[i];
     }
 }
-IMD void dev_so3_log(const double* R, double* out) {  // include/so3_math.h:92-98
+IMD void dev_so3_log(const double* R, double* out) {  // include/so3_math.h:92-98: theta = acos((tr - 1) / 2); theta < 1e-3 ? K / 2 : theta / (2 sin theta) K
     const double tr = R[0] + R[4] + R[8];
-    const double theta = (tr > 3.0 - 1e-6) ? 0.0 : acos(0.5 * (tr - 1));
+    const double ct = 0.5 * (tr - 1);
     const double K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
-    if (fabs(theta) < 0.001) { out[0] = 0.5 * K[0]; out[1] = 0.5 * K[1]; out[2] = 0.5 * K[2]; }
-    else { const double f = 0.5 * theta / sin(theta); out[0] = f * K[0]; out[1] = f * K[1]; out[2] = f * K[2]; }
+    const double s2 = 0.25 * (K[0] * K[0] + K[1] * K[1] + K[2] * K[2]);   // sin^2 theta (K is twice the sine times the axis)
+    double f = 0.5;
+    if (!(tr > 3.0 - 1e-6)) {
+        if (ct > 0 && s2 < 0.0025) {
+            // theta / sin(theta) = asin(s) / s, s = sin(theta) < 0.05: the series of the arc sine (the reference's acos(1 - theta^2 / 2) only resolves theta to 1e-16 / theta^2 anyway)
+            const double q = 1.0 + s2 * (1.0 / 6.0 + s2 * (3.0 / 40.0 + s2 * (15.0 / 336.0 + s2 * (105.0 / 3456.0 + s2 * (945.0 / 42240.0 + s2 * (10395.0 / 599040.0))))));
+            if (!(s2 * q * q < 1e-6)) f = 0.5 * q;          // theta = s q against the 1e-3 cut
+        } else {
+            const double theta = acos(ct);
+            if (!(fabs(theta) < 0.001)) f = 0.5 * theta / sqrt((1.0 - ct) * (1.0 + ct));
+        }
+    }
+    out[0] = f * K[0]; out[1] = f * K[1]; out[2] = f * K[2];
 }
 // hth: 6x6 row-major, htz: 6 (LDS).  W: >= 260 doubles of LDS scratch.  cov: the prior covariance (only read when the loop stops).
 // Returns true when the loop stops with this pass (rs->done set, posterior written to reg_out).
@@ -312,42 +352,57 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
 // One point of one residual pass: transformLidar + covariance propagation (lio_state_estimation :1302-1359), BuildResidualListOMP with the
 // near-voxel retry (:171-222), residual (:1372-1392), H / R^-1 (:1493-1575); adds the point's terms of H^T R^-1 H / H^T R^-1 z and the counters
 // to acc[RES_NR] and writes the per-point match outputs.  Shared by the single-pass kernel and the persistent one.
+// What does not depend on the iterate is computed once per scan (residual_prep) and stays in registers over the passes of the resident grid.
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
+struct PointPrep {
+    double pimu[3];     // the point in the IMU frame
+    double bcov[9];     // calcBodyVar of the lidar-frame point (:1302-1316)
+    double b[9];        // (-[p_imu]x) Srot (-[p_imu]x)^T with the z == 0 -> 1e-3 quirk
+    double bv[9];       // calcBodyVar of the IMU-frame point (H build, :1509-1517)
+    unsigned long long key; int root;   // root voxel the previous pass found the point in (PREP_NO_KEY: none yet)
+};
+#define PREP_NO_KEY 0xFFFFFFFFFFFFFFFEull
+IMD void residual_prep(const ScanParams& sp, const float* __restrict__ pts, const int i, PointPrep& q) {
+    const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
+    double pz[3] = {p[0], p[1], p[2]};
+    if (pz[2] == 0) pz[2] = 0.001;
+    calc_body_var(pz, sp.dept_err, sp.dvar_beam, q.bcov);
+    double pimu_z[3];
+    m3_vec(sp.extR, pz, pimu_z);
+    pimu_z[0] += sp.extT[0]; pimu_z[1] += sp.extT[1]; pimu_z[2] += sp.extT[2];
+    m3_vec(sp.extR, p, q.pimu);
+    q.pimu[0] += sp.extT[0]; q.pimu[1] += sp.extT[1]; q.pimu[2] += sp.extT[2];
+    {
+        double cm[9], nc[9], nct[9], tmp[9];
+        skew(pimu_z, cm);
+#pragma unroll
+        for (int k = 0; k < 9; k++) nc[k] = -cm[k];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) nct[r * 3 + c] = -cm[c * 3 + r];
+        m3_mul(nc, sp.rot_var, tmp);
+        m3_mul(tmp, nct, q.b);
+    }
+    double pthis[3] = {q.pimu[0], q.pimu[1], q.pimu[2]};
+    calc_body_var(pthis, sp.dept_err, sp.calib_laser ? sp.dvar_calib : sp.dvar_beam, q.bv);
+    q.key = PREP_NO_KEY; q.root = -1;
+}
 // sp: the per-scan constants (kernel arguments: scalar loads); Rm / tv / RextR: the iterate of this pass (wave-uniform)
-IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const double* Rm, const double* tv, const double* RextR, const float* __restrict__ pts, const int i, double* acc, unsigned long long& tprev,
-                        int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
-        const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
-        // --- per-scan part of lio_state_estimation (:1302-1316): body covariance + cross matrix of the IMU-frame point
-        double pz[3] = {p[0], p[1], p[2]};
-        if (pz[2] == 0) pz[2] = 0.001;
-        double bcov[9];
-        calc_body_var(pz, sp.dept_err, sp.dvar_beam, bcov);
-        double pimu_z[3];
-        m3_vec(sp.extR, pz, pimu_z);
-        pimu_z[0] += sp.extT[0]; pimu_z[1] += sp.extT[1]; pimu_z[2] += sp.extT[2];
+IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* Rm, const double* tv, const double* RextR, PointPrep& q, const int i, double* acc, unsigned long long& tprev,
+                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
         // --- transformLidar (:1344): f64 compute, f32 store
-        double pimu[3], pwd[3];
-        m3_vec(sp.extR, p, pimu);
-        pimu[0] += sp.extT[0]; pimu[1] += sp.extT[1]; pimu[2] += sp.extT[2];
-        m3_vec(Rm, pimu, pwd);
+        double pwd[3];
+        m3_vec(Rm, q.pimu, pwd);
         pwd[0] += tv[0]; pwd[1] += tv[1]; pwd[2] += tv[2];
         const double pw[3] = {(double)(float)pwd[0], (double)(float)pwd[1], (double)(float)pwd[2]};
         // --- covariance propagation (:1346-1359)
         double var[9];
         {
-            double a[9], cm[9], nc[9], nct[9], tmp[9], b[9];
-            m3_sandwich(Rm, bcov, a);
-            skew(pimu_z, cm);
+            double a[9];
+            m3_sandwich(Rm, q.bcov, a);
 #pragma unroll
-            for (int k = 0; k < 9; k++) nc[k] = -cm[k];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) nct[r * 3 + c] = -cm[c * 3 + r];
-            m3_mul(nc, sp.rot_var, tmp);
-            m3_mul(tmp, nct, b);
-#pragma unroll
-            for (int k = 0; k < 9; k++) var[k] = (a[k] + b[k]) + sp.t_var[k];
+            for (int k = 0; k < 9; k++) var[k] = (a[k] + q.b[k]) + sp.t_var[k];
         }
         RDBG(0);
         // --- BuildResidualListOMP (:171-222)
@@ -357,11 +412,19 @@ IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const double* 
         for (int j = 0; j < 3; j++) { loc[j] = loc_axis(pw[j] / m.voxel_size_d); kx[j] = (int64_t)loc[j]; }
         // sharded map: a point is matched by the rank that owns its root voxel (every rank sees the whole scan; the 48 sums are all-reduced)
         const bool mine = m.shard_world <= 1 || shard_owner(m, kx[0], kx[1], kx[2]) == m.shard_rank;
-        const int64_t slot = mine ? hash_find(m, pack_key(kx[0], kx[1], kx[2])) : -1;
+        const uint64_t key = pack_key(kx[0], kx[1], kx[2]);
+        int root = -1;
+        if (mine) {
+            if (key == q.key) root = q.root;   // the point stayed in the voxel of the previous pass (the map does not change during a scan's passes)
+            else {
+                const int64_t slot = hash_find(m, key);
+                root = slot >= 0 ? m.htab[slot].root : -2;   // -2: no such voxel
+                q.key = key; q.root = root;
+            }
+        }
         BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
         int n_tests = 0, n_extra = 0;
-        if (slot >= 0) {
-            const int root = m.htab[slot].root;
+        if (root != -2 && mine) {
             if (root >= 0) match_tree(m, root, pw, var, sp.sigma_num, best, n_tests);
             RDBG(1);
             if (root >= 0 && !best.ok) {  // near-voxel retry with the literal unit mismatch
@@ -386,25 +449,20 @@ IMD void residual_point(const RegMapDev& m, const ScanParams& sp, const double* 
         o_match[i] = matched ? 1 : 0;
         o_node[i] = best.node;
         if (matched) {
-            const int nd = best.node;
-            const double nrm_d[3] = {m.nodes[nd].p_normal[0], m.nodes[nd].p_normal[1], m.nodes[nd].p_normal[2]};
-            const double cen[3] = {m.nodes[nd].p_center[0], m.nodes[nd].p_center[1], m.nodes[nd].p_center[2]};
+            const PlaneRegs& P = best.P;
             // residual (:1372-1392): float normals, unrounded world point
-            const float nxf = (float)nrm_d[0], nyf = (float)nrm_d[1], nzf = (float)nrm_d[2];
-            const float dis = (float)(pwd[0] * (double)nxf + pwd[1] * (double)nyf + pwd[2] * (double)nzf + (double)m.nodes[nd].d);
+            const float nxf = (float)P.n[0], nyf = (float)P.n[1], nzf = (float)P.n[2];
+            const float dis = (float)(pwd[0] * (double)nxf + pwd[1] * (double)nyf + pwd[2] * (double)nzf + (double)P.d);
             o_dis[i] = dis;
-            o_normal[(size_t)i * 3 + 0] = nrm_d[0]; o_normal[(size_t)i * 3 + 1] = nrm_d[1]; o_normal[(size_t)i * 3 + 2] = nrm_d[2];
+            o_normal[(size_t)i * 3 + 0] = P.n[0]; o_normal[(size_t)i * 3 + 1] = P.n[1]; o_normal[(size_t)i * 3 + 2] = P.n[2];
             // H / R^-1 (:1493-1575)
             const double nv[3] = {(double)nxf, (double)nyf, (double)nzf};
             double cm[9];
-            skew(pimu, cm);
-            double pthis[3] = {pimu[0], pimu[1], pimu[2]};
-            double bv[9], varw[9];
-            calc_body_var(pthis, sp.dept_err, sp.calib_laser ? sp.dvar_calib : sp.dvar_beam, bv);
-            m3_sandwich(RextR, bv, varw);
-            const double J[6] = {pwd[0] - cen[0], pwd[1] - cen[1], pwd[2] - cen[2], -nrm_d[0], -nrm_d[1], -nrm_d[2]};
-            double sigma_l;
-            plane_sigma(m, nd, J, &sigma_l);
+            skew(q.pimu, cm);
+            double varw[9];
+            m3_sandwich(RextR, q.bv, varw);
+            const double J[6] = {pwd[0] - P.c[0], pwd[1] - P.c[1], pwd[2] - P.c[2], -P.n[0], -P.n[1], -P.n[2]};
+            const double sigma_l = plane_sigma(P.pv, J);
             double vn[3];
             m3t_vec(varw, nv, vn);
             const double nvn = vn[0] * nv[0] + vn[1] * nv[1] + vn[2] * nv[2];
@@ -452,7 +510,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
     double acc[RES_NR];
 #pragma unroll
     for (int k = 0; k < RES_NR; k++) acc[k] = 0;
-    if (i < n) residual_point(m, sp, sp.R, sp.t, sp.RextR, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+    if (i < n) { PointPrep q; residual_prep(sp, pts, i, q); residual_pass(m, sp, sp.R, sp.t, sp.RextR, q, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal); }
     RDBG(3);
     __shared__ double red[RES_NR][65];
     __shared__ int s_last;
@@ -508,38 +566,218 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The whole iterated update of a scan as ONE launch (Voxel_mapping::lio_state_estimation, src/voxel_mapping.cpp:1284-1652).
-// Round 2 enqueued one residual_kernel per EKF iteration: four dispatches in a row, each paying the launch / drain of a kernel boundary
-// (~6-8 us of a ~27 us pass) and re-reading its arguments.  Here the grid stays resident: every wavefront owns the point tiles
-// blockIdx.x, blockIdx.x + gridDim.x, ... for all passes; a pass ends in a grid-wide hand-over --
-//   block partials -> write-through stores;  arrive counter (one returning atomic);  the LAST wavefront to arrive adds the partials in block
-//   order, runs the 18-state update (ekf_step_wave) and publishes the new iterate;  epoch word = pass number, the others poll it --
-// and the next pass starts from the published pose.  No deadlock: the grid is capped (launch_residual_persistent) far below what the chip
-// holds resident, and nothing the grid waits for is queued behind it.  Values that cross wavefronts inside the launch (partials, iterate, loop
-// state, epoch) are write-through stores / coherent loads: the eight XCDs do not share an L2.
-// The gain constants P11^-1 and P21 P11^-1 (kernel arguments in round 2: they no longer fit beside the prior covariance) are computed by every
-// wavefront at launch into LDS: a 6x6 Gauss-Jordan in registers, ~1 k cycles off the critical tail.
+// Round 2 enqueued one residual_kernel per EKF iteration and let the LAST block of each launch add the block partials and run the 18-state
+// update: per pass ~9 us of point work and ~15 us of serial tail (arrive atomic, three dependent batches of partial loads, the update, the
+// publication of the new pose, the relaunch).  Here the grid stays resident for all passes and the tail is an ALL-GATHER instead of a hand-over:
+//   * a block = 4 wavefronts = 256 points per pass (tiles strided over the grid); per-wavefront LDS transpose sums, combined in wave order;
+//   * the block's 32 partial sums go out as write-through stores into this pass's slots of a buffer that holds a SENTINEL (a NaN bit pattern
+//     no computation produces) everywhere else: the data is its own flag -- no arrive counter, no release fence, no ordering between words;
+//   * wavefront 0 of EVERY block polls all slots of the pass (coherent loads, retried until no sentinel is left), adds them in block order and
+//     runs the update itself.  Every block thereby holds the same iterate bit for bit (same values, same order, same instructions) and goes on
+//     to the next pass without waiting for anybody's publication.  Block 0 also writes what leaves the kernel (posterior for the map update /
+//     the host).
+//   * slots are per pass and per scan parity; a launch re-arms the OTHER parity's slots for the next scan.
+// No deadlock: the grid is capped (launch_residual_persistent) far below what the chip holds resident and waits for nothing queued behind it.
+// The update itself (rp_update) is the algebra of ekf_host.hpp / the reference regrouped for latency: with K1 = [X; T X] (X = (H^T R^-1 H +
+// P11^-1)^-1, T = P21 P11^-1) the solution is K1 (H^T z - H^T H vec6) + vec -- G = K1 H^T H is never formed -- and the posterior covariance
+// P - K1 (H^T H P[0:6,:]) is only evaluated by the pass that stops the loop.
 // ---------------------------------------------------------------------------------------------------------------------
-#define RP_MAX_BLOCKS 512
-#define RP_HIST_DOUBLES 32     /* per-pass record of the iterate: st[24], tot[4], rematch, done */
-__global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
-                                                                  double* __restrict__ partials_all, double* __restrict__ hist_all, unsigned int* __restrict__ sync, unsigned int epoch_base,
-                                                                  double* __restrict__ reg_out, double ticket,
-                                                                  int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
-                                                                  float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
-    __shared__ double red[RES_NR][65];
-    __shared__ double pc[108];       // [0,36) P11^-1, [36,108) P21 P11^-1
-    __shared__ int s_last;
-    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
-    const int lane = threadIdx.x;
-    const ScanParams& sp = a.sp;     // per-scan constants stay kernel arguments (scalar loads); only the iterate below changes between passes
-    double Rm[9], tv[3], RextR[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) { Rm[k] = a.sp.R[k]; RextR[k] = a.sp.RextR[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; k++) tv[k] = a.sp.t[k];
-    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
-    // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
+#define RP_MAX_BLOCKS 128
+#define RP_SENTINEL 0x7FF8DEADBEEF0001ull
+struct RpShared {
+    double red[4][RES_NR][65];   // per-wavefront transposes
+    double wsum[4][RES_NR];
+    double pc[108];              // [0,36) P11^-1, [36,108) T = P21 P11^-1
+    double st[24];               // the iterate (identical in every block)
+    double sums[48];             // this pass: 36 HTH (row-major) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
+    double X[36], y[6], sol[18];
+    double M[108], XM[108];      // stop pass: H^T H P[0:6,:] and X times it
+    double tot[4];               // cumulative over the passes: n_plane_tests, n_extra_probe, passes, n_match
+    int rematch, stop;
+};
+IMD void lds_wave_sync() {   // make this wavefront's LDS writes visible to its own later reads (the other wavefronts of the block are parked at a barrier)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// one wavefront; S.sums / S.st / S.rematch / S.tot in, S.st / S.rematch / S.tot / S.stop out.  cov = the prior covariance (kernel argument).
+__device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, const int it, const int lane, const bool writer, RegState* __restrict__ rs,
+                                          double* __restrict__ reg_out, const double ticket, unsigned long long* __restrict__ dbg) {
+    unsigned long long tk = dbg ? __builtin_readcyclecounter() : 0;
+#define EDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0 && writer) dbg[40 + (k)] += _t - tk; tk = _t; } } while (0)
+    // ---- X = (H^T R^-1 H + P11^-1)^-1: lane j < 12 holds column j of [S | I]; Gauss-Jordan without pivoting (symmetric positive definite)
     {
+        double c6[6];
+        const int j = lane < 12 ? lane : 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++) c6[r] = j < 6 ? S.sums[r * 6 + j] + S.pc[r * 6 + j] : ((r == j - 6) ? 1.0 : 0.0);
+#pragma unroll
+        for (int col = 0; col < 6; col++) {
+            const double d = rl_d(c6[col], col);
+            double f[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) f[r] = rl_d(c6[r], col);
+            c6[col] = c6[col] * fast_rcp(d);
+#pragma unroll
+            for (int r = 0; r < 6; r++) if (r != col) c6[r] -= f[r] * c6[col];
+        }
+        if (lane >= 6 && lane < 12) {
+#pragma unroll
+            for (int r = 0; r < 6; r++) S.X[r * 6 + (lane - 6)] = c6[r];
+        }
+    }
+    EDBG(0);
+    // ---- vec = prior [-] state (every lane computes the same 18 values)
+    double st[24], vec[18];
+#pragma unroll
+    for (int k = 0; k < 24; k++) st[k] = S.st[k];
+    {
+        double Rt[9], rotd[9], pR[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) pR[k] = a.prior[k];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j2 = 0; j2 < 3; j2++) Rt[i * 3 + j2] = st[j2 * 3 + i];
+        m3_mul(Rt, pR, rotd);
+        dev_so3_log(rotd, vec);
+#pragma unroll
+        for (int k = 0; k < 15; k++) vec[3 + k] = a.prior[9 + k] - st[9 + k];
+    }
+    EDBG(1);
+    // ---- solution = K1 (H^T z - H^T H vec6) + vec,  K1 = [X; T X]
+    lds_wave_sync();
+    if (lane < 6) {
+        double w[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double sacc = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) sacc += S.sums[r * 6 + c] * vec[c];
+            w[r] = S.sums[36 + r] - sacc;
+        }
+        double yv = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) yv += S.X[lane * 6 + c] * w[c];
+        S.y[lane] = yv;
+    }
+    lds_wave_sync();
+    if (lane < 18) {
+        double v = 0, sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 18; k++) if (lane == k) v = vec[k];
+        if (lane < 6) sacc = S.y[lane];
+        else {
+#pragma unroll
+            for (int q = 0; q < 6; q++) sacc += S.pc[36 + (lane - 6) * 6 + q] * S.y[q];
+        }
+        S.sol[lane] = sacc + v;
+    }
+    lds_wave_sync();
+    double sol[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) sol[k] = S.sol[k];
+    EDBG(2);
+    // ---- state += solution, stop rule (voxel_mapping.cpp:1600-1650)
+    {
+        double E[9], Rn[9];
+        dev_so3_exp(sol[0], sol[1], sol[2], E);
+        m3_mul(st, E, Rn);
+#pragma unroll
+        for (int k = 0; k < 9; k++) st[k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 15; k++) st[9 + k] += sol[3 + k];
+    }
+    const double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
+    const double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    const bool converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
+    int rematch = S.rematch;
+    if (converged || ((rematch == 0) && (it == (a.max_iter - 2)))) rematch++;
+    const bool stop = rematch >= 2 || (it == a.max_iter - 1);
+    const double t_tests = S.tot[0] + S.sums[44], t_extra = S.tot[1] + S.sums[45], t_pass = S.tot[2] + 1.0, t_match = S.tot[3] + S.sums[42];
+    lds_wave_sync();
+    if (lane < 24) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
+        S.st[lane] = v;
+    }
+    if (lane == 0) { S.rematch = rematch; S.stop = stop ? 1 : 0; S.tot[0] = t_tests; S.tot[1] = t_extra; S.tot[2] = t_pass; S.tot[3] = t_match; }
+    EDBG(3);
+    EDBG(4);
+    if (dbg && lane == 0 && writer) dbg[47] += 1;
+#undef EDBG
+}
+
+// The pass that stops the loop, block 0, all 256 threads: posterior covariance P - K1 (H^T H P[0:6,:]) (M = H^T H P6, XM = X M, rows 6..17 = T XM),
+// posterior pose for the map update / full-scan transform queued behind this launch (read after the kernel boundary) and for the host, ticket.
+__device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, RegState* __restrict__ rs, double* __restrict__ reg_out, const double ticket) {
+    const int tid = threadIdx.x;
+    const double* cov = a.mat;
+    if (tid < 108) {
+        const int r = tid / 18, c = tid % 18;
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sacc += S.sums[r * 6 + k] * cov[k * 18 + c];
+        S.M[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 108) {
+        const int r = tid / 18, c = tid % 18;
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sacc += S.X[r * 6 + k] * S.M[k * 18 + c];
+        S.XM[tid] = sacc;
+    }
+    __syncthreads();
+    for (int e = tid; e < 324; e += 256) {
+        const int r = e / 18, c = e % 18;
+        double upd;
+        if (r < 6) upd = S.XM[r * 18 + c];
+        else {
+            upd = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) upd += S.pc[36 + (r - 6) * 6 + k] * S.XM[k * 18 + c];
+        }
+        const double sacc = cov[e] - upd;
+        __hip_atomic_store((unsigned long long*)&reg_out[24 + e], (unsigned long long)__double_as_longlong(sacc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (r < 3 && c < 3) rs->sp.rot_var[r * 3 + c] = sacc;                       // the map update propagates the POSTERIOR covariance blocks
+        if (r >= 3 && r < 6 && c >= 3 && c < 6) rs->sp.t_var[(r - 3) * 3 + (c - 3)] = sacc;
+    }
+    if (tid < 24) {
+        const double v = S.st[tid];
+        rs->st[tid] = v;
+        __hip_atomic_store((unsigned long long*)&reg_out[tid], (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid < 9) {
+            rs->sp.R[tid] = v;
+            const int r = tid / 3, c = tid % 3;
+            rs->sp.RextR[tid] = S.st[r * 3 + 0] * a.sp.extR[0 * 3 + c] + S.st[r * 3 + 1] * a.sp.extR[1 * 3 + c] + S.st[r * 3 + 2] * a.sp.extR[2 * 3 + c];
+        } else if (tid < 12) rs->sp.t[tid - 9] = v;
+    }
+    if (tid == 64) {
+        rs->rematch = S.rematch; rs->done = 1;
+        const double o[6] = {S.tot[2], S.sums[42], S.sums[43], S.tot[0], S.tot[1], S.tot[3]};
+        for (int k = 0; k < 6; k++) __hip_atomic_store((unsigned long long*)&reg_out[348 + k], (unsigned long long)__double_as_longlong(o[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&reg_out[REG_OUT_DOUBLES - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
+                                                                   double* __restrict__ slots, double* __restrict__ slots_next, int n_slots_next,
+                                                                   double* __restrict__ reg_out, double ticket,
+                                                                   int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
+                                                                   float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+    __shared__ RpShared S;
+    __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const ScanParams& sp = a.sp;     // per-scan constants stay kernel arguments (scalar loads); only the iterate changes between passes
+    unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+    // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
+    if (wv == 0) {
+        // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
         double c6[6];
         const int j = lane < 12 ? lane : 0;
 #pragma unroll
@@ -550,130 +788,121 @@ __global__ __launch_bounds__(64) void residual_persistent_kernel(RegMapDev m, Re
             double f[6];
 #pragma unroll
             for (int r = 0; r < 6; r++) f[r] = rl_d(c6[r], col);
-            c6[col] = c6[col] / d;
+            c6[col] = c6[col] * fast_rcp(d);
 #pragma unroll
             for (int r = 0; r < 6; r++) if (r != col) c6[r] -= f[r] * c6[col];
         }
         if (lane >= 6 && lane < 12) {
 #pragma unroll
-            for (int r = 0; r < 6; r++) pc[r * 6 + (lane - 6)] = c6[r];
+            for (int r = 0; r < 6; r++) S.pc[r * 6 + (lane - 6)] = c6[r];
         }
-        __syncthreads();
+        lds_wave_sync();
         for (int e = lane; e < 72; e += 64) {
             const int i = e / 6, q = e % 6;
             double sacc = 0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) sacc += a.mat[(6 + i) * 18 + k] * pc[k * 6 + q];
-            pc[36 + e] = sacc;
+            for (int k = 0; k < 6; k++) sacc += a.mat[(6 + i) * 18 + k] * S.pc[k * 6 + q];
+            S.pc[36 + e] = sacc;
         }
-        __syncthreads();
+        if (lane < 24) S.st[lane] = a.st[lane];
+        if (lane == 0) { S.rematch = 0; S.stop = 0; S.tot[0] = S.tot[1] = S.tot[2] = S.tot[3] = 0.0; }
     }
+    __syncthreads();
     const int ntiles = (n + 63) / 64;
+    const int G = (int)gridDim.x;
+    const bool one_tile = ntiles <= G * 4;
+    PointPrep prep;
+    prep.key = PREP_NO_KEY; prep.root = -1;
     for (int it = 0; it < a.max_iter; it++) {
-        // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] points done [2] arrived [3] partials summed [4] update done [5] published [6] last?
-        unsigned long long* const tr = (sp.dbg && lane == 0 && it < 8) ? sp.dbg + (64 + 16384 * 8) + ((size_t)it * 512 + blockIdx.x) * 8 : nullptr;
-        // everything that crosses wavefronts inside the launch has its own address per pass (block partials, the iterate + loop state): a line
-        // is written once and read after that, never re-read from an XCD's L2 that may have kept an earlier pass's copy
-        double* const partials = partials_all + (size_t)it * gridDim.x * RES_NR;
-        const double* const hprev = hist_all + (size_t)(it > 0 ? it - 1 : 0) * RP_HIST_DOUBLES;
-        if (it > 0) {
-            // the update of pass it - 1 has been published when the epoch word says so
-            __builtin_amdgcn_s_setprio(0);
-            while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch_base + (unsigned int)it) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_s_setprio(3);
-            if (dev_observe(&hprev[29]) != 0.0) break;   // the loop stopped with that pass
-            // (wave-uniform: through readfirstlane into scalar registers -- 21 doubles in vector registers for the whole pass otherwise)
+        // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] block partials out [2] all partials in [3] update done
+        unsigned long long* const tr = (sp.dbg && threadIdx.x == 0 && it < 8) ? sp.dbg + (64 + 16384 * 8) + ((size_t)it * 512 + blockIdx.x) * 8 : nullptr;
+        if (tr) tr[0] = __builtin_amdgcn_s_memrealtime();
+        if (sp.dbg && lane == 0) { atomicAdd(&sp.dbg[6], 1ull); if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
+        // the iterate of this pass: wave-uniform, through readfirstlane into scalar registers
+        double Rm[9], tv[3], RextR[9];
 #pragma unroll
-            for (int k = 0; k < 9; k++) Rm[k] = uni_d(dev_observe(&hprev[k]));
+        for (int k = 0; k < 9; k++) Rm[k] = uni_d(S.st[k]);
 #pragma unroll
-            for (int k = 0; k < 3; k++) tv[k] = uni_d(dev_observe(&hprev[9 + k]));
-            {
-                double t9[9];
-                m3_mul(Rm, sp.extR, t9);
+        for (int k = 0; k < 3; k++) tv[k] = uni_d(S.st[9 + k]);
+        {
+            double t9[9];
+            m3_mul(Rm, sp.extR, t9);
 #pragma unroll
-                for (int k = 0; k < 9; k++) RextR[k] = uni_d(t9[k]);
-            }
-            if (sp.dbg) tprev = __builtin_readcyclecounter();
+            for (int k = 0; k < 9; k++) RextR[k] = uni_d(t9[k]);
         }
-        if (sp.dbg && lane == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
-        if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[6] = 0; }
+        if (sp.dbg) tprev = __builtin_readcyclecounter();
         double acc[RES_NR];
 #pragma unroll
         for (int k = 0; k < RES_NR; k++) acc[k] = 0;
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += G * 4) {
             const int i = tile * 64 + lane;
-            if (i < n) residual_point(m, sp, Rm, tv, RextR, pts, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+            if (i < n) {
+                if (!(one_tile && it > 0)) residual_prep(sp, pts, i, prep);   // one tile per wavefront (any down-sampled scan): the pass-independent part is computed once
+                residual_pass(m, sp, Rm, tv, RextR, prep, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
+            }
         }
         RDBG(3);
-        if (tr) tr[1] = __builtin_amdgcn_s_memrealtime();
-        // ---- block sums (LDS transpose: lane k adds column k in lane order -- fixed order) -> write-through partials -> arrive
-        __syncthreads();   // (the previous pass's readers of `red` are done)
+        // ---- per-wavefront sums (LDS transpose: lane k adds column k in lane order -- a fixed order), combined in wave order
 #pragma unroll
-        for (int k = 0; k < RES_NR; k++) red[k][lane] = acc[k];
-        __syncthreads();
+        for (int k = 0; k < RES_NR; k++) S.red[wv][k][lane] = acc[k];
+        lds_wave_sync();
         {
             const int k = lane & 31, half = lane >> 5;
             double ssum = 0;
-            for (int j = 0; j < 32; j++) ssum += red[k][half * 32 + j];
+            for (int j = 0; j < 32; j++) ssum += S.red[wv][k][half * 32 + j];
             ssum += __shfl_xor(ssum, 32, 64);
-            if (lane < RES_NR) dev_publish(&partials[(size_t)blockIdx.x * RES_NR + lane], ssum);
+            if (lane < RES_NR) S.wsum[wv][lane] = ssum;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) s_last = (atomicAdd(&sync[0], 1u) == gridDim.x - 1) ? 1 : 0;
         __syncthreads();
-        RDBG(4);
-        if (tr) { tr[2] = __builtin_amdgcn_s_memrealtime(); tr[6] = (unsigned long long)s_last; }
-        if (!s_last) continue;
-        // ---- last wavefront of the pass: stage what the 18-state update needs (LDS, beside the running sums), add the partials, update
-        double* L = &red[0][0];
-        double* Cst = L + 400;
-        __syncthreads();
-        for (int e = lane; e < EKF_C_DOUBLES; e += 64) {
-            double v;
-            if (e < 108) v = pc[e];
-            else if (e < 132) v = it == 0 ? a.st[e - 108] : dev_observe(&hprev[e - 108]);
-            else if (e < 156) v = a.prior[e - 132];
-            else if (e < 160) v = it == 0 ? 0.0 : dev_observe(&hprev[24 + (e - 156)]);
-            else v = it == 0 ? 0.0 : dev_observe(&hprev[28]);
-            Cst[e] = v;
-        }
-        double tot = 0;
-        {
+        double* const pass_slots = slots + (size_t)it * RP_MAX_BLOCKS * RES_NR;
+        if (wv == 0) {
+            if (lane < RES_NR) dev_publish(&pass_slots[(size_t)blockIdx.x * RES_NR + lane], ((S.wsum[0][lane] + S.wsum[1][lane]) + S.wsum[2][lane]) + S.wsum[3][lane]);
+            RDBG(4);
+            if (tr) tr[1] = __builtin_amdgcn_s_memrealtime();
+            // ---- all-gather: poll every block's slots of this pass until no sentinel is left; blocks are added in ascending order, two
+            // interleaved halves of the list combined last (fixed order: every block computes the same bits)
             const int k = lane & 31;
-            const unsigned int nb = gridDim.x;
-            for (unsigned int b0 = (unsigned int)(lane >> 5); b0 < nb; b0 += 64) {
+            double tot = 0;
+            __builtin_amdgcn_s_setprio(1);
+            for (int b0 = lane >> 5; b0 < G; b0 += 64) {
                 double v[32];
+                for (;;) {
+                    bool ok = true;
 #pragma unroll
-                for (int u = 0; u < 32; u++) {
-                    const unsigned int b = b0 + 2u * u;
-                    v[u] = b < nb ? dev_observe(&partials[(size_t)b * RES_NR + k]) : 0.0;
+                    for (int u = 0; u < 32; u++) {
+                        const int b = b0 + 2 * u;
+                        unsigned long long bits = 0;
+                        if (b < G) bits = __hip_atomic_load((const unsigned long long*)&pass_slots[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && bits != RP_SENTINEL;
+                        v[u] = __longlong_as_double((long long)bits);
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int u = 0; u < 32; u++) tot += v[u];
             }
+            __builtin_amdgcn_s_setprio(3);
             tot += __shfl_xor(tot, 32, 64);
+            if (tr) tr[2] = __builtin_amdgcn_s_memrealtime();
+            // host layout of the sums: 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
+            S.wsum[0][lane & 31] = tot;   // (both halves hold the same totals)
+            lds_wave_sync();
+            double v48 = 0;
+            if (lane < 36) { const int r = lane / 6, c = lane % 6; v48 = S.wsum[0][r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
+            else if (lane < 42) v48 = S.wsum[0][21 + (lane - 36)];
+            else if (lane < 46) v48 = S.wsum[0][27 + (lane - 42)];
+            if (lane < 46) S.sums[lane] = v48;
+            lds_wave_sync();
+            rp_update(S, a, it, lane, blockIdx.x == 0, rs, reg_out, ticket, sp.dbg);
+            if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
+            RDBG(5);
         }
-        if (lane == 0) __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
-        L[lane] = tot;
         __syncthreads();
-        double v48 = 0;   // 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
-        if (lane < 36) { const int r = lane / 6, c = lane % 6; v48 = L[r <= c ? sym21_index(r, c) : sym21_index(c, r)]; }
-        else if (lane < 42) v48 = L[21 + (lane - 36)];
-        else if (lane < 46) v48 = L[27 + (lane - 42)];
-        __syncthreads();
-        if (lane < 46) L[64 + lane] = v48;
-        __syncthreads();
-        if (lane == 0) { Cst[156] += L[64 + 44]; Cst[157] += L[64 + 45]; Cst[159] += L[64 + 42]; }
-        __syncthreads();
-        const bool stop = ekf_step_wave(rs, Cst, a.mat, L + 64, L + 64 + 36, L[64 + 42], L[64 + 43], L + 128, lane, it, a.max_iter, a.sp.extR, reg_out, ticket, sp.dbg, hist_all + (size_t)it * RP_HIST_DOUBLES);
-        if (tr) tr[4] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (lane == 0) __hip_atomic_store(&sync[1], epoch_base + (unsigned int)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tr) tr[5] = __builtin_amdgcn_s_memrealtime();
-        RDBG(5);
-        if (stop) break;
+        if (S.stop) {
+            if (blockIdx.x == 0) rp_finish(S, a, rs, reg_out, ticket);
+            break;
+        }
     }
 }
 
@@ -841,7 +1070,7 @@ IMD void fit_eigen(FE&& for_each_point, const int n, const float planer_threshol
         s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
     });
 #pragma unroll
-    for (int k = 0; k < 9; k++) s[k] = wave_sum(s[k]);
+    for (int k = 0; k < 9; k++) s[k] = wave_sum_fast(s[k]);
     const double dn = (double)n;
     f.c[0] = s[0] / dn; f.c[1] = s[1] / dn; f.c[2] = s[2] / dn;
     double cov[9];
@@ -900,7 +1129,7 @@ IMD void fit_plane_var(FE&& for_each_point, const int n, const PlaneFit& f, doub
         for (int r = 0; r < 6; r++) acc[9 + r] += q[3 + r];
     });
 #pragma unroll
-    for (int k = 0; k < 15; k++) acc[k] = wave_sum(acc[k]);
+    for (int k = 0; k < 15; k++) acc[k] = wave_sum_fast(acc[k]);
     const double dn = (double)n;
     const double e0 = f.ev[0], e1 = f.ev[1], e2 = f.ev[2];
     const double evmin = sel3(imin, e0, e1, e2);
@@ -1189,7 +1418,7 @@ __device__ int wave_replay_planar_root(const RegMapDev& m, const int root, const
     for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
     auto chunk_of = [&](int ci) { int c = chunks[0];
 #pragma unroll
-        for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
+        for (int k = 1; k < IM_INLINE_CHUNKS; k++) { const int ck = chunks[k]; c = (ci == k) ? ck : c; }   // (by value: a conditional on lvalues selects ADDRESSES and pins the array to memory)
         return c; };
     // running per-axis sums of the retained points: only needed when a refit falls due inside this batch
     double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
@@ -1330,12 +1559,12 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + wv;
     // IMMESH_DEBUG: one trace record per wavefront of the launch (plain stores, no contention): [0] start, [1] end (s_memrealtime, 100 MHz),
-    // [2..5] eight 32-bit cycle counts (root known, header, list, sort, load, decide, commit, plane), [6] cnt | n_ref << 8 | state << 16
+    // [2..6] ten 32-bit cycle counts (root known, node line 0, chunk table, list head, list, sort, load, decide, commit, plane), [7] cnt | n_ref << 8 | state << 16
     unsigned long long* const tr = (dbg && lane == 0 && t < DBG_FUSED_RECS) ? dbg + DBG_FUSED_OFF + (size_t)t * 8 : nullptr;
     unsigned long long tprev = dbg ? __builtin_readcyclecounter() : 0;
-    if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = tr[3] = tr[4] = tr[5] = tr[6] = 0; }
+    if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = tr[3] = tr[4] = tr[5] = tr[6] = tr[7] = 0; }
 #define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tr) ((unsigned int*)tr)[4 + (k)] = (unsigned int)(_t - tprev); tprev = _t; } } while (0)
-#define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[6] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
+#define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
     if (t >= m.counters[7]) { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); } return; }
     const uint32_t slot = m.touched[t];
     const int root = m.htab[slot].root;
@@ -1345,17 +1574,19 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     // node header and the head of the point list: independent loads, one latency
     const int flags = nd.flags, layer = nd.layer;
     const int npts = nd.npts, newp = nd.newpts;
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FDBG(1); }   // (debug build only: the three loads are timed one by one)
     int chunks[IM_INLINE_CHUNKS];
 #pragma unroll
     for (int k = 0; k < IM_INLINE_CHUNKS; k++) chunks[k] = nd.chunks[k];
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FDBG(2); }
     int cnt = 0;
     int ihead = (int)(unsigned int)(m.slot_head[slot] & 0xFFFFFFFFull);
-    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FDBG(1); }
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FDBG(3); }
     for (int i = ihead; i >= 0; i = pt_next[i]) {
         if (cnt < RL_CAP && lane == 0) { skey[wv][cnt] = sort_key[i]; sidx[wv][cnt] = i; }
         cnt++;
     }
-    FDBG(2);
+    FDBG(4);
     const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
     if (layer == 0 && (flags & want) == (NF_INIT | NF_PLANE)) { FEND(1, 0); return; }   // a full planar root (m_update_enable_ == false) drops every point
     const int ntot = npts + cnt;
@@ -1374,10 +1605,10 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        FDBG(3);
+        FDBG(5);
         auto chunk_of = [&](int ci) { int c = chunks[0];
 #pragma unroll
-            for (int k = 1; k < IM_INLINE_CHUNKS; k++) c = (ci == k) ? chunks[k] : c;
+            for (int k = 1; k < IM_INLINE_CHUNKS; k++) { const int ck = chunks[k]; c = (ci == k) ? ck : c; }   // (by value: a conditional on lvalues selects ADDRESSES and pins the array to memory)
             return c; };
         // point q of the voxel AFTER the append: q < npts retained, else this scan's point order[q - npts].  Lane i holds q = i and q = i + 64.
         const int n_ref = (newp + cnt) / 6;   // refits falling due inside the batch: new_points counts 0..5 between refits (m_update_size_threshold_ = 5)
@@ -1399,7 +1630,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
                 for (int k = 0; k < 9; k++) P1[k] = s1[k]; }
         }
         if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        FDBG(4);
+        FDBG(6);
         // ---- decisions (nothing is written yet)
         PlaneFit fit;
         long long n_ref_pts = 0;
@@ -1415,7 +1646,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
 #pragma unroll
                     for (int a = 0; a < 3; a++) { s1[a] += q[a]; s2[a] += q[a] * q[a]; } });
 #pragma unroll
-                for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
+                for (int a = 0; a < 3; a++) { s1[a] = wave_sum_fast(s1[a]); s2[a] = wave_sum_fast(s2[a]); }
                 const double dn = (double)nr;
                 double vmin = 1e300, mag = 0;
 #pragma unroll
@@ -1426,7 +1657,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
             if (!fit.planar) hand_over = true;   // the root turns non-planar in the middle of the batch: the general kernel's job (children)
             n_last = nr;
         }
-        FDBG(5);
+        FDBG(7);
         if (!hand_over) {
             // ---- commit: chunks for the new points, the points, the header, the plane
             const int c_first = (npts + IM_CHUNK_PTS - 1) >> 4, c_last = (ntot - 1) >> 4;   // chunk slots first touched by this batch
@@ -1453,14 +1684,14 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
                 for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
                 if (n_ref) { atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_ref_pts); }
             }
-            FDBG(6);
+            FDBG(8);
             if (n_ref > 0) {   // (n_last is the last refit's point count: fit holds its eigen-decomposition)
                 double pv[21];
                 auto fe = [&](auto&& fn) __attribute__((always_inline)) { if (lane < n_last) fn(P0); if (lane + 64 < n_last) fn(P1); };
                 fit_plane_var(fe, n_last, fit, pv);
                 fit_store(nd, fit, pv, lane);
             }
-            FDBG(7);
+            FDBG(9);
             FEND(2, n_ref);
             return;
         }
@@ -1606,10 +1837,11 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
     const int nb = (n + 63) / 64;
     KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
-void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, double* hist, unsigned int* sync,
-                                unsigned int epoch_base, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
-    const int nb = std::min((n + 63) / 64, RP_MAX_BLOCKS);   // resident grid: 512 single-wavefront blocks at 2 per SIMD are a quarter of the chip
-    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, hist, sync, epoch_base, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
+                                double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+    const int nb = std::min((n + 255) / 256, RP_MAX_BLOCKS);   // resident grid: at most 128 four-wavefront blocks, half a CU's worth each
+    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, reg_out, ticket, o_match, o_node,
+            o_dis, o_rinv, o_normal);
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);

@@ -32,7 +32,7 @@ class _OracleHotPath(capi.HotPath):
         self._prof = bool(on)
 
     def profile_read(self, reset=False):
-        return {"mesh_delaunay64_kernel": {"launches": 2, "total_ms": 0.25}, "residual_kernel": {"launches": 8, "total_ms": 0.16}}
+        return {"mesh_delaunay64_kernel": {"launches": 2, "total_ms": 0.25}, "residual_persistent_kernel": {"launches": 2, "total_ms": 0.16}}
 
     def last_timing(self):
         return {"total": 1.0, "register": 0.3, "map_update": 0.2, "mesh": 0.5}

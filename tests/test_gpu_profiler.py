@@ -37,5 +37,5 @@ def test_profiled_scans_with_mesher(hip_lib, mode):
         assert info["n_match"] > 1000
     ks = h.profile_read()
     h.profile_enable(False)
-    assert ks["residual_kernel"]["launches"] >= 5 * 3 and ks["mesh_delaunay64_kernel"]["launches"] == 5
+    assert ks["residual_persistent_kernel"]["launches"] == 5 and ks["mesh_delaunay64_kernel"]["launches"] == 5   # one resident launch per scan for all EKF passes
     assert 0.005 < ks["mesh_delaunay64_kernel"]["total_ms"] / 5 < 5.0

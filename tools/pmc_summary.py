@@ -7,7 +7,7 @@ from pmc_traffic import short
 rows = []
 for r in csv.DictReader(open(sys.argv[1], newline="")):
     rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
-first = min((d for d, k, *_ in rows if k == "residual_kernel"), default=0)
+first = min((d for d, k, *_ in rows if k.startswith("residual")), default=0)
 agg = defaultdict(lambda: defaultdict(list)); dur = defaultdict(list)
 for d, k, c, v, t in rows:
     if d >= first and not k.startswith(("at::", "__amd")):

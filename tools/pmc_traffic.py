@@ -35,7 +35,7 @@ def load(path, counter):
             if r["Counter_Name"] == counter:
                 rows.append((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), float(r["Counter_Value"])))
     rows.sort()
-    first = next((d for d, k, _ in rows if k == "residual_kernel"), 0)
+    first = next((d for d, k, _ in rows if k.startswith("residual")), 0)
     agg = defaultdict(list)
     for d, k, v in rows:
         if d >= first:

@@ -15,9 +15,9 @@ if len(f):
     f = f[f[:, 0] >= f[:, 0].max() - 30000]      # the LAST launch only (records of earlier launches with more wavefronts stay behind): 300 us window
     t0 = f[:, 0].min()
     start, end = (f[:, 0] - t0) * 0.01, (f[:, 1] - t0) * 0.01          # us
-    flags = f[:, 6]
+    flags = f[:, 7]
     state = (flags >> 16) & 0xFF; cnt = flags & 0xFF; nref = (flags >> 8) & 0xFF
-    ph_all = np.ascontiguousarray(f[:, 2:6]).view(np.uint32).reshape(len(f), 8).astype(np.float64)
+    ph_all = np.ascontiguousarray(f[:, 2:7]).view(np.uint32).reshape(len(f), 10).astype(np.float64)
     print(f"replay_fused: {len(f)} wavefronts traced, span {end.max():.1f} us; exit-only {int((state == 0).sum())}, dropped {int((state == 1).sum())}, "
           f"done {int((state == 2).sum())} (with a fit {int(((state == 2) & (nref > 0)).sum())}), handed over {int((state == 3).sum())}")
     for name, sel in (("exit-only", state == 0), ("dropped", state == 1), ("done, no fit", (state == 2) & (nref == 0)), ("done, fit", (state == 2) & (nref > 0)), ("handed over", state == 3)):
@@ -28,7 +28,7 @@ if len(f):
               f"duration p50/p99/max {np.percentile(d, 50):6.2f} {np.percentile(d, 99):6.2f} {d.max():6.2f} us | end max {end[sel].max():6.1f} us | cnt max {int(cnt[sel].max())}")
         if name != "exit-only":
             ph = ph_all[sel]
-            names = ["root", "header", "list", "sort", "load", "decide", "commit", "plane"]
+            names = ["root", "node0", "chunks", "head", "list", "sort", "load", "decide", "commit", "plane"]
             print("     phases (cycles, mean / max): " + "  ".join(f"{n} {ph[:, i].mean():.0f}/{ph[:, i].max():.0f}" for i, n in enumerate(names)))
 r = w[R_OFF:R_OFF + 8 * 512 * 8].reshape(8, 512, 8).astype(np.int64)
 if (r[0, :, 0] > 0).any():
@@ -40,13 +40,9 @@ if (r[0, :, 0] > 0).any():
         b = r[it][r[it, :, 0] > 0]
         if len(b) == 0 or b[:, 0].min() < t0:
             continue
-        st, pts, arr = (b[:, 0] - t0) * 0.01, (b[:, 1] - t0) * 0.01, (b[:, 2] - t0) * 0.01
-        last = b[b[:, 6] == 1]
-        line = f"  pass {it}: {len(b)} blocks; start min/max {st.min():6.2f} {st.max():6.2f}; points done p50/max {np.percentile(pts, 50):6.2f} {pts.max():6.2f}; arrived max {arr.max():6.2f}"
-        if len(last):
-            l = (last[0] - t0) * 0.01
-            line += f"; last wavefront: summed {l[3]:6.2f} update {l[4]:6.2f} published {l[5]:6.2f}"
-        print(line)
+        st, out, gat, upd = (b[:, 0] - t0) * 0.01, (b[:, 1] - t0) * 0.01, (b[:, 2] - t0) * 0.01, (b[:, 3] - t0) * 0.01
+        print(f"  pass {it}: {len(b)} blocks; start min/max {st.min():6.2f} {st.max():6.2f}; block partials out p50/max {np.percentile(out, 50):6.2f} {out.max():6.2f}; "
+              f"all gathered min/max {gat.min():6.2f} {gat.max():6.2f}; update done min/max {upd.min():6.2f} {upd.max():6.2f}")
 e = w[40:48].astype(np.int64)
 if e[7] > 0:
     print(f"ekf_step_wave cycles (mean over {e[7]} updates): gauss-jordan {e[0] / e[7]:.0f}  gain products {e[1] / e[7]:.0f}  log / solution {e[2] / e[7]:.0f}  exp / state {e[3] / e[7]:.0f}  publish (+ covariance on stop) {e[4] / e[7]:.0f}")
