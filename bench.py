@@ -102,24 +102,101 @@ def build_big_map(h, cfg, torch, dev, target_voxels, side_m, seed=20260924, also
     return nv
 
 
+def livox_scan_torch(torch, dev, k, R, t, n_pts, extT, seed=20260924, range_sigma=0.02, bearing_sigma_deg=0.05, blind=1.0):
+    """synth.livox_scan on the GPU (harness only: the long steady-state leg needs hundreds of scans, the numpy ray caster takes seconds per scan).
+    Same scan model -- Halton(2,3) directions offset per scan, the same procedural world, range / bearing noise -- with torch's generator."""
+    m = int(n_pts * 2.2) + 64
+    start = 1 + k * m
+    az = (synth.halton(m, 2, start) - 0.5) * np.deg2rad(70.4)
+    el = (synth.halton(m, 3, start) - 0.5) * np.deg2rad(77.2)
+    dirs = torch.from_numpy(np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)).to(dev)
+    Rt = torch.from_numpy(np.asarray(R, dtype=np.float64)).to(dev)
+    o = np.asarray(R, dtype=np.float64) @ np.asarray(extT, dtype=np.float64) + np.asarray(t, dtype=np.float64)
+    d = dirs @ Rt.T
+    L = synth.LATTICE
+    inf = float("inf")
+    tb = torch.full((m,), inf, dtype=torch.float64, device=dev)
+    tg = (synth.GROUND_Z - o[2]) / d[:, 2]
+    ok = (d[:, 2] < 0) & (tg > 0)
+    tb = torch.where(ok, tg, tb)
+    inv = 1.0 / torch.where(d.abs() < 1e-12, torch.full_like(d, 1e-12), d)
+    ci, cj, rc = int(np.floor(o[0] / L)), int(np.floor(o[1] / L)), int(np.ceil(100.0 / L)) + 1
+    ot = torch.from_numpy(o).to(dev)
+    for i in range(ci - rc, ci + rc + 1):
+        for j in range(cj - rc, cj + rc + 1):
+            lo = np.array([i * L + synth.BOX_LO, j * L + synth.BOX_LO, synth.GROUND_Z]); hi = np.array([i * L + synth.BOX_HI, j * L + synth.BOX_HI, synth.BOX_TOP])
+            if np.linalg.norm(0.5 * (lo + hi)[:2] - o[:2]) > 108.0:
+                continue
+            t1 = (torch.from_numpy(lo).to(dev) - ot) * inv; t2 = (torch.from_numpy(hi).to(dev) - ot) * inv
+            tn = torch.minimum(t1, t2).max(dim=1).values; tf = torch.maximum(t1, t2).min(dim=1).values
+            hit = (tn <= tf) & (tn > 0) & (tn < tb)
+            tb = torch.where(hit, tn, tb)
+    keep = torch.isfinite(tb) & (tb <= 100.0) & (tb > blind)
+    dirs, rg = dirs[keep][:n_pts], tb[keep][:n_pts]
+    g = torch.Generator(device=dev); g.manual_seed(seed + 7919 * k)
+    n = rg.shape[0]
+    pert = torch.randn((n, 3), device=dev, dtype=torch.float64, generator=g) * np.deg2rad(bearing_sigma_deg)
+    dn = dirs + torch.linalg.cross(pert, dirs)
+    dn = dn / dn.norm(dim=1, keepdim=True)
+    rn = rg + torch.randn(n, device=dev, dtype=torch.float64, generator=g) * range_sigma
+    inten = 10.0 + 80.0 * torch.rand(n, device=dev, dtype=torch.float64, generator=g)
+    return torch.cat([dn * rn[:, None], inten[:, None]], dim=1).to(torch.float32).contiguous()
+
+
+def corridor_cloud(torch, dev, n_scans, spacing=0.07, reach=45.0, seed=20260926):
+    """Dense cloud (world frame, (n, 4) float32 xyzI) of the world surfaces around the stream's trajectory: what seeds the MESH map to the density a
+    surveyed area has ("mesh map pre-seeded from the same survey, capped at the corridor").  Jittered lattice of `spacing` on the
+    ground and on the walls of the boxes inside the corridor: finer than the 0.1 m minimum vertex spacing, so the vertex lattice saturates."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    ts = np.array([synth.trajectory_pose(k)[1] for k in range(n_scans + 1)])
+    x0, x1, y0, y1 = ts[:, 0].min() - 5.0, ts[:, 0].max() + reach, ts[:, 1].min() - reach, ts[:, 1].max() + reach
+    L = synth.LATTICE
+    xs = torch.arange(x0, x1, spacing, device=dev, dtype=torch.float32); ys = torch.arange(y0, y1, spacing, device=dev, dtype=torch.float32)
+    X = xs[:, None].expand(len(xs), len(ys)).reshape(-1); Y = ys[None, :].expand(len(xs), len(ys)).reshape(-1)
+    X = X + (torch.rand(X.shape, device=dev, generator=g) - 0.5) * 0.8 * spacing; Y = Y + (torch.rand(Y.shape, device=dev, generator=g) - 0.5) * 0.8 * spacing
+    fx, fy = torch.remainder(X, L), torch.remainder(Y, L)
+    keep = ~((fx > synth.BOX_LO) & (fx < synth.BOX_HI) & (fy > synth.BOX_LO) & (fy < synth.BOX_HI))
+    X, Y = X[keep], Y[keep]
+    parts = [torch.stack([X, Y, synth.GROUND_Z + torch.randn(X.shape, device=dev, generator=g) * 0.02], dim=1)]
+    us = torch.arange(synth.BOX_LO, synth.BOX_HI, spacing, device=dev, dtype=torch.float32); zs = torch.arange(synth.GROUND_Z, synth.BOX_TOP, spacing, device=dev, dtype=torch.float32)
+    U = us[:, None].expand(len(us), len(zs)).reshape(-1); Z = zs[None, :].expand(len(us), len(zs)).reshape(-1)
+    for i in range(int(np.floor(x0 / L)), int(np.ceil(x1 / L))):
+        for j in range(int(np.floor(y0 / L)), int(np.ceil(y1 / L))):
+            for axis, val in ((0, synth.BOX_LO), (0, synth.BOX_HI), (1, synth.BOX_LO), (1, synth.BOX_HI)):
+                u = U + (torch.rand(U.shape, device=dev, generator=g) - 0.5) * 0.8 * spacing; z = Z + (torch.rand(U.shape, device=dev, generator=g) - 0.5) * 0.8 * spacing
+                w = val + torch.randn(U.shape, device=dev, generator=g) * 0.02
+                parts.append(torch.stack([i * L + w, j * L + u, z], dim=1) if axis == 0 else torch.stack([i * L + u, j * L + w, z], dim=1))
+    P = torch.cat(parts, dim=0)
+    P = P[(P[:, 0] >= x0) & (P[:, 0] <= x1) & (P[:, 1] >= y0) & (P[:, 1] <= y1)]
+    return torch.cat([P, torch.full((P.shape[0], 1), 50.0, device=dev)], dim=1).contiguous()
+
+
+def _gen_scan(job):
+    k, n_pts, extT, kitti, f = job
+    if not os.path.exists(f):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.hdl64_scan(k, R, t) if kitti else synth.livox_scan(k, R, t, n_pts=n_pts, extT=np.array(extT))
+        tmp = f + f".{os.getpid()}.tmp.npy"     # ranks generate the same scans concurrently: publish atomically
+        np.save(tmp, raw)
+        os.replace(tmp, f)
+    raw = np.load(f)
+    return raw, synth.voxel_grid_downsample(raw, 0.5 if kitti else 0.4)   # filter_size_surf: avia.yaml:5 / velodyne.yaml:5
+
+
 def make_scans(n_scans, n_pts, cfg, cache_dir, kitti=False):
-    """Synthetic Livox-shaped stream: raw scans (lidar frame, xyzI) + the VoxelGrid-downsampled clouds."""
+    """Synthetic Livox-shaped stream: raw scans (lidar frame, xyzI) + the VoxelGrid-downsampled clouds.  The numpy ray caster takes
+    1-2 s per scan: the scans of a run are generated by a pool of host processes (the CPU-baseline leg wants >= 220 of them)."""
     os.makedirs(cache_dir, exist_ok=True)
-    extT = np.array(list(cfg.extT))
-    raws, downs = [], []
-    for k in range(n_scans):
-        f = os.path.join(cache_dir, f"hdl64_{k}.npy" if kitti else f"livox_{n_pts}_{k}.npy")
-        if os.path.exists(f):
-            raw = np.load(f)
-        else:
-            R, t = synth.trajectory_pose(k)
-            raw = synth.hdl64_scan(k, R, t) if kitti else synth.livox_scan(k, R, t, n_pts=n_pts, extT=extT)
-            tmp = f + f".{os.getpid()}.tmp.npy"     # ranks generate the same scans concurrently: publish atomically
-            np.save(tmp, raw)
-            os.replace(tmp, f)
-        raws.append(raw)
-        downs.append(synth.voxel_grid_downsample(raw, 0.5 if kitti else 0.4))   # filter_size_surf: avia.yaml:5 / velodyne.yaml:5
-    return raws, downs
+    extT = tuple(cfg.extT)
+    jobs = [(k, n_pts, extT, kitti, os.path.join(cache_dir, f"hdl64_{k}.npy" if kitti else f"livox_{n_pts}_{k}.npy")) for k in range(n_scans)]
+    nproc = max(1, min(64, (os.cpu_count() or 1) - 2, n_scans))
+    if nproc > 1 and sum(0 if os.path.exists(j[4]) else 1 for j in jobs) > 4:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(nproc) as pool:
+            out = pool.map(_gen_scan, jobs, chunksize=1)
+    else:
+        out = [_gen_scan(j) for j in jobs]
+    return [o[0] for o in out], [o[1] for o in out]
 
 
 # algorithmic bytes of one launch of each kernel (SURVEY.md 8(d) record sizes; DESIGN.md "Kernels")
@@ -198,9 +275,21 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     comm = "none"
     if sharded:
         comm = D.attach_collectives(h, hip, dist, args.backend, dev, world, bool(args.mesh))
-    n_extra = 2 * args.profile_scans if full else 0
+    n_extra = (2 * args.profile_scans if full else 0) + (args.nu_scans if args.mesh else 0)
     n_total = args.warmup + args.steps + n_extra
-    raws, downs = make_scans(n_total + 1 + (world - 1), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
+    n_cpu = int(min(260, 24 + args.cpu_seconds * 12)) if (full and args.cpu_seconds > 0 and rank == 0 and not args.gpu_scans) else 0   # the CPU-baseline leg replays the stream from scan 1: 20 + 200 + the all-cores sample
+    extT_np = np.array(list(cfg.extT))
+    if args.gpu_scans and not kitti:
+        # scans ray-cast on the GPU (harness), down-sampled by the library's own VoxelGrid BEFORE the timed region: the long steady-state leg
+        raws, downs, d_raw, d_down = [], [], [], []
+        for kk in range(n_total + 1):
+            Rk, tk = synth.trajectory_pose(kk)
+            r = livox_scan_torch(torch, dev, kk, Rk, tk, args.pts, extT_np)
+            dn, _ = h.downsample(r.data_ptr(), 0.4, n=r.shape[0], stride=4, to_host=True)
+            d_raw.append(r); d_down.append(torch.from_numpy(dn).to(dev)); raws.append(np.empty((r.shape[0], 0))); downs.append(dn)
+    else:
+        raws, downs = make_scans(max(n_total + 1 + (world - 1), n_cpu), args.pts, cfg, os.path.join(os.environ.get("TMPDIR", "/tmp"), "immesh_scan_cache"), kitti)
+        cpu_raws, cpu_downs = raws, downs
     if kitti:   # the map grows from the stream itself (3 m root voxels, max_layer 4)
         R0_, t0_ = synth.trajectory_pose(0)
         h.map_build(np.ascontiguousarray(raws[0][:, :3]), capi.make_state(R=R0_, t=t0_))
@@ -208,10 +297,26 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     else:
         n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)
     idx = D.stream_of_rank(0 if sharded else rank, n_total)   # replicas: rank r replays the stream phase-shifted by r scans; sharded: one stream
-    raws, downs = [raws[i] for i in idx], [downs[i] for i in idx]
-    d_raw = [torch.from_numpy(r).to(dev) for r in raws]
-    d_down = [torch.from_numpy(d).to(dev) for d in downs]
+    if not (args.gpu_scans and not kitti):
+        raws, downs = [raws[i] for i in idx], [downs[i] for i in idx]
+        d_raw = [torch.from_numpy(r).to(dev) for r in raws]
+        d_down = [torch.from_numpy(d).to(dev) for d in downs]
     n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))
+    mesh_seed = None
+    if args.dense_mesh and args.mesh and not kitti:
+        # the mesh map pre-seeded from the survey, capped at the stream's corridor.  The cloud goes through the mesher in
+        # packages of mesh_append_budget points (every point is offered: step 1), before the stream starts
+        t_seed = time.time()
+        P = corridor_cloud(torch, dev, n_total)
+        cam0 = synth.trajectory_pose(0)[1] + np.array([0.0, 0.0, 1.0])
+        pkg = int(cfg.mesh_append_budget)
+        for a in range(0, P.shape[0], pkg):
+            ch = P[a:a + pkg].contiguous()
+            h.mesh_scan(ch.data_ptr(), cam0, frame_idx=0, n=ch.shape[0], fetch=False)
+        cs = h.counters()
+        mesh_seed = {"cloud_points": int(P.shape[0]), "vertices": int(cs["n_vertices"]), "triangles_live": int(cs["n_triangles_live"]), "seconds": round(time.time() - t_seed, 1)}
+        log(f"[bench] mesh map pre-seeded from the corridor survey: {mesh_seed}")
+        del P
 
     # scan 0 seeds the stream state; constant-velocity prior (Forward_without_imu) between scans
     R0, t0 = synth.trajectory_pose(idx[0])
@@ -251,11 +356,28 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()
-    res = {"elapsed": elapsed, "cnt": cnt, "n_ds_mean": n_ds_mean, "n_map": int(n_map), "mesh_mode": mesh_mode, "n_raw": int(np.mean([len(r) for r in raws])), "comm": comm,
+    nu_hist = None
+    if (mesh_mode & 3) and args.nu_scans > 0 and not sharded:
+        # neighbourhood sizes of the scans right after the timed region (serial): which triangulation kernel takes which share of the voxels
+        sizes = []
+        for _ in range(args.nu_scans):
+            if k >= len(d_down):
+                break
+            st, _ = run(k, st, mode=1); k += 1
+            sizes.append(h.mesh_neighbourhood_sizes())
+        if sizes:
+            a_ = np.concatenate(sizes)
+            edges = [0, 16, 32, 48, 64, 96, 128, 256, 1 << 30]
+            nu_hist = {"scans": len(sizes), "voxels": int(len(a_)), "mean": round(float(a_.mean()), 1) if len(a_) else 0.0, "max": int(a_.max()) if len(a_) else 0,
+                       "histogram": {f"{edges[i] + 1}-{edges[i + 1] if edges[i + 1] < (1 << 30) else 'inf'}": int(((a_ > edges[i]) & (a_ <= edges[i + 1])).sum()) for i in range(len(edges) - 1)},
+                       "share_delaunay64_kernel": round(float((a_ <= 64).mean()), 4) if len(a_) else None,
+                       "share_general_kernel_65_256": round(float(((a_ > 64) & (a_ <= 256)).mean()), 4) if len(a_) else None,
+                       "share_big_path_above_256": round(float((a_ > 256).mean()), 4) if len(a_) else None}
+    res = {"elapsed": elapsed, "cnt": cnt, "n_ds_mean": n_ds_mean, "nu_hist": nu_hist, "mesh_seed": mesh_seed, "n_map": int(n_map), "mesh_mode": mesh_mode, "n_raw": int(np.mean([len(r) for r in raws])), "comm": comm,
            "pose_err": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1])),
            "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
                               if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
-           "cpu_inputs": (cfg, raws, downs, R0, t0)}
+           "cpu_inputs": (cfg, cpu_raws, cpu_downs, R0, t0) if not (args.gpu_scans and not kitti) else None}
     if sharded:
         res["shard_traffic"] = h.shard_traffic()
 
@@ -350,12 +472,15 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
                                   "mesh": round(float(np.percentile(stages[:, 2], 50)), 3)},
                 "threads": {"mesher": mesher_threads, "matcher": matcher_threads}, "map_root_voxels": n_map, "warmup_scans": warm}
 
-    warm = 2 if budget_s < 5 else 5
+    # reference threading = 200 scans after 20 warm-up scans (or what the CPU budget allows); every-loop-parallel = the physical cores
+    # (on 2 x SMT the logical count only adds contention to these short loops), a shorter sample
+    warm = 2 if budget_s < 5 else 20
     ref_thr = (min(12, ncores), min(4, ncores))
-    avail = len(raws) - 1                      # the stream is shared by the two variants: ~2/3 of it for the reference's threading
-    n_all = max(4, avail // 3) if ncores > 1 else 0
-    v_ref = cpu_pass(ref_thr[0], ref_thr[1], budget_s * 0.7, min(warm, max(0, avail - n_all - 3)), avail - n_all)
-    v_all = cpu_pass(ncores, ncores, budget_s * 0.3, 1, n_all) if ncores > 1 else v_ref
+    phys = max(1, ncores // 2) if ncores >= 16 else ncores
+    avail = len(raws) - 1                      # the stream is shared by the two variants
+    n_all = min(24, max(4, avail // 8)) if ncores > 1 else 0
+    v_ref = cpu_pass(ref_thr[0], ref_thr[1], budget_s * 0.75, min(warm, max(0, avail - n_all - 3)), min(avail - n_all, warm + 200))
+    v_all = cpu_pass(phys, phys, budget_s * 0.25, 1, n_all) if ncores > 1 else v_ref
     o.close()
     best, cores = (v_all, ncores) if v_all["scans_per_s"] > v_ref["scans_per_s"] else (v_ref, ref_thr[0])
     return {"value": best["scans_per_s"], "unit": "scans/s", "cores": cores, "kind": "port",
@@ -405,6 +530,10 @@ def main():
     ap.add_argument("--cpu-map-voxels", type=float, default=1.0e6, help="root voxels of the survey corridor the CPU-baseline leg pre-builds for the oracle (0 = scan 0 only)")
     ap.add_argument("--host-inputs", type=int, default=0, help="1 = every scan is handed over as HOST buffers (the library stages them over PCIe inside the timed region): the PCIe-inclusive rate")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
+    ap.add_argument("--gpu-scans", type=int, default=0, help="1 = the scan stream is ray-cast on the GPU by the harness (torch) and down-sampled by the library before the timed region: "
+                    "hundreds of scans in seconds (the steady-state leg); the CPU-baseline leg needs the default host-generated stream")
+    ap.add_argument("--dense-mesh", type=int, default=0, help="1 = pre-seed the MESH map from a dense survey of the stream's corridor (SURVEY 8(d) C3) before the stream starts")
+    ap.add_argument("--nu-scans", type=int, default=5, help="scans after the timed region whose per-voxel neighbourhood sizes n_u are collected (histogram + kernel shares)")
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
     ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
@@ -452,7 +581,7 @@ def main():
     def watchdog():
         # every rank runs one: when a leg after the timed region hangs (a collective of the sharded leg with a dead peer, say), rank 0 prints the line
         # as it stands and every rank leaves -- the launcher must not be left waiting for the others
-        if not printed.wait(2.0 * args.profile_timeout + args.cpu_seconds + (30.0 if rank == 0 else 40.0)):
+        if not printed.wait(3.0 * args.profile_timeout + args.cpu_seconds + (30.0 if rank == 0 else 40.0)):
             if out is not None:
                 out["profile_leg_note"] = ((out.get("profile_leg_note") or "") + " watchdog: a leg after the timed region did not finish; the line was printed without it").strip()
             emit()
@@ -487,6 +616,7 @@ def main():
             "stages_ms_serial": None,
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},
             "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
+            "n_u": res["nu_hist"], "mesh_seed": res["mesh_seed"],
             "roofline": None, "cpu_baseline": None, "kernels_ms_per_scan": {},
         }
         if only_sharded:
@@ -541,7 +671,7 @@ def main():
             out["sharded"] = {"error": str(e)[:200]}
 
     # ---- CPU baseline leg (rank 0, N = 1 semantics: the oracle on this box's host cores)
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and args.cpu_seconds > 0 and not args.gpu_scans:
         out["cpu_baseline"] = cpu_baseline_leg(args, res["cpu_inputs"], args.cpu_seconds)
 
     # ---- BASELINE configs[1] and configs[3] as short child runs of this script (N = 1 headline runs only)
@@ -549,17 +679,26 @@ def main():
     if rank == 0 and want_extra:
         extra = {}
         env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20))]),
+        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20)), "--cpu-seconds", "8"]),
                              ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
-                             ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"])):
-            cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags
+                             ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"]),
+                             ("full pipeline, MESH map pre-seeded from the corridor survey (SURVEY 8(d) C3 density)", ["--dense-mesh", "1", "--gpu-scans", "1"]),
+                             ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"])):
+            cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
                 lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 if r.returncode == 0 and lines:
                     d = json.loads(lines[-1])
-                    extra[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "metric": d["metric"], "n_ds_mean": d["config"]["n_ds_mean"],
+                    extra[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "metric": d["metric"], "n_ds_mean": d["config"]["n_ds_mean"],
                                     "map_root_voxels": d["config"]["map_root_voxels"], "scan_thread_ms": d["scan_thread_ms"]}
+                    if d.get("cpu_baseline"):
+                        cb = d["cpu_baseline"]
+                        extra[label]["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "ms_per_scan": cb["ms_per_scan"],
+                                                        "reference_threading": cb["reference_threading"], "sample": cb["sample"]}
+                    for kk_ in ("n_u", "mesh_seed", "counters_per_scan"):
+                        if d.get(kk_) and (kk_ != "counters_per_scan" or "dense" in label or "MESH" in label):
+                            extra[label][kk_] = d[kk_]
                 else:
                     extra[label] = {"error": f"rc {r.returncode}"}
             except Exception as e:   # noqa: BLE001

@@ -246,6 +246,20 @@ class HotPath:
         self._check(f(self.ctx, _ptr(pts_xyzi), len(pts_xyzi), leaf), "reconstruct_mesh_from_pointcloud")
         return self.mesh_fetch()
 
+    def reconstruct_mesh_from_pointcloud_dev(self, dev_ptr, n, leaf=0.01):
+        """the offline entry on a device-resident (n x 4 float32) cloud; the result lists are not fetched"""
+        f = self._f("reconstruct_mesh_from_pointcloud"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double]; f.restype = C.c_int
+        self._check(f(self.ctx, dev_ptr, n, leaf), "reconstruct_mesh_from_pointcloud")
+
+    def mesh_neighbourhood_sizes(self):
+        """n_u of every voxel the newest finished mesh job triangulated (diagnostics; HIP library only)."""
+        f = self._f("mesh_neighbourhood_sizes"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]; f.restype = C.c_int
+        n = C.c_int32(0)
+        self._check(f(self.ctx, None, 0, C.byref(n)), "mesh_neighbourhood_sizes")
+        out = np.zeros(max(1, n.value), np.int32)
+        self._check(f(self.ctx, _ptr(out), len(out), C.byref(n)), "mesh_neighbourhood_sizes")
+        return out[:n.value]
+
     def mesh_wait(self):
         f = self._f("mesh_wait"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx), "mesh_wait")

@@ -61,9 +61,9 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.htab, 0xFF, hcap * sizeof(HashEnt), c->stream));   // key = IM_KEY_EMPTY, root = -1
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
     m.upd_seq = 0;
-    A(c->d_stats, 8);
+    A(c->d_stats, STATS_WORDS);
     if (getenv("IMMESH_DEBUG")) { A(c->reg_dbg, REG_DBG_WORDS); HIPCHK(c, hipMemsetAsync(c->reg_dbg, 0, (size_t)REG_DBG_WORDS * 8, c->stream)); }
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, 8 * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, STATS_WORDS * sizeof(int64_t), c->stream));
 
     const int64_t ns = g.cap_scan_points > 0 ? g.cap_scan_points : 600000;
     c->cap_scan = ns;
@@ -79,6 +79,7 @@ static int alloc_all(immesh_ctx* c) {
     A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns);
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     A(c->d_dump_count, 2);
+    A(c->d_touched, 2 * ns + 16);
     A(c->d_regstate, 1);
     for (int q = 0; q < 2; q++) { A(c->d_rp_slots[q], RP_SLOT_DOUBLES); launch_fill_u64(c->stream, (unsigned long long*)c->d_rp_slots[q], RP_SLOT_SENTINEL, RP_SLOT_DOUBLES); }
     HIPCHK(c, hipMemsetAsync(c->d_regstate, 0, sizeof(RegState), c->stream));
@@ -185,7 +186,7 @@ static int settle(immesh_ctx* c, bool synced = false) {
     c->pending = false;
     hipEvent_t* e = c->ev + 4 * c->ev_par;
     c->timing[1] = c->timing[2] = 0.f;
-    if (c->timing_valid) {
+    if (c->timing_valid[c->ev_par]) {
         (void)hipEventElapsedTime(&c->timing[1], e[0], e[1]);
         (void)hipEventElapsedTime(&c->timing[2], e[1], e[2]);
     }
@@ -415,7 +416,7 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         // map_incremental_grow: no global sort -- points are chained per root voxel and each voxel's wavefront orders its own points
         // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
         c->map.upd_seq++;
-        c->map.touched = (uint32_t*)c->d_seg_start;
+        c->map.touched = c->d_touched;
         launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a, d_raw, world, n_raw);
         // the scan's input clouds are consumed here (the replay works on its own copies) and the mesher's scan is in its world buffer: ONE event
         // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
@@ -503,14 +504,16 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         // (the transform of the full scan for the mesher rides in the first launch of the map update)
         if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw))) return rc;
         if (timed) (void)hipEventRecord(ev[2], c->stream);
-        c->timing_valid = timed;
+        c->timing_valid[par] = timed;
         rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
         imh::store_state(st, state_inout);
         if (n_iter_out) *n_iter_out = n_iter;
         if (n_match_out) *n_match_out = n_match;
-        if (rc) return rc;
-        // this scan's passes ran behind the previous scan's map update on the same stream: that update is complete now
-        if ((rc = settle(c, true))) return rc;   // (deferred capacity error of the previous update; this scan's pose has been handed back)
+        // this scan's passes ran behind the previous scan's map update on the same stream: that update is complete now.  On either error return
+        // THIS scan's map update is still in flight: it is left pending (under its own event parity) so that the next call settles it and reads its
+        // capacity flags
+        const int rc_prev = rc ? 0 : settle(c, true);   // (deferred capacity error of the previous update; this scan's pose has been handed back)
+        if (rc || rc_prev) { c->ev_par = par; c->pending = true; return rc ? rc : rc_prev; }
         c->ev_par = par;
         long job = 0;
         if (mesh_mode) job = mesh_submit(c, world, n_raw, st.t, frame_idx, true);
@@ -531,7 +534,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         return rc;
     }
     c->ev_par = par;
-    c->timing_valid = true;
+    c->timing_valid[par] = true;
     (void)hipEventRecord(ev[1], c->stream);
     long job = 0;
     // IMMESH_SERIAL_ORDER: map growth first, then the hand-over to the mesher -- the order of the reference's map_incremental_grow; the default
@@ -708,9 +711,10 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
-    int64_t stats[8];
+    int64_t stats[STATS_WORDS];
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 64; k++) { stats[0] += stats[16 + k * 16]; stats[1] += stats[16 + k * 16 + 1]; }   // the fused replay kernel's shards
     HIPCHK(c, hipMemcpy(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
     *out = c->cnt;
     out->n_refits = stats[0]; out->n_refit_pts = stats[1];

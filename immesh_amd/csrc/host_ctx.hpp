@@ -1,6 +1,7 @@
 // Host-side context of libimmesh_hip.so: owns the HIP stream, every HBM-resident pool and the scratch buffers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -33,7 +34,7 @@ struct immesh_ctx {
     hipStream_t stream_pre = nullptr;    // the stages before the path (decode / undistort / down-sample): they do not touch the map, so they run beside the previous scan's map update
     hipEvent_t ev_inputs_free = nullptr; // recorded on `stream` when the last asynchronous scan has consumed its input clouds (after point_var + transform)
     hipEvent_t ev_inputs_cur = nullptr;  // the event that currently carries that meaning (the mesher's "scan is in its world buffer" event when one was recorded)
-    bool timing_valid = true;            // the last immesh_process_scan recorded its stage events (synchronous calls only)
+    bool timing_valid[2] = {true, true}; // per event parity: that immesh_process_scan recorded its stage events (synchronous calls only)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // two sets of four (scan parity)
     int ev_par = 0;
     bool pending = false;            // the last immesh_process_scan returned without waiting for its map update (IMMESH_SCAN_NOWAIT)
@@ -78,6 +79,7 @@ struct immesh_ctx {
     int32_t *d_idx_a = nullptr, *d_idx_b = nullptr, *d_idx_c = nullptr;
     uint32_t *d_slot = nullptr, *d_slot_s = nullptr;
     int32_t* d_seg_start = nullptr;
+    uint32_t* d_touched = nullptr;   // map update: (hash slot, root node) per touched root voxel
     int32_t* d_nseg = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -94,7 +96,7 @@ struct immesh_ctx {
 
     KProf prof;
     void* rccl_comm = nullptr;       // ncclComm_t of a sharded context after immesh_rccl_init (comm_rccl.cpp); null: host callbacks
-    int64_t rccl_calls = 0;
+    std::atomic<int64_t> rccl_calls{0};   // (counted from the scan thread and from the mesher's worker thread)
 
     // cumulative counters (host side)
     immesh_counters_t cnt;

@@ -26,6 +26,7 @@ struct PlaneRecDev {  // layout == immesh_plane_rec (include/immesh_c_api.h)
 };
 
 #define REG_DBG_WORDS (64 + 16384 * 8 + 8 * 512 * 8)   /* IMMESH_DEBUG buffer (reg_kernels.hip DBG_*): counters + per-wavefront trace records */
+#define STATS_WORDS (16 + 64 * 16)   /* refit counters: [0] refits [1] refit points, then 64 shards of the fused replay kernel (one 128-byte line each) */
 #define RES_NV_HOST 48
 #define RES_NR_HOST 32
 

@@ -54,7 +54,8 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand);
     A(m.ch_keys, ccap); A(m.ch_head, ccap);
     A(m.recent, cap_cand);
-    A(m.act_key, cap_active); A(m.act_vox, cap_active); A(m.act_key_s, cap_active); A(m.act_vox_s, cap_active);
+    int64_t cap_active_p2 = 1; while (cap_active_p2 < cap_active) cap_active_p2 <<= 1;   // mesh_append_finish_kernel's ordering network pads to a power of two
+    A(m.act_key, cap_active_p2); A(m.act_vox, cap_active_p2); A(m.act_key_s, cap_active); A(m.act_vox_s, cap_active);
     A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active); A(m.rel_nq, cap_active);
     A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
     A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
@@ -74,7 +75,7 @@ int mesh_alloc(immesh_ctx* c) {
     std::memset(&m1, 0, sizeof(m1));
     A(m1.v_smooth_new, cap_verts * 3); A(m1.vx_rank, cap_voxels); A(m1.vx_rank_seq, cap_voxels);
     A(m1.sc, SC_COUNT);
-    A(m1.act_key, cap_active); A(m1.act_vox, cap_active); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
+    A(m1.act_key, cap_active_p2); A(m1.act_vox, cap_active_p2); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
     A(m1.rel_ids, cap_active * MV_REL_CAP); A(m1.rel_n, cap_active); A(m1.rel_nq, cap_active);
 #undef A
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
@@ -260,10 +261,9 @@ static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::fu
         // RCCL on device buffers: all-gather the record counts (the host needs the largest one to size the payload gather), then the payload padded
         // to it; every other rank's records are unpacked straight from the gathered buffer -- no host staging, one small read-back
         int rc;
-        if (!h.d_xcounts && (rc = c->dalloc(&h.d_xcounts, 64))) { h.err = c->err; return rc; }
+        if (!h.d_xcounts || world > 64) { h.err = "sharded mesher: RCCL exchange not initialised (immesh_rccl_init)"; return IMMESH_E_INVAL; }
         if ((rc = rccl_allgather_bytes(c, h.d_xcount, h.d_xcounts, 4, s, &h.err))) return rc;
         int32_t counts32[64];
-        if (world > 64) { h.err = "sharded mesher: more than 64 ranks"; return IMMESH_E_INVAL; }
         MHIPCHK(c, hipMemcpyAsync(counts32, h.d_xcounts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
         MHIPCHK(c, hipStreamSynchronize(s));
         int64_t maxc = 0;
@@ -607,6 +607,27 @@ int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
     std::lock_guard<std::mutex> lk(h.mu);
     if (h.current <= 0) { std::memset(sizes, 0, sizeof(*sizes)); return 0; }
     *sizes = h.res[h.current & 1].sizes;
+    return 0;
+}
+
+// diagnostics (bench.py's density leg): the 20-NN neighbourhood size n_u of every voxel the newest finished job triangulated, in active order
+int immesh_mesh_neighbourhood_sizes(immesh_ctx* c, int32_t* out, int32_t cap, int32_t* n_out) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    (void)hipSetDevice(c->cfg.device);
+    MeshHost& h = c->mesh_host;
+    int par, n;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        if (h.current <= 0) { *n_out = 0; return 0; }
+        if (h.current < h.submitted) { c->err = "a newer mesh job is in flight (immesh_mesh_wait first)"; return IMMESH_E_INVAL; }
+        par = (int)(h.current & 1);
+        n = h.res[par].sizes.n_voxels_meshed;
+    }
+    *n_out = n;
+    if (out && n > 0) {
+        if (n > cap) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
+        HIPCHK(c, hipMemcpy(out, h.mpar[par].rel_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

@@ -330,7 +330,8 @@ __global__ void mesh_select_active_kernel(MeshDev m_in) {
 // was a few microseconds of work behind ~5 us of launch latency on the mesher's phase-A chain.
 IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #define MV_FIN_CAND 16384
-#define MV_FIN_ACT 8192        /* >= MV_FIN_CAND / 3: an active voxel holds at least three vertices */
+#define MV_FIN_ACT 8192        /* visited voxels whose selection + ordering run in LDS; more than that (sparse far-field scans) take the global arrays */
+// (~100 KB of static LDS for one workgroup: the 160 KB of a gfx950 CU -- the only target of this library, see the Makefile -- is assumed)
 __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts) {
     MESH_DYN(m_in);
     __shared__ unsigned long long skey[MV_FIN_ACT];
@@ -388,41 +389,48 @@ __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, 
     }
     __threadfence();
     __syncthreads();
-    // ---- voxels to (re)mesh this scan: visited, m_meshing_times < 1, m_new_added_pts_count >= 0, >= 3 vertices (ImMesh_mesh_reconstruction.cpp:132-151)
+    // ---- voxels to (re)mesh this scan: visited, m_meshing_times < 1, m_new_added_pts_count >= 0, >= 3 vertices (ImMesh_mesh_reconstruction.cpp:132-151),
+    //      then their ascending-(x, y, z) order.  A voxel goes active with ONE new vertex beside two older ones, so the active set is bounded by the
+    //      visited voxels, not by a third of the candidates: the LDS arrays serve up to MV_FIN_ACT visited voxels (any dense scan), a sparse far-field
+    //      scan that visits more selects and orders in the global act_key / act_vox arrays -- same network, global round trips, still one launch.
     const int n_recent = m.sc[SC_RECENT];
-    for (int r = tid; r < n_recent; r += 1024) {
-        const int vi = m.recent[r];
-        if (ld_agent(&m.vx_meshing_times[vi]) >= 1 || ld_agent(&m.vx_new_added[vi]) < 0) continue;
-        st_agent(&m.vx_meshing_times[vi], ld_agent(&m.vx_meshing_times[vi]) + 1);
-        st_agent(&m.vx_new_added[vi], 0);
-        if (ld_agent(&m.vx_npts[vi]) < 3) continue;
-        const int a = atomicAdd(&s_n, 1);
-        if (a >= MV_FIN_ACT) { m.sc[SC_OVERFLOW] = 8; continue; }
-        skey[a] = m.vx_key[vi];
-        svox[a] = vi;
-    }
-    __syncthreads();
-    const int na = min(s_n, MV_FIN_ACT);
-    const int np2 = next_pow2_i(max(na, 1));
-    for (int k = na + tid; k < np2; k += 1024) { skey[k] = ~0ull; svox[k] = -1; }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)            // ascending packed key == ascending (x, y, z); keys are unique (one entry per voxel)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < (np2 >> 1); p += 1024) {
-                const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
-                const bool up = ((i & k) == 0);
-                const unsigned long long x = skey[i], y = skey[ixj];
-                if ((x > y) == up) { skey[i] = y; skey[ixj] = x; const int t = svox[i]; svox[i] = svox[ixj]; svox[ixj] = t; }
-            }
-            __syncthreads();
+    auto select_and_order = [&](auto* K, auto* V, const int cap) {
+        for (int r = tid; r < n_recent; r += 1024) {
+            const int vi = m.recent[r];
+            if (ld_agent(&m.vx_meshing_times[vi]) >= 1 || ld_agent(&m.vx_new_added[vi]) < 0) continue;
+            st_agent(&m.vx_meshing_times[vi], ld_agent(&m.vx_meshing_times[vi]) + 1);
+            st_agent(&m.vx_new_added[vi], 0);
+            if (ld_agent(&m.vx_npts[vi]) < 3) continue;
+            const int a = atomicAdd(&s_n, 1);
+            if (a >= cap) { m.sc[SC_OVERFLOW] = 8; continue; }
+            K[a] = m.vx_key[vi];
+            V[a] = vi;
         }
-    for (int r = tid; r < na; r += 1024) {
-        const int vi = svox[r];
-        m.act_vox_s[r] = vi;
-        m.vx_rank[vi] = r;
-        m.vx_rank_seq[vi] = m.seq;
-    }
-    if (tid == 0) m.sc[SC_ACTIVE] = na;
+        __syncthreads();
+        const int na = min(s_n, cap);
+        const int np2 = next_pow2_i(max(na, 1));
+        for (int k = na + tid; k < np2; k += 1024) { K[k] = ~0ull; V[k] = -1; }
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1)            // ascending packed key == ascending (x, y, z); keys are unique (one entry per voxel)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = tid; p < (np2 >> 1); p += 1024) {
+                    const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
+                    const bool up = ((i & k) == 0);
+                    const unsigned long long x = K[i], y = K[ixj];
+                    if ((x > y) == up) { K[i] = y; K[ixj] = x; const int t = V[i]; V[i] = V[ixj]; V[ixj] = t; }
+                }
+                __syncthreads();
+            }
+        for (int r = tid; r < na; r += 1024) {
+            const int vi = V[r];
+            m.act_vox_s[r] = vi;
+            m.vx_rank[vi] = r;
+            m.vx_rank_seq[vi] = m.seq;
+        }
+        if (tid == 0) m.sc[SC_ACTIVE] = na;
+    };
+    if (n_recent <= MV_FIN_ACT) select_and_order(skey, svox, MV_FIN_ACT);
+    else select_and_order(m.act_key, m.act_vox, m.cap_active);   // (the arrays are allocated up to the next power of two: the network pads)
 }
 void launch_mesh_append_finish(hipStream_t s, const MeshDev& m, const float* pts) { KLAUNCH(mesh_append_finish_kernel, dim3(1), dim3(1024), 0, s, m, pts); }
 
@@ -1163,20 +1171,21 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
     if (m.dbg && lane == 0) atomicMax(&m.dbg[14], ((__builtin_readcyclecounter() - tvox0) << 16) | (unsigned long long)n);
     __syncthreads();
 }
-// neighbourhoods above 256 vertices (space-filling clouds; never with the shipped configurations): the big-LDS instantiation
-__global__ __launch_bounds__(64) void mesh_delaunay_big_kernel(MeshDev m_in) {
-    MESH_DYN(m_in);
-    const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
-    for (int r = blockIdx.x; r < n_active; r += gridDim.x)
-        if (m.rel_n[r] > 256) mesh_delaunay_voxel<MV_REL_CAP>(m, sp, r);
-}
-// neighbourhoods of 65..256 vertices, and the voxels the register fast path (mesh_delaunay64_kernel, launched before) handed over
+// What the register fast path (mesh_delaunay64_kernel, launched before) does not take, ONE launch (two used to cost two dispatches per scan
+// for -- with the shipped configurations -- nothing to do): even blocks take the neighbourhoods of 65..256 vertices and the voxels the fast path
+// handed over, odd blocks the neighbourhoods above 256 vertices (space-filling clouds) with the big-LDS instantiation.
 __global__ __launch_bounds__(64) void mesh_delaunay_general_kernel(MeshDev m_in) {
     MESH_DYN(m_in);
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
-    for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
-        const int n = m.rel_n[r];
-        if ((n > 64 && n <= 256) || (n > 0 && n <= 64 && m.vox_ntris[r] < 0)) mesh_delaunay_voxel<256>(m, sp, r);
+    const int half = (int)(gridDim.x >> 1);
+    if (blockIdx.x & 1) {
+        for (int r = (int)(blockIdx.x >> 1); r < n_active; r += half)
+            if (m.rel_n[r] > 256) mesh_delaunay_voxel<MV_REL_CAP>(m, sp, r);
+    } else {
+        for (int r = (int)(blockIdx.x >> 1); r < n_active; r += half) {
+            const int n = m.rel_n[r];
+            if ((n > 64 && n <= 256) || (n > 0 && n <= 64 && m.vox_ntris[r] < 0)) mesh_delaunay_voxel<256>(m, sp, r);
+        }
     }
 }
 
@@ -1566,8 +1575,7 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
     KLAUNCH(mesh_delaunay64_kernel, dim3(2048 / mesh_grid_div()), dim3(64), 0, s, m);          // n_u <= 64: register fast path
-    KLAUNCH(mesh_delaunay_general_kernel, dim3(512), dim3(64), 0, s, m);     // 64 < n_u <= 256, and what the fast path handed over
-    KLAUNCH(mesh_delaunay_big_kernel, dim3(256), dim3(64), 0, s, m);         // n_u > 256
+    KLAUNCH(mesh_delaunay_general_kernel, dim3(1024), dim3(64), 0, s, m);    // even blocks: 64 < n_u <= 256 and what the fast path handed over; odd blocks: n_u > 256
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }

@@ -1023,7 +1023,13 @@ __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams 
     if (pt_next) {  // push the point on its root voxel's list for this update; the first point to arrive registers the voxel as touched
         const unsigned long long mine = ((unsigned long long)(unsigned int)m.upd_seq << 32) | (unsigned int)i;
         const unsigned long long old = atomicExch(&m.slot_head[slot], mine);
-        if ((unsigned int)(old >> 32) != (unsigned int)m.upd_seq) { pt_next[i] = -1; m.touched[atomicAdd(&m.counters[7], 1)] = (uint32_t)slot; }
+        if ((unsigned int)(old >> 32) != (unsigned int)m.upd_seq) {
+            pt_next[i] = -1;
+            // (slot, root node): the replay kernel starts from the node without a second trip through the hash; a root another lane of this launch
+            // is still creating reads as -1 here and is looked up there
+            const int k = atomicAdd(&m.counters[7], 1);
+            m.touched[2 * (size_t)k] = (uint32_t)slot; m.touched[2 * (size_t)k + 1] = (uint32_t)m.htab[slot].root;
+        }
         else pt_next[i] = (int)(unsigned int)(old & 0xFFFFFFFFull);
     }
 }
@@ -1557,7 +1563,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     __shared__ int order[4][RL_CAP];
     __builtin_amdgcn_s_setprio(3);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wv;
+    const int t = blockIdx.x * 4 + wv;   // (four wavefronts per workgroup: one-wavefront workgroups were measured dispatch-bound -- ~130 workgroups per us)
     // IMMESH_DEBUG: one trace record per wavefront of the launch (plain stores, no contention): [0] start, [1] end (s_memrealtime, 100 MHz),
     // [2..6] ten 32-bit cycle counts (root known, node line 0, chunk table, list head, list, sort, load, decide, commit, plane), [7] cnt | n_ref << 8 | state << 16
     unsigned long long* const tr = (dbg && lane == 0 && t < DBG_FUSED_RECS) ? dbg + DBG_FUSED_OFF + (size_t)t * 8 : nullptr;
@@ -1565,9 +1571,11 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = tr[3] = tr[4] = tr[5] = tr[6] = tr[7] = 0; }
 #define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tr) ((unsigned int*)tr)[4 + (k)] = (unsigned int)(_t - tprev); tprev = _t; } } while (0)
 #define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
-    if (t >= m.counters[7]) { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); } return; }
-    const uint32_t slot = m.touched[t];
-    const int root = m.htab[slot].root;
+    const int n_touched = m.counters[7];
+    const uint32_t slot = m.touched[2 * (size_t)t];          // (read beside the counter, not behind it: the list has room for every wavefront of the grid)
+    int root = (int)m.touched[2 * (size_t)t + 1];
+    if (t >= n_touched) { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); } return; }
+    if (root < 0) root = m.htab[slot].root;
     if (root < 0) return;
     FDBG(0);
     NodeRec& nd = m.nodes[root];
@@ -1682,7 +1690,8 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
                 nd.npts = ntot; nd.newpts = (newp + cnt) % 6;
 #pragma unroll
                 for (int k = 0; k < IM_INLINE_CHUNKS; k++) nd.chunks[k] = chunks[k];
-                if (n_ref) { atomicAdd((unsigned long long*)&stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&stats[1], (unsigned long long)n_ref_pts); }
+                // refit counters: 64 shards, one 128-byte line each (thousands of wavefronts adding to ONE address serialise at the memory side: ~30 ns per atomic)
+                if (n_ref) { int64_t* sh = stats + 16 + (size_t)(t & 63) * 16; atomicAdd((unsigned long long*)&sh[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&sh[1], (unsigned long long)n_ref_pts); }
             }
             FDBG(8);
             if (n_ref > 0) {   // (n_last is the last refit's point count: fit holds its eigen-decomposition)

@@ -50,7 +50,7 @@ struct RegMapDev {
     // pools
     double* chunk_data;         // [cap_chunks * IM_CHUNK_PTS * IM_PT_DOUBLES]
     int32_t* ext_tables;        // [cap_ext * IM_EXT_CHUNKS]
-    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels [7] touched slots of the current update [8] leaf-list chunks used [9] bump allocator of the long-list scratch (replay_list_kernel)
+    // counters: [0] nodes used [1] chunk bump [2] ready-free top [3] pending-free top [4] ext used [5] overflow flag [6] root voxels [7] touched slots of the current update [8] leaf-list chunks used [9] bump allocator of the long-list scratch (replay_list_kernel) [10] length of the work list the fused replay kernel hands to replay_list_kernel [11] spare
     int32_t* counters;
     int32_t* free_ready;        // chunk ids available for allocation
     int32_t* free_pending;      // chunk ids freed by the running kernel (merged into ready afterwards)
@@ -59,7 +59,7 @@ struct RegMapDev {
     int32_t cap_leaf_chunks;
     // per-update root-voxel point lists (map_incremental_grow): head word per hash slot = (update seq << 32 | last point index), stamped so it never needs clearing
     unsigned long long* slot_head;  // [hcap]
-    uint32_t* touched;          // hash slots touched by the current update (counters[7] entries)
+    uint32_t* touched;          // (hash slot, root node) of the voxels touched by the current update (counters[7] pairs)
     int32_t upd_seq;
     // multi-GPU sharding of the registration map: root voxels are owned in bricks of 2^shard_brick_log2 voxels per axis,
     // owner = hash(brick) mod shard_world; a rank also keeps the 1-voxel halo around its bricks (the near-voxel retry looks one voxel over)
@@ -126,9 +126,12 @@ IMD int64_t hash_find_or_insert(const RegMapDev& m, uint64_t key, bool* created)
 
 // ---- chunk pool --------------------------------------------------------------------------------------------------
 IMD int alloc_chunk(const RegMapDev& m) {
-    int i = atomicSub(&m.counters[2], 1) - 1;
-    if (i >= 0) return m.free_ready[i];
-    atomicAdd(&m.counters[2], 1);  // undo
+    // the ready stack is empty most of the time on a settled map: look before popping (a pop that fails costs two more contended atomics)
+    if (__hip_atomic_load(&m.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+        int i = atomicSub(&m.counters[2], 1) - 1;
+        if (i >= 0) return m.free_ready[i];
+        atomicAdd(&m.counters[2], 1);  // undo
+    }
     const int c = atomicAdd(&m.counters[1], 1);
     if (c >= m.cap_chunks) { m.counters[5] = 1; return -1; }
     return c;

@@ -127,6 +127,9 @@ typedef struct immesh_mesh_sizes_t {
     int32_t reserved;
 } immesh_mesh_sizes_t;
 int immesh_mesh_sizes(immesh_ctx* ctx, immesh_mesh_sizes_t* sizes);
+/* Diagnostics: the neighbourhood size n_u (vertices of the voxel + its 20-NN union, retrieve_neighbor_pts_kdtree  src/meshing/mesh_rec_geometry.cpp:336-377)
+ * of every voxel the newest finished job triangulated, in that job's voxel order.  out may be NULL to query the count. */
+int immesh_mesh_neighbourhood_sizes(immesh_ctx* ctx, int32_t* out, int32_t cap, int32_t* n_out);
 /* All lists are sorted (triplets: ids ascending inside a triplet, triplets lexicographic; smooth ids ascending).
  * Any pointer may be NULL to skip that list. */
 int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd,

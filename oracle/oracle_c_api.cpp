@@ -262,6 +262,13 @@ int orc_mesh_sizes(void* p, immesh_mesh_sizes_t* s) {
     s->n_upd = (int)m.tri_upd.size() / 3; s->n_smooth = (int)m.smooth_ids.size(); s->n_voxels_meshed = m.v_act; s->reserved = 0;
     return 0;
 }
+int orc_mesh_neighbourhood_sizes(void* p, int32_t* out, int32_t cap, int32_t* n_out) {
+    OrcCtx* o = (OrcCtx*)p;
+    const MeshScanOut& m = o->mout;
+    *n_out = (int32_t)m.n_u_list.size();
+    if (out) { if ((int32_t)m.n_u_list.size() > cap) return -4; std::memcpy(out, m.n_u_list.data(), m.n_u_list.size() * 4); }
+    return 0;
+}
 int orc_mesh_fetch(void* p, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd, uint8_t* flip_upd,
                    int32_t* smooth_ids, double* smooth_xyz) {
     OrcCtx* o = (OrcCtx*)p;

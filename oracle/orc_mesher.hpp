@@ -42,6 +42,7 @@ struct MeshScanOut {
     std::vector<int> smooth_ids;        // vertices whose smoothed position was (re)set this scan (ascending)
     std::vector<double> smooth_xyz;
     int v_act = 0;
+    std::vector<int> n_u_list;          // neighbourhood size of every triangulated voxel, in voxel order (diagnostics)
 };
 
 struct Mesher {
@@ -257,6 +258,7 @@ struct Mesher {
             const std::vector<int>& ids = w.ids;
             const std::vector<int>& tri_ids = w.tri_ids;
             const std::set<long> rel(ids.begin(), ids.end());
+            out.n_u_list.push_back((int)ids.size());
             if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); cnt->t_v += (long)tri_ids.size() / 3; }
             // a21 find_relative_triangulation_combination, triangle.hpp:223-246
             std::set<Tri> old;

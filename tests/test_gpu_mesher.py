@@ -44,6 +44,7 @@ def test_mesh_stream_parity(oracle_lib, hip_lib):
         mo = o.mesh_scan(pts, cam, frame_idx=k)
         mh = h.mesh_scan(pts, cam, frame_idx=k)
         _compare_scan(mo, mh, f"scan {k}")
+        np.testing.assert_array_equal(h.mesh_neighbourhood_sizes(), o.mesh_neighbourhood_sizes())   # n_u per voxel, in voxel order
         tot_add += len(mo["tri_add"]); tot_rem += len(mo["tri_rem"])
     assert tot_add > 10000 and tot_rem > 1000
     co, ch = o.counters(), h.counters()
@@ -285,3 +286,29 @@ def test_hip_diff_lists_on_the_reference_triangle_manager(hip_lib, ref_tri_lib):
     assert n_rem > 1000 and len(live) == len(dev) == h.counters()["n_triangles_live"]
     assert dev == {t: (1 if fl else 0) for t, fl in live.items()}
     mirror.close()
+
+
+def test_more_active_voxels_than_the_lds_stage_holds(oracle_lib, hip_lib):
+    """A sparse, non-repetitive scan: every candidate lands in its own mesh voxel that already holds two vertices, so ~10 000 voxels go active with
+    ONE new vertex each -- more than the 8192 the single-launch admission tail orders in LDS (that used to end in IMMESH_E_CAPACITY).
+    The global-array variant of the same stage must give the oracle's lists."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20, mesh_append_budget=16000)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    vox = 0.4
+    gx, gy = np.meshgrid(np.arange(100), np.arange(100), indexing="ij")
+    base = np.stack([gx.ravel() * vox, gy.ravel() * vox, np.zeros(gx.size)], axis=1)     # 10 000 mesh voxels on a plane
+    cam = np.array([20.0, 20.0, 5.0])
+
+    rng = np.random.default_rng(11)
+
+    def scan(offsets):   # (jittered: a regular lattice would be nothing but distance ties and cocircular quadruples)
+        p = np.concatenate([base + np.array(off) + rng.uniform(-0.02, 0.02, base.shape) for off in offsets], axis=0).astype(np.float32)
+        return np.ascontiguousarray(np.concatenate([p, np.ones((len(p), 1), np.float32)], axis=1))
+
+    a = scan([(0.05, 0.05, 0.0), (0.25, 0.25, 0.01)])      # two vertices per voxel: nothing to triangulate yet
+    b = scan([(0.05, 0.30, 0.02)])                          # the third vertex of every voxel
+    for k, pts in enumerate((a, b)):
+        mo = o.mesh_scan(pts, cam, frame_idx=k)
+        mh = h.mesh_scan(pts, cam, frame_idx=k)
+        _compare_scan(mo, mh, f"scan {k}")
+    assert mo["n_voxels_meshed"] > 8192 and len(mo["tri_add"]) > 8192

@@ -3,7 +3,7 @@
 # usage: tools/r03_step.sh <tag> [pytest args]   (SKIP_TESTS=1 skips the test tier)
 R=$GRAFT_REPO_ROOT; T=${1:-step}; shift; O=$R/gpurun_out/r03; mkdir -p $O
 cd $R
-if [ -z "$SKIP_TESTS" ]; then timeout 1500 python -m pytest tests -m gpu -x -q "$@" 2>&1 | tail -15; fi
+if [ -z "$SKIP_TESTS" ]; then timeout 1500 python -m pytest ${TESTS:-tests} -m gpu -x -q "$@" 2>&1 | tail -15; fi
 cd /tmp && export TMPDIR=/tmp
 timeout 300 python $R/bench.py --cpu-seconds 0 --extra-configs 0 2>$O/$T.err | grep '^{' | tail -1 > $O/$T.json
 python -c "
