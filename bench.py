@@ -171,32 +171,27 @@ def corridor_cloud(torch, dev, n_scans, spacing=0.07, reach=45.0, seed=20260926)
     return torch.cat([P, torch.full((P.shape[0], 1), 50.0, device=dev)], dim=1).contiguous()
 
 
-def _gen_scan(job):
-    k, n_pts, extT, kitti, f = job
-    if not os.path.exists(f):
-        R, t = synth.trajectory_pose(k)
-        raw = synth.hdl64_scan(k, R, t) if kitti else synth.livox_scan(k, R, t, n_pts=n_pts, extT=np.array(extT))
-        tmp = f + f".{os.getpid()}.tmp.npy"     # ranks generate the same scans concurrently: publish atomically
-        np.save(tmp, raw)
-        os.replace(tmp, f)
-    raw = np.load(f)
-    return raw, synth.voxel_grid_downsample(raw, 0.5 if kitti else 0.4)   # filter_size_surf: avia.yaml:5 / velodyne.yaml:5
-
-
 def make_scans(n_scans, n_pts, cfg, cache_dir, kitti=False):
     """Synthetic Livox-shaped stream: raw scans (lidar frame, xyzI) + the VoxelGrid-downsampled clouds.  The numpy ray caster takes
-    1-2 s per scan: the scans of a run are generated by a pool of host processes (the CPU-baseline leg wants >= 220 of them)."""
+    1-2 s per scan, and the CPU-baseline leg wants >= 220 scans: missing scans are generated by worker PROCESSES (immesh_amd/scan_gen.py, started
+    with subprocess -- this process holds a live HIP runtime) into the cache directory."""
+    from immesh_amd import scan_gen
     os.makedirs(cache_dir, exist_ok=True)
-    extT = tuple(cfg.extT)
-    jobs = [(k, n_pts, extT, kitti, os.path.join(cache_dir, f"hdl64_{k}.npy" if kitti else f"livox_{n_pts}_{k}.npy")) for k in range(n_scans)]
-    nproc = max(1, min(64, (os.cpu_count() or 1) - 2, n_scans))
-    if nproc > 1 and sum(0 if os.path.exists(j[4]) else 1 for j in jobs) > 4:
-        import multiprocessing as mp
-        with mp.get_context("fork").Pool(nproc) as pool:
-            out = pool.map(_gen_scan, jobs, chunksize=1)
-    else:
-        out = [_gen_scan(j) for j in jobs]
-    return [o[0] for o in out], [o[1] for o in out]
+    extT = [float(v) for v in cfg.extT]
+    missing = [k for k in range(n_scans) if not os.path.exists(scan_gen.scan_path(cache_dir, n_pts, kitti, k)[:-4] + "_down.npy")]
+    nproc = max(1, min(64, (os.cpu_count() or 1) - 2, len(missing)))
+    if nproc > 1 and len(missing) > 4:
+        env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, "-m", "immesh_amd.scan_gen", cache_dir, str(n_pts), str(int(kitti))] + [repr(v) for v in extT] + [str(k) for k in missing[w::nproc]],
+                                  env=env, cwd=ROOT, stdout=subprocess.DEVNULL) for w in range(nproc)]
+        for pr in procs:
+            pr.wait()
+    raws, downs = [], []
+    for k in range(n_scans):
+        raw, down = scan_gen.generate(cache_dir, n_pts, kitti, extT, k)      # (loads what the workers delivered, generates what they did not)
+        raws.append(raw)
+        downs.append(down)
+    return raws, downs
 
 
 # algorithmic bytes of one launch of each kernel (SURVEY.md 8(d) record sizes; DESIGN.md "Kernels")
@@ -328,14 +323,26 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         # mesh map is seeded by scan 0 (the registration map is the pre-built survey); sharded: every rank takes part in the scan's all-reduces
         h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1, n_ds=len(downs[0]), n_raw=len(raws[0]))
 
+    ds_state = {"pending": None}
+
     def run(k, state, mode=None):
         prior = capi.forward_without_imu_native(hip, state)     # constant-velocity prior (Forward_without_imu), host side of the library
         down_ptr, n_ds = d_down[k].data_ptr(), len(downs[k])
         if args.host_inputs:
             return h.process_scan(downs[k], raws[k], prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode)
         if args.device_downsample:
-            _, n_ds = h.downsample(d_raw[k].data_ptr(), 0.5 if kitti else 0.4, n=len(raws[k]), stride=4, to_host=False)
-            down_ptr = h.downsample_result_ptr()
+            # pipelined: scan k's VoxelGrid was enqueued (pre-processing stream) before scan k-1 was registered and is collected here; scan k+1's goes
+            # in now, beside this scan's registration
+            leaf = 0.5 if kitti else 0.4
+            if ds_state["pending"] != k:
+                if ds_state["pending"] is not None:
+                    h.downsample_end()
+                h.downsample_begin(d_raw[k].data_ptr(), leaf, n=len(raws[k]), stride=4)
+            n_ds, down_ptr = h.downsample_end()
+            ds_state["pending"] = None
+            if k + 1 < len(d_raw):
+                h.downsample_begin(d_raw[k + 1].data_ptr(), leaf, n=len(raws[k + 1]), stride=4)
+                ds_state["pending"] = k + 1
         return h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode, n_ds=n_ds, n_raw=len(raws[k]))
 
     k = 1
@@ -343,16 +350,24 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         st, _ = run(k, st); k += 1
     h.counters(reset=True)
     torch.cuda.synchronize()
+    import gc
+    gc.collect(); gc.disable()      # a generation-2 collection of the harness's objects inside the loop is a 30 ms stall (seen: one call of 32 ms among 50 of 0.25 ms)
     D.barrier()
     t_begin = time.perf_counter()
     t_marks = [t_begin]
     for _ in range(args.steps):
         st, info = run(k, st); k += 1
         t_marks.append(time.perf_counter())
+    t_d0 = time.perf_counter()
     if mesh_mode == 2:
         h.mesh_wait()          # drain the mesher: every scan of the timed region is fully meshed before the clock stops
+    t_d1 = time.perf_counter()
     h.last_timing()            # waits for the last scan's map update (the library's own stream)
+    t_d2 = time.perf_counter()
     torch.cuda.synchronize()
+    gc.enable()
+    log(f"[bench] drain after the last scan: mesher {1e3 * (t_d1 - t_d0):.2f} ms, map update {1e3 * (t_d2 - t_d1):.2f} ms, device {1e3 * (time.perf_counter() - t_d2):.2f} ms; "
+        f"slowest calls of the timed loop (ms): {np.round(np.sort(np.diff(t_marks))[-3:] * 1e3, 2).tolist()} at scans {np.argsort(np.diff(t_marks))[-3:].tolist()}")
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()
@@ -512,6 +527,61 @@ def build_roofline(res, args):
             "source": f"HIP events, live: {args.profile_scans} scans of the same stream on the same context, right after the timed region (serial per scan, events on the library's own streams)"}
 
 
+def dry_run_leg(args, torch, hip, dev, local):
+    """configs[4] on ONE GPU: rank r of W of the sharded job, alone.  Its context is configured exactly as in the W-rank job (brick ownership + halo, per-rank
+    capacities, sharded mesher) and is fed everything the job would feed it -- the whole survey of the 50 M-voxel square, every 500 000-pt scan -- with
+    the data-path collectives stubbed (immesh_stub_collectives).  Reported: the root voxels / HBM bytes of the share and the rank's time per scan: the
+    W-rank rate is bounded by the slowest rank's time plus the (latency-bound, < 0.1 ms) collectives -- a prediction until a node exists."""
+    W, r = args.dry_run_world, args.dry_run_rank
+    cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * 1.5 / W) + (1 << 16), cap_scan_points=2_500_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
+    cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = r, W, 5, 1 if args.mesh else 0
+    h = capi.HotPath(hip, cfg, "immesh_")
+    h.stub_collectives()
+    side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0
+    t0 = time.time()
+    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)      # (a rank keeps ~1.2 / W of the voxels: the loop runs through every strip of the square)
+    t_map = time.time() - t0
+    extT = np.array(list(cfg.extT))
+    n_total = args.warmup + args.steps
+    d_raw, d_down, n_ds = [], [], []
+    for kk in range(n_total + 1):
+        Rk, tk = synth.trajectory_pose(kk)
+        rr = livox_scan_torch(torch, dev, kk, Rk, tk, args.pts, extT)
+        dn, _ = h.downsample(rr.data_ptr(), 0.4, n=rr.shape[0], stride=4, to_host=True)
+        d_raw.append(rr); d_down.append(torch.from_numpy(dn).to(dev)); n_ds.append(len(dn))
+    R0, t0_ = synth.trajectory_pose(0)
+    st = capi.make_state(R=R0, t=t0_)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    mode = 1 if args.mesh else 0          # the sharded mesher runs serial per scan (its exchanges must not interleave with the next scan's all-reduces)
+    if mode:
+        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1, n_ds=n_ds[0], n_raw=d_raw[0].shape[0])
+    k = 1
+    for _ in range(args.warmup):
+        prior = capi.forward_without_imu_native(hip, st)
+        st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+    h.counters(reset=True)
+    torch.cuda.synchronize()
+    tb = time.perf_counter()
+    for _ in range(args.steps):
+        prior = capi.forward_without_imu_native(hip, st)
+        st, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+    h.last_timing()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - tb
+    cnt = h.counters()
+    out = {"metric": f"scans/sec of ONE rank's share (rank {r} of {W}; collectives stubbed), 500k-pt scan into 50M-voxel map" if args.pts >= 400000 else f"scans/sec of rank {r} of {W} alone (collectives stubbed)",
+           "value": round(args.steps / el, 4), "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"ONE rank (rank {r} of {W}) of the sharded job on one GPU, collectives stubbed: {args.pts}-pt scans, {int(args.map_voxels)}-root-voxel survey",
+                      "n_raw": int(d_raw[1].shape[0]), "n_ds_mean": round(float(np.mean(n_ds[1:])), 1), "map_root_voxels": int(n_map), "params": "config/avia.yaml",
+                      "parallelism": f"dry run of rank {r} of {W}: brick ownership + 1-voxel halo, sharded mesher; all-reduce / all-gather replaced by local no-ops"},
+           "share": {"root_voxels_kept_by_this_rank": int(n_map), "of_total_surveyed": int(args.map_voxels), "device_bytes_allocated": int(h.device_bytes()),
+                     "map_build_seconds": round(t_map, 1), "matches_per_scan_on_this_rank": round(cnt["n_match"] / max(1, cnt["n_iter"]) , 1)},
+           "pose_err_m": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))}
+    h.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -534,6 +604,8 @@ def main():
                     "hundreds of scans in seconds (the steady-state leg); the CPU-baseline leg needs the default host-generated stream")
     ap.add_argument("--dense-mesh", type=int, default=0, help="1 = pre-seed the MESH map from a dense survey of the stream's corridor (SURVEY 8(d) C3) before the stream starts")
     ap.add_argument("--nu-scans", type=int, default=5, help="scans after the timed region whose per-voxel neighbourhood sizes n_u are collected (histogram + kernel shares)")
+    ap.add_argument("--dry-run-rank", type=int, default=-1, help=">= 0: run ONE rank of a --dry-run-world job alone on this GPU with stubbed collectives (configs[4] capacity / per-rank time)")
+    ap.add_argument("--dry-run-world", type=int, default=8)
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
     ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
@@ -561,6 +633,8 @@ def main():
     only_sharded = bool(args.shard) and world > 1
     kitti = args.config == "velodyne"
     hip = capi.load_hip_library()
+    if args.dry_run_rank >= 0:
+        return dry_run_leg(args, torch, hip, dev, local)
 
     res = measure(args, torch, D, dist, hip, rank, world, local, dev, sharded=only_sharded, full=True)
     value = D.aggregate_throughput(args.steps, 1 if only_sharded else world, res["elapsed"])
@@ -611,7 +685,7 @@ def main():
                        "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
-                       "downsample": "device (inside the timed region)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
+                       "downsample": "device, inside the timed region (asynchronous: scan k+1's VoxelGrid on the pre-processing stream beside scan k's registration)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
                        "inputs": "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region"},
             "stages_ms_serial": None,
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},
@@ -683,7 +757,8 @@ def main():
                              ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
                              ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"]),
                              ("full pipeline, MESH map pre-seeded from the corridor survey (SURVEY 8(d) C3 density)", ["--dense-mesh", "1", "--gpu-scans", "1"]),
-                             ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"])):
+                             ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
+                             ("configs[4] dry run: rank 0 of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "0", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
@@ -691,11 +766,13 @@ def main():
                 if r.returncode == 0 and lines:
                     d = json.loads(lines[-1])
                     extra[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "metric": d["metric"], "n_ds_mean": d["config"]["n_ds_mean"],
-                                    "map_root_voxels": d["config"]["map_root_voxels"], "scan_thread_ms": d["scan_thread_ms"]}
+                                    "map_root_voxels": d["config"]["map_root_voxels"], "scan_thread_ms": d.get("scan_thread_ms")}
                     if d.get("cpu_baseline"):
                         cb = d["cpu_baseline"]
                         extra[label]["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "ms_per_scan": cb["ms_per_scan"],
                                                         "reference_threading": cb["reference_threading"], "sample": cb["sample"]}
+                    if d.get("share"):
+                        extra[label]["share"] = d["share"]
                     for kk_ in ("n_u", "mesh_seed", "counters_per_scan"):
                         if d.get(kk_) and (kk_ != "counters_per_scan" or "dense" in label or "MESH" in label):
                             extra[label][kk_] = d[kk_]

@@ -422,6 +422,21 @@ class HotPath:
         m = n_match.value
         return out, {"n_iter": n_iter.value, "n_match": m, "res_mean": res.value, "match_idx": idx[:m].copy(), "normals_pd2": nv[:m].copy()}
 
+    def downsample_begin(self, pts, leaf, n=None, stride=None):
+        """enqueue the VoxelGrid of a (host array | device pointer) cloud on the pre-processing stream; collect with downsample_end()"""
+        f = self._f("downsample_begin"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double]; f.restype = C.c_int
+        if n is None:
+            n, stride = pts.shape[0], pts.shape[1]
+        self._ds_keep = pts       # (a host array has to outlive the staging copy)
+        self._check(f(self.ctx, _ptr(pts), n, stride, leaf), "downsample_begin")
+
+    def downsample_end(self):
+        """-> (n_out, pointer of the n_out x 3 float32 result: device memory for the HIP library, host memory for the oracle)"""
+        f = self._f("downsample_end"); f.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]; f.restype = C.c_int
+        n = C.c_int32(0); ptr = C.c_void_p(0)
+        self._check(f(self.ctx, C.byref(n), C.byref(ptr)), "downsample_end")
+        return n.value, ptr.value
+
     def downsample_result_ptr(self):
         f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
         return f(self.ctx)
@@ -440,6 +455,16 @@ class HotPath:
         self._allreduce_cb = proto(_cb)   # keep alive
         f = self._f("set_allreduce"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx, self._allreduce_cb, None), "set_allreduce")
+
+    def stub_collectives(self):
+        f = self._f("stub_collectives"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx), "stub_collectives")
+
+    def device_bytes(self):
+        f = self._f("device_bytes"); f.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]; f.restype = C.c_int
+        b = C.c_int64(0)
+        self._check(f(self.ctx, C.byref(b)), "device_bytes")
+        return b.value
 
     # -- RCCL inside the library (sharded contexts) ----------------------------------------------------------------
     def rccl_unique_id(self):

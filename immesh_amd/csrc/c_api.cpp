@@ -141,6 +141,8 @@ void immesh_destroy(immesh_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream_pre) { (void)hipStreamSynchronize(c->stream_pre); (void)hipStreamDestroy(c->stream_pre); }
     if (c->ev_inputs_free) (void)hipEventDestroy(c->ev_inputs_free);
+    if (c->dsa.ev) (void)hipEventDestroy(c->dsa.ev);
+    if (c->dsa.h_info) (void)hipHostFree(c->dsa.h_info);
     mesh_free(c);
     rccl_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -790,6 +792,70 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     return 0;
 }
 const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : nullptr; }
+
+// ---- the same pipeline without a host round trip in the middle: everything is enqueued on the pre-processing stream; the radix-sort width comes from
+// the previous cloud's grid extents (consecutive scans of a stream have the same extents to within a leaf or two) and is checked when the job is collected
+static int ds_bits_of(const int32_t* mm) {
+    const unsigned long long total = (unsigned long long)((long long)mm[3] - mm[0] + 1) * (unsigned long long)((long long)mm[4] - mm[1] + 1) * (unsigned long long)((long long)mm[5] - mm[2] + 1);
+    int bits = 1;
+    while (bits < 64 && (total >> bits) != 0) bits++;
+    return bits;
+}
+int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf) {
+    if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    if (c->dsa.active) { c->err = "immesh_downsample_begin: the previous job has not been collected (immesh_downsample_end)"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    ProfBind _pb(c);
+    immesh_ctx::DsAsync& a = c->dsa;
+    int rc;
+    if (!a.ev) {
+        HIPCHK(c, hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&a.h_info, 16 * sizeof(int32_t)));
+        for (int q = 0; q < 2; q++) if ((rc = c->dalloc(&a.out[q], (size_t)c->cap_scan * 3))) return rc;
+        const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        std::memcpy(a.h_info + 8, init, sizeof(init));   // (pinned: the source of the asynchronous initialisation below)
+    }
+    hipStream_t s = c->stream_pre;
+    const void* d_pts;
+    if ((rc = pre_resolve(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts))) return rc;
+    a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts; a.used_bits = a.pred_bits;
+    const float inv = (float)(1.0 / leaf);
+    int32_t* mm = c->p_nseg;
+    HIPCHK(c, hipMemcpyAsync(mm, a.h_info + 8, 6 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    launch_ds_minmax(s, (const float*)d_pts, n, stride, inv, mm);
+    launch_ds_index(s, (const float*)d_pts, n, stride, inv, mm, c->p_key_a, c->p_idx_a);
+    sort_pairs_u64(s, c->p_sort_temp, c->sort_temp_bytes, c->p_key_a, c->p_key_b, c->p_idx_a, c->p_idx_b, n, a.used_bits);
+    launch_ds_heads(s, c->p_key_b, n, c->p_idx_c);
+    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, c->p_idx_c, c->p_idx_c, n);
+    PRE_OUTPUT_FENCE(c);   // (the buffer being written was the input of the scan before the one in flight: its point_var has to be through)
+    launch_ds_centroid(s, (const float*)d_pts, n, stride, c->p_key_b, c->p_idx_b, c->p_idx_c, a.out[a.par], c->p_nseg + 8);
+    HIPCHK(c, hipMemcpyAsync(a.h_info, mm, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(a.h_info + 6, c->p_nseg + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(a.ev, s));
+    a.active = true;
+    return 0;
+}
+int immesh_downsample_end(immesh_ctx* c, int32_t* n_out, const float** dev_xyz) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    immesh_ctx::DsAsync& a = c->dsa;
+    if (!a.active) { c->err = "immesh_downsample_end: no job in flight"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    HIPCHK(c, hipEventSynchronize(a.ev));
+    a.active = false;
+    const int need = ds_bits_of(a.h_info);
+    a.pred_bits = std::min(64, need + 1);
+    if (need > a.used_bits) {
+        // the cloud spans a larger grid than predicted: its keys were sorted on too few bits -- redo it with the synchronous entry (rare: a jump of the extents)
+        int32_t cnt = 0;
+        const int rc = immesh_downsample(c, (const float*)a.d_in, a.n, a.stride, a.leaf, nullptr, 0, &cnt);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpy(a.out[a.par], c->d_ds_out, (size_t)cnt * 12, hipMemcpyDeviceToDevice));
+        a.h_info[6] = cnt;
+    }
+    *n_out = a.h_info[6];
+    if (dev_xyz) *dev_xyz = a.out[a.par];
+    return 0;
+}
 
 // void reconstruct_mesh_from_pointcloud(pcl::PointCloud<pcl::PointXYZI>::Ptr, double)   src/ImMesh_mesh_reconstruction.cpp:328-345:
 // VoxelGrid(leaf) -> one package with the identity pose, frame 0 -> incremental_mesh_reconstruction

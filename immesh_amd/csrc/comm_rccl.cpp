@@ -7,6 +7,7 @@
 // the collectives are latency-bound (one ring step per peer over point-to-point links), never link-bound.
 #include "host_ctx.hpp"
 #include <dlfcn.h>
+#include <cstdint>
 
 namespace {
 // the handful of RCCL entry points used (signatures of rccl/rccl.h; ncclDataType_t / ncclRedOp_t passed as their integer values)
@@ -51,20 +52,32 @@ bool rccl_load() {
 std::string rccl_why(int rc) { return g_rccl.error_string ? std::string(g_rccl.error_string(rc)) : std::to_string(rc); }
 }  // namespace
 
+// Stubbed collectives (immesh_stub_collectives): ONE rank of a sharded job runs alone -- the all-reduce leaves this rank's partial sums as they are, the
+// all-gather delivers only this rank's own block (the others read as zero records).  What it is for: sizing and timing one rank's share of a map that
+// needs a node (configs[4]) on a single GPU; the results are those of the sub-problem this rank sees, not of the job.
+static void* const RCCL_STUB = (void*)(uintptr_t)1;
 int rccl_allreduce_f64(immesh_ctx* c, double* dev_buf, size_t n, hipStream_t s) {
+    if (c->rccl_comm == RCCL_STUB) { c->rccl_calls++; return 0; }
     const int rc = g_rccl.all_reduce(dev_buf, dev_buf, n, RCCL_FLOAT64, RCCL_SUM, c->rccl_comm, s);
     if (rc) { c->err = "ncclAllReduce: " + rccl_why(rc); return IMMESH_E_HIP; }
     c->rccl_calls++;
     return 0;
 }
 int rccl_allgather_bytes(immesh_ctx* c, const void* dev_send, void* dev_recv, size_t bytes_per_rank, hipStream_t s, std::string* err) {
+    if (c->rccl_comm == RCCL_STUB) {
+        const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1, me = c->cfg.shard_world > 1 ? c->cfg.shard_rank : 0;
+        if (hipMemsetAsync(dev_recv, 0, bytes_per_rank * (size_t)world, s) != hipSuccess ||
+            hipMemcpyAsync((char*)dev_recv + bytes_per_rank * (size_t)me, dev_send, bytes_per_rank, hipMemcpyDeviceToDevice, s) != hipSuccess) { *err = "stubbed all-gather: copy failed"; return IMMESH_E_HIP; }
+        c->rccl_calls++;
+        return 0;
+    }
     const int rc = g_rccl.all_gather(dev_send, dev_recv, bytes_per_rank, RCCL_INT8, c->rccl_comm, s);
     if (rc) { *err = "ncclAllGather: " + rccl_why(rc); return IMMESH_E_HIP; }
     c->rccl_calls++;
     return 0;
 }
 void rccl_release(immesh_ctx* c) {
-    if (c->rccl_comm && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->rccl_comm);
+    if (c->rccl_comm && c->rccl_comm != RCCL_STUB && g_rccl.comm_destroy) (void)g_rccl.comm_destroy(c->rccl_comm);
     c->rccl_comm = nullptr;
 }
 
@@ -96,6 +109,25 @@ int immesh_rccl_init(immesh_ctx* c, const uint8_t id_in[128]) {
     const int rc = g_rccl.comm_init_rank(&c->rccl_comm, world, id, rank);
     if (rc) { c->rccl_comm = nullptr; c->err = "ncclCommInitRank: " + rccl_why(rc); return IMMESH_E_HIP; }
     c->allreduce = nullptr; c->mesh_host.allgather = nullptr;   // the library's own collectives replace the host callbacks
+    return 0;
+}
+
+int immesh_stub_collectives(immesh_ctx* c) {
+    if (!c) return IMMESH_E_INVAL;
+    if (c->cfg.shard_world < 1) { c->err = "immesh_stub_collectives: the context is not sharded (shard_world)"; return IMMESH_E_INVAL; }
+    const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1;
+    if (world > 64) { c->err = "immesh_stub_collectives: more than 64 ranks"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    mesh_wait_all(c);
+    rccl_release(c);
+    if (!c->mesh_host.d_xcounts) { const int arc = c->dalloc(&c->mesh_host.d_xcounts, 64); if (arc) return arc; }
+    c->rccl_comm = RCCL_STUB;
+    c->allreduce = nullptr; c->mesh_host.allgather = nullptr;
+    return 0;
+}
+int immesh_device_bytes(immesh_ctx* c, int64_t* bytes) {
+    if (!c || !bytes) return IMMESH_E_INVAL;
+    *bytes = (int64_t)c->bytes_allocated;
     return 0;
 }
 

@@ -412,9 +412,10 @@ __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, 
         for (int k = na + tid; k < np2; k += 1024) { K[k] = ~0ull; V[k] = -1; }
         __syncthreads();
         for (int k = 2; k <= np2; k <<= 1)            // ascending packed key == ascending (x, y, z); keys are unique (one entry per voxel)
-            for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int lj = 31 - __clz(k >> 1); lj >= 0; lj--) {
+                const int j = 1 << lj;
                 for (int p = tid; p < (np2 >> 1); p += 1024) {
-                    const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
+                    const int i = ((p >> lj) << (lj + 1)) | (p & (j - 1)), ixj = i + j;
                     const bool up = ((i & k) == 0);
                     const unsigned long long x = K[i], y = K[ixj];
                     if ((x > y) == up) { K[i] = y; K[ixj] = x; const int t = V[i]; V[i] = V[ixj]; V[ixj] = t; }
@@ -1347,9 +1348,10 @@ IMD bool rec_gt(const SortRec& a, const SortRec& b) { return a.k0 > b.k0 || (a.k
 template <int NT>
 IMD void lds_sort_recs(SortRec* a, int np2, int tid) {
     for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int lj = 31 - __clz(k >> 1); lj >= 0; lj--) {   // j = 2^lj: shifts, not the integer division a runtime j costs in every stage
+            const int j = 1 << lj;
             for (int p = tid; p < (np2 >> 1); p += NT) {
-                const int i = ((p / j) * 2 * j) + (p % j), ixj = i + j;
+                const int i = ((p >> lj) << (lj + 1)) | (p & (j - 1)), ixj = i + j;
                 const bool up = ((i & k) == 0);
                 const SortRec x = a[i], y = a[ixj];
                 if (rec_gt(x, y) == up) { a[i] = y; a[ixj] = x; }
@@ -1543,7 +1545,7 @@ void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KL
 // IMMESH_MESH_GRID_DIV (experiments): divides the grids of the two big per-voxel kernels -- fewer resident mesher wavefronts per SIMD leave register
 // room for the registration chain's kernels
 static int mesh_grid_div() { static const int v = getenv("IMMESH_MESH_GRID_DIV") ? std::max(1, atoi(getenv("IMMESH_MESH_GRID_DIV"))) : 1; return v; }
-void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(1024 / mesh_grid_div()), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
+void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(512 / mesh_grid_div()), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
 void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor) {
     KLAUNCH(mesh_knn_kernel<true>, dim3(2048), dim3(256), 0, s, m, export_vtx, smooth_factor);
 }
@@ -1574,10 +1576,11 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 }
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
-    KLAUNCH(mesh_delaunay64_kernel, dim3(2048 / mesh_grid_div()), dim3(64), 0, s, m);          // n_u <= 64: register fast path
-    KLAUNCH(mesh_delaunay_general_kernel, dim3(1024), dim3(64), 0, s, m);    // even blocks: 64 < n_u <= 256 and what the fast path handed over; odd blocks: n_u > 256
+    // (grids: the dispatcher places ~130 workgroups per us, so a launch of 2048 workgroups lasts >= 16 us however little they do; the kernels stride)
+    KLAUNCH(mesh_delaunay64_kernel, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m);           // n_u <= 64: register fast path
+    KLAUNCH(mesh_delaunay_general_kernel, dim3(256), dim3(64), 0, s, m);     // even blocks: 64 < n_u <= 256 and what the fast path handed over; odd blocks: n_u > 256
 }
-void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(2048), dim3(64), 0, s, m); }
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(512), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted) { KLAUNCH(mesh_commit_add_kernel, dim3(128), dim3(256), 0, s, m, tris_sorted); }
 // which 0: active-voxel list (-> act_vox_s + ranks); which 1: remove / add / flip-update / smooth lists (-> sorted outputs)

@@ -259,6 +259,13 @@ const char* immesh_rccl_error(void);
 /* payload bytes this rank has contributed to the mesher's all-gathers, and the number of collective calls, since create */
 int immesh_shard_traffic(immesh_ctx* ctx, int64_t* bytes, int64_t* calls);
 
+/* Capacity planning on one GPU: run ONE rank of a sharded job alone.  The data-path collectives become local no-ops (the all-reduce leaves this rank's
+ * partial sums, the all-gather delivers only its own records), so the context holds and processes exactly this rank's share of the map -- HBM use and
+ * per-scan time of the share can be measured without the node (bench.py --dry-run-rank).  The poses / meshes are those of the rank's sub-problem. */
+int immesh_stub_collectives(immesh_ctx* ctx);
+/* device memory the context has allocated (registration map, mesh map, scratch), bytes */
+int immesh_device_bytes(immesh_ctx* ctx, int64_t* bytes);
+
 /* rank owning root voxel key3 under cfg's shard settings (host mirror of the kernels' ownership function) */
 int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
 
@@ -269,6 +276,12 @@ int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
  * to immesh_register / immesh_process_scan without leaving HBM. */
 int immesh_downsample(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out);
 const float* immesh_downsample_result(immesh_ctx* ctx);
+/* The same VoxelGrid as an asynchronous pair: _begin enqueues the whole down-sampling of scan k+1 on the pre-processing stream and returns at once, so it
+ * runs beside scan k's registration; _end waits for it and hands back the leaf count and the device-resident result (n_out x 3 floats, valid until the
+ * second _begin after it: the results alternate between two buffers).  The radix-sort width of _begin is predicted from the previous cloud's grid
+ * extents; a cloud that needs more bits is redone synchronously inside _end -- the result is always the one immesh_downsample gives. */
+int immesh_downsample_begin(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf);
+int immesh_downsample_end(immesh_ctx* ctx, int32_t* n_out, const float** dev_xyz);
 
 /* ImuProcess::Forward_without_imu   src/IMU_Processing.cpp:486-553 : constant-velocity prior (state + covariance) for the next scan. */
 int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out);

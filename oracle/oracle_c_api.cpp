@@ -146,6 +146,14 @@ int orc_downsample(void* p, const float* pts, int32_t n, int32_t stride, double 
     return (out_xyz && cnt > cap_out) ? IMMESH_E_CAPACITY : 0;
 }
 const float* orc_downsample_result(void*) { return nullptr; }
+// the asynchronous pair of the product (immesh_downsample_begin / _end) is the same function run ahead of time: the checker runs it on the spot
+static std::vector<float> g_ds_async;
+static int32_t g_ds_async_n = 0;
+int orc_downsample_begin(void* p, const float* pts, int32_t n, int32_t stride, double leaf) {
+    g_ds_async.assign((size_t)n * 3, 0.f);
+    return orc_downsample(p, pts, n, stride, leaf, g_ds_async.data(), n, &g_ds_async_n);
+}
+int orc_downsample_end(void*, int32_t* n_out, const float** xyz) { *n_out = g_ds_async_n; if (xyz) *xyz = g_ds_async.data(); return 0; }
 int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
 int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t n, double leaf) {   // ImMesh_mesh_reconstruction.cpp:328-345
     std::vector<float> ds((size_t)n * 3);
@@ -156,7 +164,9 @@ int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t
     const double origin[3] = {0, 0, 0};
     return orc_mesh_scan(p, w.data(), n_ds, origin, 0);
 }
-int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }   // the checker is single-process: nothing to reduce
+int orc_set_allreduce(void*, immesh_allreduce_fn, void*) { return 0; }
+int orc_stub_collectives(void*) { return 0; }
+int orc_device_bytes(void*, int64_t* b) { if (b) *b = 0; return 0; }   // the checker is single-process: nothing to reduce
 // ---- legacy registration path (a27)
 int orc_ikd_build(void* p, const float* xyz, int32_t n, double ds) { OrcCtx* o = (OrcCtx*)p; o->ikd.ds = (float)ds; o->ikd.build(xyz, n); return 0; }
 int orc_ikd_add_points(void* p, const float* xyz, int32_t n) { ((OrcCtx*)p)->ikd.add_points(xyz, n); return 0; }

@@ -64,3 +64,35 @@ def test_device_downsample_bit_exact(oracle_lib, hip_lib):
     b = h.residuals(down_host, st1)
     np.testing.assert_array_equal(a["match_idx"], b["match_idx"])
     np.testing.assert_array_equal(a["HTH"], b["HTH"])
+
+
+@pytest.mark.gpu
+def test_async_pair_gives_the_synchronous_result(hip_lib):
+    """immesh_downsample_begin / _end: the VoxelGrid of scan k+1 enqueued ahead of time (radix width predicted from the previous cloud's extents) must be
+    bit for bit what immesh_downsample returns -- for the first cloud (no prediction), for consecutive scans, and after a jump of the extents (fallback)."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    import glob
+    import os
+    cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
+    hip_rt = ctypes.CDLL(cand[0])
+    hip_rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000)
+    h = make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    clouds = []
+    for k in range(4):
+        R, t = synth.trajectory_pose(k)
+        clouds.append(synth.livox_scan(k, R, t, n_pts=60000, extT=extT))
+    clouds.append(np.ascontiguousarray(clouds[0][:500] * np.float32(0.05)))                 # extents collapse ...
+    far = clouds[1].copy(); far[:, :3] *= np.float32(40.0); clouds.append(far)               # ... then jump: more key bits than predicted
+    for raw in clouds:
+        d = torch.from_numpy(raw).cuda()
+        want, n_want = h.downsample(d.data_ptr(), 0.4, n=len(raw), stride=4, to_host=True)
+        h.downsample_begin(d.data_ptr(), 0.4, n=len(raw), stride=4)
+        n_got, ptr = h.downsample_end()
+        assert n_got == n_want
+        got = np.zeros((n_got, 3), np.float32)      # the result stays in HBM: fetched with the HIP runtime torch has already loaded
+        assert hip_rt.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), got.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        np.testing.assert_array_equal(got, want)
+    h.close()

@@ -84,7 +84,10 @@ def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"scan {k} (identical world-frame input)")
     record_property("full_pipeline_scans_bit_exact", f"{n_exact} of 11")
     print(f"[parity] full pipeline: {n_exact} of 11 scans bit-exact (vertices + all triangle lists); mesher on identical inputs: 11 of 11")
-    assert n_exact >= 1
+    # Poses agree to ~1e-12, and a pose difference of that size rounds a world-frame f32 coordinate of the 100 000-pt scan differently now and then: once
+    # a single vertex differs the two mesh maps stay apart by that vertex, so the count of exactly equal scans is reported (7 of 11 in round 3's run), not
+    # required to be all of them; what IS required of every scan: the bounds above, and exact equality on identical world-frame input
+    assert n_exact >= 3
     co, ch = o.counters(), h.counters()
     for key in ("n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_root_voxels"):   # (n_iter per scan is compared above; the oracle also counts the stand-alone matcher pass)
         assert ch[key] == co[key], key
@@ -95,7 +98,60 @@ def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property
     assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) >= n_planar   # the grown map, again in full
 
 
-def test_hdl64_full_width_scans(oracle_lib, hip_lib):
+@pytest.mark.timeout(900)
+def test_plane_table_parity_on_the_10m_voxel_map(oracle_lib, hip_lib, record_property):
+    """The checker itself at the size of BASELINE.json's metric: BOTH sides ingest the bench's survey strips until the map holds
+    10 M root voxels (38 s on the GPU box's host in round 3; a time budget stops a slower host earlier and the size reached is recorded); the plane
+    tables, the refit counters, one full-size matcher pass and three stream scans are then compared."""
+    torch = pytest.importorskip("torch")
+    import time
+    import bench
+    dev = torch.device("cuda", 0)
+    n_vox = 10.0e6
+    cfg = capi.avia_config(cap_root_voxels=int(n_vox * 1.3) + (1 << 16), cap_scan_points=2_500_000, cap_vertices=1 << 20, cap_triangles=1 << 22)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    side = float(np.sqrt(n_vox / 8.8)) + 40.0
+    ident = capi.make_state()
+    cap = int(cfg.cap_scan_points)
+    t0 = time.time()
+    for P in bench.survey_strips(cfg, torch, dev, side):
+        for a in range(0, P.shape[0], cap):
+            chunk = P[a:a + cap]
+            h.map_update(chunk.data_ptr(), ident, n=chunk.shape[0])
+            o.map_update(np.ascontiguousarray(chunk.cpu().numpy()), ident)
+        nv = h.counters()["n_root_voxels"]
+        if nv >= n_vox or time.time() - t0 > 240.0:
+            break
+    record_property("root_voxels_compared", int(nv))
+    print(f"[parity] 10 M map: {nv} root voxels on both sides after {time.time() - t0:.0f} s")
+    assert nv >= 2_000_000 and o.counters()["n_root_voxels"] == nv
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+    n_planar = compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL)   # every initialised node of both maps (same node sets is part of the comparison)
+    assert n_planar > 0.8 * nv
+    record_property("planar_nodes_compared", n_planar)
+    extT = np.array(list(cfg.extT))
+    so = capi.make_state(R=synth.trajectory_pose(0)[0], t=synth.trajectory_pose(0)[1])
+    so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    for k in range(0, 3):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, Rk, tk, n_pts=100000, extT=extT)
+        down = synth.voxel_grid_downsample(raw, 0.4)
+        po, ph = (synth.forward_without_imu(so), synth.forward_without_imu(sh)) if k else (so, sh)
+        if k == 1:
+            ro, rh = o.residuals(down, po), h.residuals(down, po)
+            assert np.array_equal(rh["match_idx"], ro["match_idx"]) and len(ro["match_idx"]) > 5000
+            np.testing.assert_array_equal(rh["dis"], ro["dis"])
+        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=False)
+        sh, ih = h.process_scan(down, raw, ph, ph, frame_idx=k, do_mesh=0)
+        assert ih == io, (k, ih, io)
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+
+
+def test_hdl64_full_width_scans(oracle_lib, hip_lib, record_property):
     """configs[3] at its real width: 64 rings x 2032 azimuth steps, velodyne.yaml (3 m root voxels, max_layer 4, 3 EKF iterations, mesh scale 1.5)"""
     caps = dict(cap_root_voxels=1 << 16, cap_scan_points=400_000, cap_vertices=1 << 21, cap_triangles=1 << 23)
     cfg = capi.velodyne_config(**caps)
@@ -110,6 +166,7 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib):
     assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
     so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
     sh = so.copy()
+    n_exact, still_exact = 0, True
     for k in range(1, 5):
         Rk, tk = synth.trajectory_pose(k)
         raw = synth.hdl64_scan(k, Rk, tk, n_az=2032)
@@ -119,12 +176,22 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib):
             ro, rh = o.residuals(down, po), h.residuals(down, po)
             assert np.array_equal(rh["match_idx"], ro["match_idx"]) and len(ro["match_idx"]) > 3000
             np.testing.assert_allclose(rh["HTH"], ro["HTH"], rtol=1e-7, atol=1e-6)
-        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=False)
-        sh, ih = h.process_scan(down, raw, ph, ph, frame_idx=k, do_mesh=0)
+        # the FULL pipeline (registration + map growth + meshing in one call, as service_LiDAR_update runs it) ...
+        so, io = o.process_scan(down, raw, po, po, frame_idx=k, do_mesh=True)
+        sh, ih = h.process_scan(down, raw, ph, ph, frame_idx=k, do_mesh=1)
         assert ih == io, (k, ih, io)
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+        np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)
+        mo, mh = o.mesh_fetch(), h.mesh_fetch()
+        still_exact = still_exact and _exact(mo, mh)
+        n_exact += int(still_exact)
+        if not still_exact:
+            assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50, k
+        # ... and the mesher alone on bit-identical world-frame input (the oracle's pose): every list of every scan
         w = _world(raw, so, cfg)
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"hdl64 scan {k}")
+    record_property("hdl64_full_pipeline_scans_bit_exact", f"{n_exact} of 4")
+    assert n_exact >= 1
     assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
     assert o2.counters()["n_vertices"] > 5000
 
