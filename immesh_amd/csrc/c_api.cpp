@@ -184,7 +184,10 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
 // stage timings or the flags settles it first.  `synced`: the caller knows the stream has already passed that work.
 static int settle(immesh_ctx* c, bool synced = false) {
     if (!c->pending) return 0;
-    if (!synced) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!synced) {
+        if (c->tail_deferred) { launch_map_update_tail(c->stream, c->map, c->d_counters_host); c->tail_deferred = false; }   // nobody registers next: run the update's tail now
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->pending = false;
     hipEvent_t* e = c->ev + 4 * c->ev_par;
     c->timing[1] = c->timing[2] = 0.f;
@@ -243,6 +246,8 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
     RegIterArgs& a = c->reg_args;
     make_scan_params(c, st, st.cov, a.sp);
     a.max_iter = max_iter; a.pad = 0;
+    if (c->tail_deferred && !c->rccl_comm) { a.pad = 1; c->tail_deferred = false; }   // the previous scan's map update left its tail to this launch
+    else if (c->tail_deferred) { launch_map_update_tail(c->stream, c->map, c->d_counters_host); c->tail_deferred = false; }
     std::memcpy(a.st, st.R, 72); std::memcpy(a.st + 9, st.t, 24); std::memcpy(a.st + 12, st.vel, 24); std::memcpy(a.st + 15, st.bg, 24); std::memcpy(a.st + 18, st.ba, 24); std::memcpy(a.st + 21, st.g, 24);
     std::memcpy(a.prior, prior.R, 72); std::memcpy(a.prior + 9, prior.t, 24); std::memcpy(a.prior + 12, prior.vel, 24); std::memcpy(a.prior + 15, prior.bg, 24);
     std::memcpy(a.prior + 18, prior.ba, 24); std::memcpy(a.prior + 21, prior.g, 24);
@@ -253,7 +258,7 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
         a.mode = REG_MODE_FUSED; a.it = 0;
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
         const int par = (c->rp_parity ^= 1);   // this scan's slot buffer; the launch re-arms the other one for the next scan
-        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_slots[par], c->d_rp_slots[par ^ 1], c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
+        launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_slots[par], c->d_rp_slots[par ^ 1], c->d_counters_host, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
                                    c->d_dis, c->d_rinv, c->d_normal);
         return 0;
     }
@@ -410,13 +415,14 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
 // spd != nullptr: pose + covariance blocks come from device memory (the posterior the in-kernel EKF left in RegState::sp); `st` then only
 // supplies the per-configuration constants
 static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr,
-                             const ScanParams* spd = nullptr, const float* d_raw = nullptr, float* world = nullptr, int n_raw = 0) {
+                             const ScanParams* spd = nullptr, const float* d_raw = nullptr, float* world = nullptr, int n_raw = 0, bool defer_tail = false) {
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
     if (mode == 0) {
         // map_incremental_grow: no global sort -- points are chained per root voxel and each voxel's wavefront orders its own points
         // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
+        if (c->tail_deferred) { launch_map_update_tail(s, c->map, c->d_counters_host); c->tail_deferred = false; }   // (safety: a deferred tail precedes the next update; immesh_process_scan runs it in the residual kernel, every other entry settles first)
         c->map.upd_seq++;
         c->map.touched = c->d_touched;
         launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a, d_raw, world, n_raw);
@@ -424,7 +430,8 @@ static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int s
         // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
         if (world) c->ev_inputs_cur = mesh_record_ready(c);
         else if (after_point_var) { HIPCHK(c, hipEventRecord(after_point_var, s)); c->ev_inputs_cur = after_point_var; }
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->reg_dbg);
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->reg_dbg, !defer_tail);
+        c->tail_deferred = defer_tail;
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
         // buildVoxelMap: bucket all points per voxel in scan order (stable sort by slot), then initialise every voxel
@@ -504,7 +511,8 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         float* world = nullptr;
         if (mesh_mode) world = mesh_next_world_buffer(c);
         // (the transform of the full scan for the mesher rides in the first launch of the map update)
-        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw))) return rc;
+        if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw,
+                                    /*defer_tail=*/nowait && !c->rccl_comm))) return rc;
         if (timed) (void)hipEventRecord(ev[2], c->stream);
         c->timing_valid[par] = timed;
         rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);

@@ -38,6 +38,7 @@ struct immesh_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // two sets of four (scan parity)
     int ev_par = 0;
     bool pending = false;            // the last immesh_process_scan returned without waiting for its map update (IMMESH_SCAN_NOWAIT)
+    bool tail_deferred = false;      // ... and left the update's tail (free-list merge, counters to the host) to the next scan's residual_persistent_kernel
     float timing[4] = {0, 0, 0, 0};
     std::vector<void*> allocs;
     size_t bytes_allocated = 0;

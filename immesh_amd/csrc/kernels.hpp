@@ -47,7 +47,7 @@ struct RegState {
 #define REG_MODE_FUSED 1      /* residual_persistent_kernel: every pass of the scan + the 18-state update in one launch; mat = the prior covariance */
 #define REG_MODE_SUMS 3       /* parameters from RegState (it > 0) or by value (it == 0); the 48 sums go to device memory for an in-stream all-reduce, ekf_step_kernel follows */
 struct RegIterArgs {
-    int mode, it, max_iter, pad;
+    int mode, it, max_iter, pad;   // pad: residual_persistent_kernel -- 1 = run the previous map update's deferred tail in the prologue
     ScanParams sp;
     double st[24], prior[24];
     double mat[324];          // first pass: [0,36) P11^-1, [36,108) P21 P11^-1; later passes: the prior covariance
@@ -61,7 +61,7 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
 #define RP_SLOT_DOUBLES (64 * 128 * 32)
 #define RP_SLOT_SENTINEL 0x7FF8DEADBEEF0001ull
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
-                                double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`
@@ -69,7 +69,9 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next, const float* raw_xyzi = nullptr, float* world_xyzi = nullptr, int n_raw = 0);
 // (raw_xyzi != nullptr: the same launch also transforms the full xyzI scan into the world frame for the mesher)
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg = nullptr);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg = nullptr, bool with_tail = true);
+// the tail of a map update whose launch was deferred (launch_replay_lists with_tail = false; RegIterArgs::pad of the next residual_persistent_kernel)
+void launch_map_update_tail(hipStream_t s, const RegMapDev& m, int32_t* host_counters);
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);
 void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slot, const int32_t* sorted_idx, const double* pt_data, int n,
                    const int32_t* seg_start, const int32_t* nseg, int max_segments, int mode, int64_t* stats);

@@ -354,6 +354,19 @@ __device__ __forceinline__ bool ekf_step_wave(RegState* __restrict__ rs, const d
 // to acc[RES_NR] and writes the per-point match outputs.  Shared by the single-pass kernel and the persistent one.
 // What does not depend on the iterate is computed once per scan (residual_prep) and stays in registers over the passes of the resident grid.
 #define RDBG(k) do { if (sp.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&sp.dbg[k], _t - tprev); tprev = _t; } } while (0)
+// The tail of a map update (all 256 threads of one workgroup): chunks freed by the replay kernels join the free list, the per-update counters reset,
+// and the map counters (node / chunk usage, capacity flag) go to pinned host memory.  Its own one-workgroup launch for the synchronous entry points; an
+// asynchronous immesh_process_scan leaves it to the prologue of the NEXT scan's residual_persistent_kernel (one launch less on the pose chain).
+__device__ __forceinline__ void map_update_tail(const RegMapDev& m, int32_t* __restrict__ host_counters) {
+    const int np = m.counters[3];
+    const int base = m.counters[2];
+    for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
+    __syncthreads();
+    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; m.counters[10] = 0; m.counters[11] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct PointPrep {
     double pimu[3];     // the point in the IMU frame
     double bcov[9];     // calcBodyVar of the lidar-frame point (:1302-1316)
@@ -766,6 +779,7 @@ __device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, Reg
 
 __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
                                                                    double* __restrict__ slots, double* __restrict__ slots_next, int n_slots_next,
+                                                                   int32_t* __restrict__ host_counters,
                                                                    double* __restrict__ reg_out, double ticket,
                                                                    int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
                                                                    float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
@@ -776,6 +790,8 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
     // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
+    // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below
+    if (a.pad && blockIdx.x == gridDim.x - 1) map_update_tail(m, host_counters);
     if (wv == 0) {
         // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
         double c6[6];
@@ -1797,15 +1813,7 @@ __global__ void merge_free_kernel(RegMapDev m) {
 __global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; m.counters[7] = 0; }
 // Tail of the per-scan map update, one launch: chunks freed by the replay kernel join the free list, the per-update counters reset, and the map
 // counters (node / chunk usage, capacity flag) go straight to pinned host memory -- the next scan's residual passes are queued right behind it.
-__global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32_t* __restrict__ host_counters) {
-    const int np = m.counters[3];
-    const int base = m.counters[2];
-    for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
-    __syncthreads();
-    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; m.counters[10] = 0; m.counters[11] = 0; }
-    __syncthreads();
-    if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
+__global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32_t* __restrict__ host_counters) { map_update_tail(m, host_counters); }
 
 // =====================================================================================================================
 // introspection
@@ -1847,9 +1855,9 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
     KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
-                                double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = std::min((n + 255) / 256, RP_MAX_BLOCKS);   // resident grid: at most 128 four-wavefront blocks, half a CU's worth each
-    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, reg_out, ticket, o_match, o_node,
+    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
             o_dis, o_rinv, o_normal);
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
@@ -1862,14 +1870,15 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
             (float4*)world_xyzi, n_raw, nb_pv);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg) {
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg, bool with_tail) {
     KLAUNCH(replay_fused_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg);
     // the work list's length is only known on the device: a fixed grid strides over it (sized for the map-building case, where every touched voxel is on it)
     const int nb_list = std::min(std::max((n + 127) / 128, 32), 4096);
     KLAUNCH(replay_list_kernel, dim3(nb_list), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
             (const int32_t*)(m.counters + 10));
-    KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
+    if (with_tail) KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
+void launch_map_update_tail(hipStream_t s, const RegMapDev& m, int32_t* host_counters) { KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters); }
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg) {
     (void)hipMemsetAsync(nseg, 0, sizeof(int32_t), s);
     KLAUNCH(segment_heads_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sorted_slot, n, seg_start, nseg);
