@@ -216,8 +216,8 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     return None
 
 
-COMMITTED_STATS = "r02_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
-COMMITTED_TRAFFIC = "traffic_r02.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+COMMITTED_STATS = "r03_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
+COMMITTED_TRAFFIC = "traffic_r03.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
 
 
 def roofline_from_committed_profile(mesh, cnt, n_scans, n_raw, note):
@@ -297,8 +297,8 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         d_raw = [torch.from_numpy(r).to(dev) for r in raws]
         d_down = [torch.from_numpy(d).to(dev) for d in downs]
     n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))
-    mesh_seed = None
-    if args.dense_mesh and args.mesh and not kitti:
+    mesh_seed, seed_cloud = None, None
+    if args.dense_mesh and args.mesh and not kitti and not sharded:
         # the mesh map pre-seeded from the survey, capped at the stream's corridor.  The cloud goes through the mesher in
         # packages of mesh_append_budget points (every point is offered: step 1), before the stream starts
         t_seed = time.time()
@@ -311,6 +311,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         cs = h.counters()
         mesh_seed = {"cloud_points": int(P.shape[0]), "vertices": int(cs["n_vertices"]), "triangles_live": int(cs["n_triangles_live"]), "seconds": round(time.time() - t_seed, 1)}
         log(f"[bench] mesh map pre-seeded from the corridor survey: {mesh_seed}")
+        seed_cloud = P.cpu().numpy() if (full and args.cpu_seconds > 0 and rank == 0) else None   # the CPU-baseline leg seeds the oracle's mesh map with the very same cloud
         del P
 
     # scan 0 seeds the stream state; constant-velocity prior (Forward_without_imu) between scans
@@ -392,7 +393,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
            "pose_err": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1])),
            "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
                               if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
-           "cpu_inputs": (cfg, cpu_raws, cpu_downs, R0, t0) if not (args.gpu_scans and not kitti) else None}
+           "cpu_inputs": (cfg, cpu_raws, cpu_downs, R0, t0, seed_cloud) if not (args.gpu_scans and not kitti) else None}
     if sharded:
         res["shard_traffic"] = h.shard_traffic()
 
@@ -433,7 +434,7 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
     """The oracle (CPU restatement, kind "port") on the host cores: a bounded sample of the same stream.  Two variants per SURVEY 8(d): (i) the
     reference's own threading (12-thread pool over mesh voxels, maximum_thread_for_rec_mesh; 4 OpenMP threads in the matcher, MP_PROC_NUM) and
     (ii) every parallelisable loop on all cores; per-stage p50 / p95 after warm-up.  Results of the variants are identical."""
-    cfg, raws, downs, R0, t0 = hip_cfg_inputs
+    cfg, raws, downs, R0, t0, seed_cloud = hip_cfg_inputs
     orc_so = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(orc_so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
@@ -460,6 +461,12 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
                 break
     n_map = int(o.counters()["n_root_voxels"])
     so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    if args.mesh and seed_cloud is not None:   # the same pre-seeded mesh map as the GPU leg: the corridor cloud in packages of mesh_append_budget points
+        o.set_threads(ncores if ncores < 16 else ncores // 2, min(4, ncores))
+        cam0 = synth.trajectory_pose(0)[1] + np.array([0.0, 0.0, 1.0])
+        pkg = int(cfg.mesh_append_budget)
+        for a in range(0, len(seed_cloud), pkg):
+            o.mesh_scan(np.ascontiguousarray(seed_cloud[a:a + pkg]), cam0, frame_idx=0, fetch=False)
     if args.mesh:
         o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
     cursor = {"kk": 1, "so": so}
@@ -602,7 +609,8 @@ def main():
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     ap.add_argument("--gpu-scans", type=int, default=0, help="1 = the scan stream is ray-cast on the GPU by the harness (torch) and down-sampled by the library before the timed region: "
                     "hundreds of scans in seconds (the steady-state leg); the CPU-baseline leg needs the default host-generated stream")
-    ap.add_argument("--dense-mesh", type=int, default=0, help="1 = pre-seed the MESH map from a dense survey of the stream's corridor (SURVEY 8(d) C3) before the stream starts")
+    ap.add_argument("--dense-mesh", type=int, default=1, help="1 (default, SURVEY 8(d) C3: \"mesh map pre-seeded from the same survey, capped at the corridor\") = the MESH map is pre-seeded from a dense "
+                    "survey of the stream's corridor before the stream starts; 0 = seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)")
     ap.add_argument("--nu-scans", type=int, default=5, help="scans after the timed region whose per-voxel neighbourhood sizes n_u are collected (histogram + kernel shares)")
     ap.add_argument("--dry-run-rank", type=int, default=-1, help=">= 0: run ONE rank of a --dry-run-world job alone on this GPU with stubbed collectives (configs[4] capacity / per-rank time)")
     ap.add_argument("--dry-run-world", type=int, default=8)
@@ -684,6 +692,7 @@ def main():
                        "n_raw": res["n_raw"], "n_ds_mean": round(res["n_ds_mean"], 1), "map_root_voxels": res["n_map"], "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
                        "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
+                       "mesh_map": ("pre-seeded from a dense survey of the stream's corridor (SURVEY 8(d) C3)" if (args.dense_mesh and args.mesh and not kitti and not only_sharded) else "seeded by scan 0 only") if args.mesh else "none",
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device, inside the timed region (asynchronous: scan k+1's VoxelGrid on the pre-processing stream beside scan k's registration)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
                        "inputs": "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region"},
@@ -756,7 +765,7 @@ def main():
         for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20)), "--cpu-seconds", "8"]),
                              ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
                              ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"]),
-                             ("full pipeline, MESH map pre-seeded from the corridor survey (SURVEY 8(d) C3 density)", ["--dense-mesh", "1", "--gpu-scans", "1"]),
+                             ("full pipeline, mesh map seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)", ["--dense-mesh", "0"]),
                              ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
                              ("configs[4] dry run: rank 0 of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "0", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)

@@ -14,7 +14,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 import csv, sys
 from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = min((int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"].startswith("residual_kernel")), default=0)
+first = min((int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"].startswith("residual")), default=0)
 agg = defaultdict(lambda: defaultdict(list))
 for r in rows:
     if int(r["Dispatch_Id"]) < first: continue
