@@ -742,7 +742,7 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
         fprintf(stderr, "[replay_list] slowest fast-path voxel %llu cycles (%llu pts), slowest general voxel %llu cycles (%llu pts); mean cycles fast %llu (%llu voxels) general %llu (%llu voxels); list gather + sort %llu per voxel\n",
                 t[8] >> 16, t[8] & 0xFFFF, t[9] >> 16, t[9] & 0xFFFF, t[10] / std::max(1ull, t[12]), t[12], t[11] / std::max(1ull, t[13]), t[13], t[14] / std::max(1ull, t[12] + t[13]));
         const unsigned long long nwv = std::max(1ull, t[6]), npass = std::max(1ull, t[7]);
-        fprintf(stderr, "[residual cycles/wave, %llu waves in %llu passes] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block tail %llu per pass\n", t[6], t[7], t[0] / nwv, t[1] / nwv,
+        fprintf(stderr, "[residual cycles of wavefront 0, %llu blocks x passes in %llu passes] prep %llu match %llu retry %llu hbuild %llu reduce %llu | last-block tail %llu per pass\n", t[6], t[7], t[0] / nwv, t[1] / nwv,
                 t[2] / nwv, t[3] / nwv, t[4] / nwv, t[5] / npass);
     }
     if (reset) {

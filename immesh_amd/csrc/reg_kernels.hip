@@ -602,6 +602,7 @@ struct RpShared {
     double wsum[4][RES_NR];
     double pc[108];              // [0,36) P11^-1, [36,108) T = P21 P11^-1
     double st[24];               // the iterate (identical in every block)
+    double prior[24];            // the prior state (the update's prior [-] iterate reads it per lane)
     double sums[48];             // this pass: 36 HTH (row-major) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
     double X[36], y[6], sol[18];
     double M[108], XM[108];      // stop pass: H^T H P[0:6,:] and X times it
@@ -613,14 +614,53 @@ IMD void lds_wave_sync() {   // make this wavefront's LDS writes visible to its 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-// one wavefront; S.sums / S.st / S.rematch / S.tot in, S.st / S.rematch / S.tot / S.stop out.  cov = the prior covariance (kernel argument).
-__device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, const int it, const int lane, const bool writer, RegState* __restrict__ rs,
-                                          double* __restrict__ reg_out, const double ticket, unsigned long long* __restrict__ dbg) {
+// vec6 = (prior [-] iterate)[0:6] of the pass (rotation difference through Log, translation difference): every lane of the wavefront computes the
+// same six values.  It only needs the iterate, so the caller evaluates it while the other blocks' partial sums are still in flight.
+__device__ __forceinline__ void rp_prior_minus_state(const RpShared& S, double* __restrict__ R12, double* __restrict__ vec6) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) R12[k] = S.st[k];
+    double Rt[9], rotd[9], pR[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) pR[k] = S.prior[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; j2++) Rt[i * 3 + j2] = R12[j2 * 3 + i];
+    m3_mul(Rt, pR, rotd);
+    dev_so3_log(rotd, vec6);
+#pragma unroll
+    for (int k = 0; k < 3; k++) vec6[3 + k] = S.prior[9 + k] - R12[9 + k];
+}
+// The 18-state update on one wavefront; S.sums / S.st / S.rematch / S.tot in, S.st / S.rematch / S.tot / S.stop / S.X out.  Laid out for the latency of a
+// lone wavefront: nothing is handed over through LDS inside the update.  Lanes 6..11 own one column of X = (H^T R^-1 H + P11^-1)^-1 each (the
+// Gauss-Jordan leaves it in their registers; X is symmetric, so the column serves as the row); w = H^T z - H^T H vec6 and y = X w travel between
+// lanes as v_readlane broadcasts; lane l < 18 then owns component l of the solution K1 w + vec (rows 6..17: T y, T row l - 6 from LDS) and lanes
+// 6..17 add theirs to their own state component; only the rotation / translation part (solution[0:6] = y + vec6, uniform) is computed by every lane.
+__device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, const int it, const int lane, const bool writer, const double* __restrict__ R12,
+                                          const double* __restrict__ vec6, unsigned long long* dbg) {
     unsigned long long tk = dbg ? __builtin_readcyclecounter() : 0;
 #define EDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0 && writer) dbg[40 + (k)] += _t - tk; tk = _t; } } while (0)
-    // ---- X = (H^T R^-1 H + P11^-1)^-1: lane j < 12 holds column j of [S | I]; Gauss-Jordan without pivoting (symmetric positive definite)
+    const int own = lane < 18 ? lane : 0;                 // the solution component of this lane
+    const int row = (lane >= 6 && lane < 12) ? lane - 6 : 0;
+    // ---- loads that depend on nothing computed here: this lane's row of H^T H / H^T z (w), of T (solution rows 6..17), its state / prior component
+    double hrow[6], trow[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) { hrow[c] = S.sums[row * 6 + c]; trow[c] = S.pc[36 + (own >= 6 ? own - 6 : 0) * 6 + c]; }
+    const double hz = S.sums[36 + row];
+    const double st_own = S.st[own + 6], prior_own = S.prior[own + 6];     // (components 3..17 of vec are plain differences)
+    // ---- w = H^T z - H^T H vec6 (lanes 6..11), broadcast
+    double w[6];
     {
-        double c6[6];
+        double sacc = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++) sacc += hrow[c] * vec6[c];
+        const double wl = hz - sacc;
+#pragma unroll
+        for (int c = 0; c < 6; c++) w[c] = rl_d(wl, 6 + c);
+    }
+    // ---- X: lane j < 12 holds column j of [S | I]; Gauss-Jordan without pivoting (symmetric positive definite)
+    double c6[6];
+    {
         const int j = lane < 12 ? lane : 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) c6[r] = j < 6 ? S.sums[r * 6 + j] + S.pc[r * 6 + j] : ((r == j - 6) ? 1.0 : 0.0);
@@ -636,88 +676,53 @@ __device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, con
         }
         if (lane >= 6 && lane < 12) {
 #pragma unroll
-            for (int r = 0; r < 6; r++) S.X[r * 6 + (lane - 6)] = c6[r];
+            for (int r = 0; r < 6; r++) S.X[r * 6 + (lane - 6)] = c6[r];   // (rp_finish reads it behind a barrier)
         }
     }
     EDBG(0);
-    // ---- vec = prior [-] state (every lane computes the same 18 values)
-    double st[24], vec[18];
-#pragma unroll
-    for (int k = 0; k < 24; k++) st[k] = S.st[k];
+    // ---- y = X w (lanes 6..11: column = row), broadcast; solution component of this lane
+    double y[6];
     {
-        double Rt[9], rotd[9], pR[9];
+        double yl = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) pR[k] = a.prior[k];
+        for (int c = 0; c < 6; c++) yl += c6[c] * w[c];
 #pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j2 = 0; j2 < 3; j2++) Rt[i * 3 + j2] = st[j2 * 3 + i];
-        m3_mul(Rt, pR, rotd);
-        dev_so3_log(rotd, vec);
-#pragma unroll
-        for (int k = 0; k < 15; k++) vec[3 + k] = a.prior[9 + k] - st[9 + k];
+        for (int c = 0; c < 6; c++) y[c] = rl_d(yl, 6 + c);
     }
-    EDBG(1);
-    // ---- solution = K1 (H^T z - H^T H vec6) + vec,  K1 = [X; T X]
-    lds_wave_sync();
-    if (lane < 6) {
-        double w[6];
+    double sol6[6];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double sacc = 0;
+    for (int k = 0; k < 6; k++) sol6[k] = y[k] + vec6[k];
+    double sol_own;
+    {
+        double sacc = 0;
 #pragma unroll
-            for (int c = 0; c < 6; c++) sacc += S.sums[r * 6 + c] * vec[c];
-            w[r] = S.sums[36 + r] - sacc;
-        }
-        double yv = 0;
-#pragma unroll
-        for (int c = 0; c < 6; c++) yv += S.X[lane * 6 + c] * w[c];
-        S.y[lane] = yv;
+        for (int q = 0; q < 6; q++) sacc += trow[q] * y[q];
+        sol_own = sacc + (prior_own - st_own);
     }
-    lds_wave_sync();
-    if (lane < 18) {
-        double v = 0, sacc = 0;
-#pragma unroll
-        for (int k = 0; k < 18; k++) if (lane == k) v = vec[k];
-        if (lane < 6) sacc = S.y[lane];
-        else {
-#pragma unroll
-            for (int q = 0; q < 6; q++) sacc += S.pc[36 + (lane - 6) * 6 + q] * S.y[q];
-        }
-        S.sol[lane] = sacc + v;
-    }
-    lds_wave_sync();
-    double sol[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) sol[k] = S.sol[k];
     EDBG(2);
     // ---- state += solution, stop rule (voxel_mapping.cpp:1600-1650)
+    double Rn[9];
     {
-        double E[9], Rn[9];
-        dev_so3_exp(sol[0], sol[1], sol[2], E);
-        m3_mul(st, E, Rn);
-#pragma unroll
-        for (int k = 0; k < 9; k++) st[k] = Rn[k];
-#pragma unroll
-        for (int k = 0; k < 15; k++) st[9 + k] += sol[3 + k];
+        double E[9];
+        dev_so3_exp(sol6[0], sol6[1], sol6[2], E);
+        m3_mul(R12, E, Rn);
     }
-    const double rn = sqrt(sol[0] * sol[0] + sol[1] * sol[1] + sol[2] * sol[2]);
-    const double tn = sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
+    const double rn = sqrt(sol6[0] * sol6[0] + sol6[1] * sol6[1] + sol6[2] * sol6[2]);
+    const double tn = sqrt(sol6[3] * sol6[3] + sol6[4] * sol6[4] + sol6[5] * sol6[5]);
     const bool converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
     int rematch = S.rematch;
     if (converged || ((rematch == 0) && (it == (a.max_iter - 2)))) rematch++;
     const bool stop = rematch >= 2 || (it == a.max_iter - 1);
     const double t_tests = S.tot[0] + S.sums[44], t_extra = S.tot[1] + S.sums[45], t_pass = S.tot[2] + 1.0, t_match = S.tot[3] + S.sums[42];
-    lds_wave_sync();
-    if (lane < 24) {
-        double v = 0;
+    if (lane >= 6 && lane < 18) S.st[lane + 6] = st_own + sol_own;
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 24; k++) if (lane == k) v = st[k];
-        S.st[lane] = v;
+        for (int k = 0; k < 9; k++) S.st[k] = Rn[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) S.st[9 + k] = R12[9 + k] + sol6[3 + k];
+        S.rematch = rematch; S.stop = stop ? 1 : 0; S.tot[0] = t_tests; S.tot[1] = t_extra; S.tot[2] = t_pass; S.tot[3] = t_match;
     }
-    if (lane == 0) { S.rematch = rematch; S.stop = stop ? 1 : 0; S.tot[0] = t_tests; S.tot[1] = t_extra; S.tot[2] = t_pass; S.tot[3] = t_match; }
     EDBG(3);
-    EDBG(4);
     if (dbg && lane == 0 && writer) dbg[47] += 1;
 #undef EDBG
 }
@@ -788,16 +793,30 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const ScanParams& sp = a.sp;     // per-scan constants stay kernel arguments (scalar loads); only the iterate changes between passes
     unsigned long long tprev = sp.dbg ? __builtin_readcyclecounter() : 0;
+    const unsigned long long t_entry = sp.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // (trace: [4] of the pass-0 record = kernel entry, [5] = block 0 finished)
     // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
-    // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below
-    if (a.pad && blockIdx.x == gridDim.x - 1) map_update_tail(m, host_counters);
+    // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below.  It gets a workgroup of its
+    // own (the launcher adds one): inside a working block it delayed that block's first partial sums, i.e. everybody's first gather
+    const int G = (int)gridDim.x - 1;
+    if ((int)blockIdx.x == G) {
+        if (a.pad) map_update_tail(m, host_counters);
+        return;
+    }
     if (wv == 0) {
-        // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I]
-        double c6[6];
+        // ---- per-scan constants of the gain: a.mat = the prior covariance P (18 x 18); lane j < 12 holds column j of [P11 | I].  Everything read
+        //      from the argument block is requested up front (one round trip to wherever the runtime keeps kernel arguments, not three)
+        double c6[6], trw[2][6];
         const int j = lane < 12 ? lane : 0;
 #pragma unroll
         for (int r = 0; r < 6; r++) c6[r] = j < 6 ? a.mat[r * 18 + j] : ((r == j - 6) ? 1.0 : 0.0);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int e = lane + 64 * h, i = e < 72 ? e / 6 : 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) trw[h][k] = a.mat[(6 + i) * 18 + k];
+        }
+        const double st_l = a.st[lane < 24 ? lane : 0], prior_l = a.prior[lane < 24 ? lane : 0];
 #pragma unroll
         for (int col = 0; col < 6; col++) {
             const double d = rl_d(c6[col], col);
@@ -813,27 +832,30 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
             for (int r = 0; r < 6; r++) S.pc[r * 6 + (lane - 6)] = c6[r];
         }
         lds_wave_sync();
-        for (int e = lane; e < 72; e += 64) {
-            const int i = e / 6, q = e % 6;
-            double sacc = 0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) sacc += a.mat[(6 + i) * 18 + k] * S.pc[k * 6 + q];
-            S.pc[36 + e] = sacc;
+        for (int h = 0; h < 2; h++) {
+            const int e = lane + 64 * h;
+            if (e < 72) {
+                const int q = e % 6;
+                double sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) sacc += trw[h][k] * S.pc[k * 6 + q];
+                S.pc[36 + e] = sacc;
+            }
         }
-        if (lane < 24) S.st[lane] = a.st[lane];
+        if (lane < 24) { S.st[lane] = st_l; S.prior[lane] = prior_l; }
         if (lane == 0) { S.rematch = 0; S.stop = 0; S.tot[0] = S.tot[1] = S.tot[2] = S.tot[3] = 0.0; }
     }
     __syncthreads();
     const int ntiles = (n + 63) / 64;
-    const int G = (int)gridDim.x;
     const bool one_tile = ntiles <= G * 4;
     PointPrep prep;
     prep.key = PREP_NO_KEY; prep.root = -1;
     for (int it = 0; it < a.max_iter; it++) {
         // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] block partials out [2] all partials in [3] update done
         unsigned long long* const tr = (sp.dbg && threadIdx.x == 0 && it < 8) ? sp.dbg + (64 + 16384 * 8) + ((size_t)it * 512 + blockIdx.x) * 8 : nullptr;
-        if (tr) tr[0] = __builtin_amdgcn_s_memrealtime();
-        if (sp.dbg && lane == 0) { atomicAdd(&sp.dbg[6], 1ull); if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }
+        if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); if (it == 0) tr[4] = t_entry; }
+        if (sp.dbg && threadIdx.x == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }   // (the RDBG phase sums are wavefront 0's)
         // the iterate of this pass: wave-uniform, through readfirstlane into scalar registers
         double Rm[9], tv[3], RextR[9];
 #pragma unroll
@@ -879,19 +901,24 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
             // interleaved halves of the list combined last (fixed order: every block computes the same bits)
             const int k = lane & 31;
             double tot = 0;
+            double R12[12], vec6[6];
+            bool have_vec = false;
             __builtin_amdgcn_s_setprio(1);
             for (int b0 = lane >> 5; b0 < G; b0 += 64) {
                 double v[32];
                 for (;;) {
-                    bool ok = true;
+                    unsigned long long bits[32];
 #pragma unroll
                     for (int u = 0; u < 32; u++) {
                         const int b = b0 + 2 * u;
-                        unsigned long long bits = 0;
-                        if (b < G) bits = __hip_atomic_load((const unsigned long long*)&pass_slots[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && bits != RP_SENTINEL;
-                        v[u] = __longlong_as_double((long long)bits);
+                        bits[u] = 0;
+                        if (b < G) bits[u] = __hip_atomic_load((const unsigned long long*)&pass_slots[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    // the part of the update that needs only the iterate runs while the first round of loads is in flight
+                    if (!have_vec) { rp_prior_minus_state(S, R12, vec6); have_vec = true; }
+                    bool ok = true;
+#pragma unroll
+                    for (int u = 0; u < 32; u++) { ok = ok && bits[u] != RP_SENTINEL; v[u] = __longlong_as_double((long long)bits[u]); }
                     if (__all(ok)) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -910,13 +937,16 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
             else if (lane < 46) v48 = S.wsum[0][27 + (lane - 42)];
             if (lane < 46) S.sums[lane] = v48;
             lds_wave_sync();
-            rp_update(S, a, it, lane, blockIdx.x == 0, rs, reg_out, ticket, sp.dbg);
+            rp_update(S, a, it, lane, blockIdx.x == 0, R12, vec6, sp.dbg);
             if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
             RDBG(5);
         }
         __syncthreads();
         if (S.stop) {
-            if (blockIdx.x == 0) rp_finish(S, a, rs, reg_out, ticket);
+            if (blockIdx.x == 0) {
+                rp_finish(S, a, rs, reg_out, ticket);
+                if (sp.dbg && threadIdx.x == 0) sp.dbg[(64 + 16384 * 8) + 5] = __builtin_amdgcn_s_memrealtime();
+            }
             break;
         }
     }
@@ -1857,7 +1887,7 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
                                 int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = std::min((n + 255) / 256, RP_MAX_BLOCKS);   // resident grid: at most 128 four-wavefront blocks, half a CU's worth each
-    KLAUNCH(residual_persistent_kernel, dim3(nb), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
+    KLAUNCH(residual_persistent_kernel, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
             o_dis, o_rinv, o_normal);
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {

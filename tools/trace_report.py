@@ -36,6 +36,11 @@ if (r[0, :, 0] > 0).any():
     r = np.where((r[:, :, 0:1] >= t_last - 30000), r, 0)      # the last scan only
     t0 = r[0][r[0, :, 0] > 0][:, 0].min()
     print("residual_persistent (us since the first wavefront's start):")
+    b0 = r[0][r[0, :, 0] > 0]
+    if (b0[:, 4] > 0).any():
+        ent = (b0[:, 4] - t0) * 0.01
+        fin = (r[0, 0, 5] - t0) * 0.01
+        print(f"  kernel entry (first wavefront of a block) min/max {ent.min():6.2f} {ent.max():6.2f}; block 0 finished (posterior out, ticket) {fin:6.2f}")
     for it in range(8):
         b = r[it][r[it, :, 0] > 0]
         if len(b) == 0 or b[:, 0].min() < t0:
@@ -45,4 +50,4 @@ if (r[0, :, 0] > 0).any():
               f"all gathered min/max {gat.min():6.2f} {gat.max():6.2f}; update done min/max {upd.min():6.2f} {upd.max():6.2f}")
 e = w[40:48].astype(np.int64)
 if e[7] > 0:
-    print(f"ekf_step_wave cycles (mean over {e[7]} updates): gauss-jordan {e[0] / e[7]:.0f}  gain products {e[1] / e[7]:.0f}  log / solution {e[2] / e[7]:.0f}  exp / state {e[3] / e[7]:.0f}  publish (+ covariance on stop) {e[4] / e[7]:.0f}")
+    print(f"ekf_step_wave cycles (mean over {e[7]} updates): w + gauss-jordan {e[0] / e[7]:.0f}  y + solution {e[2] / e[7]:.0f}  exp / state {e[3] / e[7]:.0f}  (prior [-] iterate: overlapped with the gather)")
