@@ -201,8 +201,10 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     if kname == "residual_kernel":      # per EKF iteration: point 12 B + key/slot 12 B per point, 12 B per extra probe, 229 B per plane test
         launches = c["n_iter"]
         return (n_ds * 24 * launches + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / launches
-    if kname == "residual_persistent_kernel":   # ONE launch per scan runs every EKF iteration: the same per-iteration bytes, summed over the scan's iterations
-        return (n_ds * 24 * c["n_iter"] + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / n_scans
+    if kname == "residual_persistent_kernel":
+        # ONE launch per scan runs every EKF iteration (the same per-iteration bytes, summed over the scan's iterations) and, as its epilogue, the map
+        # update's per-point preparation (point 12 B in, Point_with_var 96 B + sort key 8 + slot 12 out) and the full scan's transform (16 B in, 16 B out)
+        return (n_ds * 24 * c["n_iter"] + c["n_extra_probe"] * 12 + c["n_plane_tests"] * 229) / n_scans + n_ds * (12 + 96 + 8 + 12) + n_raw * 32
     if kname == "point_var_kernel":     # point 12 B in, Point_with_var 96 B + sort key 8 + slot 12 out
         return n_ds * (12 + 96 + 8 + 12)
     if kname == "replay_kernel":        # per scan: every point record once (96 B) + every refit re-reads its retained points (96 B each) and writes a plane (229 B)
@@ -516,13 +518,13 @@ def build_roofline(res, args):
     kstats, pc = res["kstats"], res["pc"]
     best = None
     for name, s_ in kstats.items():
-        if s_["launches"] and algorithmic_bytes(name, pc, args.profile_scans, args.pts) is not None:
+        if s_["launches"] and algorithmic_bytes(name, pc, args.profile_scans, args.pts if args.mesh else 0) is not None:
             if best is None or s_["total_ms"] > kstats[best]["total_ms"]:
                 best = name
     if not best:
         return None
     per_scan_launches = kstats[best]["launches"] / args.profile_scans
-    by = algorithmic_bytes(best, pc, args.profile_scans, args.pts)
+    by = algorithmic_bytes(best, pc, args.profile_scans, args.pts if args.mesh else 0)
     if best.split("<")[0] not in ("residual_kernel", "residual_persistent_kernel"):
         by = by / max(1.0, per_scan_launches)
     avg_ms = kstats[best]["total_ms"] / kstats[best]["launches"]

@@ -81,6 +81,8 @@ static int alloc_all(immesh_ctx* c) {
     A(c->d_dump_count, 2);
     A(c->d_touched, 2 * ns + 16);
     A(c->d_regstate, 1);
+    A(c->d_epi, 8);
+    HIPCHK(c, hipMemsetAsync(c->d_epi, 0, 32, c->stream));
     for (int q = 0; q < 2; q++) { A(c->d_rp_slots[q], RP_SLOT_DOUBLES); launch_fill_u64(c->stream, (unsigned long long*)c->d_rp_slots[q], RP_SLOT_SENTINEL, RP_SLOT_DOUBLES); }
     HIPCHK(c, hipMemsetAsync(c->d_regstate, 0, sizeof(RegState), c->stream));
     A(c->d_und_in, ns * 5); A(c->d_und_out, ns * 4); A(c->d_und_tab, 64 * 23 + 24);
@@ -90,6 +92,9 @@ static int alloc_all(immesh_ctx* c) {
     HIPCHK(c, hipHostMalloc((void**)&c->h_reg_out, REG_OUT_DOUBLES * sizeof(double), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_reg_out_host, c->h_reg_out, 0));
     std::memset(c->h_reg_out, 0, REG_OUT_DOUBLES * sizeof(double));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_epi_flag, 64, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_epi_flag_host, c->h_epi_flag, 0));
+    std::memset(c->h_epi_flag, 0, 64);
     HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 16 * sizeof(int32_t), hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_counters_host, c->h_counters, 0));
     return 0;
@@ -148,6 +153,7 @@ void immesh_destroy(immesh_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_out48) (void)hipHostFree(c->h_out48);
     if (c->h_reg_out) (void)hipHostFree(c->h_reg_out);
+    if (c->h_epi_flag) (void)hipHostFree(c->h_epi_flag);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -241,7 +247,7 @@ static int fetch_matches(immesh_ctx* c, int n, std::vector<int8_t>& mt) {
 // The iterated update with the 18-state step on the device (reg_kernels.hip: ekf_step_wave in the last block of every residual pass): all
 // passes of the scan are enqueued up front, a pass that finds the loop already stopped returns at once.  The posterior stays on the device
 // (RegState::sp) for the map update / full-scan transform queued behind it; the host only collects it.
-static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, const imh::State& st) {
+static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, const imh::State& st, const RpEpilogue* ep = nullptr) {
     const int max_iter = c->cfg.max_iter;
     RegIterArgs& a = c->reg_args;
     make_scan_params(c, st, st.cov, a.sp);
@@ -258,8 +264,9 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
         a.mode = REG_MODE_FUSED; a.it = 0;
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
         const int par = (c->rp_parity ^= 1);   // this scan's slot buffer; the launch re-arms the other one for the next scan
+        RpEpilogue none{};
         launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_slots[par], c->d_rp_slots[par ^ 1], c->d_counters_host, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
-                                   c->d_dis, c->d_rinv, c->d_normal);
+                                   c->d_dis, c->d_rinv, c->d_normal, ep ? *ep : none);
         return 0;
     }
     for (int it = 0; it < max_iter; it++) {
@@ -415,22 +422,25 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
 // spd != nullptr: pose + covariance blocks come from device memory (the posterior the in-kernel EKF left in RegState::sp); `st` then only
 // supplies the per-configuration constants
 static int map_ingest_device(immesh_ctx* c, const float* d_pts, int64_t n, int stride, const imh::State& st, int mode, hipEvent_t after_point_var = nullptr,
-                             const ScanParams* spd = nullptr, const float* d_raw = nullptr, float* world = nullptr, int n_raw = 0, bool defer_tail = false) {
+                             const ScanParams* spd = nullptr, const float* d_raw = nullptr, float* world = nullptr, int n_raw = 0, bool defer_tail = false, bool prep_done = false) {
     ScanParams sp;
     make_scan_params(c, st, st.cov, sp);
     hipStream_t s = c->stream;
     if (mode == 0) {
         // map_incremental_grow: no global sort -- points are chained per root voxel and each voxel's wavefront orders its own points
         // (ascending covariance norm, ties by scan index = std::sort(pv_list, var_contrast) restricted to that voxel) before replaying them
-        if (c->tail_deferred) { launch_map_update_tail(s, c->map, c->d_counters_host); c->tail_deferred = false; }   // (safety: a deferred tail precedes the next update; immesh_process_scan runs it in the residual kernel, every other entry settles first)
-        c->map.upd_seq++;
-        c->map.touched = c->d_touched;
-        launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a, d_raw, world, n_raw);
-        // the scan's input clouds are consumed here (the replay works on its own copies) and the mesher's scan is in its world buffer: ONE event
-        // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
-        if (world) c->ev_inputs_cur = mesh_record_ready(c);
-        else if (after_point_var) { HIPCHK(c, hipEventRecord(after_point_var, s)); c->ev_inputs_cur = after_point_var; }
-        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->reg_dbg, !defer_tail);
+        if (!prep_done) {   // (prep_done: the registration launch ran this part as its epilogue -- immesh_process_scan's fused path)
+            if (c->tail_deferred) { launch_map_update_tail(s, c->map, c->d_counters_host); c->tail_deferred = false; }   // (safety: a deferred tail precedes the next update; immesh_process_scan runs it in the residual kernel, every other entry settles first)
+            c->map.upd_seq++;
+            c->map.touched = c->d_touched;
+            launch_point_var(s, c->map, sp, spd, d_pts, (int)n, stride, mode, c->d_ptdata, c->d_key_a, c->d_slot, c->d_idx_a, d_raw, world, n_raw);
+            // the scan's input clouds are consumed here (the replay works on its own copies) and the mesher's scan is in its world buffer: ONE event
+            // record serves both -- every record is a barrier packet in the queue, ~6 us of bubble on the pose chain (rocprofv3 timeline, round 2)
+            if (world) { c->ev_inputs_cur = mesh_record_ready(c); c->inputs_seq = 0; }
+            else if (after_point_var) { HIPCHK(c, hipEventRecord(after_point_var, s)); c->ev_inputs_cur = after_point_var; c->inputs_seq = 0; }
+        }
+        launch_replay_lists(s, c->map, c->d_idx_a, c->d_key_a, c->d_ptdata, (int)n, c->d_stats, c->d_counters_host, c->d_idx_b, c->d_idx_c, c->d_slot_s, c->reg_dbg, !defer_tail,
+                            prep_done ? (unsigned long long*)(c->d_epi + 2) : nullptr, prep_done ? c->d_epi_flag_host : nullptr, c->epi_seq);
         c->tail_deferred = defer_tail;
         return 0;   // (the tail kernel has already put the counters into pinned host memory)
     } else {
@@ -506,13 +516,26 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         // Everything of the scan is enqueued before the host looks at a single result: the residual passes with the in-kernel 18-state update,
         // the full-scan transform and the map update (both read the posterior from RegState::sp on the device).  The host then collects the
         // pose -- by then the device is already growing the map -- and hands the scan to the mesher.
-        if ((rc = register_enqueue_fused(c, (const float*)d_down, n_ds, prior, st))) return rc;
-        if (timed) (void)hipEventRecord(ev[1], c->stream);
         float* world = nullptr;
         if (mesh_mode) world = mesh_next_world_buffer(c);
-        // (the transform of the full scan for the mesher rides in the first launch of the map update)
+        // One launch registers the scan AND prepares its map update (point covariances, root voxels, per-voxel lists) AND moves the full scan into the
+        // mesher's world buffer: the resident grid holds the posterior when its loop stops (RpEpilogue).  Sharded map (in-stream all-reduce between
+        // the passes): the per-pass launches, then point_var_kernel as before.
+        RpEpilogue ep{};
+        const bool epi = !c->rccl_comm;
+        if (epi) {
+            c->map.upd_seq++;
+            c->map.touched = c->d_touched;
+            ep.enabled = 1; ep.n_raw = world ? n_raw : 0;
+            ep.pt_data = c->d_ptdata; ep.sort_key = c->d_key_a; ep.slot_out = c->d_slot; ep.pt_next = c->d_idx_a;
+            ep.raw = world ? (const float*)d_raw : nullptr; ep.world = world;
+            ++c->epi_seq;   // (stored to the flags by the launch queued behind the registration: launch_replay_lists below)
+        }
+        if ((rc = register_enqueue_fused(c, (const float*)d_down, n_ds, prior, st, epi ? &ep : nullptr))) return rc;
+        if (epi) c->inputs_seq = c->epi_seq;
+        if (timed) (void)hipEventRecord(ev[1], c->stream);
         if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw,
-                                    /*defer_tail=*/nowait && !c->rccl_comm))) return rc;
+                                    /*defer_tail=*/nowait && !c->rccl_comm, /*prep_done=*/epi))) return rc;
         if (timed) (void)hipEventRecord(ev[2], c->stream);
         c->timing_valid[par] = timed;
         rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
@@ -526,7 +549,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if (rc || rc_prev) { c->ev_par = par; c->pending = true; return rc ? rc : rc_prev; }
         c->ev_par = par;
         long job = 0;
-        if (mesh_mode) job = mesh_submit(c, world, n_raw, st.t, frame_idx, true);
+        if (mesh_mode) job = epi ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
         c->timing[3] = 0.f;
         c->pending = true;
         if (nowait) return 0;
@@ -562,7 +585,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if ((rc = mesh_transform_full(c, (const float*)d_raw, world, n_raw, st))) return rc;
         job = mesh_submit(c, world, n_raw, st.t, frame_idx);
     }
-    if (serial_order) { (void)hipEventRecord(c->ev_inputs_free, c->stream); c->ev_inputs_cur = c->ev_inputs_free; }
+    if (serial_order) { (void)hipEventRecord(c->ev_inputs_free, c->stream); c->ev_inputs_cur = c->ev_inputs_free; c->inputs_seq = 0; }
     else {
         if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free))) return rc;
         (void)hipEventRecord(ev[2], c->stream);
@@ -583,6 +606,22 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
 // The stages before the path run on their own stream (they do not read the map) with their own scratch, so they overlap the previous scan's
 // map update when immesh_process_scan was asynchronous.  What they share with that scan are its INPUT clouds: the result buffers below are the
 // down-sampled / raw clouds an asynchronous immesh_process_scan may still be reading (point_var, transform) -- writers wait for ev_inputs_free.
+// "the last asynchronous scan has consumed its input clouds": an event on the registration stream, or -- when the registration launch consumed them in
+// its epilogue -- that launch's flag in pinned memory (it arrives a few microseconds behind the pose the caller already holds)
+static int pre_inputs_fence(immesh_ctx* c) {
+    if (c->inputs_seq) {
+        volatile unsigned long long* f = c->h_epi_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*f < c->inputs_seq) {
+            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return 0;
+    }
+    HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_cur, 0));
+    return 0;
+}
 static int pre_resolve(immesh_ctx* c, const void* p, size_t bytes, void* staging, const void** dev_out) {
     hipPointerAttribute_t attr;
     const hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -590,12 +629,12 @@ static int pre_resolve(immesh_ctx* c, const void* p, size_t bytes, void* staging
     if (e == hipSuccess) is_dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
     else (void)hipGetLastError();
     if (is_dev) { *dev_out = p; return 0; }
-    HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_cur, 0));   // the staging buffers double as immesh_process_scan's own staging
+    if (const int frc = pre_inputs_fence(c)) return frc;   // the staging buffers double as immesh_process_scan's own staging
     HIPCHK(c, hipMemcpyAsync(staging, p, bytes, hipMemcpyHostToDevice, c->stream_pre));
     *dev_out = staging;
     return 0;
 }
-#define PRE_OUTPUT_FENCE(c) HIPCHK(c, hipStreamWaitEvent((c)->stream_pre, (c)->ev_inputs_cur, 0))
+#define PRE_OUTPUT_FENCE(c) do { if (const int _frc = pre_inputs_fence(c)) return _frc; } while (0)
 
 // ---- sensor decode: flag -> exclusive scan -> compact, in arrival order
 static int decode_finish(immesh_ctx* c, int n, float* out_xyzit, int32_t* n_out) {

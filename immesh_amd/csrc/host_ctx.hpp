@@ -58,6 +58,13 @@ struct immesh_ctx {
     struct DsAsync { bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
+    // epilogue of the registration launch (map update preparation + full-scan transform): [0] arrival counter, [2..3] "done" flag (64-bit) on the
+    // device; the same flag in pinned memory for the host; epi_seq = last sequence number handed to a launch, inputs_seq != 0: the host-side
+    // "input clouds consumed" fence is that flag reaching inputs_seq (instead of ev_inputs_cur)
+    unsigned int* d_epi = nullptr;
+    unsigned long long* h_epi_flag = nullptr;
+    unsigned long long* d_epi_flag_host = nullptr;
+    unsigned long long epi_seq = 0, inputs_seq = 0;
     double* d_rp_slots[2] = {nullptr, nullptr};   // residual_persistent_kernel: block-partial slots (per pass x block), one buffer per scan parity
     double* d_out48 = nullptr;
     double* h_out48 = nullptr;       // pinned, device-mapped
@@ -149,7 +156,8 @@ void rccl_release(immesh_ctx* c);
 // mesher host orchestration (mesh_host.cpp)
 int mesh_alloc(immesh_ctx* c);
 void mesh_free(immesh_ctx* c);
-long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded = false);
+long mesh_submit(immesh_ctx* c, const float* d_pts_world_xyzi, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded = false,
+                 const unsigned long long* wait_flag = nullptr, unsigned long long wait_seq = 0);   // wait_flag: the scan's producer stores wait_seq there (no event)
 hipEvent_t mesh_record_ready(immesh_ctx* c);   // record the NEXT job's "scan is in its world buffer" event on the registration stream now (before more work is queued behind it)
 float* mesh_next_world_buffer(immesh_ctx* c);
 int mesh_wait(immesh_ctx* c, long id);

@@ -60,8 +60,21 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
 // slots / slots_next: the two parities of the block-partial buffer, RP_SLOT_DOUBLES each, filled with RP_SLOT_SENTINEL before first use
 #define RP_SLOT_DOUBLES (64 * 128 * 32)
 #define RP_SLOT_SENTINEL 0x7FF8DEADBEEF0001ull
+// The map update's preparation (point_var: world points, covariances, root voxels, per-voxel lists) and the transform of the full scan for the mesher
+// as the EPILOGUE of the registration launch: every block of the resident grid holds the posterior when the loop stops, so neither a kernel boundary
+// nor a launch is needed in between (immesh_process_scan; the other entry points keep point_var_kernel).  `m` must already be the map of THIS
+// update (upd_seq advanced).  The launch queued behind it (replay_fused_kernel, launch_replay_lists' flag arguments) stores a sequence number to a
+// device flag (the mesher's first kernel waits for it instead of an event record -- a barrier packet -- on the pose chain) and to a pinned one (the
+// host's "input clouds consumed" fence): behind the kernel boundary, so the epilogue itself needs no fence.
+struct RpEpilogue {
+    int enabled, n_raw;
+    double* pt_data; unsigned long long* sort_key; uint32_t* slot_out; int32_t* pt_next;
+    const float* raw; float* world;          // xyzI in / out (nullptr: no mesher)
+};
+#define RP_TAIL_WORD (63 * 128 * 32)   /* slot word the deferred-tail workgroup publishes (pass 63 is never run: max_iter < 64) */
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
-                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal);
+                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal,
+                                const RpEpilogue& ep);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`
@@ -69,7 +82,7 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
                       unsigned long long* sort_key, uint32_t* slot, int32_t* pt_next, const float* raw_xyzi = nullptr, float* world_xyzi = nullptr, int n_raw = 0);
 // (raw_xyzi != nullptr: the same launch also transforms the full xyzI scan into the world frame for the mesher)
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg = nullptr, bool with_tail = true);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg = nullptr, bool with_tail = true, unsigned long long* flag_dev = nullptr, unsigned long long* flag_host = nullptr, unsigned long long flag_seq = 0);
 // the tail of a map update whose launch was deferred (launch_replay_lists with_tail = false; RegIterArgs::pad of the next residual_persistent_kernel)
 void launch_map_update_tail(hipStream_t s, const RegMapDev& m, int32_t* host_counters);
 void launch_segment_heads(hipStream_t s, const uint32_t* sorted_slot, int n, int32_t* seg_start, int32_t* nseg);

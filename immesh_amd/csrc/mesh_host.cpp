@@ -63,8 +63,11 @@ int mesh_alloc(immesh_ctx* c) {
         MeshOutSet& o = h.outs[k];
         A(o.tri_add, cap_list * 3); A(o.flip_add, cap_list); A(o.tri_rem, cap_list * 3); A(o.tri_upd, cap_list * 3); A(o.flip_upd, cap_list);
         A(o.smooth_ids, cap_list); A(o.smooth_xyz, cap_list * 3);
-        A(h.d_world[k], cap_cand * 4);
     }
+    for (int k = 0; k < MESH_WORLD_BUFS; k++) A(h.d_world[k], cap_cand * 4);
+    A(m.tick0, 4);   // (one 64-bit word per job parity)
+    HIPCHK(c, hipMemsetAsync(m.tick0, 0, 32, c->stream));
+    A(m.dv_scratch, (size_t)32 * 128 * 1024);   // (MV_GEN_BLOCKS x MV_GEN_SCRATCH of mesh_kernels.hip)
     A(h.p_a, cap_list);
     h.sort_temp_bytes = exclusive_sum_temp_bytes((int)cap_cand) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
@@ -107,8 +110,9 @@ int mesh_alloc(immesh_ctx* c) {
         HIPCHK(c, hipHostMalloc((void**)&h.h_dyn[k], sizeof(MeshDyn), hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer((void**)&h.h_dyn_dev[k], h.h_dyn[k], 0));
         std::memset(h.h_dyn[k], 0, sizeof(MeshDyn));
-        HIPCHK(c, hipHostMalloc((void**)&h.h_sc2[k], SC_COUNT * 4));
-        std::memset(h.h_sc2[k], 0, SC_COUNT * 4);
+        HIPCHK(c, hipHostMalloc((void**)&h.h_sc2[k], MESH_PUB_WORDS * 4, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&h.h_sc2_dev[k], h.h_sc2[k], 0));
+        std::memset(h.h_sc2[k], 0, MESH_PUB_WORDS * 4);
     }
     h.h_sc = h.h_sc2[0];
     m.dyn = h.d_dyn[0];
@@ -121,6 +125,7 @@ int mesh_alloc(immesh_ctx* c) {
         v.sc = m1.sc; v.act_key = m1.act_key; v.act_vox = m1.act_vox; v.act_key_s = m1.act_key_s; v.act_vox_s = m1.act_vox_s;
         v.rel_ids = m1.rel_ids; v.rel_n = m1.rel_n; v.rel_nq = m1.rel_nq;
         v.dyn = h.d_dyn[1];
+        v.tick0 = m.tick0 + 1;
         for (int k = 0; k < 2; k++) {
             const MeshOutSet& o = h.outs[k];
             MeshDev& w = h.mpar[k];
@@ -158,7 +163,7 @@ int mesh_alloc(immesh_ctx* c) {
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&h.ev_b[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreate(&h.ev_b[k]));   // (doubles as the end time of the job: every record is a barrier packet on the phase-B chain)
         HIPCHK(c, hipEventCreate(&h.ev_t0[k])); HIPCHK(c, hipEventCreate(&h.ev_t1[k]));
     }
     std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
@@ -247,7 +252,7 @@ static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
     launch_mesh_finalize(s, m);                               // (+ the removals: Triangle_manager::remove_triangle_list)
     launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
     launch_mesh_commit_add(s, m, h.p_a);
-    MHIPCHK(c, hipMemcpyAsync(h.h_sc2[par], m.sc, SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    launch_mesh_publish(s, m, h.h_sc2_dev[par]);
     return 0;
 }
 
@@ -346,8 +351,12 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     if (sp.n_cand > m.cap_cand) { h.err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
     const int64_t ccap = np2((int64_t)sp.n_cand * 4);
     h.h_dyn[par]->sp = sp; h.h_dyn[par]->seq = h.seq; h.h_dyn[par]->ch_mask = (uint64_t)ccap - 1;
-    MHIPCHK(c, hipStreamWaitEvent(sa, job.ready, 0));   // the scan (transform / host copy) was produced on the registration stream
-    MHIPCHK(c, hipEventRecord(h.ev_t0[par], sa));
+    h.h_dyn[par]->wait_flag = job.wait_flag; h.h_dyn[par]->wait_seq = job.wait_seq;
+    h.h_dyn[par]->pts = d_pts;
+    bool is_world = false;
+    for (int k = 0; k < MESH_WORLD_BUFS; k++) is_world = is_world || d_pts == h.d_world[k];
+    // the scan (transform / host copy) was produced on the registration stream: an event, or -- immesh_process_scan's fused path -- a flag the first kernel polls
+    if (!job.wait_flag) MHIPCHK(c, hipStreamWaitEvent(sa, job.ready, 0));
     int rc = 0;
     if (sp.n_cand > 65536) {
         // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
@@ -361,13 +370,14 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
             if (h.h_sc2[par][SC_UNDECIDED] == 0) break;
         }
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
-    } else if (h.use_graph && !h.prof.on && m.shard_world <= 1 && d_pts == h.d_world[par]) {
+    } else if (h.use_graph && !h.prof.on && m.shard_world <= 1 && is_world) {
         // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
         if (h.graph_ncand[par] != sp.n_cand) {
             for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
             h.graph_ncand[par] = sp.n_cand;
         }
-        if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true); }))) return rc;
+        // (captured with a null scan pointer: the kernels take it from MeshDyn, so one graph serves every world buffer)
+        if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, nullptr, sp.n_cand, ccap, true); }))) return rc;
     } else {
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true))) return rc;
     }
@@ -382,19 +392,18 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         launch_mesh_pack_marks(sa, m, (MeshMkRec*)h.d_xsend, h.d_xcount);
         if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), [&](const void* d, int n) { launch_mesh_unpack_marks(sa, m, (const MeshMkRec*)d, n); }))) return rc;
         if ((rc = mesh_enqueue_b(c, m, par, sa, 2))) return rc;
-        MHIPCHK(c, hipEventRecord(h.ev_t1[par], sa));
         MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
         return 0;
     }
+    // (an event between the phases -- a poll at the head of phase B would hold LDS phase A's single-workgroup launch needs: measured deadlock --
+    //  but none behind phase B: mesh_publish_kernel's ticket in pinned memory / the worker's poll)
     MHIPCHK(c, hipEventRecord(h.ev_a[par], sa));
     MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
-    if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && d_pts == h.d_world[par]) {
+    if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && is_world) {
         if ((rc = mesh_graph_run(c, h.graph_exec_b[par], sb, [&] { return mesh_enqueue_b(c, m, par, sb); }))) return rc;
     } else {
         if ((rc = mesh_enqueue_b(c, m, par, sb))) return rc;
     }
-    MHIPCHK(c, hipEventRecord(h.ev_t1[par], sb));
-    MHIPCHK(c, hipEventRecord(h.ev_b[par], sb));
     return 0;
 }
 
@@ -441,7 +450,7 @@ static void mesh_worker_main(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     (void)hipSetDevice(c->cfg.device);
     g_kprof = &h.prof;
-    struct Flight { MeshJob job; MeshResult r; bool launched_ok; };
+    struct Flight { MeshJob job; MeshResult r; bool launched_ok; int seq; bool by_ticket; unsigned polls; };
     std::deque<Flight> fl;
     for (;;) {
         // ---- take a new job when one is queued and the pipeline has room
@@ -461,6 +470,8 @@ static void mesh_worker_main(immesh_ctx* c) {
             h.err.clear();
             bool synced = false;
             f.r.rc = mesh_scan_launch(c, job, synced);
+            f.seq = h.seq; f.polls = 0;
+            f.by_ticket = c->mesh.shard_world <= 1;   // (the sharded mesher runs on one stream and keeps its event)
             if (f.r.rc) f.r.err = h.err; else f.launched_ok = true;
             fl.push_back(f);
             continue;
@@ -469,7 +480,16 @@ static void mesh_worker_main(immesh_ctx* c) {
         Flight& f = fl.front();
         const int par = (int)(f.job.id & 1);
         if (f.launched_ok) {
-            const hipError_t q = hipEventQuery(h.ev_b[par]);
+            hipError_t q;
+            if (f.by_ticket) {
+                // mesh_publish_kernel's ticket in pinned memory; the stream is consulted now and then so that a faulted launch cannot leave the worker polling
+                q = (*(volatile int32_t*)(h.h_sc2[par] + MESH_PUB_SEQ) == f.seq) ? hipSuccess : hipErrorNotReady;
+                if (q == hipErrorNotReady && (++f.polls & 0xFFF) == 0) {
+                    const hipError_t qs = hipStreamQuery(h.stream_b);
+                    if (qs != hipErrorNotReady && *(volatile int32_t*)(h.h_sc2[par] + MESH_PUB_SEQ) != f.seq) q = (qs == hipSuccess) ? hipErrorUnknown : qs;
+                }
+                if (q == hipSuccess) std::atomic_thread_fence(std::memory_order_acquire);
+            } else q = hipEventQuery(h.ev_b[par]);
             if (q == hipErrorNotReady) {
                 bool more;
                 { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? 2u : 1u); }
@@ -479,7 +499,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             h.err.clear();
             if (q != hipSuccess) { f.r.rc = IMMESH_E_HIP; f.r.err = std::string("mesh job: ") + hipGetErrorString(q); }
             else {
-                (void)hipEventElapsedTime(&f.r.ms, h.ev_t0[par], h.ev_t1[par]);
+                f.r.ms = (float)((double)*(volatile unsigned long long*)(h.h_sc2[par] + MESH_PUB_TICKS) * 1e-5);   // (100 MHz ticks of the device's real-time counter)
                 f.r.rc = mesh_scan_finish(c, f.job, f.r.sizes);
                 if (f.r.rc) f.r.err = h.err;
             }
@@ -499,7 +519,7 @@ static void mesh_worker_main(immesh_ctx* c) {
 }
 
 // Called on the scan thread.  d_pts = world-frame xyzI already (being) produced on c->stream; returns the job id.
-// At most two jobs are outstanding (their scans live in the two world buffers), so this blocks while job id-2 is still running.
+// The worker keeps two jobs in flight; their scans and those of the jobs queued behind them live in the MESH_WORLD_BUFS world buffers.
 hipEvent_t mesh_record_ready(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     long next;
@@ -507,7 +527,7 @@ hipEvent_t mesh_record_ready(immesh_ctx* c) {
     (void)hipEventRecord(h.ev_ready[next & 1], c->stream);
     return h.ev_ready[next & 1];
 }
-long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded) {
+long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded, const unsigned long long* wait_flag, unsigned long long wait_seq) {
     MeshHost& h = c->mesh_host;
     MeshJob job;
     {
@@ -517,7 +537,8 @@ long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sen
     job.d_pts = d_pts; job.n_raw = n_raw; job.frame_idx = frame_idx;
     job.cam[0] = sensor_pos[0]; job.cam[1] = sensor_pos[1]; job.cam[2] = sensor_pos[2];
     job.ready = h.ev_ready[job.id & 1];
-    if (!ready_recorded) (void)hipEventRecord(job.ready, c->stream);
+    job.wait_flag = wait_flag; job.wait_seq = wait_seq;
+    if (!ready_recorded && !wait_flag) (void)hipEventRecord(job.ready, c->stream);
     {
         std::lock_guard<std::mutex> lk(h.mu);
         h.q.push_back(job);
@@ -526,13 +547,13 @@ long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sen
     h.cv_job.notify_one();
     return job.id;
 }
-// world buffer the NEXT job will use; blocks until the job that last used it (next id - 2) has finished
+// world buffer the NEXT job will use; blocks until the job that last used it (next id - MESH_WORLD_BUFS) has finished
 float* mesh_next_world_buffer(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     std::unique_lock<std::mutex> lk(h.mu);
     const long next = h.submitted + 1;
-    h.cv_done.wait(lk, [&] { return h.completed >= next - 2; });
-    return h.d_world[next & 1];
+    h.cv_done.wait(lk, [&] { return h.completed >= next - MESH_WORLD_BUFS; });
+    return h.d_world[next % MESH_WORLD_BUFS];
 }
 // wait for job `id` (0 = the newest submitted) and make it the one immesh_mesh_sizes / fetch / last_timing report
 int mesh_wait(immesh_ctx* c, long id) {

@@ -81,6 +81,8 @@ IMD float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
     const MeshScanParams sp = (arg).dyn->sp;           \
     m.seq = (arg).dyn->seq;                            \
     m.ch_mask = (arg).dyn->ch_mask;                    \
+    const float* const dyn_pts = (arg).dyn->pts;       \
+    (void)dyn_pts;                                     \
     (void)sp
 
 IMD void list_push(const MeshDev& m, int32_t* list, int counter, int v) {
@@ -121,20 +123,45 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < ccap; k += stride) { m.ch_keys[k] = MKEY_EMPTY; m.ch_head[k] = -1; }
     if (i == 0) {
+        *m.tick0 = __builtin_amdgcn_s_memrealtime();
         MeshDyn d = *h_dyn;
+        bool late = false;
+        if (d.wait_flag) {   // the producer was enqueued before this launch; bounded all the same (~1 s) -- reported through the hang guard of the admission
+            unsigned int spins = 0;
+            while (__hip_atomic_load(d.wait_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < d.wait_seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 20)) { late = true; break; }
+            }
+        }
         const int base = m.pc[PC_VERTS];
         d.sp.vtx_base = base;
         *m.dyn = d;
         for (int k = 0; k < SC_COUNT; k++) m.sc[k] = 0;
         m.sc[SC_VTXBASE] = base;
+        if (late) m.sc[SC_UNDECIDED] = 1;
     }
 }
+// last launch of a job: the per-scan counters, the job's device time and -- last -- its sequence number go to pinned host memory (the worker thread
+// polls the sequence number: no device-to-host copy packet, no event record behind the last kernel of phase B)
+__global__ void mesh_publish_kernel(MeshDev m_in, int32_t* __restrict__ host_sc) {
+    const int k = threadIdx.x;
+    if (k < SC_COUNT) __hip_atomic_store(&host_sc[k], m_in.sc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (k == 0) {
+        const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - *m_in.tick0;
+        __hip_atomic_store((unsigned long long*)&host_sc[MESH_PUB_TICKS], ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k == 0) __hip_atomic_store(&host_sc[MESH_PUB_SEQ], m_in.dyn->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_mesh_publish(hipStream_t s, const MeshDev& m, int32_t* host_sc) { static_assert(SC_COUNT <= 64, "one wavefront publishes the counters"); KLAUNCH(mesh_publish_kernel, dim3(1), dim3(64), 0, s, m, host_sc); }
 void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dyn_dev, unsigned long long ccap) {
     KLAUNCH(mesh_begin_scan_kernel, dim3(128), dim3(256), 0, s, m, h_dyn_dev, ccap);
 }
 
-__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts) {
+__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
     MESH_DYN(m_in);
+    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n_cand) return;
     const float* p = pts + 4 * (size_t)i * sp.step;
@@ -207,8 +234,9 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
 // loop's outcome.  Each lane re-evaluates until every lower-index conflicting candidate is decided (bounded; relaunched by the host).
-__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, const float* __restrict__ pts, int max_iter) {
+__global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, const float* __restrict__ pts_arg, int max_iter) {
     MESH_DYN(m_in);
+    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     // Lanes of one wavefront may depend on each other, so the decision store must happen INSIDE the loop body and the loop must be left
     // by the whole wavefront together (__all): with a per-lane `return` the compiler may sink the store to the loop exit, which the
@@ -271,8 +299,9 @@ __global__ void mesh_append_flags_kernel(MeshDev m_in) {
 }
 
 // new vertex id = vtx_base + (number of accepted candidates with a lower scan index): ids grow in scan order as in the reference
-__global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m_in, const float* __restrict__ pts) {
+__global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
     MESH_DYN(m_in);
+    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sp.n_cand) return;
     const bool acc = m.cand_status[i] == ST_ACCEPT;
@@ -332,8 +361,9 @@ IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #define MV_FIN_CAND 16384
 #define MV_FIN_ACT 8192        /* visited voxels whose selection + ordering run in LDS; more than that (sparse far-field scans) take the global arrays */
 // (~100 KB of static LDS for one workgroup: the 160 KB of a gfx950 CU -- the only target of this library, see the Makefile -- is assumed)
-__global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts) {
+__global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
     MESH_DYN(m_in);
+    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     __shared__ unsigned long long skey[MV_FIN_ACT];
     __shared__ int svox[MV_FIN_ACT];
     __shared__ int sscan[1024];
@@ -874,22 +904,44 @@ IMD int tri_find_or_insert(const MeshDev& m, int a, int b, int c, int* spare) {
 
 #define DBG_T(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
 // The general per-voxel triangulation (any neighbourhood size up to CAP): triangle table in LDS.  One wavefront; r = rank of the active voxel.
-template <int CAP>
-__device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const MeshScanParams& sp, const int r) {
+// GLOBAL = false: the per-voxel tables live in LDS (~31 KB at CAP = 256).  GLOBAL = true: in this block's slice of MeshDev::dv_scratch (the tables of
+// CAP = MV_REL_CAP are ~120 KB: as static LDS they made every block of the launch claim a whole CU, and the launch -- which has nothing to do in
+// the shipped configurations -- waited tens of microseconds for empty CUs whenever the registration chain's kernels were resident).
+#define MV_GEN_BLOCKS 32
+#define MV_GEN_SCRATCH (128 * 1024)
+template <int CAP, bool GLOBAL>
+__device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const MeshScanParams& sp, const int r, unsigned char* gs) {
     constexpr int TCAP = 2 * CAP + 8;
-    __shared__ int ids[CAP];
-    __shared__ float pf[CAP * 3];
-    __shared__ double xy[CAP * 2];
-    __shared__ unsigned long long keys[CAP];
-    __shared__ __attribute__((aligned(16))) unsigned short tri[TCAP * 4];
+    constexpr int LC = GLOBAL ? 1 : CAP, LT = GLOBAL ? 1 : TCAP;
+    __shared__ int ids_l[LC];
+    __shared__ float pf_l[LC * 3];
+    __shared__ double xy_l[LC * 2];
+    __shared__ unsigned long long keys_l[LC];
+    __shared__ __attribute__((aligned(16))) unsigned short tri_l[LT * 4];
     __shared__ unsigned short cav[DT_CAV_CAP];
     __shared__ unsigned short ea[DT_CAV_CAP * 3], eb[DT_CAV_CAP * 3];
-    __shared__ unsigned int fresh[TCAP];
-    __shared__ unsigned char fhit[TCAP];
-    __shared__ double sm[CAP * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
+    __shared__ unsigned int fresh_l[LT];
+    __shared__ unsigned char fhit_l[LT];
+    __shared__ double sm_l[LC * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
     __shared__ int s_cnt[2];
-    __shared__ int old_t[2 * CAP], old_v1[2 * CAP], old_v2[2 * CAP];   // live triangles whose smallest vertex is in the neighbourhood
-    __shared__ unsigned short old_i[2 * CAP];
+    __shared__ int old_t_l[2 * LC], old_v1_l[2 * LC], old_v2_l[2 * LC];   // live triangles whose smallest vertex is in the neighbourhood
+    __shared__ unsigned short old_i_l[2 * LC];
+    constexpr size_t O_XY = 0, O_SM = O_XY + 16ull * CAP, O_KEYS = O_SM + 24ull * CAP, O_TRI = O_KEYS + 8ull * CAP, O_IDS = O_TRI + 8ull * TCAP, O_PF = O_IDS + 4ull * CAP,
+                     O_FRESH = O_PF + 12ull * CAP, O_OT = O_FRESH + 4ull * TCAP, O_OV1 = O_OT + 8ull * CAP, O_OV2 = O_OV1 + 8ull * CAP, O_OI = O_OV2 + 8ull * CAP,
+                     O_FHIT = O_OI + 4ull * CAP, O_END = O_FHIT + TCAP;
+    static_assert(!GLOBAL || O_END <= MV_GEN_SCRATCH, "scratch slice too small");
+    int* const ids = GLOBAL ? (int*)(gs + O_IDS) : ids_l;
+    float* const pf = GLOBAL ? (float*)(gs + O_PF) : pf_l;
+    double* const xy = GLOBAL ? (double*)(gs + O_XY) : xy_l;
+    unsigned long long* const keys = GLOBAL ? (unsigned long long*)(gs + O_KEYS) : keys_l;
+    unsigned short* const tri = GLOBAL ? (unsigned short*)(gs + O_TRI) : tri_l;
+    unsigned int* const fresh = GLOBAL ? (unsigned int*)(gs + O_FRESH) : fresh_l;
+    unsigned char* const fhit = GLOBAL ? (unsigned char*)(gs + O_FHIT) : fhit_l;
+    double* const sm = GLOBAL ? (double*)(gs + O_SM) : sm_l;
+    int* const old_t = GLOBAL ? (int*)(gs + O_OT) : old_t_l;
+    int* const old_v1 = GLOBAL ? (int*)(gs + O_OV1) : old_v1_l;
+    int* const old_v2 = GLOBAL ? (int*)(gs + O_OV2) : old_v2_l;
+    unsigned short* const old_i = GLOBAL ? (unsigned short*)(gs + O_OI) : old_i_l;
 
     const int lane = threadIdx.x;
     const int n = m.rel_n[r];
@@ -1172,21 +1224,16 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
     if (m.dbg && lane == 0) atomicMax(&m.dbg[14], ((__builtin_readcyclecounter() - tvox0) << 16) | (unsigned long long)n);
     __syncthreads();
 }
-// What the register fast path (mesh_delaunay64_kernel, launched before) does not take, ONE launch (two used to cost two dispatches per scan
-// for -- with the shipped configurations -- nothing to do): even blocks take the neighbourhoods of 65..256 vertices and the voxels the fast path
-// handed over, odd blocks the neighbourhoods above 256 vertices (space-filling clouds) with the big-LDS instantiation.
+// What the register fast path (mesh_delaunay64_kernel, launched before) does not take, ONE small launch (with the shipped configurations it has
+// nothing to do, so what counts is how quickly its blocks are placed and gone): neighbourhoods of 65..256 vertices and the voxels the fast path
+// handed over from LDS tables, neighbourhoods above 256 vertices (space-filling clouds) from tables in global scratch.
 __global__ __launch_bounds__(64) void mesh_delaunay_general_kernel(MeshDev m_in) {
     MESH_DYN(m_in);
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
-    const int half = (int)(gridDim.x >> 1);
-    if (blockIdx.x & 1) {
-        for (int r = (int)(blockIdx.x >> 1); r < n_active; r += half)
-            if (m.rel_n[r] > 256) mesh_delaunay_voxel<MV_REL_CAP>(m, sp, r);
-    } else {
-        for (int r = (int)(blockIdx.x >> 1); r < n_active; r += half) {
-            const int n = m.rel_n[r];
-            if ((n > 64 && n <= 256) || (n > 0 && n <= 64 && m.vox_ntris[r] < 0)) mesh_delaunay_voxel<256>(m, sp, r);
-        }
+    for (int r = (int)blockIdx.x; r < n_active; r += (int)gridDim.x) {
+        const int n = m.rel_n[r];
+        if (n > 256) mesh_delaunay_voxel<MV_REL_CAP, true>(m, sp, r, m.dv_scratch + (size_t)blockIdx.x * MV_GEN_SCRATCH);
+        else if (n > 64 || (n > 0 && m.vox_ntris[r] < 0)) mesh_delaunay_voxel<256, false>(m, sp, r, nullptr);
     }
 }
 
@@ -1209,6 +1256,7 @@ IMD void mesh_commit_rem_slice(const MeshDev& m, const int32_t* __restrict__ tri
     }
 }
 __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
+    __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     mesh_commit_rem_slice(m, m.list_rem, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);   // Triangle_manager::remove_triangle_list rides along (independent data)
     const int lane = threadIdx.x;
@@ -1386,6 +1434,7 @@ IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
     pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
 }
 __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int which, SortRec* __restrict__ recs_out) {
+    __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     __shared__ SortRec recs[LS_CHUNK];
     LSortPlan pl;
@@ -1422,6 +1471,7 @@ IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& k
     return lo;
 }
 __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+    __builtin_amdgcn_s_setprio(2);
     MESH_DYN(m_in);
     LSortPlan pl;
     lsort_plan_dev(m, which, pl);
@@ -1489,6 +1539,7 @@ __global__ void mesh_commit_rem_kernel(MeshDev m_in, const int32_t* __restrict__
 // Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
 __global__ void mesh_commit_add_kernel(MeshDev m_in, const int32_t* __restrict__ tris) {
+    __builtin_amdgcn_s_setprio(2);
     MESH_DYN(m_in);
     const int n = min(m.sc[SC_ADD], m.cap_list);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1578,9 +1629,9 @@ void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
     // (grids: the dispatcher places ~130 workgroups per us, so a launch of 2048 workgroups lasts >= 16 us however little they do; the kernels stride)
     KLAUNCH(mesh_delaunay64_kernel, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m);           // n_u <= 64: register fast path
-    KLAUNCH(mesh_delaunay_general_kernel, dim3(256), dim3(64), 0, s, m);     // even blocks: 64 < n_u <= 256 and what the fast path handed over; odd blocks: n_u > 256
+    KLAUNCH(mesh_delaunay_general_kernel, dim3(MV_GEN_BLOCKS), dim3(64), 0, s, m);     // 64 < n_u and what the fast path handed over
 }
-void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(512), dim3(64), 0, s, m); }
+void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(128), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted) { KLAUNCH(mesh_commit_add_kernel, dim3(128), dim3(256), 0, s, m, tris_sorted); }
 // which 0: active-voxel list (-> act_vox_s + ranks); which 1: remove / add / flip-update / smooth lists (-> sorted outputs)

@@ -49,6 +49,10 @@ struct MeshDyn {
     MeshScanParams sp;
     int32_t seq, pad;
     unsigned long long ch_mask;
+    // != nullptr: the scan reaches its world buffer in the epilogue of the registration launch, which then stores wait_seq there -- the first
+    // kernel of the scan waits for it (no event record -- a barrier packet -- on the pose chain)
+    const unsigned long long* wait_flag; unsigned long long wait_seq;
+    const float* pts;   // the scan (world-frame xyzI): the admission kernels take it from here when their argument is null (graph replay: any world buffer)
 };
 
 struct MeshDev {
@@ -81,6 +85,8 @@ struct MeshDev {
     int32_t cap_verts, cap_voxels, cap_tris, cap_adj_chunks, cap_cand, cap_active, cap_list;
     // parameters
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
+    unsigned long long* tick0;   // s_memrealtime of the job's first kernel (per parity); mesh_publish_kernel turns it into the job's device time
+    unsigned char* dv_scratch;   // mesh_delaunay_general_kernel: per-block tables of the neighbourhoods above 256 vertices (MV_GEN_BLOCKS x MV_GEN_SCRATCH bytes)
     int32_t shard_rank, shard_world, shard_brick_log2;   // sharded mesher: owner-computes per mesh-voxel brick (shard_world <= 1: off)
     int32_t seq;                         // scan sequence number (>= 1); kernels take it (and ch_mask) from *dyn
     MeshDyn* dyn;                        // per-scan parameters (device memory)
@@ -99,7 +105,11 @@ struct MeshDev {
 // triangle marks its triangulations produced (rk = (voxel rank << 1) | add, word = the rank's current flip word; rk = -1: removal mark)
 struct MeshSmRec { int32_t id, pad; double x, y, z; };
 struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
-struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; };
+#define MESH_WORLD_BUFS 4
+#define MESH_PUB_SEQ (SC_COUNT + 0)     /* job sequence number: the completion ticket the worker polls */
+#define MESH_PUB_TICKS (SC_COUNT + 2)   /* 64-bit: device time of the job, 100 MHz ticks */
+#define MESH_PUB_WORDS (SC_COUNT + 8)
+struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; const unsigned long long* wait_flag = nullptr; unsigned long long wait_seq = 0; };
 struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz; };
 struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; };
 
@@ -108,7 +118,8 @@ struct MeshHost {
     int64_t cum[SC_COUNT];
     int32_t* p_a = nullptr;    // add list as sorted triangle indices (input of the adjacency commit)
     int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters of the job being finished (points into h_sc2)
-    int32_t* h_sc2[2] = {nullptr, nullptr};
+    int32_t* h_sc2[2] = {nullptr, nullptr};      // pinned + mapped: [0, SC_COUNT) the job's counters, then MESH_PUB_* words written by mesh_publish_kernel
+    int32_t* h_sc2_dev[2] = {nullptr, nullptr};
     int32_t* h_pc = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -123,7 +134,9 @@ struct MeshHost {
     hipStream_t stream_b = nullptr;          // ... and phase B
     hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
     hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};   // phase A / B of the job of that parity finished
-    float* d_world[2] = {nullptr, nullptr};  // world-frame full scans, double-buffered (job id parity)
+    // world-frame full scans.  The mesher pipelines two jobs (phase A of one over phase B of the other) and takes ~2.4 scan periods per job, so the scan
+    // thread writes up to MESH_WORLD_BUFS scans ahead of the oldest running job (buffer = job id mod MESH_WORLD_BUFS) before it has to wait
+    float* d_world[MESH_WORLD_BUFS] = {};
     MeshOutSet outs[2];                      // result lists, double-buffered (job id parity)
     MeshResult res[2];
     std::thread worker;
@@ -161,6 +174,7 @@ struct MeshHost {
 void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xyzi, int n, const double* R, const double* t, const double* extR,
                            const double* extT, const double* rt_dev = nullptr);
 void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dyn_dev, unsigned long long ccap);
+void launch_mesh_publish(hipStream_t s, const MeshDev& m, int32_t* host_sc);         // last launch of a job: counters, device time, ticket -> pinned memory
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter);
 void launch_mesh_append_commit(hipStream_t s, const MeshDev& m, int n_cand, const float* pts);

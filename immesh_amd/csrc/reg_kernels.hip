@@ -727,9 +727,14 @@ __device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, con
 #undef EDBG
 }
 
-// The pass that stops the loop, block 0, all 256 threads: posterior covariance P - K1 (H^T H P[0:6,:]) (M = H^T H P6, XM = X M, rows 6..17 = T XM),
-// posterior pose for the map update / full-scan transform queued behind this launch (read after the kernel boundary) and for the host, ticket.
-__device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, RegState* __restrict__ rs, double* __restrict__ reg_out, const double ticket) {
+IMD float4 transform_value(const double* extR, const double* extT, const double* R, const double* t, const float4 v);
+IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, const int stride, const int mode,
+                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next);
+
+// The pass that stops the loop, all 256 threads: the posterior covariance is P - K1 (H^T H P[0:6,:]); M = H^T H P6 and XM = X M (rows 0..5 of the
+// correction; rows 6..17 = T XM) are left in LDS.  Every block does this when the map update's preparation runs as the epilogue (it propagates
+// the posterior 3 x 3 rotation / translation blocks), block 0 always.
+__device__ __forceinline__ void rp_posterior(RpShared& S, const RegIterArgs& a) {
     const int tid = threadIdx.x;
     const double* cov = a.mat;
     if (tid < 108) {
@@ -748,6 +753,12 @@ __device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, Reg
         S.XM[tid] = sacc;
     }
     __syncthreads();
+}
+// block 0, behind rp_posterior: posterior state / covariance for the host (pinned memory), posterior pose for whatever is queued behind this
+// launch (RegState::sp, read after the kernel boundary), ticket.
+__device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, RegState* __restrict__ rs, double* __restrict__ reg_out, const double ticket) {
+    const int tid = threadIdx.x;
+    const double* cov = a.mat;
     for (int e = tid; e < 324; e += 256) {
         const int r = e / 18, c = e % 18;
         double upd;
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
                                                                    int32_t* __restrict__ host_counters,
                                                                    double* __restrict__ reg_out, double ticket,
                                                                    int8_t* __restrict__ o_match, int32_t* __restrict__ o_node,
-                                                                   float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+                                                                   float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal, RpEpilogue ep) {
     __shared__ RpShared S;
     __builtin_amdgcn_s_setprio(3);   // the pose chain: issue ahead of the mesher's waves sharing the SIMD
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -796,11 +807,17 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     const unsigned long long t_entry = sp.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // (trace: [4] of the pass-0 record = kernel entry, [5] = block 0 finished)
     // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long*)slots_next)[RP_TAIL_WORD] = RP_SENTINEL;
     // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below.  It gets a workgroup of its
     // own (the launcher adds one): inside a working block it delayed that block's first partial sums, i.e. everybody's first gather
     const int G = (int)gridDim.x - 1;
     if ((int)blockIdx.x == G) {
         if (a.pad) map_update_tail(m, host_counters);
+        // the epilogue below works on the counters the tail resets: its completion is published like a block partial (release: fence, then the
+        // word) and every block's first gather waits for it along with the partials
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) dev_publish(&slots[RP_TAIL_WORD], 1.0);
         return;
     }
     if (wv == 0) {
@@ -914,9 +931,11 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
                         bits[u] = 0;
                         if (b < G) bits[u] = __hip_atomic_load((const unsigned long long*)&pass_slots[(size_t)b * RES_NR + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    unsigned long long tailbits = 0;
+                    if (it == 0) tailbits = __hip_atomic_load((const unsigned long long*)&slots[RP_TAIL_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // the part of the update that needs only the iterate runs while the first round of loads is in flight
                     if (!have_vec) { rp_prior_minus_state(S, R12, vec6); have_vec = true; }
-                    bool ok = true;
+                    bool ok = tailbits != RP_SENTINEL;
 #pragma unroll
                     for (int u = 0; u < 32; u++) { ok = ok && bits[u] != RP_SENTINEL; v[u] = __longlong_as_double((long long)bits[u]); }
                     if (__all(ok)) break;
@@ -943,9 +962,50 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
         }
         __syncthreads();
         if (S.stop) {
+            if (blockIdx.x == 0 || ep.enabled) rp_posterior(S, a);
             if (blockIdx.x == 0) {
                 rp_finish(S, a, rs, reg_out, ticket);
                 if (sp.dbg && threadIdx.x == 0) sp.dbg[(64 + 16384 * 8) + 5] = __builtin_amdgcn_s_memrealtime();
+            }
+            if (ep.enabled) {
+                // ---- epilogue: map_incremental_grow's per-point preparation with the posterior every block holds (same expressions as rp_finish
+                //      leaves in RegState::sp for point_var_kernel), then the full scan into the world frame for the mesher
+                unsigned long long* const tre = (sp.dbg && threadIdx.x == 0) ? sp.dbg + (64 + 16384 * 8) + (size_t)blockIdx.x * 8 : nullptr;   // (pass-0 record: [5] epilogue start [6] points prepared [7] end)
+                if (tre && blockIdx.x != 0) tre[5] = __builtin_amdgcn_s_memrealtime();
+                ScanParams q = a.sp;
+#pragma unroll
+                for (int k = 0; k < 9; k++) q.R[k] = S.st[k];
+#pragma unroll
+                for (int k = 0; k < 3; k++) q.t[k] = S.st[9 + k];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        q.RextR[r * 3 + c] = S.st[r * 3 + 0] * a.sp.extR[0 * 3 + c] + S.st[r * 3 + 1] * a.sp.extR[1 * 3 + c] + S.st[r * 3 + 2] * a.sp.extR[2 * 3 + c];
+                        q.rot_var[r * 3 + c] = a.mat[r * 18 + c] - S.XM[r * 18 + c];
+                        q.t_var[r * 3 + c] = a.mat[(3 + r) * 18 + (3 + c)] - S.XM[(3 + r) * 18 + (3 + c)];
+                    }
+                // (the transform's loads are requested first and consumed last: ~12 points per thread, one memory latency instead of twelve)
+                const float4* const raw4 = (const float4*)ep.raw;
+                float4* const world4 = (float4*)ep.world;
+                const int tstride = G * 256, t0i = blockIdx.x * 256 + threadIdx.x;
+                constexpr int TB = 16;
+                float4 rv[TB];
+                if (raw4) {
+#pragma unroll
+                    for (int u = 0; u < TB; u++) { const int i = t0i + u * tstride; if (i < ep.n_raw) rv[u] = raw4[i]; }
+                }
+                for (int i = t0i; i < n; i += tstride) point_var_point(m, q, pts, i, 3, 0, ep.pt_data, ep.sort_key, ep.slot_out, ep.pt_next);
+                if (tre) tre[6] = __builtin_amdgcn_s_memrealtime();
+                if (raw4) {
+#pragma unroll
+                    for (int u = 0; u < TB; u++) { const int i = t0i + u * tstride; if (i < ep.n_raw) world4[i] = transform_value(a.sp.extR, a.sp.extT, q.R, q.t, rv[u]); }
+                    for (int i = t0i + TB * tstride; i < ep.n_raw; i += tstride) world4[i] = transform_value(a.sp.extR, a.sp.extT, q.R, q.t, raw4[i]);
+                }
+                if (tre) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tre[7] = __builtin_amdgcn_s_memrealtime(); }
+                // No completion protocol here: what consumes these stores in THIS stream sits behind the kernel boundary, and the flags that tell the
+                // mesher's stream / the host "the scan is in its world buffer, the input clouds are consumed" are stored by the first workgroup of the
+                // next launch (replay_fused_kernel) -- behind the same boundary, so no fence (an L2 write-back + invalidate per block) is needed
             }
             break;
         }
@@ -982,37 +1042,22 @@ __global__ __launch_bounds__(64) void ekf_step_kernel(RegIterArgs a, RegState* r
 // =====================================================================================================================
 // mode 0: map_incremental_grow  (var = (R extR) bcov (R extR)^T + (-[p_imu]x) Srot (-[p_imu]x)^T + St, p_imu with the z==0 -> 1e-3 quirk)
 // mode 1: voxel_map_init        (var = R bcov R^T + (-[p_lidar]x) Srot (..)^T + St, p_lidar after calcBodyVar's z==0 -> 1e-4 quirk)
-__global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const ScanParams* __restrict__ spd, const float* __restrict__ pts, int n, int stride, int mode,
-                                                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out,
-                                                         int32_t* __restrict__ pt_next, const float4* __restrict__ raw, float4* __restrict__ world, int n_raw, int nb_pv) {
-    if ((int)blockIdx.x >= nb_pv) {
-        // transformLidar of the FULL scan for the mesher (voxel_mapping_common.cpp:709-726) rides in the same launch: it was a launch of its own
-        // on the pose chain, between the last residual pass and this kernel
-        const int i = ((int)blockIdx.x - nb_pv) * 256 + threadIdx.x;
-        if (i >= n_raw) return;
-        const ScanParams* q = spd ? spd : &sp;
-        double R[9], t[3];
-#pragma unroll
-        for (int k = 0; k < 9; k++) R[k] = q->R[k];
-#pragma unroll
-        for (int k = 0; k < 3; k++) t[k] = q->t[k];
-        const float4 v = raw[i];
-        const double p[3] = {(double)v.x, (double)v.y, (double)v.z};
-        double pi[3], pw[3];
-        m3_vec(sp.extR, p, pi);
-        pi[0] += sp.extT[0]; pi[1] += sp.extT[1]; pi[2] += sp.extT[2];
-        m3_vec(R, pi, pw);
-        world[i] = make_float4((float)(pw[0] + t[0]), (float)(pw[1] + t[1]), (float)(pw[2] + t[2]), v.w);
-        return;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (spd) {   // posterior of the scan just registered, left on the device by the in-kernel EKF update
-#pragma unroll
-        for (int k = 0; k < 9; k++) { sp.R[k] = spd->R[k]; sp.RextR[k] = spd->RextR[k]; sp.rot_var[k] = spd->rot_var[k]; sp.t_var[k] = spd->t_var[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) sp.t[k] = spd->t[k];
-    }
+// transformLidar of one point of the FULL scan for the mesher (voxel_mapping_common.cpp:709-726): world = R (extR p + extT) + t, f64 compute, f32 store
+IMD float4 transform_value(const double* extR, const double* extT, const double* R, const double* t, const float4 v) {
+    const double p[3] = {(double)v.x, (double)v.y, (double)v.z};
+    double pi[3], pw[3];
+    m3_vec(extR, p, pi);
+    pi[0] += extT[0]; pi[1] += extT[1]; pi[2] += extT[2];
+    m3_vec(R, pi, pw);
+    return make_float4((float)(pw[0] + t[0]), (float)(pw[1] + t[1]), (float)(pw[2] + t[2]), v.w);
+}
+IMD void transform_point(const double* extR, const double* extT, const double* R, const double* t, const float4* __restrict__ raw, float4* __restrict__ world, const int i) {
+    world[i] = transform_value(extR, extT, R, t, raw[i]);
+}
+// one point of the map update's preparation (sp = the pose / covariance blocks to propagate with): world point, covariance, sort key, root voxel
+// (found or created), push on the voxel's list of this update.  Shared by point_var_kernel and the epilogue of residual_persistent_kernel.
+IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, const int stride, const int mode,
+                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next) {
     const double p[3] = {(double)pts[(size_t)i * stride + 0], (double)pts[(size_t)i * stride + 1], (double)pts[(size_t)i * stride + 2]};
     double pimu[3], pwd[3];
     m3_vec(sp.extR, p, pimu);
@@ -1078,6 +1123,33 @@ __global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams 
         }
         else pt_next[i] = (int)(unsigned int)(old & 0xFFFFFFFFull);
     }
+}
+
+__global__ __launch_bounds__(256) void point_var_kernel(RegMapDev m, ScanParams sp, const ScanParams* __restrict__ spd, const float* __restrict__ pts, int n, int stride, int mode,
+                                                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out,
+                                                         int32_t* __restrict__ pt_next, const float4* __restrict__ raw, float4* __restrict__ world, int n_raw, int nb_pv) {
+    if ((int)blockIdx.x >= nb_pv) {
+        // the transform of the full scan rides in the same launch: it was a launch of its own on the pose chain
+        const int i = ((int)blockIdx.x - nb_pv) * 256 + threadIdx.x;
+        if (i >= n_raw) return;
+        const ScanParams* q = spd ? spd : &sp;
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = q->R[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k] = q->t[k];
+        transform_point(sp.extR, sp.extT, R, t, raw, world, i);
+        return;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (spd) {   // posterior of the scan just registered, left on the device by the in-kernel EKF update
+#pragma unroll
+        for (int k = 0; k < 9; k++) { sp.R[k] = spd->R[k]; sp.RextR[k] = spd->RextR[k]; sp.rot_var[k] = spd->rot_var[k]; sp.t_var[k] = spd->t_var[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) sp.t[k] = spd->t[k];
+    }
+    point_var_point(m, sp, pts, i, stride, mode, pt_data, sort_key, slot_out, pt_next);
 }
 
 // segment heads of the slot-sorted point list
@@ -1603,24 +1675,33 @@ __global__ __launch_bounds__(256) void replay_kernel(RegMapDev m, const uint32_t
 // Round 2 ran this as three launches (light -> list -> refit: three plane-fit latencies in a row, 40 + 57 + 18 us).
 __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const int32_t* __restrict__ pt_next, const unsigned long long* __restrict__ sort_key,
                                                             const double* __restrict__ pt_data, int64_t* stats, uint32_t* __restrict__ general_list,
-                                                            unsigned long long* __restrict__ dbg) {
+                                                            unsigned long long* __restrict__ dbg, unsigned long long* flag_dev, unsigned long long* flag_host,
+                                                            unsigned long long flag_seq) {
+    // the registration launch before this one left the scan in the mesher's world buffer and consumed the input clouds (RpEpilogue): say so
+    if (flag_dev && blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(flag_dev, flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(flag_host, flag_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __shared__ unsigned long long skey[4][RL_CAP];
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(1);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wv;   // (four wavefronts per workgroup: one-wavefront workgroups were measured dispatch-bound -- ~130 workgroups per us)
-    // IMMESH_DEBUG: one trace record per wavefront of the launch (plain stores, no contention): [0] start, [1] end (s_memrealtime, 100 MHz),
+    // A resident grid strides over the touched voxels (four wavefronts per workgroup: one-wavefront workgroups were measured dispatch-bound, ~130
+    // workgroups per us; one workgroup per four down-sampled POINTS -- the count of touched voxels is only known on the device -- kept the
+    // dispatcher busy for 15 us placing 2000 workgroups, 40 % of whose wavefronts found nothing to do, and the mesher's launches waiting behind them).
+    const int t_first = blockIdx.x * 4 + wv, t_stride = gridDim.x * 4;
+    uint32_t slot_first = m.touched[2 * (size_t)t_first];    // (read beside the counter, not behind it: the list has room for every wavefront of the grid)
+    int root_first = (int)m.touched[2 * (size_t)t_first + 1];
+    const int n_touched = m.counters[7];
+#define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tr) ((unsigned int*)tr)[4 + (k)] = (unsigned int)(_t - tprev); tprev = _t; } } while (0)
+#define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
+    auto process = [&](const int t, const uint32_t slot, int root) __attribute__((always_inline)) {
+    // IMMESH_DEBUG: one trace record per touched voxel (plain stores, no contention): [0] start, [1] end (s_memrealtime, 100 MHz),
     // [2..6] ten 32-bit cycle counts (root known, node line 0, chunk table, list head, list, sort, load, decide, commit, plane), [7] cnt | n_ref << 8 | state << 16
     unsigned long long* const tr = (dbg && lane == 0 && t < DBG_FUSED_RECS) ? dbg + DBG_FUSED_OFF + (size_t)t * 8 : nullptr;
     unsigned long long tprev = dbg ? __builtin_readcyclecounter() : 0;
     if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); tr[2] = tr[3] = tr[4] = tr[5] = tr[6] = tr[7] = 0; }
-#define FDBG(k) do { if (dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tr) ((unsigned int*)tr)[4 + (k)] = (unsigned int)(_t - tprev); tprev = _t; } } while (0)
-#define FEND(state, nref) do { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); tr[7] = (unsigned long long)((unsigned)cnt | ((unsigned)(nref) << 8) | ((unsigned)(state) << 16)); } } while (0)
-    const int n_touched = m.counters[7];
-    const uint32_t slot = m.touched[2 * (size_t)t];          // (read beside the counter, not behind it: the list has room for every wavefront of the grid)
-    int root = (int)m.touched[2 * (size_t)t + 1];
-    if (t >= n_touched) { if (tr) { tr[1] = __builtin_amdgcn_s_memrealtime(); } return; }
     if (root < 0) root = m.htab[slot].root;
     if (root < 0) return;
     FDBG(0);
@@ -1753,6 +1834,11 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     }
     if (lane == 0) general_list[atomicAdd(&m.counters[10], 1)] = slot;
     FEND(3, 0);
+    };
+    for (int t = t_first; t < n_touched; t += t_stride) {
+        if (t != t_first) { slot_first = m.touched[2 * (size_t)t]; root_first = (int)m.touched[2 * (size_t)t + 1]; }
+        process(t, slot_first, root_first);
+    }
 #undef FDBG
 #undef FEND
 }
@@ -1768,7 +1854,7 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
     __shared__ int stacks[4][48];
-    __builtin_amdgcn_s_setprio(3);   // map growth is on the pose chain too (the next scan's registration waits for it)
+    __builtin_amdgcn_s_setprio(1);   // map growth is on the pose chain too (the next scan's registration waits for it)
     const int wv = threadIdx.x >> 6;
     const int nw = *n_work;
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
@@ -1885,10 +1971,11 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
     KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
-                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
+                                int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal,
+                                const RpEpilogue& ep) {
     const int nb = std::min((n + 255) / 256, RP_MAX_BLOCKS);   // resident grid: at most 128 four-wavefront blocks, half a CU's worth each
     KLAUNCH(residual_persistent_kernel, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
-            o_dis, o_rinv, o_normal);
+            o_dis, o_rinv, o_normal, ep);
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);
@@ -1900,8 +1987,9 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
             (float4*)world_xyzi, n_raw, nb_pv);
 }
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
-                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg, bool with_tail) {
-    KLAUNCH(replay_fused_kernel, dim3((n + 3) / 4), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg);
+                         int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg, bool with_tail,
+                         unsigned long long* flag_dev, unsigned long long* flag_host, unsigned long long flag_seq) {
+    KLAUNCH(replay_fused_kernel, dim3(std::min((n + 3) / 4, 768)), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg, flag_dev, flag_host, flag_seq);
     // the work list's length is only known on the device: a fixed grid strides over it (sized for the map-building case, where every touched voxel is on it)
     const int nb_list = std::min(std::max((n + 127) / 128, 32), 4096);
     KLAUNCH(replay_list_kernel, dim3(nb_list), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,

@@ -41,6 +41,9 @@ if (r[0, :, 0] > 0).any():
         ent = (b0[:, 4] - t0) * 0.01
         fin = (r[0, 0, 5] - t0) * 0.01
         print(f"  kernel entry (first wavefront of a block) min/max {ent.min():6.2f} {ent.max():6.2f}; block 0 finished (posterior out, ticket) {fin:6.2f}")
+        if (b0[:, 7] > 0).any():
+            e5 = (b0[1:, 5] - t0) * 0.01; e6 = (b0[:, 6] - t0) * 0.01; e7 = (b0[:, 7] - t0) * 0.01
+            print(f"  epilogue: start (blocks > 0) min/max {e5.min():6.2f} {e5.max():6.2f}; points prepared p50/max {np.percentile(e6, 50):6.2f} {e6.max():6.2f}; scan transformed p50/max {np.percentile(e7, 50):6.2f} {e7.max():6.2f}")
     for it in range(8):
         b = r[it][r[it, :, 0] > 0]
         if len(b) == 0 or b[:, 0].min() < t0:
