@@ -1413,6 +1413,11 @@ IMD void lds_sort_recs(SortRec* a, int np2, int tid) {
 //   mesh_merge_emit_kernel   one thread per record: final position = position in its own chunk + number of smaller records in every
 //                            other chunk (binary searches, 4 chunks in flight); the output entry is written directly at that position
 #define LS_CHUNK 1024
+// Per-scan lists of a stream are a few hundred entries: the LDS bitonic sort of a chunk is a chain of log^2 barrier-separated stages (55 at 1024
+// records, 27 us on the mesher's longest chain), so short lists are cut into chunks of 256 (36 stages of half the width; the merge pays two or three more
+// binary searches per record); long lists (offline clouds) keep 1024 -- the merge is linear in the number of chunks.
+#define LS_CHUNK_SMALL 256
+#define LS_SMALL_LIST 4096
 IMD void lsort_locate(const LSortPlan& pl, int blk, const int* base, int& job, int& local) {
     job = 0;
 #pragma unroll
@@ -1428,8 +1433,10 @@ IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
 #pragma unroll
     for (int j = 0; j < LS_JOBS; j++) {
         pl.n[j] = n[j]; pl.blk_base[j] = blk; pl.eblk_base[j] = eblk; pl.rec_off[j] = off;
-        const int chunks = (n[j] + LS_CHUNK - 1) / LS_CHUNK;
-        blk += chunks; eblk += (n[j] + 255) / 256; off += chunks * LS_CHUNK;
+        const int cs = n[j] <= LS_SMALL_LIST ? LS_CHUNK_SMALL : LS_CHUNK;
+        pl.cs[j] = cs;
+        const int chunks = (n[j] + cs - 1) / cs;
+        blk += chunks; eblk += (n[j] + 255) / 256; off += chunks * cs;
     }
     pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
 }
@@ -1444,7 +1451,8 @@ __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int 
         int job, chunk;
         lsort_locate(pl, blk, pl.blk_base, job, chunk);
         const int n = pl.n[job];
-        const int first = chunk * LS_CHUNK, cnt = min(LS_CHUNK, n - first);
+        const int cs = pl.cs[job];
+        const int first = chunk * cs, cnt = min(cs, n - first);
         const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : (job == 3 ? m.list_smooth : nullptr)));
         const int np2 = next_pow2_i(cnt);
         for (int i = tid; i < np2; i += 256) {
@@ -1483,18 +1491,19 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int 
     if (i >= n) continue;
     const SortRec* base = recs + (size_t)pl.rec_off[job];
     const SortRec r = base[i];
-    const int own = i / LS_CHUNK, nchunks = (n + LS_CHUNK - 1) / LS_CHUNK;
-    int rank = i - own * LS_CHUNK;
+    const int cs = pl.cs[job];
+    const int own = i / cs, nchunks = (n + cs - 1) / cs;
+    int rank = i - own * cs;
     for (int c0 = 0; c0 < nchunks; c0 += 4) {  // four independent binary searches in flight
         int lo[4], hi[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int cc = c0 + u; lo[u] = 0; hi[u] = (cc < nchunks && cc != own) ? min(LS_CHUNK, n - cc * LS_CHUNK) : 0; }
+        for (int u = 0; u < 4; u++) { const int cc = c0 + u; lo[u] = 0; hi[u] = (cc < nchunks && cc != own) ? min(cs, n - cc * cs) : 0; }
         for (int step = 0; step < 11; step++) {
 #pragma unroll
             for (int u = 0; u < 4; u++)
                 if (lo[u] < hi[u]) {
                     const int mid = (lo[u] + hi[u]) >> 1;
-                    const SortRec v = base[(size_t)(c0 + u) * LS_CHUNK + mid];
+                    const SortRec v = base[(size_t)(c0 + u) * cs + mid];
                     if (rec_gt(r, v)) lo[u] = mid + 1; else hi[u] = mid;
                 }
         }

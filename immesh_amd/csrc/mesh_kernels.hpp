@@ -38,7 +38,7 @@ enum {
 enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
 
 #define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
-struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; };
+struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; int cs[LS_JOBS]; };   // cs: chunk size of the job
 
 struct MeshScanParams {
     double cam[3];
