@@ -58,9 +58,10 @@ struct immesh_ctx {
     struct DsAsync { bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
-    // epilogue of the registration launch (map update preparation + full-scan transform): [0] arrival counter, [2..3] "done" flag (64-bit) on the
-    // device; the same flag in pinned memory for the host; epi_seq = last sequence number handed to a launch, inputs_seq != 0: the host-side
-    // "input clouds consumed" fence is that flag reaching inputs_seq (instead of ev_inputs_cur)
+    // epilogue of the registration launch (map update preparation + full-scan transform): the "scan is in its world buffer / input clouds consumed" flag,
+    // 64-bit at d_epi + 2 on the device (the mesher's first kernel polls it) and in pinned memory for the host; stored by the launch queued behind the
+    // registration.  epi_seq = last sequence number handed out; inputs_seq != 0: the host-side "input clouds consumed" fence is the pinned flag reaching
+    // inputs_seq (instead of ev_inputs_cur)
     unsigned int* d_epi = nullptr;
     unsigned long long* h_epi_flag = nullptr;
     unsigned long long* d_epi_flag_host = nullptr;

@@ -164,7 +164,6 @@ int mesh_alloc(immesh_ctx* c) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&h.ev_b[k]));   // (doubles as the end time of the job: every record is a barrier packet on the phase-B chain)
-        HIPCHK(c, hipEventCreate(&h.ev_t0[k])); HIPCHK(c, hipEventCreate(&h.ev_t1[k]));
     }
     std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
     h.stop = false;
@@ -192,8 +191,6 @@ void mesh_free(immesh_ctx* c) {
         if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
         if (h.ev_a[k]) (void)hipEventDestroy(h.ev_a[k]);
         if (h.ev_b[k]) (void)hipEventDestroy(h.ev_b[k]);
-        if (h.ev_t0[k]) (void)hipEventDestroy(h.ev_t0[k]);
-        if (h.ev_t1[k]) (void)hipEventDestroy(h.ev_t1[k]);
         if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
         if (h.graph_exec_b[k]) { (void)hipGraphExecDestroy(h.graph_exec_b[k]); h.graph_exec_b[k] = nullptr; }
         if (h.h_dyn[k]) (void)hipHostFree(h.h_dyn[k]);

@@ -132,7 +132,7 @@ struct MeshHost {
     // asynchronous execution
     hipStream_t stream = nullptr;            // the mesher's own streams: phase A ...
     hipStream_t stream_b = nullptr;          // ... and phase B
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // (a job's device time comes from mesh_publish_kernel, not from events)
     hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};   // phase A / B of the job of that parity finished
     // world-frame full scans.  The mesher pipelines two jobs (phase A of one over phase B of the other) and takes ~2.4 scan periods per job, so the scan
     // thread writes up to MESH_WORLD_BUFS scans ahead of the oldest running job (buffer = job id mod MESH_WORLD_BUFS) before it has to wait
