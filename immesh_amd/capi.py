@@ -437,6 +437,11 @@ class HotPath:
         self._check(f(self.ctx, C.byref(n), C.byref(ptr)), "downsample_end")
         return n.value, ptr.value
 
+    def inputs_consumed(self):
+        """block until the last asynchronous process_scan has consumed its (device-resident) input clouds"""
+        f = self._f("inputs_consumed"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx), "inputs_consumed")
+
     def downsample_result_ptr(self):
         f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p
         return f(self.ctx)

@@ -622,6 +622,22 @@ static int pre_inputs_fence(immesh_ctx* c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_cur, 0));
     return 0;
 }
+int immesh_inputs_consumed(immesh_ctx* c) {
+    if (!c) return IMMESH_E_INVAL;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->inputs_seq) {   // the registration launch consumed them in its epilogue: the flag the launch behind it stores, in pinned memory
+        volatile unsigned long long* f = c->h_epi_flag;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*f < c->inputs_seq) {
+            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return 0;
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev_inputs_cur));
+    return 0;
+}
 static int pre_resolve(immesh_ctx* c, const void* p, size_t bytes, void* staging, const void** dev_out) {
     hipPointerAttribute_t attr;
     const hipError_t e = hipPointerGetAttributes(&attr, p);

@@ -282,6 +282,12 @@ const float* immesh_downsample_result(immesh_ctx* ctx);
  * extents; a cloud that needs more bits is redone synchronously inside _end -- the result is always the one immesh_downsample gives. */
 int immesh_downsample_begin(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf);
 int immesh_downsample_end(immesh_ctx* ctx, int32_t* n_out, const float** dev_xyz);
+/* The device buffers handed to an ASYNCHRONOUS immesh_process_scan (pts_down, pts_raw) are still read for a few microseconds after the call has
+ * returned with the pose (the map update's preparation and the full-scan transform run behind the last registration pass).  The library's own
+ * pre-processing entry points order themselves behind that; an application that refills such a buffer with its own kernels / copies calls this first:
+ * it returns once the last asynchronous scan has consumed its input clouds.  (The reference has no counterpart: its scan thread owns the clouds until
+ * map_incremental_grow returns, src/ImMesh_mesh_reconstruction.cpp:377-444, called at src/voxel_mapping.cpp:1973.) */
+int immesh_inputs_consumed(immesh_ctx* ctx);
 
 /* ImuProcess::Forward_without_imu   src/IMU_Processing.cpp:486-553 : constant-velocity prior (state + covariance) for the next scan. */
 int immesh_forward_without_imu(const double* state_in, double dt, double cov_gyr, double cov_acc, double* state_out);

@@ -154,6 +154,7 @@ int orc_downsample_begin(void* p, const float* pts, int32_t n, int32_t stride, d
     return orc_downsample(p, pts, n, stride, leaf, g_ds_async.data(), n, &g_ds_async_n);
 }
 int orc_downsample_end(void*, int32_t* n_out, const float** xyz) { *n_out = g_ds_async_n; if (xyz) *xyz = g_ds_async.data(); return 0; }
+int orc_inputs_consumed(void*) { return 0; }   // (the checker is synchronous: a call has consumed its inputs when it returns)
 int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
 int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t n, double leaf) {   // ImMesh_mesh_reconstruction.cpp:328-345
     std::vector<float> ds((size_t)n * 3);

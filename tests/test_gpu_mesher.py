@@ -168,9 +168,15 @@ def test_async_pipeline_matches_serial(hip_lib):
         h.map_build(np.ascontiguousarray(scans[0][1].cpu().numpy()[:, :3]), st)
         st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
         for k in range(1, 6):
-            down, raw = scans[k][0], scans[k][1]
+            down, raw = scans[k][0].clone(), scans[k][1].clone()
+            torch.cuda.current_stream().synchronize()   # (stream, not device: the library's worker may be capturing a graph -- hipDeviceSynchronize is not permitted then)
             prior = synth.forward_without_imu(st)
             st, _ = h.process_scan(down.data_ptr(), raw.data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=down.shape[0], n_raw=raw.shape[0])
+            # the input clouds of an asynchronous call are still read after it has returned with the pose: immesh_inputs_consumed is the fence an
+            # application needs before it refills them (here: poisons them -- a scan that had not been consumed would change pose and mesh)
+            h.inputs_consumed()
+            down.fill_(float("nan")); raw.fill_(float("nan"))
+            torch.cuda.current_stream().synchronize()
         h.mesh_wait()
         last = h.mesh_fetch()
         results[mode] = (st.copy(), last, h.counters())
