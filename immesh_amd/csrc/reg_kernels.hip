@@ -1114,11 +1114,19 @@ IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* 
     if (pt_next) {  // push the point on its root voxel's list for this update; the first point to arrive registers the voxel as touched
         const unsigned long long mine = ((unsigned long long)(unsigned int)m.upd_seq << 32) | (unsigned int)i;
         const unsigned long long old = atomicExch(&m.slot_head[slot], mine);
-        if ((unsigned int)(old >> 32) != (unsigned int)m.upd_seq) {
+        const bool first = (unsigned int)(old >> 32) != (unsigned int)m.upd_seq;
+        // the touched list grows by ONE atomic per wavefront (the first arrivers of a wavefront share it): ~4 900 returning atomics on one address were
+        // the longest dependent step of this function
+        const unsigned long long fm = __ballot(first);
+        if (first) {
             pt_next[i] = -1;
+            const int lane = (int)(threadIdx.x & 63), leader = __builtin_ctzll(fm);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&m.counters[7], (int)__popcll(fm));
+            base = __shfl(base, leader, 64);
+            const int k = base + (int)__popcll(fm & ((1ull << lane) - 1ull));
             // (slot, root node): the replay kernel starts from the node without a second trip through the hash; a root another lane of this launch
             // is still creating reads as -1 here and is looked up there
-            const int k = atomicAdd(&m.counters[7], 1);
             m.touched[2 * (size_t)k] = (uint32_t)slot; m.touched[2 * (size_t)k + 1] = (uint32_t)m.htab[slot].root;
         }
         else pt_next[i] = (int)(unsigned int)(old & 0xFFFFFFFFull);
