@@ -260,6 +260,16 @@ class HotPath:
         self._check(f(self.ctx, _ptr(out), len(out), C.byref(n)), "mesh_neighbourhood_sizes")
         return out[:n.value]
 
+    def mesh_world_scan(self):
+        """the world-frame scan (n x 4 float32) the newest finished mesh job was handed (parity diagnostics)"""
+        f = self._f("mesh_world_scan"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]; f.restype = C.c_int
+        n = C.c_int32(0)
+        self._check(f(self.ctx, None, 0, C.byref(n)), "mesh_world_scan")
+        out = np.zeros((n.value, 4), np.float32)
+        if n.value:
+            self._check(f(self.ctx, _ptr(out), n.value, C.byref(n)), "mesh_world_scan")
+        return out
+
     def mesh_wait(self):
         f = self._f("mesh_wait"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx), "mesh_wait")
@@ -441,6 +451,12 @@ class HotPath:
         """block until the last asynchronous process_scan has consumed its (device-resident) input clouds"""
         f = self._f("inputs_consumed"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx), "inputs_consumed")
+
+    def registration_fallbacks(self):
+        f = self._f("registration_fallbacks"); f.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]; f.restype = C.c_int
+        n = C.c_int64(0)
+        self._check(f(self.ctx, C.byref(n)), "registration_fallbacks")
+        return n.value
 
     def downsample_result_ptr(self):
         f = self._f("downsample_result"); f.argtypes = [C.c_void_p]; f.restype = C.c_void_p

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <new>
 
+#define RP_ABORTED 1   /* internal: register_collect_fused found the resident-grid registration aborted (bounded gather) */
 static thread_local std::string g_create_error;
 thread_local KProf* g_kprof = nullptr;
 
@@ -133,6 +134,12 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
     // per-config constants of calcBodyVar: pow(sin(DEG2RAD(deg)),2) with PCL's DEG2RAD(x) = x*0.017453293 and float `degree_inc`
     { const double s = std::sin((double)(float)cfg->beam_err * 0.017453293); c->dvar_beam = s * s; }
     { const double s = std::sin((double)(float)0.01 * 0.017453293); c->dvar_calib = s * s; }
+    {   // resident-grid registration: never more than HALF of the workgroups the device holds at once (two contexts cannot wait for each other's CUs)
+        const int resident = residual_persistent_resident_blocks(cfg->device);
+        c->rp_max_blocks = std::max(1, resident / 2 - 1);
+        if (const char* e = getenv("IMMESH_RP_BLOCKS")) c->rp_max_blocks = std::max(1, atoi(e));
+        c->rp_force_abort = getenv("IMMESH_RP_FORCE_ABORT") != nullptr;
+    }
     int rc = alloc_all(c);
     if (!rc) rc = mesh_alloc(c);
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) { rc = IMMESH_E_HIP; c->err = "initialisation kernels failed"; }
@@ -244,6 +251,33 @@ static int fetch_matches(immesh_ctx* c, int n, std::vector<int8_t>& mt) {
     return 0;
 }
 
+// The same iterated update as a chain of launches per pass: residual_kernel (sums to device memory) -> [ncclAllReduce of the device-resident sums] ->
+// the 18-state update as its own one-wavefront launch (ekf_step_kernel); all passes enqueued up front, no host involvement, no co-residency needed.
+// Serves the sharded map (the all-reduce sits between pass and update) and is the fallback of a resident-grid registration that gave up.
+// c->reg_args (.sp, .st, .prior, .max_iter) and c->reg_ticket are set by the caller.
+static int register_enqueue_chain(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& st) {
+    RegIterArgs& a = c->reg_args;
+    const int max_iter = c->cfg.max_iter;
+    for (int it = 0; it < max_iter; it++) {
+        a.it = it; a.mode = REG_MODE_SUMS;
+        if (it == 0) {
+            double p11[36];
+            for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) p11[r * 6 + q] = st.cov[r * 18 + q];
+            if (!imh::invert(p11, a.mat, 6)) { c->err = "singular prior covariance"; return IMMESH_E_INVAL; }
+            for (int i = 0; i < 12; i++)
+                for (int q = 0; q < 6; q++) { double sacc = 0; for (int k = 0; k < 6; k++) sacc += st.cov[(6 + i) * 18 + k] * a.mat[k * 6 + q]; a.mat[36 + i * 6 + q] = sacc; }
+        }
+        else if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat));
+        launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, c->d_out48, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
+                        c->d_dis, c->d_rinv, c->d_normal);
+        if (c->rccl_comm) {
+            const int rc = rccl_allreduce_f64(c, c->d_out48, RES_NV_HOST - 2, c->stream);
+            if (rc) return rc;
+        }
+        launch_ekf_step(c->stream, a, c->d_regstate, c->d_out48, c->d_reg_out_host, c->reg_ticket);
+    }
+    return 0;
+}
 // The iterated update with the 18-state step on the device (reg_kernels.hip: ekf_step_wave in the last block of every residual pass): all
 // passes of the scan are enqueued up front, a pass that finds the loop already stopped returns at once.  The posterior stays on the device
 // (RegState::sp) for the map update / full-scan transform queued behind it; the host only collects it.
@@ -258,36 +292,18 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
     std::memcpy(a.prior, prior.R, 72); std::memcpy(a.prior + 9, prior.t, 24); std::memcpy(a.prior + 12, prior.vel, 24); std::memcpy(a.prior + 15, prior.bg, 24);
     std::memcpy(a.prior + 18, prior.ba, 24); std::memcpy(a.prior + 21, prior.g, 24);
     c->reg_ticket = (double)(++c->res_ticket);
-    const bool rccl = c->rccl_comm != nullptr;   // sharded map: the 46 sums are all-reduced in-stream between pass and update
-    if (!rccl) {
+    if (!c->rccl_comm) {
         // ONE launch for the scan: a resident grid runs every pass and the 18-state update (residual_persistent_kernel); a.mat = the prior covariance
         a.mode = REG_MODE_FUSED; a.it = 0;
+        if (c->rp_force_abort) a.pad |= 2;   // (IMMESH_RP_FORCE_ABORT: the test hook of the bounded gather)
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
         const int par = (c->rp_parity ^= 1);   // this scan's slot buffer; the launch re-arms the other one for the next scan
         RpEpilogue none{};
         launch_residual_persistent(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_rp_slots[par], c->d_rp_slots[par ^ 1], c->d_counters_host, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
-                                   c->d_dis, c->d_rinv, c->d_normal, ep ? *ep : none);
+                                   c->d_dis, c->d_rinv, c->d_normal, ep ? *ep : none, c->rp_max_blocks);
         return 0;
     }
-    for (int it = 0; it < max_iter; it++) {
-        // sharded map: residual pass (sums to device memory) -> ncclAllReduce on the device-resident sums -> the 18-state update as its own
-        // (one-wavefront) launch; all passes enqueued up front, no host involvement
-        a.it = it; a.mode = REG_MODE_SUMS;
-        if (it == 0) {
-            double p11[36];
-            for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) p11[r * 6 + q] = st.cov[r * 18 + q];
-            if (!imh::invert(p11, a.mat, 6)) { c->err = "singular prior covariance"; return IMMESH_E_INVAL; }
-            for (int i = 0; i < 12; i++)
-                for (int q = 0; q < 6; q++) { double sacc = 0; for (int k = 0; k < 6; k++) sacc += st.cov[(6 + i) * 18 + k] * a.mat[k * 6 + q]; a.mat[36 + i * 6 + q] = sacc; }
-        }
-        else if (it == 1) std::memcpy(a.mat, st.cov, sizeof(a.mat));
-        launch_residual(c->stream, c->map, a, c->d_regstate, d_pts, n_ds, c->d_partials, c->d_done, c->d_out48, c->d_reg_out_host, c->reg_ticket, c->d_match, c->d_mnode,
-                        c->d_dis, c->d_rinv, c->d_normal);
-        int rc = rccl_allreduce_f64(c, c->d_out48, RES_NV_HOST - 2, c->stream);
-        if (rc) return rc;
-        launch_ekf_step(c->stream, a, c->d_regstate, c->d_out48, c->d_reg_out_host, c->reg_ticket);
-    }
-    return 0;
+    return register_enqueue_chain(c, d_pts, n_ds, st);
 }
 static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
     volatile double* flag = c->h_reg_out + (REG_OUT_DOUBLES - 1);
@@ -301,6 +317,7 @@ static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* 
     if (*flag != ticket) { c->err = "registration kernels did not complete"; return IMMESH_E_HIP; }
     std::atomic_thread_fence(std::memory_order_acquire);
     const double* o = c->h_reg_out;
+    if (o[348] < 0) return RP_ABORTED;   // the resident grid gave up in a gather (it could not become resident): nothing was written, `st` is untouched
     imh::load_state(o, st);
     const int iters = (int)o[348];
     if (n_iter) *n_iter = iters;
@@ -314,16 +331,28 @@ static int register_collect_fused(immesh_ctx* c, int n_ds, imh::State& st, int* 
     c->last_n_ds = n_ds;
     return 0;
 }
+// A resident-grid registration that gave up: register the scan with the per-pass chain instead.  The aborted launch (and whatever was queued behind it)
+// has drained when this returns to the caller's collect.
+static int register_fallback_chain(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& st) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rp_fallbacks++;
+    c->reg_args.pad = 0;
+    c->reg_ticket = (double)(++c->res_ticket);
+    return register_enqueue_chain(c, d_pts, n_ds, st);
+}
 static bool use_fused_ekf(const immesh_ctx* c) {
     static const bool host_ekf = getenv("IMMESH_HOST_EKF") != nullptr;   // debugging: the round-1 host loop (one round trip per pass)
-    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && c->cfg.max_iter < 64 && (c->cfg.shard_world <= 1 || c->rccl_comm != nullptr);
+    return !host_ekf && !c->allreduce && c->cfg.max_iter >= 2 && c->cfg.max_iter < 62 && (c->cfg.shard_world <= 1 || c->rccl_comm != nullptr);
 }
 
 // the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
 static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
     if (use_fused_ekf(c)) {
-        const int rc = register_enqueue_fused(c, d_pts, n_ds, prior, st);
+        int rc = register_enqueue_fused(c, d_pts, n_ds, prior, st);
         if (rc) return rc;
+        rc = register_collect_fused(c, n_ds, st, n_iter, n_match, res_mean);
+        if (rc != RP_ABORTED) return rc;
+        if ((rc = register_fallback_chain(c, d_pts, n_ds, st))) return rc;
         return register_collect_fused(c, n_ds, st, n_iter, n_match, res_mean);
     }
     imh::EkfLoop ekf;
@@ -539,6 +568,19 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if (timed) (void)hipEventRecord(ev[2], c->stream);
         c->timing_valid[par] = timed;
         rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
+        bool fell_back = false;
+        if (rc == RP_ABORTED) {
+            // the resident grid gave up (bounded gather): neither the registration nor its epilogue wrote anything, the replay launches queued behind it
+            // found no touched voxel.  Register with the per-pass chain, then prepare the map update with point_var_kernel (+ the transform) as the
+            // synchronous entry points do
+            fell_back = true;
+            if ((rc = register_fallback_chain(c, (const float*)d_down, n_ds, st))) return rc;
+            if ((rc = map_ingest_device(c, (const float*)d_down, n_ds, 3, st, 0, c->ev_inputs_free, &c->d_regstate->sp, world ? (const float*)d_raw : nullptr, world, n_raw,
+                                        /*defer_tail=*/false, /*prep_done=*/false))) return rc;
+            if (timed) (void)hipEventRecord(ev[2], c->stream);
+            rc = register_collect_fused(c, n_ds, st, &n_iter, &n_match, nullptr);
+            if (rc == RP_ABORTED) { c->err = "registration did not complete"; rc = IMMESH_E_HIP; }
+        }
         imh::store_state(st, state_inout);
         if (n_iter_out) *n_iter_out = n_iter;
         if (n_match_out) *n_match_out = n_match;
@@ -549,7 +591,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if (rc || rc_prev) { c->ev_par = par; c->pending = true; return rc ? rc : rc_prev; }
         c->ev_par = par;
         long job = 0;
-        if (mesh_mode) job = epi ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
+        if (mesh_mode) job = (epi && !fell_back) ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
         c->timing[3] = 0.f;
         c->pending = true;
         if (nowait) return 0;
@@ -962,6 +1004,12 @@ int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3) {
     if (cfg->shard_world <= 1) return 0;
     const int b = cfg->shard_brick_log2 > 0 ? cfg->shard_brick_log2 : 5;
     return (int)(h_hash64(h_pack(key3[0] >> b, key3[1] >> b, key3[2] >> b)) % (uint64_t)cfg->shard_world);
+}
+
+int immesh_registration_fallbacks(immesh_ctx* c, int64_t* n) {
+    if (!c || !n) return IMMESH_E_INVAL;
+    *n = c->rp_fallbacks;
+    return 0;
 }
 
 int immesh_profile_enable(immesh_ctx* c, int32_t on) {

@@ -58,6 +58,9 @@ struct immesh_ctx {
     struct DsAsync { bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
+    int rp_max_blocks = 127;         // grid cap of residual_persistent_kernel: half of the device's resident workgroups - 1 (occupancy query at create)
+    bool rp_force_abort = false;     // IMMESH_RP_FORCE_ABORT (tests): every resident-grid registration gives up in its first gather
+    int64_t rp_fallbacks = 0;        // scans registered by the per-pass chain because the resident grid gave up
     // epilogue of the registration launch (map update preparation + full-scan transform): the "scan is in its world buffer / input clouds consumed" flag,
     // 64-bit at d_epi + 2 on the device (the mesher's first kernel polls it) and in pinned memory for the host; stored by the launch queued behind the
     // registration.  epi_seq = last sequence number handed out; inputs_seq != 0: the host-side "input clouds consumed" fence is the pinned flag reaching

@@ -47,7 +47,7 @@ struct RegState {
 #define REG_MODE_FUSED 1      /* residual_persistent_kernel: every pass of the scan + the 18-state update in one launch; mat = the prior covariance */
 #define REG_MODE_SUMS 3       /* parameters from RegState (it > 0) or by value (it == 0); the 48 sums go to device memory for an in-stream all-reduce, ekf_step_kernel follows */
 struct RegIterArgs {
-    int mode, it, max_iter, pad;   // pad: residual_persistent_kernel -- 1 = run the previous map update's deferred tail in the prologue
+    int mode, it, max_iter, pad;   // pad: residual_persistent_kernel -- bit 0 = run the previous map update's deferred tail in the prologue, bit 1 = test hook: abort in the first gather
     ScanParams sp;
     double st[24], prior[24];
     double mat[324];          // first pass: [0,36) P11^-1, [36,108) P21 P11^-1; later passes: the prior covariance
@@ -71,10 +71,12 @@ struct RpEpilogue {
     double* pt_data; unsigned long long* sort_key; uint32_t* slot_out; int32_t* pt_next;
     const float* raw; float* world;          // xyzI in / out (nullptr: no mesher)
 };
-#define RP_TAIL_WORD (63 * 128 * 32)   /* slot word the deferred-tail workgroup publishes (pass 63 is never run: max_iter < 64) */
+#define RP_TAIL_WORD (63 * 128 * 32)   /* slot word the deferred-tail workgroup publishes (passes 62, 63 are never run: max_iter < 62) */
+#define RP_ABORT_WORD (62 * 128 * 32)  /* slot word a block publishes when its gather runs out of patience (the grid did not become resident) */
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
                                 int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal,
-                                const RpEpilogue& ep);
+                                const RpEpilogue& ep, int max_blocks);
+int residual_persistent_resident_blocks(int device);
 // the 18-state update as its own launch (sharded map with an in-stream all-reduce of the 48 sums between the residual pass and the update)
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket);
 // spd != nullptr: the parameters are read from device memory (RegState::sp of the scan just registered) instead of `sp`

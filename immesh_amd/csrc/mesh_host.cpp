@@ -462,7 +462,7 @@ static void mesh_worker_main(immesh_ctx* c) {
         }
         if (have) {
             Flight f;
-            f.job = job; f.r.id = job.id; f.launched_ok = false;
+            f.job = job; f.r.id = job.id; f.r.d_pts = job.d_pts; f.r.n_raw = job.n_raw; f.launched_ok = false;
             std::memset(&f.r.sizes, 0, sizeof(f.r.sizes));
             h.err.clear();
             bool synced = false;
@@ -645,6 +645,26 @@ int immesh_mesh_neighbourhood_sizes(immesh_ctx* c, int32_t* out, int32_t cap, in
     if (out && n > 0) {
         if (n > cap) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
         HIPCHK(c, hipMemcpy(out, h.mpar[par].rel_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// diagnostics (parity tests): the world-frame scan of the newest finished job, straight from its world buffer
+int immesh_mesh_world_scan(immesh_ctx* c, float* out_xyzi, int32_t cap_pts, int32_t* n_out) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    (void)hipSetDevice(c->cfg.device);
+    MeshHost& h = c->mesh_host;
+    const float* d_pts; int n;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        if (h.current <= 0) { *n_out = 0; return 0; }
+        if (h.current < h.submitted - (MESH_WORLD_BUFS - 2)) { c->err = "the job's world buffer has been handed to a newer scan"; return IMMESH_E_INVAL; }
+        d_pts = h.res[h.current & 1].d_pts; n = h.res[h.current & 1].n_raw;
+    }
+    *n_out = n;
+    if (out_xyzi && n > 0) {
+        if (n > cap_pts) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
+        HIPCHK(c, hipMemcpy(out_xyzi, d_pts, (size_t)n * 16, hipMemcpyDeviceToHost));
     }
     return 0;
 }

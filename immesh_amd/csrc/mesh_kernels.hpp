@@ -111,7 +111,7 @@ struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 #define MESH_PUB_WORDS (SC_COUNT + 8)
 struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; const unsigned long long* wait_flag = nullptr; unsigned long long wait_seq = 0; };
 struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz; };
-struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; };
+struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; const float* d_pts = nullptr; int n_raw = 0; };
 
 struct MeshHost {
     int32_t seq = 0;

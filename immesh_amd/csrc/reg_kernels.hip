@@ -590,12 +590,18 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
 //     to the next pass without waiting for anybody's publication.  Block 0 also writes what leaves the kernel (posterior for the map update /
 //     the host).
 //   * slots are per pass and per scan parity; a launch re-arms the OTHER parity's slots for the next scan.
-// No deadlock: the grid is capped (launch_residual_persistent) far below what the chip holds resident and waits for nothing queued behind it.
+// No deadlock between two contexts: the grid is capped at HALF of what the device holds resident (immesh_ctx::rp_max_blocks, from the occupancy
+// query at create) and waits for nothing queued behind it.  More contexts than that, or a device somebody else has filled, could still leave
+// blocks undispatched while the resident ones wait for their slots: the gather is therefore BOUNDED (RP_SPIN_TICKS of the 100 MHz real-time
+// counter).  A block that runs out of patience publishes the abort word; every block looks at it in every poll, nobody runs the epilogue, the
+// result block says "aborted" (passes = -1) and the host registers the scan with the per-pass chain instead (residual_kernel -> ekf_step_kernel,
+// which needs no co-residency).  A pass-0 abort is seen by every block before it can stop (the loop runs at least two passes).
 // The update itself (rp_update) is the algebra of ekf_host.hpp / the reference regrouped for latency: with K1 = [X; T X] (X = (H^T R^-1 H +
 // P11^-1)^-1, T = P21 P11^-1) the solution is K1 (H^T z - H^T H vec6) + vec -- G = K1 H^T H is never formed -- and the posterior covariance
 // P - K1 (H^T H P[0:6,:]) is only evaluated by the pass that stops the loop.
 // ---------------------------------------------------------------------------------------------------------------------
 #define RP_MAX_BLOCKS 128
+#define RP_SPIN_TICKS 100000000ull   /* 1 s */
 #define RP_SENTINEL 0x7FF8DEADBEEF0001ull
 struct RpShared {
     double red[4][RES_NR][65];   // per-wavefront transposes
@@ -807,12 +813,12 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     const unsigned long long t_entry = sp.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // (trace: [4] of the pass-0 record = kernel entry, [5] = block 0 finished)
     // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ((unsigned long long*)slots_next)[RP_TAIL_WORD] = RP_SENTINEL;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ((unsigned long long*)slots_next)[RP_TAIL_WORD] = RP_SENTINEL; ((unsigned long long*)slots_next)[RP_ABORT_WORD] = RP_SENTINEL; }
     // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below.  It gets a workgroup of its
     // own (the launcher adds one): inside a working block it delayed that block's first partial sums, i.e. everybody's first gather
     const int G = (int)gridDim.x - 1;
     if ((int)blockIdx.x == G) {
-        if (a.pad) map_update_tail(m, host_counters);
+        if (a.pad & 1) map_update_tail(m, host_counters);
         // the epilogue below works on the counters the tail resets: its completion is published like a block partial (release: fence, then the
         // word) and every block's first gather waits for it along with the partials
         __threadfence();
@@ -921,7 +927,10 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
             double R12[12], vec6[6];
             bool have_vec = false;
             __builtin_amdgcn_s_setprio(1);
-            for (int b0 = lane >> 5; b0 < G; b0 += 64) {
+            bool aborted = false;
+            unsigned long long spin_t0 = 0;
+            unsigned int spins = 0;
+            for (int b0 = lane >> 5; b0 < G && !aborted; b0 += 64) {
                 double v[32];
                 for (;;) {
                     unsigned long long bits[32];
@@ -933,18 +942,30 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
                     }
                     unsigned long long tailbits = 0;
                     if (it == 0) tailbits = __hip_atomic_load((const unsigned long long*)&slots[RP_TAIL_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long abortbits = __hip_atomic_load((const unsigned long long*)&slots[RP_ABORT_WORD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // the part of the update that needs only the iterate runs while the first round of loads is in flight
                     if (!have_vec) { rp_prior_minus_state(S, R12, vec6); have_vec = true; }
                     bool ok = tailbits != RP_SENTINEL;
 #pragma unroll
                     for (int u = 0; u < 32; u++) { ok = ok && bits[u] != RP_SENTINEL; v[u] = __longlong_as_double((long long)bits[u]); }
+                    // (a.pad & 2: the test hook -- every block gives up in its first poll, as if the grid had not become resident)
+                    if (__any(abortbits != RP_SENTINEL) || (a.pad & 2)) { aborted = true; break; }
                     if (__all(ok)) break;
+                    // bounded: the slots of a block that is not resident never arrive (see the header comment)
+                    if ((++spins & 63u) == 0) {
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (spin_t0 == 0) spin_t0 = now;
+                        else if (now - spin_t0 > RP_SPIN_TICKS) { aborted = true; break; }
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int u = 0; u < 32; u++) tot += v[u];
             }
             __builtin_amdgcn_s_setprio(3);
+            if (__any(aborted)) {   // (wave-uniform: the lanes have reconverged behind the loop)
+                if (lane == 0) { dev_publish(&slots[RP_ABORT_WORD], 1.0); S.stop = 2; }
+            } else {
             tot += __shfl_xor(tot, 32, 64);
             if (tr) tr[2] = __builtin_amdgcn_s_memrealtime();
             // host layout of the sums: 36 HTH (row-major 6x6) + 6 HTz + n_match + sum|dis| + n_plane_tests + n_extra_probe
@@ -959,8 +980,18 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
             rp_update(S, a, it, lane, blockIdx.x == 0, R12, vec6, sp.dbg);
             if (tr) tr[3] = __builtin_amdgcn_s_memrealtime();
             RDBG(5);
+            }
         }
         __syncthreads();
+        if (S.stop == 2) {
+            // aborted: nothing of the scan has been written (no epilogue); every aborting block stores the same words
+            if (threadIdx.x == 0) {
+                __hip_atomic_store((unsigned long long*)&reg_out[348], (unsigned long long)__double_as_longlong(-1.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&reg_out[REG_OUT_DOUBLES - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            break;
+        }
         if (S.stop) {
             if (blockIdx.x == 0 || ep.enabled) rp_posterior(S, a);
             if (blockIdx.x == 0) {
@@ -1980,10 +2011,19 @@ void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, Re
 }
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
                                 int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal,
-                                const RpEpilogue& ep) {
-    const int nb = std::min((n + 255) / 256, RP_MAX_BLOCKS);   // resident grid: at most 128 four-wavefront blocks, half a CU's worth each
+                                const RpEpilogue& ep, int max_blocks) {
+    // resident grid: at most max_blocks (<= RP_MAX_BLOCKS) four-wavefront blocks + the tail's -- half of what the device holds resident, so that two
+    // contexts registering at the same time can never wait for each other's CUs
+    const int nb = std::max(1, std::min((n + 255) / 256, std::min(max_blocks, RP_MAX_BLOCKS)));
     KLAUNCH(residual_persistent_kernel, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
             o_dis, o_rinv, o_normal, ep);
+}
+// workgroups of residual_persistent_kernel the device holds resident at once (registers + LDS decide: one per CU on an MI355X)
+int residual_persistent_resident_blocks(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, residual_persistent_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
+    return std::max(1, per_cu) * cus;
 }
 void launch_ekf_step(hipStream_t s, const RegIterArgs& a, RegState* rs, const double* sums48, double* reg_out, double ticket) {
     KLAUNCH(ekf_step_kernel, dim3(1), dim3(64), 0, s, a, rs, sums48, reg_out, ticket);

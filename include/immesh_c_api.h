@@ -130,6 +130,11 @@ int immesh_mesh_sizes(immesh_ctx* ctx, immesh_mesh_sizes_t* sizes);
 /* Diagnostics: the neighbourhood size n_u (vertices of the voxel + its 20-NN union, retrieve_neighbor_pts_kdtree  src/meshing/mesh_rec_geometry.cpp:336-377)
  * of every voxel the newest finished job triangulated, in that job's voxel order.  out may be NULL to query the count. */
 int immesh_mesh_neighbourhood_sizes(immesh_ctx* ctx, int32_t* out, int32_t cap, int32_t* n_out);
+/* Diagnostics (parity tests): the world-frame scan the newest finished job meshed -- world_lidar_full as transformLidar left it
+ * (src/voxel_mapping_common.cpp:709-726: f64 compute, f32 store), i.e. for immesh_process_scan the cloud the registration launch's epilogue wrote
+ * with the posterior pose.  out_xyzi: cap_pts x 4 floats (host), may be NULL to query the count.  A full-pipeline run is compared exactly by
+ * feeding this cloud to a second mesher (tests/test_gpu_parity_fullsize.py). */
+int immesh_mesh_world_scan(immesh_ctx* ctx, float* out_xyzi, int32_t cap_pts, int32_t* n_out);
 /* All lists are sorted (triplets: ids ascending inside a triplet, triplets lexicographic; smooth ids ascending).
  * Any pointer may be NULL to skip that list. */
 int immesh_mesh_fetch(immesh_ctx* ctx, float* new_vtx_xyz, int32_t* tri_add, uint8_t* flip_add, int32_t* tri_rem, int32_t* tri_upd,
@@ -315,6 +320,11 @@ typedef struct immesh_counters_t {  /* cumulative since create / last reset; SUR
     int64_t n_root_voxels, n_nodes, n_vertices, n_triangles_live;
 } immesh_counters_t;
 int immesh_counters(immesh_ctx* ctx, immesh_counters_t* out, int32_t reset);
+
+/* Diagnostics: scans whose one-launch registration (a resident grid whose workgroups gather each other's partial sums) could not get all of its
+ * workgroups onto the device within its spin bound and were registered by the per-pass launch chain instead -- same result to rounding, more
+ * launches.  Non-zero only when other work has filled the device (more than two contexts registering large scans at once). */
+int immesh_registration_fallbacks(immesh_ctx* ctx, int64_t* n);
 
 /* timing of the last immesh_process_scan, milliseconds from HIP events on the ctx stream:
  * [0] total  [1] register  [2] map update  [3] mesh

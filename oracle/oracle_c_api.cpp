@@ -24,6 +24,7 @@ struct OrcCtx {
     Mesher mesher;
     MeshScanOut mout;
     orc::IkdMap ikd;
+    std::vector<float> last_world;   // the world-frame scan the newest mesh job was handed (orc_mesh_world_scan)
     OrcCtx() : reg(&vm) {}
 };
 
@@ -116,7 +117,15 @@ int orc_map_update(void* p, const float* pts, int32_t n_ds, const double* state)
 int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx) {
     (void)frame_idx;
     OrcCtx* o = (OrcCtx*)p;
+    o->last_world.assign(pts_world_xyzi, pts_world_xyzi + (size_t)n_raw * 4);
     o->mesher.mesh_scan(pts_world_xyzi, n_raw, sensor_pos, o->mout);
+    return 0;
+}
+int orc_mesh_world_scan(void* p, float* out_xyzi, int32_t cap_pts, int32_t* n_out) {
+    OrcCtx* o = (OrcCtx*)p;
+    const int32_t n = (int32_t)(o->last_world.size() / 4);
+    *n_out = n;
+    if (out_xyzi) { if (n > cap_pts) return -4; std::memcpy(out_xyzi, o->last_world.data(), o->last_world.size() * 4); }
     return 0;
 }
 int orc_forward_without_imu(const double*, double, double, double, double*) { return -1; }  // harness-side prior lives in synth.py for the checker
@@ -154,6 +163,7 @@ int orc_downsample_begin(void* p, const float* pts, int32_t n, int32_t stride, d
     return orc_downsample(p, pts, n, stride, leaf, g_ds_async.data(), n, &g_ds_async_n);
 }
 int orc_downsample_end(void*, int32_t* n_out, const float** xyz) { *n_out = g_ds_async_n; if (xyz) *xyz = g_ds_async.data(); return 0; }
+int orc_registration_fallbacks(void*, int64_t* n) { if (n) *n = 0; return 0; }
 int orc_inputs_consumed(void*) { return 0; }   // (the checker is synchronous: a call has consumed its inputs when it returns)
 int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);
 int orc_reconstruct_mesh_from_pointcloud(void* p, const float* pts_xyzi, int32_t n, double leaf) {   // ImMesh_mesh_reconstruction.cpp:328-345
@@ -318,7 +328,7 @@ int orc_process_scan(void* p, const float* pts_down, int32_t n_ds, const float* 
     o->reg.map_grow(pts_down, n_ds, s);
     auto t2 = std::chrono::steady_clock::now();
     if (do_mesh & 3) {   // bit 4 (IMMESH_SCAN_NOWAIT) has no meaning for the synchronous checker
-        std::vector<float> world;
+        std::vector<float>& world = o->last_world;
         transform_full(o->cfg, s, pts_raw_xyzi, n_raw, world);
         o->mesher.mesh_scan(world.data(), n_raw, s.t, o->mout);
     }

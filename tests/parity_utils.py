@@ -57,3 +57,79 @@ def compare_plane_tables_fast(a, b, tol=1e-5):
     scale = np.abs(pa).max(axis=(1, 2))
     assert np.all(np.abs(pb - pa).max(axis=(1, 2)) <= tol * scale + 1e-18)
     return int(pl.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# Strict comparison of a COMPOSED run (registration -> map growth -> meshing in one call per scan) against the oracle.
+#
+# north_star: "vertex indices bit-exact on identical input scans, pose within 1e-5".  The two pipelines estimate poses that agree to ~1e-12 (different
+# summation order of H^T R^-1 H over the points, a regrouped but algebraically identical 18-state update).  transformLidar
+# (src/voxel_mapping_common.cpp:709-726) computes the world frame in f64 and STORES f32, so a pose difference of 1e-12 occasionally rounds one
+# coordinate of a 100 000-pt scan to the neighbouring float.  From then on the two mesh maps legitimately differ by what that candidate changed.
+# A bound like "at most 5 vertices apart" would let a real mesher bug in a composed run through, so the check is exact, in three parts:
+#   (1) every scan: the device's world-frame cloud and the oracle's differ by AT MOST ONE f32 ULP per coordinate (attribution: nothing but the
+#       rounding of a pose that agrees to the registration bar), and the count of differing mesher candidates is recorded;
+#   (2) every scan, also after a divergence: a SHADOW oracle mesher that is fed the device's own world-frame cloud (immesh_mesh_world_scan) must
+#       reproduce every list of the device pipeline bit for bit -- the oracle "re-based" on the device's inputs, so scan 11 of a composed run is
+#       compared as exactly as scan 1;
+#   (3) as long as no candidate coordinate has differed yet, the device's lists must equal the FULL oracle pipeline's lists bit for bit; the first
+#       scan whose lists differ must be one whose candidate clouds differ (otherwise the divergence is a bug, not a rounding flip).
+def f32_ulp_distance(a, b):
+    """element-wise distance in units in the last place between two float32 arrays"""
+    ia = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+LIST_KEYS = ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "flip_upd", "smooth_ids")
+
+
+def lists_equal(mo, mh):
+    return mh["vtx_base"] == mo["vtx_base"] and all(np.array_equal(mh[k], mo[k]) for k in LIST_KEYS)
+
+
+class ComposedRunChecker:
+    def __init__(self, shadow_oracle, append_budget, compare_scan):
+        self.shadow, self.budget, self.compare_scan = shadow_oracle, int(append_budget), compare_scan
+        self.in_sync = True          # no mesher candidate has differed between the two pipelines so far
+        self.n_exact = 0             # scans whose lists equal the FULL oracle pipeline's
+        self.n_shadow_exact = 0      # scans whose lists equal the shadow oracle's (must be all of them)
+        self.first_divergence = None
+        self.flips = []              # per scan: (coordinates that differ by one ulp, candidates among them)
+
+    def seed(self, world_xyzi, sensor_pos, frame_idx=0):
+        """a scan both pipelines were handed as the SAME world-frame cloud (map seeding): the shadow follows"""
+        self.shadow.mesh_scan(world_xyzi, sensor_pos, frame_idx=frame_idx)
+
+    def check_scan(self, k, o, h, pose_h, mo, mh):
+        wo, wh = o.mesh_world_scan(), h.mesh_world_scan()
+        assert wo.shape == wh.shape and len(wh) > 0, k
+        assert np.array_equal(wo[:, 3], wh[:, 3]), f"scan {k}: intensity channel differs"
+        ulp = f32_ulp_distance(wh[:, :3], wo[:, :3])
+        assert ulp.max() <= 1, f"scan {k}: a world-frame coordinate differs by {int(ulp.max())} ulp (poses agree to 1e-5 only if this is <= 1)"
+        step = max(1, int(round(len(wh) // self.budget)))     # ImMesh_mesh_reconstruction.cpp:111 (integer division first)
+        pt_differs = (ulp > 0).any(axis=1)
+        n_cand_flips = int(pt_differs[::step].sum())
+        self.flips.append((int((ulp > 0).sum()), n_cand_flips))
+        # (2) the oracle re-based on the device's own world-frame cloud: exact for every scan of the composed run
+        ms = self.shadow.mesh_scan(wh, np.asarray(pose_h[9:12], np.float64), frame_idx=k)
+        self.compare_scan(ms, mh, f"scan {k} (shadow oracle on the device's world-frame cloud)")
+        self.n_shadow_exact += 1
+        # (3) against the full oracle pipeline: exact until a candidate coordinate rounds the other way
+        same = lists_equal(mo, mh)
+        if self.in_sync and n_cand_flips == 0:
+            assert same, f"scan {k}: lists differ although every candidate of every scan so far was bit-identical"
+        if self.in_sync and not same:
+            assert n_cand_flips > 0
+            self.first_divergence = k
+        if n_cand_flips > 0:
+            self.in_sync = False
+        if same and self.first_divergence is None:
+            self.n_exact += 1
+        return same
+
+    def summary(self):
+        return {"scans_equal_to_full_oracle": self.n_exact, "scans_equal_to_shadow_oracle": self.n_shadow_exact, "first_divergence": self.first_divergence,
+                "ulp_flips_per_scan(coords,candidates)": self.flips}

@@ -4,15 +4,16 @@
   (ii)  configs[3]: full-width HDL-64 scans (2032 azimuth steps x 64 rings = 130 048 rays, velodyne.yaml, max_layer 4, 3 m roots);
   (iii) configs[4]'s scan size: one 500 000-pt scan.
 Bars (north_star): match-index sets identical, plane tables / pose within 1e-5, vertex ids + positions and every triangle list bit-exact.
-Pose-dependent f32 roundings: the full pipeline's world-frame scan is f32(f64 transform) with poses that agree to ~1e-12, so single
-vertices may round differently; the mesher is therefore ALSO compared on bit-identical world-frame inputs (the oracle's poses), where
-every list must be equal for every scan, and the full-pipeline run reports how many scans stayed exactly equal."""
+The COMPOSED run (registration -> map growth -> meshing in one call) is compared exactly for every scan (parity_utils.ComposedRunChecker):
+the device's world-frame cloud may differ from the oracle's by at most one f32 ulp per coordinate (poses agree to ~1e-12; transformLidar stores
+f32), a shadow oracle mesher fed the device's own cloud must reproduce every list of every scan bit for bit, and until a mesher candidate has
+rounded the other way the lists must equal the full oracle pipeline's.  The mesher is ALSO compared on the oracle's world-frame clouds."""
 import numpy as np
 import pytest
 
 from immesh_amd import capi, synth
 from conftest import make_oracle, make_hip
-from parity_utils import compare_plane_tables_fast
+from parity_utils import compare_plane_tables_fast, ComposedRunChecker
 from test_gpu_mesher import _compare_scan
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
@@ -56,7 +57,8 @@ def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property
     so = capi.make_state(R=R0, t=t0)
     so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
     sh = so.copy()
-    n_exact, still_exact = 0, True
+    o3 = make_oracle(oracle_lib, capi.avia_config(cap_root_voxels=1 << 12, **{k: v for k, v in caps.items() if k != "cap_root_voxels"}))   # shadow mesher
+    chk = ComposedRunChecker(o3, cfg.mesh_append_budget, _compare_scan)
     for k in range(0, 11):
         Rk, tk = synth.trajectory_pose(k)
         raw = synth.livox_scan(k, Rk, tk, n_pts=100000, extT=extT)
@@ -75,19 +77,14 @@ def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
         np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)      # posterior covariance
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
-        still_exact = still_exact and _exact(mo, mh)
-        n_exact += int(still_exact)
-        if not still_exact:   # a world point rounded differently somewhere: the maps have diverged by single vertices, nothing more
-            assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50, k
-        # the mesher on bit-identical inputs (the oracle's pose): every list of every scan
-        w = _world(raw, so, cfg)
+        chk.check_scan(k, o, h, sh, mo, mh)   # the composed run, exactly (<= 1 ulp clouds, shadow oracle on the device's cloud, full oracle until a candidate flips)
+        # the mesher on the ORACLE's world-frame cloud: every list of every scan
+        w = o.mesh_world_scan()
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"scan {k} (identical world-frame input)")
-    record_property("full_pipeline_scans_bit_exact", f"{n_exact} of 11")
-    print(f"[parity] full pipeline: {n_exact} of 11 scans bit-exact (vertices + all triangle lists); mesher on identical inputs: 11 of 11")
-    # Poses agree to ~1e-12, and a pose difference of that size rounds a world-frame f32 coordinate of the 100 000-pt scan differently now and then: once
-    # a single vertex differs the two mesh maps stay apart by that vertex, so the count of exactly equal scans is reported (7 of 11 in round 3's run), not
-    # required to be all of them; what IS required of every scan: the bounds above, and exact equality on identical world-frame input
-    assert n_exact >= 3
+    sm = chk.summary()
+    record_property("composed_run", str(sm))
+    print(f"[parity] composed run, 11 scans: {sm}")
+    assert sm["scans_equal_to_shadow_oracle"] == 11
     co, ch = o.counters(), h.counters()
     for key in ("n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_root_voxels"):   # (n_iter per scan is compared above; the oracle also counts the stand-alone matcher pass)
         assert ch[key] == co[key], key
@@ -166,7 +163,7 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib, record_property):
     assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
     so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
     sh = so.copy()
-    n_exact, still_exact = 0, True
+    chk = ComposedRunChecker(make_oracle(oracle_lib, capi.velodyne_config(**caps)), cfg.mesh_append_budget, _compare_scan)
     for k in range(1, 5):
         Rk, tk = synth.trajectory_pose(k)
         raw = synth.hdl64_scan(k, Rk, tk, n_az=2032)
@@ -183,15 +180,13 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib, record_property):
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
         np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
-        still_exact = still_exact and _exact(mo, mh)
-        n_exact += int(still_exact)
-        if not still_exact:
-            assert abs(len(mh["new_vtx"]) - len(mo["new_vtx"])) <= 5 and abs(len(mh["tri_add"]) - len(mo["tri_add"])) <= 50, k
-        # ... and the mesher alone on bit-identical world-frame input (the oracle's pose): every list of every scan
-        w = _world(raw, so, cfg)
+        chk.check_scan(k, o, h, sh, mo, mh)
+        # ... and the mesher alone on the oracle's world-frame cloud: every list of every scan
+        w = o.mesh_world_scan()
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"hdl64 scan {k}")
-    record_property("hdl64_full_pipeline_scans_bit_exact", f"{n_exact} of 4")
-    assert n_exact >= 1
+    record_property("hdl64_composed_run", str(chk.summary()))
+    print(f"[parity] hdl64 composed run, 4 scans: {chk.summary()}")
+    assert chk.summary()["scans_equal_to_shadow_oracle"] == 4
     assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 500
     assert o2.counters()["n_vertices"] > 5000
 

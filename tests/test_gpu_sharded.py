@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from immesh_amd import capi, synth
+from parity_utils import f32_ulp_distance
 from conftest import make_hip
 from parity_utils import compare_plane_tables
 
@@ -186,7 +187,7 @@ def test_rccl_inside_the_library_world_size_one(hip_lib):
     per-pass chain.  What it exercises is the RCCL symbols, the communicator life cycle and the in-stream pass / reduce / update chain."""
     scans = _scans(4)
     cfg1 = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 16, cap_triangles=1 << 18, shard_rank=0, shard_world=1)
-    h, ref = make_hip(hip_lib, cfg1), make_hip(hip_lib, _cfg())
+    h, ref, shadow = make_hip(hip_lib, cfg1), make_hip(hip_lib, _cfg()), make_hip(hip_lib, _cfg())
     h.rccl_init(h.rccl_unique_id())
     R0, t0, raw0, _ = scans[0]
     st = capi.make_state(R=R0, t=t0)
@@ -204,10 +205,14 @@ def test_rccl_inside_the_library_world_size_one(hip_lib):
         np.testing.assert_allclose(st[24:], sr[24:], rtol=0, atol=1e-12)
         mh, mr = h.mesh_fetch(), ref.mesh_fetch()
         assert len(mh["tri_add"]) > 0
-        if np.array_equal(mh["new_vtx"], mr["new_vtx"]):   # (poses that agree to 1e-12 may round a world-frame vertex differently; when they do not, the lists are identical)
-            for key in ("tri_add", "tri_rem"):
-                np.testing.assert_array_equal(mh[key], mr[key])
-    h.close(); ref.close()
+        # the two poses agree to ~1e-12, so a world-frame f32 coordinate may round the other way: at most one ulp apart, and the RCCL context's mesh
+        # lists are compared EXACTLY on its own world-frame cloud (a second unsharded mesher is fed that cloud -- never a conditional assert)
+        wh, wr = h.mesh_world_scan(), ref.mesh_world_scan()
+        assert f32_ulp_distance(wh[:, :3], wr[:, :3]).max() <= 1
+        ms = shadow.mesh_scan(wh, st[9:12], frame_idx=k)
+        for key in ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "flip_upd", "smooth_ids"):
+            np.testing.assert_array_equal(mh[key], ms[key], err_msg=f"scan {k} {key}")
+    h.close(); ref.close(); shadow.close()
 
 
 def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
