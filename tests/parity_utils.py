@@ -67,8 +67,9 @@ def compare_plane_tables_fast(a, b, tol=1e-5):
 # (src/voxel_mapping_common.cpp:709-726) computes the world frame in f64 and STORES f32, so a pose difference of 1e-12 occasionally rounds one
 # coordinate of a 100 000-pt scan to the neighbouring float.  From then on the two mesh maps legitimately differ by what that candidate changed.
 # A bound like "at most 5 vertices apart" would let a real mesher bug in a composed run through, so the check is exact, in three parts:
-#   (1) every scan: the device's world-frame cloud and the oracle's differ by AT MOST ONE f32 ULP per coordinate (attribution: nothing but the
-#       rounding of a pose that agrees to the registration bar), and the count of differing mesher candidates is recorded;
+#   (1) every scan: the device's world-frame cloud and the oracle's differ by AT MOST ONE f32 SPACING + the pose difference d = |dt| + |dR| |p|
+#       (itself asserted below 1e-8; measured ~1e-12) per coordinate -- attribution: nothing but the rounding of a pose that agrees far inside the
+#       registration bar -- and the count of differing mesher candidates is recorded;
 #   (2) every scan, also after a divergence: a SHADOW oracle mesher that is fed the device's own world-frame cloud (immesh_mesh_world_scan) must
 #       reproduce every list of the device pipeline bit for bit -- the oracle "re-based" on the device's inputs, so scan 11 of a composed run is
 #       compared as exactly as scan 1;
@@ -81,6 +82,13 @@ def f32_ulp_distance(a, b):
     ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
     ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
     return np.abs(ia - ib)
+
+
+def clouds_within_rounding(a, b, d=1e-9):
+    """two f32 clouds that are roundings of f64 clouds at most d apart: every coordinate within one float spacing + d"""
+    a, b = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+    spacing = np.spacing(np.maximum(np.abs(a), np.abs(b))).astype(np.float64)
+    return bool((np.abs(a.astype(np.float64) - b.astype(np.float64)) <= spacing + d).all())
 
 
 LIST_KEYS = ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "flip_upd", "smooth_ids")
@@ -103,12 +111,25 @@ class ComposedRunChecker:
         """a scan both pipelines were handed as the SAME world-frame cloud (map seeding): the shadow follows"""
         self.shadow.mesh_scan(world_xyzi, sensor_pos, frame_idx=frame_idx)
 
-    def check_scan(self, k, o, h, pose_h, mo, mh):
+    def check_scan(self, k, o, h, pose_h, mo, mh, pose_o=None, lever=None):
         wo, wh = o.mesh_world_scan(), h.mesh_world_scan()
         assert wo.shape == wh.shape and len(wh) > 0, k
         assert np.array_equal(wo[:, 3], wh[:, 3]), f"scan {k}: intensity channel differs"
         ulp = f32_ulp_distance(wh[:, :3], wo[:, :3])
-        assert ulp.max() <= 1, f"scan {k}: a world-frame coordinate differs by {int(ulp.max())} ulp (poses agree to 1e-5 only if this is <= 1)"
+        # (1) attribution.  Both clouds are f32(R p + t) of the SAME body points with two poses; two reals that are d apart round to floats at most
+        # d + one spacing apart, and d <= |dt| + |dR| |p|.  (A plain "<= 1 ulp" is too strict only next to zero, where a float spacing is below d.)
+        d = 0.0
+        if pose_o is not None:
+            dR = np.abs(np.asarray(pose_h[:9]) - np.asarray(pose_o[:9])).max()
+            dt = np.abs(np.asarray(pose_h[9:12]) - np.asarray(pose_o[9:12])).max()
+            d = dt + 3.0 * dR * (lever if lever is not None else 500.0)
+            assert d < 1e-8, f"scan {k}: poses differ by more than rounding ({d})"
+        a64, b64 = wh[:, :3].astype(np.float64), wo[:, :3].astype(np.float64)
+        spacing = np.spacing(np.maximum(np.abs(wh[:, :3]), np.abs(wo[:, :3]))).astype(np.float64)
+        bad = np.abs(a64 - b64) > spacing + d
+        assert not bad.any(), f"scan {k}: {int(bad.sum())} world-frame coordinates differ by more than one float spacing + the pose difference {d}"
+        if pose_o is None:
+            assert ulp.max() <= 1, f"scan {k}: a world-frame coordinate differs by {int(ulp.max())} ulp"
         step = max(1, int(round(len(wh) // self.budget)))     # ImMesh_mesh_reconstruction.cpp:111 (integer division first)
         pt_differs = (ulp > 0).any(axis=1)
         n_cand_flips = int(pt_differs[::step].sum())

@@ -137,7 +137,7 @@ def test_process_scan_full_pipeline(oracle_lib, hip_lib, mesh_mode):
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
         # the composed run, exactly: world-frame clouds within one f32 ulp (poses agree to ~1e-12, transformLidar stores f32), every list equal to a
         # shadow oracle fed the device's own cloud, and equal to the full oracle pipeline until a mesher candidate rounds the other way
-        chk.check_scan(k, o, h, sh, mo, mh)
+        chk.check_scan(k, o, h, sh, mo, mh, pose_o=so, lever=float(np.abs(raw[:, :3]).max()) + 1.0)
         tm = h.last_timing()
         assert tm["total"] > 0 and tm["mesh"] > 0
     print(f"[full pipeline, mesh_mode {mesh_mode}] {chk.summary()}")

@@ -77,7 +77,7 @@ def test_avia_100k_stream_into_1m_voxel_map(oracle_lib, hip_lib, record_property
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
         np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)      # posterior covariance
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
-        chk.check_scan(k, o, h, sh, mo, mh)   # the composed run, exactly (<= 1 ulp clouds, shadow oracle on the device's cloud, full oracle until a candidate flips)
+        chk.check_scan(k, o, h, sh, mo, mh, pose_o=so, lever=float(np.abs(raw[:, :3]).max()) + 1.0)   # the composed run, exactly (<= 1 ulp clouds, shadow oracle on the device's cloud, full oracle until a candidate flips)
         # the mesher on the ORACLE's world-frame cloud: every list of every scan
         w = o.mesh_world_scan()
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"scan {k} (identical world-frame input)")
@@ -180,7 +180,7 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib, record_property):
         np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
         np.testing.assert_allclose(sh[24:], so[24:], rtol=0, atol=1e-9)
         mo, mh = o.mesh_fetch(), h.mesh_fetch()
-        chk.check_scan(k, o, h, sh, mo, mh)
+        chk.check_scan(k, o, h, sh, mo, mh, pose_o=so, lever=float(np.abs(raw[:, :3]).max()) + 1.0)
         # ... and the mesher alone on the oracle's world-frame cloud: every list of every scan
         w = o.mesh_world_scan()
         _compare_scan(o2.mesh_scan(w, so[9:12], frame_idx=k), h2.mesh_scan(w, so[9:12], frame_idx=k), f"hdl64 scan {k}")
