@@ -349,30 +349,71 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         return h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode, n_ds=n_ds, n_raw=len(raws[k]))
 
     k = 1
-    for _ in range(args.warmup):
-        st, _ = run(k, st); k += 1
-    h.counters(reset=True)
-    torch.cuda.synchronize()
     import gc
-    gc.collect(); gc.disable()      # a generation-2 collection of the harness's objects inside the loop is a 30 ms stall (seen: one call of 32 ms among 50 of 0.25 ms)
-    D.barrier()
-    t_begin = time.perf_counter()
-    t_marks = [t_begin]
-    for _ in range(args.steps):
-        st, info = run(k, st); k += 1
-        t_marks.append(time.perf_counter())
-    t_d0 = time.perf_counter()
-    if mesh_mode == 2:
-        h.mesh_wait()          # drain the mesher: every scan of the timed region is fully meshed before the clock stops
-    t_d1 = time.perf_counter()
-    h.last_timing()            # waits for the last scan's map update (the library's own stream)
-    t_d2 = time.perf_counter()
-    torch.cuda.synchronize()
-    gc.enable()
-    log(f"[bench] drain after the last scan: mesher {1e3 * (t_d1 - t_d0):.2f} ms, map update {1e3 * (t_d2 - t_d1):.2f} ms, device {1e3 * (time.perf_counter() - t_d2):.2f} ms; "
-        f"slowest calls of the timed loop (ms): {np.round(np.sort(np.diff(t_marks))[-3:] * 1e3, 2).tolist()} at scans {np.argsort(np.diff(t_marks))[-3:].tolist()}")
-    D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
+    shim_info = None
+    if args.dropin_shim:
+        # ---- the same stream THROUGH THE DROP-IN: two threads as the reference runs them, host clouds, lists fetched, mirrors applied
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "libimmesh_dropin_async.so"], stdout=subprocess.DEVNULL)
+        sl = ctypes.CDLL(os.path.join(ROOT, "drop_in", "libimmesh_dropin_async.so"))
+        sl.dropin_create.restype = ctypes.c_void_p; sl.dropin_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        sl.dropin_destroy.argtypes = [ctypes.c_void_p, ctypes.c_int]; sl.dropin_seed_mirror.argtypes = [ctypes.c_void_p]
+        sl.dropin_mirror_sizes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        sl.dropin_run_stream.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_double] * 3 + [ctypes.c_void_p] * 3
+        drv = sl.dropin_create(h.ctx, extT_np.ctypes.data_as(ctypes.c_void_p), 0)
+        if not drv or sl.dropin_seed_mirror(drv) != 0:
+            raise SystemExit("drop-in driver: create / mirror seeding failed")
+
+        def shim_stream(k0, n, state):
+            rr = [np.ascontiguousarray(raws[i], np.float32) for i in range(k0, k0 + n)]; dd = [np.ascontiguousarray(downs[i], np.float32) for i in range(k0, k0 + n)]
+            pr = (ctypes.c_void_p * n)(*[a.ctypes.data for a in rr]); pd = (ctypes.c_void_p * n)(*[a.ctypes.data for a in dd])
+            nr = np.array([len(a) for a in rr], np.int32); nd = np.array([len(a) for a in dd], np.int32)
+            so = np.array(state, np.float64); ms = np.zeros(2)
+            rc = sl.dropin_run_stream(drv, n, pr, nr.ctypes.data_as(ctypes.c_void_p), pd, nd.ctypes.data_as(ctypes.c_void_p), so.ctypes.data_as(ctypes.c_void_p), 0.1, 0.3, 0.5, None, None,
+                                      ms.ctypes.data_as(ctypes.c_void_p))
+            if rc != 0:
+                raise SystemExit(f"dropin_run_stream failed ({rc})")
+            return so, ms
+        st, _ = shim_stream(k, args.warmup, st); k += args.warmup
+        h.counters(reset=True)
+        torch.cuda.synchronize()
+        gc.collect(); gc.disable()
+        D.barrier()
+        st, ms = shim_stream(k, args.steps, st); k += args.steps
+        gc.enable()
+        nvm, nlm = ctypes.c_int64(0), ctypes.c_int64(0)
+        sl.dropin_mirror_sizes(drv, ctypes.byref(nvm), ctypes.byref(nlm))
+        sl.dropin_destroy(drv, 0)
+        cm = h.counters()
+        shim_info = {"ms_until_last_pose": round(float(ms[0]), 3), "ms_until_mirrors_current": round(float(ms[1]), 3), "mirror_vertices": int(nvm.value), "mirror_live_triangles": int(nlm.value),
+                     "mirror_equals_device": bool(nvm.value == cm["n_vertices"] and nlm.value == cm["n_triangles_live"])}
+        log(f"[bench] through the drop-in shim: {shim_info}")
+        D.barrier()
+        elapsed = D.max_over_ranks(float(ms[1]) * 1e-3, dev)
+        t_marks = []
+    else:
+        for _ in range(args.warmup):
+            st, _ = run(k, st); k += 1
+        h.counters(reset=True)
+        torch.cuda.synchronize()
+        gc.collect(); gc.disable()      # a generation-2 collection of the harness's objects inside the loop is a 30 ms stall (seen: one call of 32 ms among 50 of 0.25 ms)
+        D.barrier()
+        t_begin = time.perf_counter()
+        t_marks = [t_begin]
+        for _ in range(args.steps):
+            st, info = run(k, st); k += 1
+            t_marks.append(time.perf_counter())
+        t_d0 = time.perf_counter()
+        if mesh_mode == 2:
+            h.mesh_wait()          # drain the mesher: every scan of the timed region is fully meshed before the clock stops
+        t_d1 = time.perf_counter()
+        h.last_timing()            # waits for the last scan's map update (the library's own stream)
+        t_d2 = time.perf_counter()
+        torch.cuda.synchronize()
+        gc.enable()
+        log(f"[bench] drain after the last scan: mesher {1e3 * (t_d1 - t_d0):.2f} ms, map update {1e3 * (t_d2 - t_d1):.2f} ms, device {1e3 * (time.perf_counter() - t_d2):.2f} ms; "
+            f"slowest calls of the timed loop (ms): {np.round(np.sort(np.diff(t_marks))[-3:] * 1e3, 2).tolist()} at scans {np.argsort(np.diff(t_marks))[-3:].tolist()}")
+        D.barrier()
+        elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()
     nu_hist = None
     if (mesh_mode & 3) and args.nu_scans > 0 and not sharded:
@@ -391,7 +432,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
                        "share_delaunay64_kernel": round(float((a_ <= 64).mean()), 4) if len(a_) else None,
                        "share_general_kernel_65_256": round(float(((a_ > 64) & (a_ <= 256)).mean()), 4) if len(a_) else None,
                        "share_big_path_above_256": round(float((a_ > 256).mean()), 4) if len(a_) else None}
-    res = {"elapsed": elapsed, "cnt": cnt, "n_ds_mean": n_ds_mean, "nu_hist": nu_hist, "mesh_seed": mesh_seed, "n_map": int(n_map), "mesh_mode": mesh_mode, "n_raw": int(np.mean([len(r) for r in raws])), "comm": comm,
+    res = {"elapsed": elapsed, "shim": shim_info, "cnt": cnt, "n_ds_mean": n_ds_mean, "nu_hist": nu_hist, "mesh_seed": mesh_seed, "n_map": int(n_map), "mesh_mode": mesh_mode, "n_raw": int(np.mean([len(r) for r in raws])), "comm": comm,
            "pose_err": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(idx[k - 1])[1])),
            "scan_thread_ms": ({"p50": round(float(np.percentile(np.diff(t_marks) * 1e3, 50)), 4), "p95": round(float(np.percentile(np.diff(t_marks) * 1e3, 95)), 4)}
                               if len(t_marks) > 2 else None),   # host time per immesh_process_scan call (asynchronous mode: until the pose is final)
@@ -608,6 +649,8 @@ def main():
     ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
     ap.add_argument("--cpu-map-voxels", type=float, default=1.0e6, help="root voxels of the survey corridor the CPU-baseline leg pre-builds for the oracle (0 = scan 0 only)")
     ap.add_argument("--host-inputs", type=int, default=0, help="1 = every scan is handed over as HOST buffers (the library stages them over PCIe inside the timed region): the PCIe-inclusive rate")
+    ap.add_argument("--dropin-shim", type=int, default=0, help="1 = the timed region runs THROUGH THE DROP-IN (drop_in/immesh_shim_async.cpp behind drop_in/dropin_driver.cpp): pcl-shaped host clouds in, "
+                    "one immesh_process_scan(ASYNC) per scan on the scan thread, every frame's result lists fetched and applied to the Global_map / Triangle_manager mirrors by the service thread")
     ap.add_argument("--async-mesh", type=int, default=1, help="1 = meshing of scan k overlaps registration of scan k+1 (the reference's mesh service thread); 0 = strictly serial per scan")
     ap.add_argument("--gpu-scans", type=int, default=0, help="1 = the scan stream is ray-cast on the GPU by the harness (torch) and down-sampled by the library before the timed region: "
                     "hundreds of scans in seconds (the steady-state leg); the CPU-baseline leg needs the default host-generated stream")
@@ -697,11 +740,12 @@ def main():
                        "mesh_map": ("pre-seeded from a dense survey of the stream's corridor (SURVEY 8(d) C3)" if (args.dense_mesh and args.mesh and not kitti and not only_sharded) else "seeded by scan 0 only") if args.mesh else "none",
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device, inside the timed region (asynchronous: scan k+1's VoxelGrid on the pre-processing stream beside scan k's registration)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
-                       "inputs": "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region"},
+                       "inputs": ("pcl-shaped host clouds through the drop-in shim (packed + staged over PCIe inside the timed region; result lists fetched, host mirrors applied)" if args.dropin_shim else
+                                  "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region")},
             "stages_ms_serial": None,
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},
             "scan_thread_ms": res["scan_thread_ms"], "pose_err_m": round(res["pose_err"], 4),
-            "n_u": res["nu_hist"], "mesh_seed": res["mesh_seed"],
+            "n_u": res["nu_hist"], "mesh_seed": res["mesh_seed"], "drop_in_shim": res.get("shim"),
             "roofline": None, "cpu_baseline": None, "kernels_ms_per_scan": {},
         }
         if only_sharded:
@@ -767,6 +811,7 @@ def main():
         for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20)), "--cpu-seconds", "8"]),
                              ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
                              ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"]),
+                             ("full pipeline THROUGH THE DROP-IN SHIM (what an unchanged ImMesh_node.cpp sees: pcl host clouds in, lists fetched, Triangle_manager / Global_map mirrors applied)", ["--dropin-shim", "1"]),
                              ("full pipeline, mesh map seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)", ["--dense-mesh", "0"]),
                              ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
                              ("configs[4] dry run: rank 0 of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "0", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
@@ -784,6 +829,8 @@ def main():
                                                         "reference_threading": cb["reference_threading"], "sample": cb["sample"]}
                     if d.get("share"):
                         extra[label]["share"] = d["share"]
+                    if d.get("drop_in_shim"):
+                        extra[label]["drop_in_shim"] = d["drop_in_shim"]
                     for kk_ in ("n_u", "mesh_seed", "counters_per_scan"):
                         if d.get(kk_) and (kk_ != "counters_per_scan" or "dense" in label or "MESH" in label):
                             extra[label][kk_] = d[kk_]

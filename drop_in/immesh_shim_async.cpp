@@ -1,0 +1,190 @@
+// The SERVICE-LEVEL drop-in: the reference's two threads -- the scan thread's per-scan section of service_LiDAR_update (src/voxel_mapping.cpp:1959-1973:
+// lio_state_estimation, then map_incremental_grow) and the mesher's service_reconstruct_mesh (src/ImMesh_mesh_reconstruction.cpp:272-310) -- on the
+// ASYNCHRONOUS path of libimmesh_hip.so, the one bench.py's headline is quoted on:
+//   scan thread      lio_state_estimation(state_propagat)   = ONE immesh_process_scan(raw + down-sampled cloud, IMMESH_MESH_ASYNC): returns with the
+//                                                              posterior; map growth and the mesh job are queued on the device behind it
+//                    map_incremental_grow()                  = the hand-over the reference does at :413-417, minus the cloud (it is already in HBM):
+//                                                              a package {frame index, pose} for the service thread
+//   service thread   service_reconstruct_mesh()              = pop a package -> incremental_mesh_reconstruction(nullptr, q, t, frame)
+//                    incremental_mesh_reconstruction(..)     = immesh_mesh_collect_begin (wait for that scan's job) + immesh_mesh_sizes / _fetch + the host
+//                                                              mirrors (Global_map::m_rgb_pts_vec, Triangle_manager: all removes, then all adds, :228-244)
+//                                                              + immesh_mesh_collect_end
+// Same signatures, classes and globals as the reference (compiled here against drop_in/stubs; -DIMMESH_SHIM_REAL_HEADERS inside the reference tree);
+// immesh_shim.cpp is the synchronous three-call variant of the same bodies.  Nothing is dropped: a scan whose mesh job would overwrite results the
+// service thread has not collected yet blocks in immesh_process_scan (immesh_mesh_collect_enable).
+#ifdef IMMESH_SHIM_REAL_HEADERS
+#include "voxel_mapping.hpp"
+#else
+#include "immesh_ref_shapes.hpp"
+#endif
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <list>
+#include <mutex>
+#include <thread>
+#include "immesh_c_api.h"
+
+static immesh_ctx* g_immesh_ctx = nullptr;
+int g_frame_idx = 0;                                             // src/ImMesh_mesh_reconstruction.cpp:312
+std::mutex g_mutex_data_package_lock;                            // :78
+std::list<Rec_mesh_data_package> g_rec_mesh_data_package_list;   // :79
+std::atomic<bool> g_immesh_service_stop{false};                  // (the reference's service loops never return; the test driver needs them to)
+std::atomic<long> g_immesh_frames_meshed{0};
+void (*g_immesh_after_frame)(int frame_idx) = nullptr;           // test hook: called by the service thread after a frame's mirrors are up to date
+
+static void to_c(const StatesGroup& s, double* o) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o[r * 3 + c] = s.rot_end(r, c);
+    for (int i = 0; i < 3; i++) { o[9 + i] = s.pos_end(i); o[12 + i] = s.vel_end(i); o[15 + i] = s.bias_g(i); o[18 + i] = s.bias_a(i); o[21 + i] = s.gravity(i); }
+    for (int r = 0; r < 18; r++) for (int c = 0; c < 18; c++) o[24 + r * 18 + c] = s.cov(r, c);
+}
+static void from_c(const double* o, StatesGroup& s) {
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) s.rot_end(r, c) = o[r * 3 + c];
+    for (int i = 0; i < 3; i++) { s.pos_end(i) = o[9 + i]; s.vel_end(i) = o[12 + i]; s.bias_g(i) = o[15 + i]; s.bias_a(i) = o[18 + i]; s.gravity(i) = o[21 + i]; }
+    for (int r = 0; r < 18; r++) for (int c = 0; c < 18; c++) s.cov(r, c) = o[24 + r * 18 + c];
+}
+static void fail(immesh_ctx* c, const char* what, int rc) {
+    std::fprintf(stderr, "[immesh shim] %s failed (%d): %s\n", what, rc, c ? immesh_last_error(c) : immesh_create_error());
+    if (rc == IMMESH_E_HIP || rc == IMMESH_E_NODEV || !c) std::exit(1);
+}
+
+// ---- end of Voxel_mapping::init_ros_node() (src/voxel_mapping.cpp:1654), after read_ros_parameters() ----------------------------------
+void Voxel_mapping::immesh_shim_init() {
+    if (!m_hip) {   // (a test harness may hand over a context that already holds a map: immesh_shim_adopt)
+        immesh_config cfg;
+        immesh_default_config(&cfg);
+        cfg.voxel_size = m_max_voxel_size; cfg.max_layer = m_max_layer; cfg.max_points_size = m_max_points_size;
+        for (int i = 0; i < 5; i++) cfg.layer_init[i] = m_layer_init_size[i];
+        cfg.planer_threshold = m_min_eigen_value; cfg.dept_err = m_dept_err; cfg.beam_err = m_beam_err;
+        cfg.calib_laser = m_p_pre->calib_laser;
+        cfg.max_iter = NUM_MAX_ITERATIONS; cfg.sigma_num = 3.0;   // src/voxel_mapping.cpp:1365
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) cfg.extR[r * 3 + c] = m_extR(r, c); cfg.extT[r] = m_extT(r); }
+        cfg.mesh_min_spacing = m_meshing_points_minimum_scale * m_meshing_distance_scale;   // ImMesh_node.cpp:254-270
+        cfg.mesh_voxel = m_meshing_voxel_resolution * m_meshing_distance_scale;
+        cfg.mesh_region = m_meshing_region_size * m_meshing_distance_scale;
+        cfg.mesh_append_budget = m_meshing_number_of_pts_append_to_map;
+        m_hip = immesh_create(&cfg);
+        if (!m_hip) fail(nullptr, "immesh_create", IMMESH_E_NODEV);   // no CPU fallback
+    }
+    g_immesh_ctx = m_hip;
+    const int rc = immesh_mesh_collect_enable(m_hip, 1);
+    if (rc) fail(m_hip, "immesh_mesh_collect_enable", rc);
+}
+
+// ---- bool Voxel_mapping::voxel_map_init()   src/voxel_mapping.cpp:1243 -------------------------------------------------------------------
+bool Voxel_mapping::voxel_map_init() {
+    const size_t n = m_feats_undistort->size();
+    m_immesh_xyz.resize(n * 3);
+    for (size_t i = 0; i < n; i++) { const PointType& p = m_feats_undistort->points[i]; m_immesh_xyz[3 * i] = p.x; m_immesh_xyz[3 * i + 1] = p.y; m_immesh_xyz[3 * i + 2] = p.z; }
+    double st[IMMESH_STATE_DOUBLES];
+    to_c(state, st);
+    const int rc = immesh_map_build(m_hip, m_immesh_xyz.data(), (int64_t)n, st);
+    if (rc) { fail(m_hip, "immesh_map_build", rc); return false; }
+    return true;
+}
+
+// ---- void Voxel_mapping::lio_state_estimation(StatesGroup&)   src/voxel_mapping.cpp:1284 -------------------------------------------------
+// The whole per-scan section in one call.  m_laserCloudOri / m_corr_normvect are filled on demand (immesh_fetch_effect_features): their one
+// reader outside this function is the optional publish_effect_world (src/voxel_mapping_common.cpp:533-546).
+void Voxel_mapping::lio_state_estimation(StatesGroup& state_propagat) {
+    const int n_ds = (int)m_feats_down_body->size(), n_raw = (int)m_feats_undistort->size();
+    m_immesh_xyz.resize((size_t)n_ds * 3); m_immesh_xyzi.resize((size_t)n_raw * 4);   // (pcl points are padded to 32 / 48 bytes; the ABI takes packed floats)
+    for (int i = 0; i < n_ds; i++) { const PointType& p = m_feats_down_body->points[i]; m_immesh_xyz[3 * i] = p.x; m_immesh_xyz[3 * i + 1] = p.y; m_immesh_xyz[3 * i + 2] = p.z; }
+    for (int i = 0; i < n_raw; i++) { const PointType& p = m_feats_undistort->points[i]; m_immesh_xyzi[4 * i] = p.x; m_immesh_xyzi[4 * i + 1] = p.y; m_immesh_xyzi[4 * i + 2] = p.z; m_immesh_xyzi[4 * i + 3] = p.intensity; }
+    double prior[IMMESH_STATE_DOUBLES], st[IMMESH_STATE_DOUBLES];
+    to_c(state_propagat, prior); to_c(state, st);
+    int iters = 0;
+    // (host buffers: the library stages them into HBM on its stream and has consumed the staging copy before the next call refills it)
+    const int rc = immesh_process_scan(m_hip, m_immesh_xyz.data(), n_ds, m_immesh_xyzi.data(), n_raw, prior, st, g_frame_idx, IMMESH_MESH_ASYNC, &iters, &m_effct_feat_num);
+    if (rc) { fail(m_hip, "immesh_process_scan", rc); return; }
+    from_c(st, state);
+    m_immesh_scan_queued = true;
+}
+void Voxel_mapping::immesh_fetch_effect_features() {
+    const int cap = (int)m_feats_down_body->size();
+    std::vector<float> eff_pts((size_t)cap * 3), eff_nd((size_t)cap * 4);
+    int32_t n = 0;
+    const int rc = immesh_last_matches(m_hip, eff_pts.data(), eff_nd.data(), cap, &n);
+    if (rc) { fail(m_hip, "immesh_last_matches", rc); return; }
+    m_laserCloudOri->resize(n); m_corr_normvect->resize(n);
+    double res = 0;
+    for (int i = 0; i < n; i++) {
+        PointType& p = m_laserCloudOri->points[i]; PointType& q = m_corr_normvect->points[i];
+        p.x = eff_pts[3 * i]; p.y = eff_pts[3 * i + 1]; p.z = eff_pts[3 * i + 2];
+        q.x = eff_nd[4 * i]; q.y = eff_nd[4 * i + 1]; q.z = eff_nd[4 * i + 2]; q.intensity = eff_nd[4 * i + 3];
+        res += q.intensity < 0 ? -q.intensity : q.intensity;
+    }
+    m_res_mean_last = n ? res / n : 0.0;
+}
+
+// ---- void Voxel_mapping::map_incremental_grow()   src/ImMesh_mesh_reconstruction.cpp:377-424 --------------------------------------------
+// Map growth and the full-scan transform were queued by lio_state_estimation's call; what is left of the body is the hand-over to the service thread
+// (:413-417) -- without the cloud, which never leaves HBM.
+void Voxel_mapping::map_incremental_grow() {
+    if (!m_immesh_scan_queued) return;
+    m_immesh_scan_queued = false;
+    g_mutex_data_package_lock.lock();
+    g_rec_mesh_data_package_list.emplace_back(nullptr, Eigen::Quaterniond(), state.pos_end, g_frame_idx);
+    g_mutex_data_package_lock.unlock();
+    g_frame_idx++;
+}
+
+// ---- void incremental_mesh_reconstruction(cloud, q, t, frame_idx)   src/ImMesh_mesh_reconstruction.cpp:92-267 ------------------------------
+// frame_pts == nullptr: the frame's job was queued by immesh_process_scan; collect it (jobs are handed out in submission order, one per package)
+void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, Eigen::Quaterniond, Eigen::Vector3d pose_t, int frame_idx) {
+    immesh_ctx* c = g_immesh_ctx;
+    (void)frame_pts; (void)pose_t;
+    int64_t ordinal = 0;
+    int rc;
+    while ((rc = immesh_mesh_collect_begin(c, 100, &ordinal)) == IMMESH_NOT_READY) { if (g_immesh_service_stop.load()) return; }
+    if (rc) { fail(c, "mesh job", rc); (void)immesh_mesh_collect_end(c); return; }
+    immesh_mesh_sizes_t z;
+    immesh_mesh_sizes(c, &z);
+    std::vector<float> vtx((size_t)3 * z.n_new_vtx);
+    std::vector<int32_t> add((size_t)3 * z.n_add), rem((size_t)3 * z.n_rem), upd((size_t)3 * z.n_upd), sid(z.n_smooth);
+    std::vector<uint8_t> fadd(z.n_add), fupd(z.n_upd);
+    std::vector<double> sxyz((size_t)3 * z.n_smooth);
+    rc = immesh_mesh_fetch(c, vtx.data(), add.data(), fadd.data(), rem.data(), upd.data(), fupd.data(), sid.data(), sxyz.data());
+    (void)immesh_mesh_collect_end(c);     // the lists are on the host: the device buffers may be reused
+    if (rc) { fail(c, "immesh_mesh_fetch", rc); return; }
+    // ---- host mirrors: Global_map::m_rgb_pts_vec (index == vertex id, pointcloud_rgbd.cpp:518-527) and the Triangle_manager
+    for (int i = 0; i < z.n_new_vtx; i++) {
+        auto pt = std::make_shared<RGB_pts>();
+        pt->set_pos(vec_3(vtx[3 * i], vtx[3 * i + 1], vtx[3 * i + 2]));
+        pt->m_pt_index = (int)g_map_rgb_pts_mesh.m_rgb_pts_vec.size();
+        g_map_rgb_pts_mesh.m_rgb_pts_vec.push_back(pt);
+    }
+    for (int i = 0; i < z.n_smooth; i++) g_map_rgb_pts_mesh.m_rgb_pts_vec[sid[i]]->set_smooth_pos(vec_3(sxyz[3 * i], sxyz[3 * i + 1], sxyz[3 * i + 2]));
+    Triangle_set to_rem;   // all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244)
+    for (int i = 0; i < z.n_rem; i++) to_rem.insert(g_triangles_manager.find_triangle(rem[3 * i], rem[3 * i + 1], rem[3 * i + 2]));
+    g_triangles_manager.remove_triangle_list(to_rem, frame_idx);
+    for (int i = 0; i < z.n_add; i++) g_triangles_manager.insert_triangle(add[3 * i], add[3 * i + 1], add[3 * i + 2], 1, frame_idx)->m_index_flip = fadd[i];
+    for (int i = 0; i < z.n_upd; i++) { Triangle_ptr t = g_triangles_manager.find_triangle(upd[3 * i], upd[3 * i + 1], upd[3 * i + 2]); if (t) t->m_index_flip = fupd[i]; }
+    if (g_immesh_after_frame) g_immesh_after_frame(frame_idx);
+    g_immesh_frames_meshed.fetch_add(1);
+}
+
+// ---- void service_reconstruct_mesh()   src/ImMesh_mesh_reconstruction.cpp:272-310 ------------------------------------------------------------
+// The reference commits each package to a 12-thread pool whose tasks serialise on g_mutex_reconstruct_mesh; here the frame's work already runs on the
+// device, so the service thread itself collects the results, in order.
+void service_reconstruct_mesh() {
+    while (!g_immesh_service_stop.load()) {
+        g_mutex_data_package_lock.lock();
+        if (g_rec_mesh_data_package_list.empty()) {
+            g_mutex_data_package_lock.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            continue;
+        }
+        Rec_mesh_data_package pk = g_rec_mesh_data_package_list.front();
+        g_rec_mesh_data_package_list.pop_front();
+        g_mutex_data_package_lock.unlock();
+        incremental_mesh_reconstruction(pk.m_frame_pts, pk.m_pose_q, pk.m_pose_t, pk.m_frame_idx);
+    }
+}
+
+// ---- void save_to_ply_file(std::string, double smooth_factor, double knn)   src/meshing/mesh_rec_geometry.cpp:71-131 -----------------------
+void save_to_ply_file(std::string ply_file, double smooth_factor, double knn) {
+    const int rc = immesh_save_ply(g_immesh_ctx, ply_file.c_str(), smooth_factor, (int32_t)knn);
+    if (rc) fail(g_immesh_ctx, "immesh_save_ply", rc);
+}

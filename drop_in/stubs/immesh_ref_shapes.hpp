@@ -4,6 +4,9 @@
 // Eigen, PCL, common_lib.h, triangle.hpp, pointcloud_rgbd.hpp).  Nothing here is linked into libimmesh_hip.so.
 #pragma once
 #include <algorithm>
+#include <array>
+#include <unordered_map>
+#include <unordered_set>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -53,11 +56,12 @@ class Global_map { public: std::vector<std::shared_ptr<RGB_pts>> m_rgb_pts_vec; 
 class Triangle { public: int m_tri_pts_id[3] = {0, 0, 0}; int m_index_flip = 0; Triangle(int a, int b, int c) : m_tri_pts_id{a, b, c} { std::sort(m_tri_pts_id, m_tri_pts_id + 3); } };
 using Triangle_ptr = std::shared_ptr<Triangle>;
 using Triangle_set = std::set<Triangle_ptr>;
-class Triangle_manager {   // same three entry points and semantics as triangle.hpp:212 (remove_triangle_list), :311 (find_triangle), :330 (insert_triangle)
+struct Triplet_hash { size_t operator()(const std::array<int, 3>& k) const { unsigned long long x = ((unsigned long long)(unsigned)k[0] * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(unsigned)k[1] << 21) ^ ((unsigned long long)(unsigned)k[2] << 42); x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; return (size_t)(x ^ (x >> 32)); } };
+class Triangle_manager {   // same three entry points and semantics as triangle.hpp:212 (remove_triangle_list), :311 (find_triangle), :330 (insert_triangle); hashed like m_triangle_hash
   public:
-    std::map<std::vector<int>, Triangle_ptr> m_triangle_hash;   // entries persist after erase, like m_triangle_hash
-    Triangle_set m_live;
-    Triangle_ptr find_triangle(int a, int b, int c) { int k[3] = {a, b, c}; std::sort(k, k + 3); auto it = m_triangle_hash.find({k[0], k[1], k[2]}); return it == m_triangle_hash.end() ? nullptr : it->second; }
+    std::unordered_map<std::array<int, 3>, Triangle_ptr, Triplet_hash> m_triangle_hash;   // entries persist after erase, like m_triangle_hash
+    std::unordered_set<Triangle_ptr> m_live;
+    Triangle_ptr find_triangle(int a, int b, int c) { std::array<int, 3> k = {a, b, c}; std::sort(k.begin(), k.end()); auto it = m_triangle_hash.find(k); return it == m_triangle_hash.end() ? nullptr : it->second; }
     void remove_triangle_list(const Triangle_set& s, const int = 0) { for (auto& t : s) if (t) m_live.erase(t); }
     Triangle_ptr insert_triangle(int a, int b, int c, int = 0, const int& = 0) {
         Triangle_ptr t = find_triangle(a, b, c);
@@ -90,12 +94,24 @@ class Voxel_mapping {   // src/voxel_mapping.hpp:132-420 -- only what the replac
     double m_meshing_distance_scale = 1.0, m_meshing_points_minimum_scale = 0.1, m_meshing_voxel_resolution = 0.4, m_meshing_region_size = 10.0;   // :279-282
     int m_meshing_number_of_pts_append_to_map = 10000;        // :286
     std::shared_ptr<Preprocess_shape> m_p_pre = std::make_shared<Preprocess_shape>();
-    immesh_ctx* m_hip = nullptr;                              // the one member the drop-in adds
+    immesh_ctx* m_hip = nullptr;                              // what the drop-in adds: the context, ...
+    std::vector<float> m_immesh_xyz, m_immesh_xyzi;           // ... packed staging of the pcl clouds (asynchronous shim: reused from scan to scan) ...
+    bool m_immesh_scan_queued = false;                        // ... and "lio_state_estimation queued this scan's map growth + mesh job"
     void immesh_shim_init();                                  // end of init_ros_node() (src/voxel_mapping.cpp:1654)
+    void immesh_fetch_effect_features();                      // asynchronous shim: m_laserCloudOri / m_corr_normvect on demand (publish_effect_world)
     void map_incremental_grow();                              // :365  (src/ImMesh_mesh_reconstruction.cpp:377)
     bool voxel_map_init();                                    // :409  (src/voxel_mapping.cpp:1243)
     void lio_state_estimation(StatesGroup& state_propagat);   // :412  (src/voxel_mapping.cpp:1284)
 };
+struct Rec_mesh_data_package {   // src/ImMesh_mesh_reconstruction.cpp:63-76
+    pcl::PointCloud<pcl::PointXYZI>::Ptr m_frame_pts;
+    Eigen::Quaterniond m_pose_q;
+    Eigen::Vector3d m_pose_t;
+    int m_frame_idx;
+    Rec_mesh_data_package(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, Eigen::Quaterniond pose_q, Eigen::Vector3d pose_t, int frame_idx)
+        : m_frame_pts(frame_pts), m_pose_q(pose_q), m_pose_t(pose_t), m_frame_idx(frame_idx) {}
+};
+void service_reconstruct_mesh();                                                                                                                       // src/ImMesh_mesh_reconstruction.cpp:272
 void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, Eigen::Quaterniond pose_q, Eigen::Vector3d pose_t, int frame_idx);   // src/ImMesh_mesh_reconstruction.cpp:92
 void reconstruct_mesh_from_pointcloud(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, double minimum_pts_distance = 0.01);                               // :328, src/voxel_mapping.hpp:131
 void save_to_ply_file(std::string ply_file, double smooth_factor = 0.1, double knn = 20);                                                               // src/meshing/mesh_rec_geometry.hpp:40

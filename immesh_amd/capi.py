@@ -452,6 +452,34 @@ class HotPath:
         f = self._f("inputs_consumed"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx), "inputs_consumed")
 
+    def last_matches(self):
+        """(matched body points n x 3, normal + residual n x 4) of the last registration on the context"""
+        f = self._f("last_matches"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]; f.restype = C.c_int
+        n = C.c_int32(0)
+        self._check(f(self.ctx, None, None, 0, C.byref(n)), "last_matches")
+        p, q = np.zeros((n.value, 3), np.float32), np.zeros((n.value, 4), np.float32)
+        if n.value:
+            self._check(f(self.ctx, _ptr(p), _ptr(q), n.value, C.byref(n)), "last_matches")
+        return p, q
+
+    def mesh_collect_enable(self, on=True):
+        f = self._f("mesh_collect_enable"); f.argtypes = [C.c_void_p, C.c_int32]; f.restype = C.c_int
+        self._check(f(self.ctx, 1 if on else 0), "mesh_collect_enable")
+
+    def mesh_collect_begin(self, timeout_ms=1000):
+        """-> job ordinal, or None when no job finished within the timeout"""
+        f = self._f("mesh_collect_begin"); f.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]; f.restype = C.c_int
+        o = C.c_int64(0)
+        rc = f(self.ctx, timeout_ms, C.byref(o))
+        if rc == 1:
+            return None
+        self._check(rc, "mesh_collect_begin")
+        return o.value
+
+    def mesh_collect_end(self):
+        f = self._f("mesh_collect_end"); f.argtypes = [C.c_void_p]; f.restype = C.c_int
+        self._check(f(self.ctx), "mesh_collect_end")
+
     def registration_fallbacks(self):
         f = self._f("registration_fallbacks"); f.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]; f.restype = C.c_int
         n = C.c_int64(0)

@@ -347,6 +347,7 @@ static bool use_fused_ekf(const immesh_ctx* c) {
 
 // the iterated update on device-resident points; leaves per-point match outputs of the LAST iteration in the ctx
 static int register_device(immesh_ctx* c, const float* d_pts, int n_ds, const imh::State& prior, imh::State& st, int* n_iter, int* n_match, double* res_mean) {
+    c->last_reg_pts = d_pts;
     if (use_fused_ekf(c)) {
         int rc = register_enqueue_fused(c, d_pts, n_ds, prior, st);
         if (rc) return rc;
@@ -393,21 +394,39 @@ int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double*
     if (n_match_out) *n_match_out = n_match;
     if (res_mean_out) *res_mean_out = res;
     if (eff_pts_body || eff_norm_dis) {
-        std::vector<int8_t> mt;
-        if ((rc = fetch_matches(c, n_ds, mt))) return rc;
-        std::vector<float> hp((size_t)n_ds * 3), hd(n_ds);
-        std::vector<double> hn((size_t)n_ds * 3);
-        HIPCHK(c, hipMemcpy(hp.data(), d_pts, (size_t)n_ds * 12, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(hd.data(), c->d_dis, (size_t)n_ds * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(hn.data(), c->d_normal, (size_t)n_ds * 24, hipMemcpyDeviceToHost));
-        int k = 0;
-        for (int i = 0; i < n_ds; i++)
-            if (mt[i]) {
-                if (eff_pts_body) for (int a = 0; a < 3; a++) eff_pts_body[k * 3 + a] = hp[(size_t)i * 3 + a];
-                if (eff_norm_dis) { for (int a = 0; a < 3; a++) eff_norm_dis[k * 4 + a] = (float)hn[(size_t)i * 3 + a]; eff_norm_dis[k * 4 + 3] = hd[i]; }
-                k++;
-            }
+        int32_t k = 0;
+        if ((rc = immesh_last_matches(c, eff_pts_body, eff_norm_dis, n_ds, &k))) return rc;
     }
+    return 0;
+}
+
+int immesh_last_matches(immesh_ctx* c, float* eff_pts_body, float* eff_norm_dis, int32_t cap, int32_t* n_out) {
+    if (!c || !n_out) return IMMESH_E_INVAL;
+    (void)hipSetDevice(c->cfg.device);
+    const int n_ds = c->last_n_ds;
+    const float* d_pts = c->last_reg_pts;
+    *n_out = 0;
+    if (n_ds <= 0 || !d_pts) return 0;
+    int rc;
+    std::vector<int8_t> mt;
+    if ((rc = fetch_matches(c, n_ds, mt))) return rc;
+    int m = 0;
+    for (int i = 0; i < n_ds; i++) m += mt[i] != 0;
+    *n_out = m;
+    if (!eff_pts_body && !eff_norm_dis) return 0;
+    if (m > cap) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
+    std::vector<float> hp((size_t)n_ds * 3), hd(n_ds);
+    std::vector<double> hn((size_t)n_ds * 3);
+    HIPCHK(c, hipMemcpy(hp.data(), d_pts, (size_t)n_ds * 12, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hd.data(), c->d_dis, (size_t)n_ds * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hn.data(), c->d_normal, (size_t)n_ds * 24, hipMemcpyDeviceToHost));
+    int k = 0;
+    for (int i = 0; i < n_ds; i++)
+        if (mt[i]) {
+            if (eff_pts_body) for (int a = 0; a < 3; a++) eff_pts_body[k * 3 + a] = hp[(size_t)i * 3 + a];
+            if (eff_norm_dis) { for (int a = 0; a < 3; a++) eff_norm_dis[k * 4 + a] = (float)hn[(size_t)i * 3 + a]; eff_norm_dis[k * 4 + 3] = hd[i]; }
+            k++;
+        }
     return 0;
 }
 
@@ -560,6 +579,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
             ep.raw = world ? (const float*)d_raw : nullptr; ep.world = world;
             ++c->epi_seq;   // (stored to the flags by the launch queued behind the registration: launch_replay_lists below)
         }
+        c->last_reg_pts = (const float*)d_down;
         if ((rc = register_enqueue_fused(c, (const float*)d_down, n_ds, prior, st, epi ? &ep : nullptr))) return rc;
         if (epi) c->inputs_seq = c->epi_seq;
         if (timed) (void)hipEventRecord(ev[1], c->stream);

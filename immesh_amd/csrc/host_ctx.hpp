@@ -115,6 +115,7 @@ struct immesh_ctx {
     // cumulative counters (host side)
     immesh_counters_t cnt;
     int last_n_ds = 0;
+    const float* last_reg_pts = nullptr;   // device cloud of the last registration (immesh_last_matches)
 
     // ---- mesher
     MeshDev mesh;

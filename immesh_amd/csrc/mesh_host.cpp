@@ -3,6 +3,7 @@
 // sizes launches from a handful of device counters and moves the result lists on immesh_mesh_fetch.
 #include "host_ctx.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <functional>
 
@@ -159,6 +160,7 @@ int mesh_alloc(immesh_ctx* c) {
             HIPCHK(c, hipStreamCreateWithPriority(&h.stream, hipStreamNonBlocking, prio_least));
             HIPCHK(c, hipStreamCreateWithPriority(&h.stream_b, hipStreamNonBlocking, prio_least));
         }
+        HIPCHK(c, hipStreamCreateWithPriority(&h.stream_fetch, hipStreamNonBlocking, prio_least));
     }
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
@@ -181,6 +183,7 @@ void mesh_free(immesh_ctx* c) {
     }
     if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); h.stream = nullptr; }
     if (h.stream_b) { (void)hipStreamSynchronize(h.stream_b); (void)hipStreamDestroy(h.stream_b); h.stream_b = nullptr; }
+    if (h.stream_fetch) { (void)hipStreamSynchronize(h.stream_fetch); (void)hipStreamDestroy(h.stream_fetch); h.stream_fetch = nullptr; }
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
@@ -549,7 +552,7 @@ float* mesh_next_world_buffer(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     std::unique_lock<std::mutex> lk(h.mu);
     const long next = h.submitted + 1;
-    h.cv_done.wait(lk, [&] { return h.completed >= next - MESH_WORLD_BUFS; });
+    h.cv_done.wait(lk, [&] { return h.completed >= next - MESH_WORLD_BUFS && (!h.collect_on || h.collected >= next - 2); });   // (result lists: two sets, job parity)
     return h.d_world[next % MESH_WORLD_BUFS];
 }
 // wait for job `id` (0 = the newest submitted) and make it the one immesh_mesh_sizes / fetch / last_timing report
@@ -619,6 +622,41 @@ int immesh_mesh_wait(immesh_ctx* c) {
     return mesh_wait(c, 0);
 }
 
+// ---- the service-thread side of asynchronous meshing (service_reconstruct_mesh, ImMesh_mesh_reconstruction.cpp:272-310) ------------------------------
+int immesh_mesh_collect_enable(immesh_ctx* c, int32_t on) {
+    if (!c) return IMMESH_E_INVAL;
+    MeshHost& h = c->mesh_host;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        h.collect_on = on != 0;
+        h.collected = h.completed;   // what has finished before this call is not handed out
+    }
+    h.cv_done.notify_all();
+    return 0;
+}
+int immesh_mesh_collect_begin(immesh_ctx* c, int32_t timeout_ms, int64_t* job_ordinal) {
+    if (!c) return IMMESH_E_INVAL;
+    MeshHost& h = c->mesh_host;
+    std::unique_lock<std::mutex> lk(h.mu);
+    if (!h.collect_on) { return IMMESH_E_INVAL; }
+    const long id = h.collected + 1;
+    if (!h.cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return h.completed >= id; })) return IMMESH_NOT_READY;
+    h.current = id;
+    if (job_ordinal) *job_ordinal = id;
+    return h.res[id & 1].rc;
+}
+int immesh_mesh_collect_end(immesh_ctx* c) {
+    if (!c) return IMMESH_E_INVAL;
+    MeshHost& h = c->mesh_host;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);
+        if (!h.collect_on || h.current != h.collected + 1) return IMMESH_E_INVAL;
+        h.collected = h.current;
+    }
+    h.cv_done.notify_all();
+    return 0;
+}
+
 int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
     if (!c || !sizes) return IMMESH_E_INVAL;
     MeshHost& h = c->mesh_host;
@@ -684,7 +722,7 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
         o = h.outs[h.current & 1];
     }
     const MeshDev& m = c->mesh;
-    hipStream_t s = c->stream;
+    hipStream_t s = h.stream_fetch;   // (the job has finished: nothing to order against; the scan thread may be enqueueing on its own streams meanwhile)
     if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
     if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, o.tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
     if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, o.flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));

@@ -144,6 +144,11 @@ struct MeshHost {
     std::condition_variable cv_job, cv_done;
     std::deque<MeshJob> q;
     long submitted = 0, completed = 0, current = 0;   // job ids start at 1; `current` = job whose results sizes/fetch return
+    // service-thread collection (immesh_mesh_collect_*): jobs are handed to the collector strictly in order; with it enabled a submission that would
+    // overwrite the result buffers of a job not yet collected (id - 2) waits -- nothing is dropped
+    bool collect_on = false;
+    long collected = 0;
+    hipStream_t stream_fetch = nullptr;      // immesh_mesh_fetch's copies: a stream of their own, so that a service thread can fetch while the scan thread enqueues
     bool stop = false;
     // per-scan parameters + graph replay
     MeshDyn* d_dyn[2] = {nullptr, nullptr};  // device copies read by the kernels (job parity)

@@ -29,6 +29,7 @@ extern "C" {
 #define IMMESH_E_NOMEM (-3)
 #define IMMESH_E_CAPACITY (-4)
 #define IMMESH_E_HIP (-5)
+#define IMMESH_NOT_READY 1   /* immesh_mesh_collect_begin: no finished job within the timeout (not an error) */
 
 typedef struct immesh_ctx immesh_ctx;
 
@@ -88,6 +89,11 @@ int immesh_map_build(immesh_ctx* ctx, const float* pts_body_xyz, int64_t n, cons
 int immesh_register(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const double* state_prior, double* state_inout,
                     int32_t* n_iter_out, int32_t* n_match_out, double* res_mean_out, float* eff_pts_body, float* eff_norm_dis);
 
+/* m_laserCloudOri / m_corr_normvect of the LAST registration on the context (immesh_register, immesh_process_scan), for the one consumer outside
+ * lio_state_estimation -- publish_effect_world, src/voxel_mapping_common.cpp:533-546: matched body points (n x 3) and float normal + residual (n x 4),
+ * match order = ascending scan index; capacity n_ds each, either may be NULL.  Valid until the next registration call; copies device -> host. */
+int immesh_last_matches(immesh_ctx* ctx, float* eff_pts_body, float* eff_norm_dis, int32_t cap, int32_t* n_out);
+
 /* One matcher + H-build pass at a fixed state: BuildResidualListOMP (src/voxel_mapping.cpp:153) + the residual /
  * Jacobian loops (:1372-1392, :1487-1575) reduced to HTH = H^T R^-1 H (6x6) and HTz = H^T R^-1 z (6).
  * Optional per-match outputs (capacity n_ds each, may be NULL): match_idx (scan index), normals (3 doubles),
@@ -115,6 +121,21 @@ int immesh_reconstruct_mesh_from_pointcloud(immesh_ctx* ctx, const float* pts_xy
  * results of the two newest jobs are kept.  immesh_mesh_wait() blocks until the newest submitted job has finished and makes its
  * results the ones immesh_mesh_sizes / immesh_mesh_fetch / immesh_last_timing report; it returns that job's status. */
 int immesh_mesh_wait(immesh_ctx* ctx);
+
+/* The service-thread side of asynchronous meshing -- the counterpart of service_reconstruct_mesh popping g_rec_mesh_data_package_list
+ * (src/ImMesh_mesh_reconstruction.cpp:272-310).  ONE other thread may call immesh_mesh_collect_begin / immesh_mesh_sizes / immesh_mesh_fetch /
+ * immesh_mesh_world_scan / immesh_mesh_collect_end on a context while the scan thread keeps calling immesh_process_scan(.., IMMESH_MESH_ASYNC):
+ *   immesh_mesh_collect_enable(ctx, 1)   once, before the first asynchronous scan.  From then on jobs are handed out strictly in submission order and a
+ *                                        scan whose mesh job would reuse the result buffers of a job not yet collected (two sets, alternating) blocks in
+ *                                        immesh_process_scan until the collector has caught up -- no frame is dropped (the reference drops frames only
+ *                                        above 1e5 queued packages, :289-294).  The scan thread must then not use immesh_mesh_wait / the synchronous modes.
+ *   immesh_mesh_collect_begin(ctx, timeout_ms, &ordinal)   waits (at most timeout_ms) for the oldest job not yet collected, makes its results the ones
+ *                                        immesh_mesh_sizes / immesh_mesh_fetch return; IMMESH_NOT_READY on timeout, else the job's status.  ordinal =
+ *                                        1 for the first job submitted on the context, 2 for the second, ...
+ *   immesh_mesh_collect_end(ctx)         releases the job's result buffers. */
+int immesh_mesh_collect_enable(immesh_ctx* ctx, int32_t on);
+int immesh_mesh_collect_begin(immesh_ctx* ctx, int32_t timeout_ms, int64_t* job_ordinal);
+int immesh_mesh_collect_end(immesh_ctx* ctx);
 
 typedef struct immesh_mesh_sizes_t {
     int32_t vtx_base;   /* id of the first vertex appended by this scan */

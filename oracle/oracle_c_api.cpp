@@ -24,6 +24,7 @@ struct OrcCtx {
     Mesher mesher;
     MeshScanOut mout;
     orc::IkdMap ikd;
+    std::vector<float> last_eff_pts, last_eff_nd;   // m_laserCloudOri / m_corr_normvect of the last registration (orc_last_matches)
     std::vector<float> last_world;   // the world-frame scan the newest mesh job was handed (orc_mesh_world_scan)
     OrcCtx() : reg(&vm) {}
 };
@@ -74,11 +75,25 @@ int orc_register(void* p, const float* pts, int32_t n_ds, const double* state_pr
     const int M = dbg.n_match.empty() ? 0 : dbg.n_match.back();
     if (n_match_out) *n_match_out = M;
     if (res_mean_out) *res_mean_out = dbg.res_mean_last;
+    o->last_eff_pts.resize((size_t)M * 3); o->last_eff_nd.resize((size_t)M * 4);
     for (int i = 0; i < M; i++) {
         const int j = dbg.match_idx_last[i];
-        if (eff_pts_body) for (int k = 0; k < 3; k++) eff_pts_body[i * 3 + k] = pts[j * 3 + k];
-        if (eff_norm_dis) { for (int k = 0; k < 3; k++) eff_norm_dis[i * 4 + k] = (float)dbg.normals_last[i * 3 + k]; eff_norm_dis[i * 4 + 3] = dbg.dis_last[i]; }
+        for (int k = 0; k < 3; k++) o->last_eff_pts[i * 3 + k] = pts[j * 3 + k];
+        for (int k = 0; k < 3; k++) o->last_eff_nd[i * 4 + k] = (float)dbg.normals_last[i * 3 + k];
+        o->last_eff_nd[i * 4 + 3] = dbg.dis_last[i];
     }
+    if (eff_pts_body && M) std::memcpy(eff_pts_body, o->last_eff_pts.data(), (size_t)M * 12);
+    if (eff_norm_dis && M) std::memcpy(eff_norm_dis, o->last_eff_nd.data(), (size_t)M * 16);
+    return 0;
+}
+int orc_last_matches(void* p, float* eff_pts_body, float* eff_norm_dis, int32_t cap, int32_t* n_out) {
+    OrcCtx* o = (OrcCtx*)p;
+    const int32_t M = (int32_t)(o->last_eff_pts.size() / 3);
+    *n_out = M;
+    if (!eff_pts_body && !eff_norm_dis) return 0;
+    if (M > cap) return -4;
+    if (eff_pts_body && M) std::memcpy(eff_pts_body, o->last_eff_pts.data(), (size_t)M * 12);
+    if (eff_norm_dis && M) std::memcpy(eff_norm_dis, o->last_eff_nd.data(), (size_t)M * 16);
     return 0;
 }
 
@@ -163,6 +178,9 @@ int orc_downsample_begin(void* p, const float* pts, int32_t n, int32_t stride, d
     return orc_downsample(p, pts, n, stride, leaf, g_ds_async.data(), n, &g_ds_async_n);
 }
 int orc_downsample_end(void*, int32_t* n_out, const float** xyz) { *n_out = g_ds_async_n; if (xyz) *xyz = g_ds_async.data(); return 0; }
+int orc_mesh_collect_enable(void*, int32_t) { return 0; }   // (the checker is synchronous: the job of a call has finished when the call returns)
+int orc_mesh_collect_begin(void*, int32_t, int64_t* ord) { if (ord) *ord = 0; return 0; }
+int orc_mesh_collect_end(void*) { return 0; }
 int orc_registration_fallbacks(void*, int64_t* n) { if (n) *n = 0; return 0; }
 int orc_inputs_consumed(void*) { return 0; }   // (the checker is synchronous: a call has consumed its inputs when it returns)
 int orc_mesh_scan(void* p, const float* pts_world_xyzi, int32_t n_raw, const double* sensor_pos, int32_t frame_idx);

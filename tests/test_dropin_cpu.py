@@ -5,7 +5,7 @@ import os
 import subprocess
 
 from conftest import make_oracle, ROOT
-from test_gpu_dropin import run_drop_in
+from test_gpu_dropin import run_drop_in, run_drop_in_async
 
 
 def test_shim_against_the_oracle_build(oracle_lib, tmp_path):
@@ -17,3 +17,14 @@ def test_shim_links_against_the_product_library():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "immesh_amd", "csrc"), "-j8"])
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "shim_main"])
     assert os.path.exists(os.path.join(ROOT, "drop_in", "shim_main"))
+
+
+def test_async_shim_against_the_oracle_build(oracle_lib):
+    """the service-level shim (two threads: scan thread + service_reconstruct_mesh) linked against the oracle, scan by scan in lock-step (the checker is
+    synchronous: a frame's lists are the current ones until the next call)"""
+    run_drop_in_async(lambda cfg: make_oracle(oracle_lib, cfg), "libimmesh_dropin_async_oracle.so", lockstep=True)
+
+
+def test_async_shim_links_against_the_product_library():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "libimmesh_dropin_async.so"])
+    assert os.path.exists(os.path.join(ROOT, "drop_in", "libimmesh_dropin_async.so"))

@@ -111,3 +111,140 @@ def run_drop_in(oracle_lib, make_direct, target, tmp_path, expect_ply=True):
     assert got[1]["nv"] > 500 and got[-1]["nl"] > 3000
     if expect_ply:
         assert os.path.getsize("/tmp/immesh_dropin_test.ply") > 10000       # save_to_ply_file through the shim
+
+
+# ---- the SERVICE-LEVEL (asynchronous) drop-in: drop_in/immesh_shim_async.cpp behind drop_in/dropin_driver.cpp (two threads, as the reference runs them) ----------
+def _dropin_lib(name):
+    import ctypes as C
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), name])
+    lib = C.CDLL(os.path.join(ROOT, "drop_in", name))
+    lib.dropin_create.restype = C.c_void_p; lib.dropin_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.dropin_destroy.argtypes = [C.c_void_p, C.c_int]
+    lib.dropin_first_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.dropin_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dropin_wait_meshed.argtypes = [C.c_void_p, C.c_long, C.c_int]
+    lib.dropin_frame_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.dropin_effect_features.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.dropin_run_stream.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _apply(live, m):
+    for tri in map(tuple, m["tri_rem"].tolist()):
+        live.pop(tri, None)
+    for tri, fl in zip(map(tuple, m["tri_add"].tolist()), m["flip_add"].tolist()):
+        live[tri] = fl
+    for tri, fl in zip(map(tuple, m["tri_upd"].tolist()), m["flip_upd"].tolist()):
+        if tri in live:
+            live[tri] = fl
+
+
+def run_drop_in_async(make_direct, libname, lockstep, shadow=None):
+    """Scans through the asynchronous shim (scan thread = this thread, service thread inside the driver) vs the SAME C-ABI calls issued directly:
+    immesh_process_scan(IMMESH_MESH_ASYNC) + immesh_mesh_wait + immesh_mesh_fetch.  States, m_effct_feat_num and, per frame, the Global_map size and the
+    live set of the Triangle_manager mirror (order-independent hash over (triplet, m_index_flip)) must be equal bit for bit."""
+    import ctypes as C
+    lib = _dropin_lib(libname)
+    cfg = capi.avia_config()
+    extT = np.array(list(cfg.extT))
+    n_scans = 7
+    scans = []
+    for k in range(n_scans):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, R, t, n_pts=30000, extT=extT)
+        down = synth.voxel_grid_downsample(raw, 0.4)
+        prior = capi.make_state(R=R, t=t + (np.array([0.01, -0.01, 0.005]) if k else 0.0), cov_diag=1e-5)
+        scans.append((np.ascontiguousarray(raw), np.ascontiguousarray(down), prior))
+    d = lib.dropin_create(None, extT.ctypes.data_as(C.c_void_p), 1)
+    assert d
+    got = []
+    try:
+        assert lib.dropin_first_scan(d, scans[0][0].ctypes.data_as(C.c_void_p), len(scans[0][0]), scans[0][2].ctypes.data_as(C.c_void_p)) == 0
+        for k in range(1, n_scans):
+            raw, down, prior = scans[k]
+            st, eff = np.zeros(348), C.c_int32(0)
+            assert lib.dropin_scan(d, raw.ctypes.data_as(C.c_void_p), len(raw), down.ctypes.data_as(C.c_void_p), len(down), prior.ctypes.data_as(C.c_void_p),
+                                   st.ctypes.data_as(C.c_void_p), C.byref(eff)) == 0
+            if lockstep:
+                assert lib.dropin_wait_meshed(d, k, 60000) == 0
+            got.append((st, eff.value))
+        assert lib.dropin_wait_meshed(d, n_scans - 1, 60000) == 0
+        stats = []
+        for f in range(n_scans - 1):
+            nv, nl, hh = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+            assert lib.dropin_frame_stats(d, f, C.byref(nv), C.byref(nl), C.byref(hh)) == 0
+            stats.append((nv.value, nl.value, hh.value))
+        n_last = len(scans[-1][1])
+        ep, en = np.zeros((n_last, 3), np.float32), np.zeros((n_last, 4), np.float32)
+        n_eff = lib.dropin_effect_features(d, ep.ctypes.data_as(C.c_void_p), en.ctypes.data_as(C.c_void_p), n_last)
+    finally:
+        lib.dropin_destroy(d, 1)
+    h = make_direct(cfg)
+    live, slive = {}, {}
+    h.map_build(np.ascontiguousarray(scans[0][0][:, :3]), scans[0][2])
+    for k in range(1, n_scans):
+        raw, down, prior = scans[k]
+        sh, ih = h.process_scan(down, raw, prior, prior, frame_idx=k - 1, do_mesh=2)
+        h.mesh_wait()
+        m = h.mesh_fetch()
+        _apply(live, m)
+        np.testing.assert_array_equal(got[k - 1][0], sh)
+        assert got[k - 1][1] == ih["n_match"]
+        nv, nl, hh = stats[k - 1]
+        assert nv == m["vtx_base"] + len(m["new_vtx"]) and nl == len(live) and hh == _live_hash(live), k
+        if shadow is not None:   # the direct calls' lists are the oracle's on the device's own world-frame cloud (composed-run check): so is the mirror
+            ms = shadow.mesh_scan(h.mesh_world_scan(), sh[9:12], frame_idx=k - 1)
+            _apply(slive, ms)
+            assert nl == len(slive) and hh == _live_hash(slive), k
+    p2, q2 = h.last_matches()
+    assert n_eff == len(p2) and np.array_equal(ep[:n_eff], p2) and np.array_equal(en[:n_eff], q2)
+    assert stats[0][0] > 500 and stats[-1][1] > 3000
+    h.close()
+
+
+def test_async_drop_in_matches_direct_calls_and_the_oracle(oracle_lib, hip_lib):
+    run_drop_in_async(lambda cfg: make_hip(hip_lib, cfg), "libimmesh_dropin_async.so", lockstep=False, shadow=make_oracle(oracle_lib, capi.avia_config()))
+
+
+def test_async_drop_in_stream_runner(hip_lib):
+    """dropin_run_stream (what bench.py times): priors by Forward_without_imu, every frame's lists fetched and applied -- equal to the direct calls"""
+    import ctypes as C
+    lib = _dropin_lib("libimmesh_dropin_async.so")
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(6):
+        R, t = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, R, t, n_pts=30000, extT=extT)
+        scans.append((np.ascontiguousarray(raw), np.ascontiguousarray(synth.voxel_grid_downsample(raw, 0.4))))
+    R0, t0 = synth.trajectory_pose(0)
+    st0 = capi.make_state(R=R0, t=t0)
+    results = []
+    for via_shim in (True, False):
+        h = make_hip(hip_lib, cfg)
+        h.map_build(np.ascontiguousarray(scans[0][0][:, :3]), st0)
+        st = st0.copy(); st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+        if via_shim:
+            d = lib.dropin_create(h.ctx, extT.ctypes.data_as(C.c_void_p), 0)     # the driver adopts the context (as bench.py hands over the 10 M-voxel map)
+            assert d
+            n = len(scans) - 1
+            raws = (C.c_void_p * n)(*[s[0].ctypes.data for s in scans[1:]]); downs = (C.c_void_p * n)(*[s[1].ctypes.data for s in scans[1:]])
+            n_raw = np.array([len(s[0]) for s in scans[1:]], np.int32); n_ds = np.array([len(s[1]) for s in scans[1:]], np.int32)
+            states, eff, ms = np.zeros((n, 348)), np.zeros(n, np.int32), np.zeros(2)
+            rc = lib.dropin_run_stream(d, n, raws, n_raw.ctypes.data_as(C.c_void_p), downs, n_ds.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), 0.1, 0.3, 0.5,
+                                       states.ctypes.data_as(C.c_void_p), eff.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
+            lib.dropin_destroy(d, 0)
+            assert rc == 0 and ms[1] >= ms[0] > 0
+            results.append((states, h.counters()))
+        else:
+            out = []
+            for raw, down in scans[1:]:
+                prior = capi.forward_without_imu_native(hip_lib, st)
+                st, _ = h.process_scan(down, raw, prior, prior, frame_idx=0, do_mesh=2)
+                out.append(st.copy())
+            h.mesh_wait()
+            results.append((np.array(out), h.counters()))
+        h.close()
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    for key in ("n_vertices", "n_triangles_live", "t_add", "t_rem", "n_match", "n_refits"):
+        assert results[0][1][key] == results[1][1][key], key
