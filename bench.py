@@ -374,17 +374,22 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
                 raise SystemExit(f"dropin_run_stream failed ({rc})")
             return so, ms
         st, _ = shim_stream(k, args.warmup, st); k += args.warmup
+        stage5 = np.zeros(5); sl.dropin_stage_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; sl.dropin_stage_ms(drv, stage5.ctypes.data_as(ctypes.c_void_p))
         h.counters(reset=True)
         torch.cuda.synchronize()
         gc.collect(); gc.disable()
         D.barrier()
         st, ms = shim_stream(k, args.steps, st); k += args.steps
         gc.enable()
+        sl.dropin_stage_ms(drv, stage5.ctypes.data_as(ctypes.c_void_p))
         nvm, nlm = ctypes.c_int64(0), ctypes.c_int64(0)
         sl.dropin_mirror_sizes(drv, ctypes.byref(nvm), ctypes.byref(nlm))
         sl.dropin_destroy(drv, 0)
         cm = h.counters()
         shim_info = {"ms_until_last_pose": round(float(ms[0]), 3), "ms_until_mirrors_current": round(float(ms[1]), 3), "mirror_vertices": int(nvm.value), "mirror_live_triangles": int(nlm.value),
+                     "host_ms_per_scan": {"scan_thread_pack_pcl_clouds": round(stage5[0] / args.steps, 4), "scan_thread_immesh_process_scan": round(stage5[1] / args.steps, 4),
+                                          "service_thread_wait_for_job": round(stage5[2] / args.steps, 4), "service_thread_fetch": round(stage5[3] / args.steps, 4),
+                                          "service_thread_mirror_update": round(stage5[4] / args.steps, 4)},
                      "mirror_equals_device": bool(nvm.value == cm["n_vertices"] and nlm.value == cm["n_triangles_live"])}
         log(f"[bench] through the drop-in shim: {shim_info}")
         D.barrier()

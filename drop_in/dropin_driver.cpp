@@ -17,6 +17,7 @@ extern std::atomic<bool> g_immesh_service_stop;
 extern std::atomic<long> g_immesh_frames_meshed;
 extern void (*g_immesh_after_frame)(int frame_idx);
 extern int g_frame_idx;
+extern std::atomic<long long> g_immesh_shim_ns[5];
 
 namespace {
 struct FrameStat { int32_t nv, nl; unsigned long long hash; };
@@ -167,6 +168,12 @@ int dropin_seed_mirror(void* p) {
     }
     for (int64_t i = 0; i < nf; i++)   // faces are (v0, v1, v2) when m_index_flip != 0 else (v0, v2, v1), v0 < v1 < v2 (immesh_mesh_export)
         g_triangles_manager.insert_triangle(f[3 * i], f[3 * i + 1], f[3 * i + 2], 1, 0)->m_index_flip = f[3 * i + 1] < f[3 * i + 2] ? 1 : 0;
+    return 0;
+}
+// host time per stage since the last call, milliseconds: pack, process_scan (scan thread); job wait, fetch, mirror update (service thread)
+int dropin_stage_ms(void* p, double* ms5) {
+    (void)p;
+    for (int i = 0; i < 5; i++) ms5[i] = (double)g_immesh_shim_ns[i].exchange(0) * 1e-6;
     return 0;
 }
 int dropin_mirror_sizes(void* p, int64_t* nv, int64_t* nl) {

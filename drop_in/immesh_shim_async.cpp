@@ -32,7 +32,11 @@ std::mutex g_mutex_data_package_lock;                            // :78
 std::list<Rec_mesh_data_package> g_rec_mesh_data_package_list;   // :79
 std::atomic<bool> g_immesh_service_stop{false};                  // (the reference's service loops never return; the test driver needs them to)
 std::atomic<long> g_immesh_frames_meshed{0};
-void (*g_immesh_after_frame)(int frame_idx) = nullptr;           // test hook: called by the service thread after a frame's mirrors are up to date
+void (*g_immesh_after_frame)(int frame_idx) = nullptr;
+// where the host time of a frame goes (nanoseconds, cumulative): [0] packing the pcl clouds [1] immesh_process_scan [2] waiting for the frame's job
+// [3] immesh_mesh_fetch [4] applying the lists to the mirrors -- [0..1] scan thread, [2..4] service thread
+std::atomic<long long> g_immesh_shim_ns[5];
+static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }           // test hook: called by the service thread after a frame's mirrors are up to date
 
 static void to_c(const StatesGroup& s, double* o) {
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o[r * 3 + c] = s.rot_end(r, c);
@@ -88,6 +92,7 @@ bool Voxel_mapping::voxel_map_init() {
 // The whole per-scan section in one call.  m_laserCloudOri / m_corr_normvect are filled on demand (immesh_fetch_effect_features): their one
 // reader outside this function is the optional publish_effect_world (src/voxel_mapping_common.cpp:533-546).
 void Voxel_mapping::lio_state_estimation(StatesGroup& state_propagat) {
+    const long long t_a = now_ns();
     const int n_ds = (int)m_feats_down_body->size(), n_raw = (int)m_feats_undistort->size();
     m_immesh_xyz.resize((size_t)n_ds * 3); m_immesh_xyzi.resize((size_t)n_raw * 4);   // (pcl points are padded to 32 / 48 bytes; the ABI takes packed floats)
     for (int i = 0; i < n_ds; i++) { const PointType& p = m_feats_down_body->points[i]; m_immesh_xyz[3 * i] = p.x; m_immesh_xyz[3 * i + 1] = p.y; m_immesh_xyz[3 * i + 2] = p.z; }
@@ -95,9 +100,11 @@ void Voxel_mapping::lio_state_estimation(StatesGroup& state_propagat) {
     double prior[IMMESH_STATE_DOUBLES], st[IMMESH_STATE_DOUBLES];
     to_c(state_propagat, prior); to_c(state, st);
     int iters = 0;
+    const long long t_b = now_ns();
     // (host buffers: the library stages them into HBM on its stream and has consumed the staging copy before the next call refills it)
     const int rc = immesh_process_scan(m_hip, m_immesh_xyz.data(), n_ds, m_immesh_xyzi.data(), n_raw, prior, st, g_frame_idx, IMMESH_MESH_ASYNC, &iters, &m_effct_feat_num);
     if (rc) { fail(m_hip, "immesh_process_scan", rc); return; }
+    g_immesh_shim_ns[0] += t_b - t_a; g_immesh_shim_ns[1] += now_ns() - t_b;
     from_c(st, state);
     m_immesh_scan_queued = true;
 }
@@ -137,8 +144,10 @@ void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_
     (void)frame_pts; (void)pose_t;
     int64_t ordinal = 0;
     int rc;
+    const long long t_a = now_ns();
     while ((rc = immesh_mesh_collect_begin(c, 100, &ordinal)) == IMMESH_NOT_READY) { if (g_immesh_service_stop.load()) return; }
     if (rc) { fail(c, "mesh job", rc); (void)immesh_mesh_collect_end(c); return; }
+    const long long t_b = now_ns();
     immesh_mesh_sizes_t z;
     immesh_mesh_sizes(c, &z);
     std::vector<float> vtx((size_t)3 * z.n_new_vtx);
@@ -148,6 +157,7 @@ void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_
     rc = immesh_mesh_fetch(c, vtx.data(), add.data(), fadd.data(), rem.data(), upd.data(), fupd.data(), sid.data(), sxyz.data());
     (void)immesh_mesh_collect_end(c);     // the lists are on the host: the device buffers may be reused
     if (rc) { fail(c, "immesh_mesh_fetch", rc); return; }
+    const long long t_c = now_ns();
     // ---- host mirrors: Global_map::m_rgb_pts_vec (index == vertex id, pointcloud_rgbd.cpp:518-527) and the Triangle_manager
     for (int i = 0; i < z.n_new_vtx; i++) {
         auto pt = std::make_shared<RGB_pts>();
@@ -161,6 +171,7 @@ void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_
     g_triangles_manager.remove_triangle_list(to_rem, frame_idx);
     for (int i = 0; i < z.n_add; i++) g_triangles_manager.insert_triangle(add[3 * i], add[3 * i + 1], add[3 * i + 2], 1, frame_idx)->m_index_flip = fadd[i];
     for (int i = 0; i < z.n_upd; i++) { Triangle_ptr t = g_triangles_manager.find_triangle(upd[3 * i], upd[3 * i + 1], upd[3 * i + 2]); if (t) t->m_index_flip = fupd[i]; }
+    g_immesh_shim_ns[2] += t_b - t_a; g_immesh_shim_ns[3] += t_c - t_b; g_immesh_shim_ns[4] += now_ns() - t_c;
     if (g_immesh_after_frame) g_immesh_after_frame(frame_idx);
     g_immesh_frames_meshed.fetch_add(1);
 }
