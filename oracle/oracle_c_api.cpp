@@ -394,6 +394,20 @@ int orc_counters(void* p, immesh_counters_t* c, int32_t reset) {
     return 0;
 }
 
+// test tap: the Point_with_var lists of the last map_build (which = 0: point = world), map_update / process_scan (1: point = world, scan order) and
+// register / residuals (2: body point, f32-rounded world point) -- tests/test_ref_voxelmap.py feeds them to the reference's own functions
+void orc_debug_tap(void* p, int32_t on) { ((OrcCtx*)p)->reg.tap_on = on != 0; }
+int64_t orc_debug_pv(void* p, int32_t which, double* pt, double* pt_world, double* var9, int64_t cap) {
+    OrcCtx* o = (OrcCtx*)p;
+    if (which < 0 || which > 2) return -1;
+    const std::vector<PointWithVar>& v = o->reg.tap[which];
+    for (int64_t i = 0; i < (int64_t)v.size() && i < cap; i++) {
+        for (int k = 0; k < 3; k++) { if (pt) pt[i * 3 + k] = v[i].p[k]; if (pt_world) pt_world[i * 3 + k] = v[i].pw[k]; }
+        if (var9) std::memcpy(var9 + i * 9, v[i].var, 72);
+    }
+    return (int64_t)v.size();
+}
+
 // ---- fine-grained hooks used only by the oracle's own unit tests ------------------------------------------------
 void orc_calc_body_var(const double* pb, float range_inc, float degree_inc, double* var9) {
     double p[3] = {pb[0], pb[1], pb[2]};
@@ -414,6 +428,28 @@ int orc_delaunay2d(const double* xy, int n, int32_t* tris, int cap) {
     const int nt = (int)f.size() / 3;
     for (int i = 0; i < nt && i < cap; i++) { tris[i * 3] = f[i * 3]; tris[i * 3 + 1] = f[i * 3 + 1]; tris[i * 3 + 2] = f[i * 3 + 2]; }
     return nt;
+}
+// the mesher's per-voxel triangulation (delaunay_triangulation restated, orc_mesher.hpp) on a free-standing vertex set: pos n x 3 (ids = 0..n-1);
+// short_axis_out = the axis it derived; returns the number of ints written (3 per accepted face, local ids in emission order)
+int orc_voxel_delaunay(const double* pos, int n, double* short_axis_out, int32_t* tris_out, int cap) {
+    Mesher m;
+    m.verts.resize(n);
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; i++) { ids[i] = i; for (int k = 0; k < 3; k++) { m.verts[i].pos[k] = pos[i * 3 + k]; m.verts[i].smooth[k] = pos[i * 3 + k]; } }
+    std::vector<int> t;
+    double sa[3] = {0, 0, 0};
+    m.delaunay_triangulation(ids, sa, t);
+    for (int k = 0; k < 3; k++) short_axis_out[k] = sa[k];
+    for (size_t i = 0; i < t.size() && (int)i < cap; i++) tris_out[i] = t[i];
+    return (int)t.size();
+}
+// correct_triangle_index restated (Mesher::flip_of) on three smoothed positions
+int orc_flip_of(const double* a, const double* b, const double* c, const double* cam, const double* short_axis) {
+    Mesher m;
+    m.verts.resize(3);
+    const double* src[3] = {a, b, c};
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { m.verts[i].pos[k] = src[i][k]; m.verts[i].smooth[k] = src[i][k]; }
+    return m.flip_of(Tri{0, 1, 2}, cam, short_axis);
 }
 // exact kNN over the mesher's current vertex set (for validation against oracle/_ref's real ikd-Tree)
 int orc_mesh_knn(void* p, const float* q, int k, double r_max, int32_t* ids, float* d2) {

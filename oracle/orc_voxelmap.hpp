@@ -439,6 +439,10 @@ struct Registration {
     VoxelMap* vm;
     std::vector<double> body_cov;   // m_body_cov_list
     std::vector<double> cross_mat;  // m_cross_mat_list
+    // test tap (orc_debug_tap): the Point_with_var lists the three callers hand to buildVoxelMap / updateVoxelMap (in scan order, before the
+    // var_contrast sort) / BuildResidualListOMP (first iteration of the call) -- the inputs the reference's own functions are fed in tests/test_ref_voxelmap.py
+    bool tap_on = false;
+    std::vector<PointWithVar> tap[3];
     explicit Registration(VoxelMap* v) : vm(v) {}
 
     // voxel_mapping.cpp:1302-1316
@@ -501,6 +505,7 @@ struct Registration {
         for (int it = 0; it < c.max_iter; it++) {
             iters++;
             make_pv_list(pts, n, state, pv_list);
+            if (tap_on && it == 0) tap[2] = pv_list;
             build_residual_list(*vm, pv_list, ptpl_list, match_idx);
             const int M = (int)ptpl_list.size();
             vm->cnt.n_match += M;
@@ -636,6 +641,7 @@ struct Registration {
             m3_mul_bt(tmp, nc, b);
             for (int k = 0; k < 9; k++) pv.var[k] = (a[k] + b[k]) + t_var[k];
         }
+        if (tap_on) tap[0] = pv_list;
         build_voxel_map(*vm, pv_list);
     }
 
@@ -661,6 +667,7 @@ struct Registration {
             m3_mul_bt(tmp, nc, b);
             for (int k = 0; k < 9; k++) pv.var[k] = (a[k] + b[k]) + t_var[k];
         }
+        if (tap_on) tap[1] = pv_list;
         // var_contrast (voxel_mapping.cpp:49): ascending ||diag(var)||; std::sort ties broken by original index here
         std::vector<double> key(n);
         for (int i = 0; i < n; i++) key[i] = std::sqrt(pv_list[i].var[0] * pv_list[i].var[0] + pv_list[i].var[4] * pv_list[i].var[4] + pv_list[i].var[8] * pv_list[i].var[8]);
