@@ -218,8 +218,19 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     return None
 
 
-COMMITTED_STATS = "r03_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
-COMMITTED_TRAFFIC = "traffic_r03.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+COMMITTED_STATS = "r04_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
+COMMITTED_TRAFFIC = "traffic_r04.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+
+
+def kernel_sources_sha():
+    """fingerprint of everything that is compiled into the kernels: a PMC traffic file measured on other sources is stale by construction"""
+    import hashlib
+    hsh = hashlib.sha256()
+    d = os.path.join(ROOT, "immesh_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".hpp")):
+            hsh.update(name.encode()); hsh.update(open(os.path.join(d, name), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def roofline_from_committed_profile(mesh, cnt, n_scans, n_raw, note):
@@ -497,17 +508,19 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
         o.map_build(np.ascontiguousarray(raws[0][:, :3]), so)   # kitti: exactly the GPU leg's map
     else:
         # the corridor of the GPU leg's survey around the trajectory (the same strips, generated on the host): >= cpu_map_voxels root voxels
+        # the SAME survey the GPU leg ingested (same generator, same device, same seed), strip by strip, until the map holds cpu_map_voxels root voxels
         import torch
         side = float(np.sqrt(cpu_map_voxels / 8.8)) + 40.0
         ident = capi.make_state()
         cap = int(cfg.cap_scan_points)
-        for P in survey_strips(cfg, torch, torch.device("cpu"), side):
-            Pn = P.numpy()
+        for P in survey_strips(cfg, torch, torch.device("cuda", int(cfg.device)) if torch.cuda.is_available() else torch.device("cpu"), side):
+            Pn = P.cpu().numpy()
             for a in range(0, len(Pn), cap):
                 o.map_update(np.ascontiguousarray(Pn[a:a + cap]), ident)
             if o.counters()["n_root_voxels"] >= cpu_map_voxels:
                 break
     n_map = int(o.counters()["n_root_voxels"])
+    log(f"[bench] CPU baseline: the oracle's map holds {n_map} root voxels")
     so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
     if args.mesh and seed_cloud is not None:   # the same pre-seeded mesh map as the GPU leg: the corridor cloud in packages of mesh_append_budget points
         o.set_threads(ncores if ncores < 16 else ncores // 2, min(4, ncores))
@@ -554,9 +567,9 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
     o.close()
     best, cores = (v_all, ncores) if v_all["scans_per_s"] > v_ref["scans_per_s"] else (v_ref, ref_thr[0])
     return {"value": best["scans_per_s"], "unit": "scans/s", "cores": cores, "kind": "port",
-            "sample": f"{best['scans']} scans of the same stream (after {best['warmup_scans']} warm-up scans) through oracle/liboracle.so; map = {best['map_root_voxels']} root voxels: the corridor of the "
-                      "same survey around the trajectory (the oracle needs minutes to ingest all 10 M voxels; map size does not enter its per-scan work, only its cache footprint); "
-                      "the faster of the two variants is `value`",
+            "sample": f"{best['scans']} scans of the same stream (after {best['warmup_scans']} warm-up scans) through oracle/liboracle.so against a map of {best['map_root_voxels']} root voxels built from the "
+                      "same survey strips as the GPU leg's map (--cpu-map-voxels; default = the metric's 10 M); the same pre-seeded mesh map; "
+                      "the faster of the two threading variants is `value` (reference threading: 12-thread mesher pool + 4 matcher threads; all-cores: every parallel loop on the physical cores, per-thread counters)",
             "ms_per_scan": best["ms_p50"], "reference_threading": v_ref, "all_cores": v_all, "host_cores": ncores}
 
 
@@ -652,7 +665,7 @@ def main():
                     "1 = only the sharded split: ONE stream, registration map and mesher sharded by voxel bricks over the ranks (strong scaling; the capacity mode of configs[4])")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo only for single-GPU functional tests)")
     ap.add_argument("--device-downsample", type=int, default=0, help="1 = the VoxelGrid down-sampling of every raw scan also runs on the device inside the timed region (SURVEY 8(f) rank 1)")
-    ap.add_argument("--cpu-map-voxels", type=float, default=1.0e6, help="root voxels of the survey corridor the CPU-baseline leg pre-builds for the oracle (0 = scan 0 only)")
+    ap.add_argument("--cpu-map-voxels", type=float, default=10.0e6, help="root voxels of the map the CPU-baseline leg builds for the oracle from the same survey strips (default: the metric's 10 M, ~40 s of host time; 0 = scan 0 only)")
     ap.add_argument("--host-inputs", type=int, default=0, help="1 = every scan is handed over as HOST buffers (the library stages them over PCIe inside the timed region): the PCIe-inclusive rate")
     ap.add_argument("--dropin-shim", type=int, default=0, help="1 = the timed region runs THROUGH THE DROP-IN (drop_in/immesh_shim_async.cpp behind drop_in/dropin_driver.cpp): pcl-shaped host clouds in, "
                     "one immesh_process_scan(ASYNC) per scan on the scan thread, every frame's result lists fetched and applied to the Global_map / Triangle_manager mirrors by the service thread")
@@ -724,8 +737,17 @@ def main():
         tr = os.path.join(ROOT, "profiles", COMMITTED_TRAFFIC)   # PMC-derived HBM bytes/launch from the committed rocprofv3 --pmc passes
         if rf is not None and os.path.exists(tr):
             try:
-                rf["traffic"] = json.load(open(tr)).get(rf["kernel"])
-                rf["traffic_source"] = f"profiles/{COMMITTED_TRAFFIC}: committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (PMC counters cannot be read in-process); not measured in this run"
+                tj = json.load(open(tr))
+                meta = tj.get("_meta", {})
+                if meta.get("kernel_sources_sha16") != kernel_sources_sha():
+                    # refuse a file measured on other kernel sources: PMC counters cannot be read in-process, and a number from another build would be passed off as this one's
+                    rf["traffic"] = None
+                    rf["traffic_source"] = (f"profiles/{COMMITTED_TRAFFIC} was measured on kernel sources {meta.get('kernel_sources_sha16')} (commit {meta.get('commit')}), this build is "
+                                            f"{kernel_sources_sha()}: stale, not reported (tools/refresh_profiles.sh regenerates it)")
+                else:
+                    rf["traffic"] = tj.get(rf["kernel"])
+                    rf["traffic_source"] = (f"profiles/{COMMITTED_TRAFFIC}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources ({meta.get('kernel_sources_sha16')}, "
+                                            f"commit {meta.get('commit')}); PMC counters cannot be read in-process, so not measured in this run")
             except Exception:   # noqa: BLE001
                 pass
         return rf

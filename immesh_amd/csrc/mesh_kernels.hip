@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < ccap; k += stride) { m.ch_keys[k] = MKEY_EMPTY; m.ch_head[k] = -1; }
     if (i == 0) {
-        *m.tick0 = __builtin_amdgcn_s_memrealtime();
         MeshDyn d = *h_dyn;
         bool late = false;
         if (d.wait_flag) {   // the producer was enqueued before this launch; bounded all the same (~1 s) -- reported through the hang guard of the admission
@@ -133,6 +132,7 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
                 if (++spins > (1u << 20)) { late = true; break; }
             }
         }
+        *m.tick0 = __builtin_amdgcn_s_memrealtime();   // (behind the poll: the job's device time does not include waiting for the registration stream)
         const int base = m.pc[PC_VERTS];
         d.sp.vtx_base = base;
         *m.dyn = d;

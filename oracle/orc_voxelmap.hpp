@@ -324,14 +324,14 @@ inline void body_to_world_d(const Config& c, const double* R, const double* t, c
 }
 
 // ---- a11: build_single_residual, voxel_mapping.cpp:247-318 ---------------------------------------------
+// (n_tests: the caller's plane-test count -- a per-thread sum in the matcher's loop; a shared atomic here made every thread of the loop wait for one cache line)
 inline void build_single_residual(VoxelMap& vm, const PointWithVar& pv, const OctoTree* oct, int layer, int max_layer, double sigma_num,
-                                  bool& is_success, double& prob, Ptpl& out) {
+                                  bool& is_success, double& prob, Ptpl& out, long& n_tests) {
     const double radius_k = 3;
     const double* pw = pv.pw;
     if (oct->plane.is_plane) {
         const Plane& pl = oct->plane;
-#pragma omp atomic
-        vm.cnt.n_plane_tests++;
+        n_tests++;
         const float dis_to_plane = (float)std::fabs(pl.normal[0] * pw[0] + pl.normal[1] * pw[1] + pl.normal[2] * pw[2] + pl.d);
         const float dis_to_center = (float)((pl.center[0] - pw[0]) * (pl.center[0] - pw[0]) + (pl.center[1] - pw[1]) * (pl.center[1] - pw[1]) +
                                             (pl.center[2] - pw[2]) * (pl.center[2] - pw[2]));
@@ -365,7 +365,7 @@ inline void build_single_residual(VoxelMap& vm, const PointWithVar& pv, const Oc
     }
     if (layer < max_layer)
         for (int l = 0; l < 8; l++)
-            if (oct->leaves[l] != nullptr) build_single_residual(vm, pv, oct->leaves[l], layer + 1, max_layer, sigma_num, is_success, prob, out);
+            if (oct->leaves[l] != nullptr) build_single_residual(vm, pv, oct->leaves[l], layer + 1, max_layer, sigma_num, is_success, prob, out, n_tests);
 }
 
 // ---- a10: BuildResidualListOMP, voxel_mapping.cpp:153-245 (serial here; result is order-independent) ---
@@ -377,7 +377,8 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
     std::vector<Ptpl> single(pv_list.size());
     std::vector<uint8_t> good(pv_list.size(), 0);
     // the reference runs this loop under OpenMP (MP_PROC_NUM = 4, CMakeLists.txt:21-24); points are independent, the list is compacted in index order
-#pragma omp parallel for schedule(static) num_threads(vm.threads) if (vm.threads > 1)
+    long n_tests = 0, n_extra = 0;
+#pragma omp parallel for schedule(static) num_threads(vm.threads) if (vm.threads > 1) reduction(+ : n_tests, n_extra)
     for (long i = 0; i < n; i++) {
         const PointWithVar& pv = pv_list[(size_t)i];
         const double q[3] = {pv.pw[0] / voxel_size, pv.pw[1] / voxel_size, pv.pw[2] / voxel_size};
@@ -389,7 +390,7 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
         OctoTree* cur = it->second;
         bool ok = false;
         double prob = 0;
-        build_single_residual(vm, pv, cur, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i]);
+        build_single_residual(vm, pv, cur, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i], n_tests);
         if (!ok) {  // near-voxel retry, literal unit-mismatch quirk, :190-222
             Key nearp = pos;
             int64_t* nk[3] = {&nearp.x, &nearp.y, &nearp.z};
@@ -397,13 +398,13 @@ inline void build_residual_list(VoxelMap& vm, const std::vector<PointWithVar>& p
                 if (loc[k] > (cur->voxel_center[k] + cur->quater_length)) *nk[k] = *nk[k] + 1;
                 else if (loc[k] < (cur->voxel_center[k] - cur->quater_length)) *nk[k] = *nk[k] - 1;
             }
-#pragma omp atomic
-            vm.cnt.n_extra_probe++;
+            n_extra++;
             auto itn = vm.map.find(nearp);
-            if (itn != vm.map.end()) build_single_residual(vm, pv, itn->second, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i]);
+            if (itn != vm.map.end()) build_single_residual(vm, pv, itn->second, 0, vm.cfg.max_layer, vm.cfg.sigma_num, ok, prob, single[(size_t)i], n_tests);
         }
         good[(size_t)i] = ok ? 1 : 0;
     }
+    vm.cnt.n_plane_tests += n_tests; vm.cnt.n_extra_probe += n_extra;
     for (long i = 0; i < n; i++)
         if (good[(size_t)i]) { ptpl_list.push_back(single[(size_t)i]); match_idx.push_back((int)i); }
 }
