@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <thread>
 
 #define RP_ABORTED 1   /* internal: register_collect_fused found the resident-grid registration aborted (bounded gather) */
 static thread_local std::string g_create_error;
@@ -670,33 +671,36 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
 // down-sampled / raw clouds an asynchronous immesh_process_scan may still be reading (point_var, transform) -- writers wait for ev_inputs_free.
 // "the last asynchronous scan has consumed its input clouds": an event on the registration stream, or -- when the registration launch consumed them in
 // its epilogue -- that launch's flag in pinned memory (it arrives a few microseconds behind the pose the caller already holds)
-static int pre_inputs_fence(immesh_ctx* c) {
-    if (c->inputs_seq) {
-        volatile unsigned long long* f = c->h_epi_flag;
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (*f < c->inputs_seq) {
-            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
+// wait (bounded) until the pinned "input clouds consumed" flag of the registration launch's epilogue has reached inputs_seq; the flag trails the pose the
+// caller already holds by a few microseconds, so the wait spins with a pause instead of sleeping, and hands over to the stream when it takes longer
+static int wait_inputs_flag(immesh_ctx* c) {
+    volatile unsigned long long* f = c->h_epi_flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*f < c->inputs_seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0x3FF) == 0) {
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (dt > std::chrono::milliseconds(500)) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));   // (a faulted stream returns its error here)
+                if (*f < c->inputs_seq) { c->err = "the scan's input clouds were not released (registration stream idle, flag not stored)"; return IMMESH_E_HIP; }
+                break;
+            }
+            if (dt > std::chrono::microseconds(200)) std::this_thread::yield();
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return 0;
     }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return 0;
+}
+static int pre_inputs_fence(immesh_ctx* c) {
+    if (c->inputs_seq) return wait_inputs_flag(c);
     HIPCHK(c, hipStreamWaitEvent(c->stream_pre, c->ev_inputs_cur, 0));
     return 0;
 }
 int immesh_inputs_consumed(immesh_ctx* c) {
     if (!c) return IMMESH_E_INVAL;
     (void)hipSetDevice(c->cfg.device);
-    if (c->inputs_seq) {   // the registration launch consumed them in its epilogue: the flag the launch behind it stores, in pinned memory
-        volatile unsigned long long* f = c->h_epi_flag;
-        const auto t0 = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (*f < c->inputs_seq) {
-            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(500)) { HIPCHK(c, hipStreamSynchronize(c->stream)); break; }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return 0;
-    }
+    if (c->inputs_seq) return wait_inputs_flag(c);   // the registration launch consumed them in its epilogue: the flag the launch behind it stores, in pinned memory
     HIPCHK(c, hipEventSynchronize(c->ev_inputs_cur));
     return 0;
 }
@@ -933,16 +937,27 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
     ProfBind _pb(c);
     immesh_ctx::DsAsync& a = c->dsa;
     int rc;
-    if (!a.ev) {
-        HIPCHK(c, hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
-        HIPCHK(c, hipHostMalloc((void**)&a.h_info, 16 * sizeof(int32_t)));
-        for (int q = 0; q < 2; q++) if ((rc = c->dalloc(&a.out[q], (size_t)c->cap_scan * 3))) return rc;
+    if (!a.ready) {   // first use: all or nothing (a failed allocation leaves the job state untouched; what was allocated stays in the context's pool)
+        hipEvent_t ev = nullptr; int32_t* info = nullptr; float* o0 = nullptr; float* o1 = nullptr; float* stg = nullptr;
+        if ((rc = c->dalloc(&o0, (size_t)c->cap_scan * 3)) || (rc = c->dalloc(&o1, (size_t)c->cap_scan * 3)) || (rc = c->dalloc(&stg, (size_t)c->cap_scan * 4))) return rc;
+        if (hipHostMalloc((void**)&info, 16 * sizeof(int32_t)) != hipSuccess) { c->err = "hipHostMalloc(downsample job)"; return IMMESH_E_NOMEM; }
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(info); c->err = "hipEventCreate(downsample job)"; return IMMESH_E_HIP; }
         const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-        std::memcpy(a.h_info + 8, init, sizeof(init));   // (pinned: the source of the asynchronous initialisation below)
+        std::memcpy(info + 8, init, sizeof(init));   // (pinned: the source of the asynchronous initialisation below)
+        a.ev = ev; a.h_info = info; a.out[0] = o0; a.out[1] = o1; a.stage = stg; a.ready = true;
     }
     hipStream_t s = c->stream_pre;
     const void* d_pts;
-    if ((rc = pre_resolve(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts))) return rc;
+    {
+        // a HOST cloud is staged into the job's OWN buffer: the context's staging buffers (d_pts_raw / d_pts_down) are written by the next
+        // immesh_process_scan / immesh_register with host inputs on the registration stream, which is not ordered against this stream
+        hipPointerAttribute_t attr;
+        const hipError_t pe = hipPointerGetAttributes(&attr, pts);
+        const bool is_dev = pe == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+        if (pe != hipSuccess) (void)hipGetLastError();
+        if (is_dev) d_pts = pts;
+        else { HIPCHK(c, hipMemcpyAsync(a.stage, pts, (size_t)n * stride * 4, hipMemcpyHostToDevice, s)); d_pts = a.stage; }
+    }
     a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts; a.used_bits = a.pred_bits;
     const float inv = (float)(1.0 / leaf);
     int32_t* mm = c->p_nseg;

@@ -55,7 +55,7 @@ struct immesh_ctx {
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     // immesh_downsample_begin / _end: two result buffers, the grid extents + leaf count of the running job in pinned memory, its parameters for the fallback
-    struct DsAsync { bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
+    struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
     int rp_max_blocks = 127;         // grid cap of residual_persistent_kernel: half of the device's resident workgroups - 1 (occupancy query at create)

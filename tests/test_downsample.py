@@ -96,3 +96,44 @@ def test_async_pair_gives_the_synchronous_result(hip_lib):
         assert hip_rt.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), got.nbytes, 2) == 0   # hipMemcpyDeviceToHost
         np.testing.assert_array_equal(got, want)
     h.close()
+
+
+@pytest.mark.gpu
+def test_async_pair_with_host_clouds_beside_host_input_scans(hip_lib):
+    """immesh_downsample_begin staged a HOST cloud into the context's staging buffer, which the next immesh_process_scan with host inputs
+    overwrites on another stream.  The job now stages into a buffer of its own: the VoxelGrid of host cloud k+1, begun BEFORE scan k is processed from
+    host buffers and collected after it, must still be the synchronous result."""
+    torch = pytest.importorskip("torch")
+    import ctypes
+    import glob
+    import os
+    cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
+    hip_rt = ctypes.CDLL(cand[0])
+    hip_rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    h, ref = make_hip(hip_lib, cfg), make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(6):
+        R, t = synth.trajectory_pose(k)
+        scans.append(np.ascontiguousarray(synth.livox_scan(k, R, t, n_pts=100000, extT=extT)))
+    R0, t0 = synth.trajectory_pose(0)
+    st = capi.make_state(R=R0, t=t0)
+    h.map_build(np.ascontiguousarray(scans[0][:, :3]), st)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    downs = [synth.voxel_grid_downsample(s, 0.4) for s in scans]
+    h.downsample_begin(scans[1], 0.4)
+    n1, _ = h.downsample_end()
+    assert n1 == len(downs[1])
+    for k in range(1, 5):
+        h.downsample_begin(scans[k + 1], 0.4)                       # host cloud k+1: staged and down-sampled on the pre-processing stream ...
+        prior = synth.forward_without_imu(st)
+        st, _ = h.process_scan(downs[k], scans[k], prior, prior, frame_idx=k, do_mesh=2)   # ... while scan k goes in as HOST buffers (the context's staging)
+        n_got, ptr = h.downsample_end()
+        want, n_want = ref.downsample(scans[k + 1], 0.4)
+        assert n_got == n_want == len(downs[k + 1])
+        got = np.zeros((n_got, 3), np.float32)
+        assert hip_rt.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), got.nbytes, 2) == 0
+        np.testing.assert_array_equal(got, want)
+    h.mesh_wait()
+    h.close(); ref.close()
