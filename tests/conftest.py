@@ -93,3 +93,22 @@ def make_oracle(oracle_lib, cfg):
 
 def make_hip(hip_lib, cfg):
     return capi.HotPath(hip_lib, cfg, prefix="immesh_")
+
+
+def fetch_device(ptr, shape, dtype=np.float32):
+    """Copy a device buffer the HIP library handed out (e.g. immesh_downsample_end) into a host array, with the HIP runtime THE LIBRARY is linked
+    against (libamdhip64.so.7 of /opt/rocm -- torch bundles a second copy of the runtime, which does not know the library's allocations)."""
+    import ctypes
+    rt = None
+    with open("/proc/self/maps") as f:
+        for ln in f:
+            if "libamdhip64.so" in ln and "/torch/" not in ln:
+                rt = ctypes.CDLL(ln.split()[-1]); break
+    if rt is None:
+        rt = ctypes.CDLL("libamdhip64.so.7")
+    rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    rt.hipMemcpy.restype = ctypes.c_int
+    out = np.zeros(shape, dtype)
+    rc = rt.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), out.nbytes, 2)   # hipMemcpyDeviceToHost
+    assert rc == 0, f"hipMemcpy(device -> host) failed: {rc}"
+    return out

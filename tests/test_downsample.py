@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from immesh_amd import capi, synth
-from conftest import make_oracle, make_hip
+from conftest import make_oracle, make_hip, fetch_device
 
 
 def _clouds():
@@ -71,12 +71,6 @@ def test_async_pair_gives_the_synchronous_result(hip_lib):
     """immesh_downsample_begin / _end: the VoxelGrid of scan k+1 enqueued ahead of time (radix width predicted from the previous cloud's extents) must be
     bit for bit what immesh_downsample returns -- for the first cloud (no prediction), for consecutive scans, and after a jump of the extents (fallback)."""
     torch = pytest.importorskip("torch")
-    import ctypes
-    import glob
-    import os
-    cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
-    hip_rt = ctypes.CDLL(cand[0])
-    hip_rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000)
     h = make_hip(hip_lib, cfg)
     extT = np.array(list(cfg.extT))
@@ -92,8 +86,7 @@ def test_async_pair_gives_the_synchronous_result(hip_lib):
         h.downsample_begin(d.data_ptr(), 0.4, n=len(raw), stride=4)
         n_got, ptr = h.downsample_end()
         assert n_got == n_want
-        got = np.zeros((n_got, 3), np.float32)      # the result stays in HBM: fetched with the HIP runtime torch has already loaded
-        assert hip_rt.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), got.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        got = fetch_device(ptr, (n_got, 3))         # the result stays in HBM
         np.testing.assert_array_equal(got, want)
     h.close()
 
@@ -104,12 +97,6 @@ def test_async_pair_with_host_clouds_beside_host_input_scans(hip_lib):
     overwrites on another stream.  The job now stages into a buffer of its own: the VoxelGrid of host cloud k+1, begun BEFORE scan k is processed from
     host buffers and collected after it, must still be the synchronous result."""
     torch = pytest.importorskip("torch")
-    import ctypes
-    import glob
-    import os
-    cand = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so*")) + ["libamdhip64.so"]
-    hip_rt = ctypes.CDLL(cand[0])
-    hip_rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
     h, ref = make_hip(hip_lib, cfg), make_hip(hip_lib, cfg)
     extT = np.array(list(cfg.extT))
@@ -132,8 +119,7 @@ def test_async_pair_with_host_clouds_beside_host_input_scans(hip_lib):
         n_got, ptr = h.downsample_end()
         want, n_want = ref.downsample(scans[k + 1], 0.4)
         assert n_got == n_want == len(downs[k + 1])
-        got = np.zeros((n_got, 3), np.float32)
-        assert hip_rt.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), got.nbytes, 2) == 0
+        got = fetch_device(ptr, (n_got, 3))
         np.testing.assert_array_equal(got, want)
     h.mesh_wait()
     h.close(); ref.close()
