@@ -105,7 +105,7 @@ int immesh_rccl_init(immesh_ctx* c, const uint8_t id_in[128]) {
     const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1, rank = c->cfg.shard_world > 1 ? c->cfg.shard_rank : 0;
     if (world > 64) { c->err = "immesh_rccl_init: more than 64 ranks (the mesher's count exchange is sized for one node)"; return IMMESH_E_INVAL; }
     // the count buffer of the mesher's exchanges: allocated here, on the calling thread with the worker idle (the allocator is not shared with it)
-    if (!c->mesh_host.d_xcounts) { const int arc = c->dalloc(&c->mesh_host.d_xcounts, 64); if (arc) return arc; }
+    if (!c->mesh_host.d_xcounts) { const int arc = c->dalloc(&c->mesh_host.d_xcounts, 128); if (arc) return arc; }
     const int rc = g_rccl.comm_init_rank(&c->rccl_comm, world, id, rank);
     if (rc) { c->rccl_comm = nullptr; c->err = "ncclCommInitRank: " + rccl_why(rc); return IMMESH_E_HIP; }
     c->allreduce = nullptr; c->mesh_host.allgather = nullptr;   // the library's own collectives replace the host callbacks
@@ -120,7 +120,7 @@ int immesh_stub_collectives(immesh_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     mesh_wait_all(c);
     rccl_release(c);
-    if (!c->mesh_host.d_xcounts) { const int arc = c->dalloc(&c->mesh_host.d_xcounts, 64); if (arc) return arc; }
+    if (!c->mesh_host.d_xcounts) { const int arc = c->dalloc(&c->mesh_host.d_xcounts, 128); if (arc) return arc; }
     c->rccl_comm = RCCL_STUB;
     c->allreduce = nullptr; c->mesh_host.allgather = nullptr;
     return 0;

@@ -44,7 +44,7 @@ int mesh_alloc(immesh_ctx* c) {
 #define A(ptr, n) if ((rc = c->dalloc(&(ptr), (size_t)(n)))) return rc
     A(m.v_pos, cap_verts * 3); A(m.v_smooth, cap_verts * 3); A(m.v_smooth_new, cap_verts * 3); A(m.v_voxel, cap_verts);
     const int64_t gcap = np2(cap_verts * 2), xcap = np2(cap_voxels * 2), tcap = np2(cap_tris * 2), ccap = np2(cap_cand * 4);
-    A(m.g_keys, gcap); A(m.g_rec, gcap * 4); m.g_mask = (uint64_t)gcap - 1;
+    A(m.g_ent, gcap); m.g_mask = (uint64_t)gcap - 1;
     A(m.x_keys, xcap); A(m.x_vals, xcap); m.x_mask = (uint64_t)xcap - 1;
     A(m.vx_key, cap_voxels); A(m.vx_npts, cap_voxels); A(m.vx_pts, cap_voxels * MV_VOX_CAP); A(m.vx_meshing_times, cap_voxels);
     A(m.vx_new_added, cap_voxels); A(m.vx_stamp, cap_voxels); A(m.vx_rank, cap_voxels); A(m.vx_rank_seq, cap_voxels); A(m.vx_short_axis, cap_voxels * 3);
@@ -52,7 +52,7 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.th_slots, tcap); m.th_mask = (uint64_t)tcap - 1;
     A(m.a_head, cap_verts); A(m.a_chunks, cap_adj * MV_ADJ_STRIDE);
     A(m.sc, SC_COUNT); A(m.pc, PC_COUNT);
-    A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand);
+    A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand); A(m.cand_pt, cap_cand + 32768); A(m.cand_flags, cap_cand); A(m.bin_cnt, 2 * (2048 + 1));
     A(m.ch_keys, ccap); A(m.ch_head, ccap);
     A(m.recent, cap_cand);
     int64_t cap_active_p2 = 1; while (cap_active_p2 < cap_active) cap_active_p2 <<= 1;   // mesh_append_finish_kernel's ordering network pads to a power of two
@@ -60,10 +60,14 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active); A(m.rel_nq, cap_active);
     A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
     A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
+    const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
+    if (shard_mesh && g.shard_brick_log2 > 0 && g.shard_brick_log2 < 2) { c->err = "sharded mesher: bricks below 4 voxels per axis are not supported (the boundary band reaches 2 voxels)"; return IMMESH_E_INVAL; }
+    if (shard_mesh) A(m.list_smooth_rx, cap_list);
     for (int k = 0; k < 2; k++) {
         MeshOutSet& o = h.outs[k];
         A(o.tri_add, cap_list * 3); A(o.flip_add, cap_list); A(o.tri_rem, cap_list * 3); A(o.tri_upd, cap_list * 3); A(o.flip_upd, cap_list);
         A(o.smooth_ids, cap_list); A(o.smooth_xyz, cap_list * 3);
+        if (shard_mesh) { A(o.own_add, cap_list); A(o.own_rem, cap_list); A(o.own_upd, cap_list); } else o.own_add = o.own_rem = o.own_upd = nullptr;
     }
     for (int k = 0; k < MESH_WORLD_BUFS; k++) A(h.d_world[k], cap_cand * 4);
     A(m.tick0, 4);   // (one 64-bit word per job parity)
@@ -85,23 +89,23 @@ int mesh_alloc(immesh_ctx* c) {
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
     m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
-    const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
     m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
     m.dbg = nullptr;
     if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 32))) return rc; m.dbg = t; (void)hipMemset(t, 0, 256); }
     hipStream_t s = c->stream;
-    launch_fill_u64(s, m.g_keys, ~0ull, (size_t)gcap);
+    HIPCHK(c, hipMemsetAsync(m.g_ent, 0xFF, (size_t)gcap * sizeof(MeshGridEnt), s));   // (key == ~0: empty)
     launch_fill_u64(s, m.x_keys, ~0ull, (size_t)xcap);
     HIPCHK(c, hipMemsetAsync(m.x_vals, 0xFF, (size_t)xcap * 4, s));
     HIPCHK(c, hipMemsetAsync(m.th_slots, 0xFF, (size_t)tcap * 4, s));
     HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.bin_cnt, 0, 2 * (2048 + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
     if (m.shard_world > 1) {   // exchange staging of the sharded mesher
         h.xcap_bytes = (size_t)cap_list * sizeof(MeshSmRec);
         { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xsend = t; }
         { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xrecv = t; }
-        { int32_t* t; if ((rc = c->dalloc(&t, 4))) return rc; h.d_xcount = t; }
+        { int32_t* t; if ((rc = c->dalloc(&t, 4))) return rc; h.d_xcount = t; }   // [0] records to send, [1] a number summed over the ranks (admission: candidates still undecided)
     }
     HIPCHK(c, hipMemsetAsync(m1.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
@@ -132,6 +136,7 @@ int mesh_alloc(immesh_ctx* c) {
             MeshDev& w = h.mpar[k];
             w.out_tri_add = o.tri_add; w.out_flip_add = o.flip_add; w.out_tri_rem = o.tri_rem; w.out_tri_upd = o.tri_upd; w.out_flip_upd = o.flip_upd;
             w.out_smooth_ids = o.smooth_ids; w.out_smooth_xyz = o.smooth_xyz;
+            w.out_own_add = o.own_add; w.out_own_rem = o.own_rem; w.out_own_upd = o.own_upd;
         }
     }
     h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
@@ -259,20 +264,21 @@ static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
 // Sharded mesher: all-gather `count` records of `rec` bytes from d_xsend over the ranks and hand every other rank's records to `unpack`.
 // Two collective calls: the counts, then the payload padded to the largest count.  Runs on the worker thread; the stream is idle on return
 // from the device-to-host copies and busy again with the unpack kernels when the function returns.
-static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::function<void(const void*, int)>& unpack) {
+static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::function<void(const void*, int)>& unpack, int64_t* aux_sum = nullptr) {
     MeshHost& h = c->mesh_host;
     const int world = c->cfg.shard_world, me = c->cfg.shard_rank;
+    if (aux_sum) *aux_sum = 0;
     if (c->rccl_comm) {
         // RCCL on device buffers: all-gather the record counts (the host needs the largest one to size the payload gather), then the payload padded
         // to it; every other rank's records are unpacked straight from the gathered buffer -- no host staging, one small read-back
         int rc;
         if (!h.d_xcounts || world > 64) { h.err = "sharded mesher: RCCL exchange not initialised (immesh_rccl_init)"; return IMMESH_E_INVAL; }
-        if ((rc = rccl_allgather_bytes(c, h.d_xcount, h.d_xcounts, 4, s, &h.err))) return rc;
-        int32_t counts32[64];
-        MHIPCHK(c, hipMemcpyAsync(counts32, h.d_xcounts, (size_t)world * 4, hipMemcpyDeviceToHost, s));
+        if ((rc = rccl_allgather_bytes(c, h.d_xcount, h.d_xcounts, 8, s, &h.err))) return rc;
+        int32_t pairs32[128], counts32[64];
+        MHIPCHK(c, hipMemcpyAsync(pairs32, h.d_xcounts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
         MHIPCHK(c, hipStreamSynchronize(s));
         int64_t maxc = 0;
-        for (int r = 0; r < world; r++) maxc = std::max<int64_t>(maxc, counts32[r]);
+        for (int r = 0; r < world; r++) { counts32[r] = pairs32[2 * r]; maxc = std::max<int64_t>(maxc, counts32[r]); if (aux_sum) *aux_sum += pairs32[2 * r + 1]; }
         h.xcalls++;
         if (maxc == 0) return 0;
         if ((size_t)maxc * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
@@ -290,15 +296,16 @@ static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::fu
         return 0;
     }
     if (!h.allgather) { h.err = "sharded mesher: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
-    int32_t cnt32 = 0;
-    MHIPCHK(c, hipMemcpyAsync(&cnt32, h.d_xcount, 4, hipMemcpyDeviceToHost, s));
+    int32_t cnt32[2] = {0, 0};
+    MHIPCHK(c, hipMemcpyAsync(cnt32, h.d_xcount, 8, hipMemcpyDeviceToHost, s));
     MHIPCHK(c, hipStreamSynchronize(s));
-    if ((size_t)cnt32 * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
-    int64_t cnt = cnt32;
-    std::vector<int64_t> counts((size_t)world, 0);
-    if (h.allgather(&cnt, 8, counts.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+    if ((size_t)cnt32[0] * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
+    const int64_t cnt = cnt32[0];
+    const int64_t mine2[2] = {cnt32[0], cnt32[1]};
+    std::vector<int64_t> pairs((size_t)world * 2, 0), counts((size_t)world, 0);
+    if (h.allgather(mine2, 16, pairs.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
     int64_t maxc = 0;
-    for (int64_t v : counts) maxc = std::max(maxc, v);
+    for (int r = 0; r < world; r++) { counts[r] = pairs[2 * (size_t)r]; maxc = std::max(maxc, counts[r]); if (aux_sum) *aux_sum += pairs[2 * (size_t)r + 1]; }
     h.xcalls++;
     if (maxc == 0) return 0;
     h.h_xsend.assign((size_t)maxc * rec, 0);
@@ -358,6 +365,37 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     // the scan (transform / host copy) was produced on the registration stream: an event, or -- immesh_process_scan's fused path -- a flag the first kernel polls
     if (!job.wait_flag) MHIPCHK(c, hipStreamWaitEvent(sa, job.ready, 0));
     int rc = 0;
+    if (m.shard_world > 1) {
+        // ---- sharded mesher.  Admission: the owner of a candidate's mesh-voxel brick tests it against the map and decides it; the ranks
+        // exchange only the boundary band (band survivors, then decisions: mesh_cand_pack_kernel) in rounds until nobody has an undecided candidate
+        // left -- two exchanges when no dependency chain crosses a brick face twice.  Then every rank commits the same new vertices (ids = the serial
+        // ones), searches / triangulates its own voxels, and the band of smoothed positions and triangle marks travels (mesh_pack_*_kernel).
+        launch_mesh_begin_scan(sa, m, h.h_dyn_dev[par], (unsigned long long)ccap);
+        launch_mesh_append_prepare(sa, m, sp.n_cand, d_pts);
+        for (int round = 0;; round++) {
+            if (round > 4096) { h.err = "sharded admission did not converge"; return IMMESH_E_HIP; }
+            MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
+            launch_mesh_cand_pack(sa, m, (MeshCdRec*)h.d_xsend, h.d_xcount);
+            int64_t undecided = 0;
+            if ((rc = mesh_exchange(c, sa, sizeof(MeshCdRec), [&](const void* d, int n) { launch_mesh_cand_unpack(sa, m, (const MeshCdRec*)d, n); }, &undecided))) return rc;
+            h.x_rounds++;
+            if (undecided == 0) break;
+            MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, sa));
+            launch_mesh_append_resolve(sa, m, sp.n_cand, d_pts, 4096);
+        }
+        if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
+        // exchange 1: this scan's smoothed positions (what correct_triangle_index reads across voxels); triangulate own voxels; exchange 2: triangle marks
+        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
+        launch_mesh_pack_smooth(sa, m, (MeshSmRec*)h.d_xsend, h.d_xcount);
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshSmRec), [&](const void* d, int n) { launch_mesh_unpack_smooth(sa, m, (const MeshSmRec*)d, n); }))) return rc;
+        if ((rc = mesh_enqueue_b(c, m, par, sa, 1))) return rc;
+        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
+        launch_mesh_pack_marks(sa, m, (MeshMkRec*)h.d_xsend, h.d_xcount);
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), [&](const void* d, int n) { launch_mesh_unpack_marks(sa, m, (const MeshMkRec*)d, n); }))) return rc;
+        if ((rc = mesh_enqueue_b(c, m, par, sa, 2))) return rc;
+        MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
+        return 0;
+    }
     if (sp.n_cand > 65536) {
         // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
         launch_mesh_begin_scan(sa, m, h.h_dyn_dev[par], (unsigned long long)ccap);
@@ -370,7 +408,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
             if (h.h_sc2[par][SC_UNDECIDED] == 0) break;
         }
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
-    } else if (h.use_graph && !h.prof.on && m.shard_world <= 1 && is_world) {
+    } else if (h.use_graph && !h.prof.on && is_world) {
         // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
         if (h.graph_ncand[par] != sp.n_cand) {
             for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
@@ -380,20 +418,6 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, nullptr, sp.n_cand, ccap, true); }))) return rc;
     } else {
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true))) return rc;
-    }
-    if (m.shard_world > 1) {
-        // owner-computes: phase A searched only this rank's voxels.  Exchange 1: this scan's smoothed positions (the boundary data
-        // correct_triangle_index reads across voxels); triangulate own voxels; exchange 2: triangle marks; then everybody commits the same diff.
-        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 4, sa));
-        launch_mesh_pack_smooth(sa, m, (MeshSmRec*)h.d_xsend, h.d_xcount);
-        if ((rc = mesh_exchange(c, sa, sizeof(MeshSmRec), [&](const void* d, int n) { launch_mesh_unpack_smooth(sa, m, (const MeshSmRec*)d, n); }))) return rc;
-        if ((rc = mesh_enqueue_b(c, m, par, sa, 1))) return rc;
-        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 4, sa));
-        launch_mesh_pack_marks(sa, m, (MeshMkRec*)h.d_xsend, h.d_xcount);
-        if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), [&](const void* d, int n) { launch_mesh_unpack_marks(sa, m, (const MeshMkRec*)d, n); }))) return rc;
-        if ((rc = mesh_enqueue_b(c, m, par, sa, 2))) return rc;
-        MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
-        return 0;
     }
     // (an event between the phases -- a poll at the head of phase B would hold LDS phase A's single-workgroup launch needs: measured deadlock --
     //  but none behind phase B: mesh_publish_kernel's ticket in pinned memory / the worker's poll)
@@ -421,12 +445,16 @@ static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes
     const int n_add = h.h_sc[SC_ADD], n_rem = h.h_sc[SC_REM], n_upd = h.h_sc[SC_UPD], n_smooth = h.h_sc[SC_SMOOTH];
     sizes.vtx_base = h.h_sc[SC_VTXBASE]; sizes.n_new_vtx = n_new; sizes.n_voxels_meshed = n_active;
     sizes.n_add = n_add; sizes.n_rem = n_rem; sizes.n_upd = n_upd; sizes.n_smooth = n_smooth; sizes.reserved = 0;
+    if (m.shard_world > 1) {   // the lists this rank REPORTS (triangles whose smallest vertex lies in its bricks); what it committed also covers its halo
+        sizes.n_add = h.h_sc[SC_ADD_OWN]; sizes.n_rem = h.h_sc[SC_REM_OWN]; sizes.n_upd = h.h_sc[SC_UPD_OWN];
+    }
+    h.fin_state[0] = n_add; h.fin_state[1] = n_rem; h.fin_state[2] = n_upd;
     h.n_vertices = sizes.vtx_base + n_new;
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
     h.cum[SC_RECENT] += n_cand;  // n_app: candidates offered
-    h.cum[SC_ADD] += n_add; h.cum[SC_REM] += n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
+    h.cum[SC_ADD] += sizes.n_add; h.cum[SC_REM] += sizes.n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
     h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
-    h.n_live += n_add - n_rem;
+    h.n_live += sizes.n_add - sizes.n_rem;   // (sharded: the triangles this rank reports -- the ranks' counts add up to the serial one)
     h.cum[SC_MAXNU] = std::max<int64_t>(h.cum[SC_MAXNU], h.h_sc[SC_MAXNU]); h.cum[SC_PASS2] += h.h_sc[SC_PASS2];
     if (m.dbg) {
         unsigned long long t[32];
@@ -501,6 +529,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             else {
                 f.r.ms = (float)((double)*(volatile unsigned long long*)(h.h_sc2[par] + MESH_PUB_TICKS) * 1e-5);   // (100 MHz ticks of the device's real-time counter)
                 f.r.rc = mesh_scan_finish(c, f.job, f.r.sizes);
+                f.r.st_add = h.fin_state[0]; f.r.st_rem = h.fin_state[1]; f.r.st_upd = h.fin_state[2];
                 if (f.r.rc) f.r.err = h.err;
             }
         } else {
@@ -723,6 +752,41 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
     }
     const MeshDev& m = c->mesh;
     hipStream_t s = h.stream_fetch;   // (the job has finished: nothing to order against; the scan thread may be enqueueing on its own streams meanwhile)
+    if (m.shard_world > 1) {
+        // sharded mesher: the device lists are what this rank COMMITTED (own bricks + halo), flagged entry by entry; the caller gets the entries
+        // this rank reports -- the union of the ranks' lists is the serial list
+        int st[3];
+        { std::lock_guard<std::mutex> lk(h.mu); const MeshResult& r = h.res[h.current & 1]; st[0] = r.st_add; st[1] = r.st_rem; st[2] = r.st_upd; }
+        const int32_t* d_tri[3] = {o.tri_add, o.tri_rem, o.tri_upd};
+        const uint8_t* d_flip[3] = {o.flip_add, nullptr, o.flip_upd};
+        const uint8_t* d_own[3] = {o.own_add, o.own_rem, o.own_upd};
+        int32_t* out_tri[3] = {tri_add, tri_rem, tri_upd};
+        uint8_t* out_flip[3] = {flip_add, nullptr, flip_upd};
+        const int want[3] = {z.n_add, z.n_rem, z.n_upd};
+        if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
+        if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, o.smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
+        if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, o.smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
+        std::vector<int32_t> tri; std::vector<uint8_t> flip, own;
+        for (int j = 0; j < 3; j++) {
+            if ((!out_tri[j] && !out_flip[j]) || st[j] <= 0) continue;
+            tri.resize((size_t)st[j] * 3); own.resize((size_t)st[j]); flip.resize((size_t)st[j]);
+            HIPCHK(c, hipMemcpyAsync(tri.data(), d_tri[j], (size_t)st[j] * 12, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(own.data(), d_own[j], (size_t)st[j], hipMemcpyDeviceToHost, s));
+            if (d_flip[j]) HIPCHK(c, hipMemcpyAsync(flip.data(), d_flip[j], (size_t)st[j], hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            int k = 0;
+            for (int e = 0; e < st[j]; e++) {
+                if (!own[(size_t)e]) continue;
+                if (k >= want[j]) { c->err = "sharded mesh fetch: more reported entries than counted"; return IMMESH_E_HIP; }
+                if (out_tri[j]) std::memcpy(out_tri[j] + (size_t)k * 3, &tri[(size_t)e * 3], 12);
+                if (out_flip[j]) out_flip[j][k] = flip[(size_t)e];
+                k++;
+            }
+            if (k != want[j]) { c->err = "sharded mesh fetch: fewer reported entries than counted"; return IMMESH_E_HIP; }
+        }
+        HIPCHK(c, hipStreamSynchronize(s));
+        return 0;
+    }
     if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
     if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, o.tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
     if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, o.flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));

@@ -26,6 +26,13 @@ using namespace imd;
 #define ST_UNDECIDED 0
 #define ST_ACCEPT 1
 #define ST_REJECT 2
+#define ST_WAIT 3            /* sharded admission: undecided, and what it waits for is another rank's decision (stalled until the next exchange) */
+// per-candidate flags of the sharded admission (MeshDev::cand_flags; zero for every candidate the rank knows nothing about)
+#define CF_OWN 1             /* this rank decides the candidate (its mesh voxel lies in one of the rank's bricks) */
+#define CF_BAND 2            /* ... and a candidate of another rank may lie within min_spacing of it */
+#define CF_SURV_SENT 4       /* announced to the other ranks as a survivor of the test against the map */
+#define CF_DEC_SENT 8        /* its decision has been sent */
+#define CF_KNOWN 16          /* another rank's band survivor, chained under its cell here */
 #define TRI_ADD_BIT 0x80000000u
 
 // x-major packing: ascending packed key == ascending (x,y,z), the order in which the CPU checker visits active voxels
@@ -35,10 +42,40 @@ IMD unsigned long long mkey(long x, long y, long z) {
 }
 IMD long rnd_cell(float p, double cell) { return (long)(int)round((double)p / cell); }  // std::round of the f64 quotient, pointcloud_rgbd.cpp:467-472
 // sharded mesher: mesh voxels are owned in bricks of 2^shard_brick_log2 voxels per axis, owner = hash(brick) mod world
-IMD int mesh_owner(const MeshDev& m, unsigned long long vkey) {
-    const long x = (long)((vkey >> 42) & MKEY_MASK) - MKEY_BIAS, y = (long)((vkey >> 21) & MKEY_MASK) - MKEY_BIAS, z = (long)(vkey & MKEY_MASK) - MKEY_BIAS;
+IMD int mesh_owner_xyz(const MeshDev& m, long x, long y, long z) {
     const int b = m.shard_brick_log2;
     return (int)(hash64(mkey(x >> b, y >> b, z >> b)) % (unsigned long long)m.shard_world);   // arithmetic shifts: bricks tile negative cells too
+}
+IMD int mesh_owner(const MeshDev& m, unsigned long long vkey) {
+    const long x = (long)((vkey >> 42) & MKEY_MASK) - MKEY_BIAS, y = (long)((vkey >> 21) & MKEY_MASK) - MKEY_BIAS, z = (long)(vkey & MKEY_MASK) - MKEY_BIAS;
+    return mesh_owner_xyz(m, x, y, z);
+}
+// The boundary band.  A box of mesh voxels [lo, hi] no wider than a brick touches at most 2 x 2 x 2 bricks -- those of its corners.
+//   box_foreign: does a brick of ANOTHER rank than `rank` touch the box?      box_has: does a brick of `rank` touch it?
+IMD bool box_foreign(const MeshDev& m, const long* lo, const long* hi, int rank) {
+    bool f = false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) f = f || mesh_owner_xyz(m, (q & 4) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 1) ? hi[2] : lo[2]) != rank;
+    return f;
+}
+IMD bool box_has(const MeshDev& m, const long* lo, const long* hi, int rank) {
+    bool f = false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) f = f || mesh_owner_xyz(m, (q & 4) ? hi[0] : lo[0], (q & 2) ? hi[1] : lo[1], (q & 1) ? hi[2] : lo[2]) == rank;
+    return f;
+}
+// a mesh voxel's reach: the vertices of its neighbourhood union lie within accept = 1.25 voxel of its own vertices, i.e. at most 2 voxel indices away
+// (mesh_rec_geometry.cpp:343) -- so what a voxel computes can matter to the voxels within +-2 of it, and only to them
+#define MV_REACH 2
+IMD void voxel_box(unsigned long long vkey, int h, long* lo, long* hi) {
+    const long x = (long)((vkey >> 42) & MKEY_MASK) - MKEY_BIAS, y = (long)((vkey >> 21) & MKEY_MASK) - MKEY_BIAS, z = (long)(vkey & MKEY_MASK) - MKEY_BIAS;
+    lo[0] = x - h; lo[1] = y - h; lo[2] = z - h; hi[0] = x + h; hi[1] = y + h; hi[2] = z + h;
+}
+// the mesh voxels a point within min_spacing of p can fall into (2 * min_spacing < voxel: two per axis at most)
+IMD void cand_box(const MeshDev& m, float px, float py, float pz, long* lo, long* hi) {
+    const float p[3] = {px, py, pz};
+#pragma unroll
+    for (int a = 0; a < 3; a++) { lo[a] = (long)round(((double)p[a] - m.min_spacing) / m.voxel); hi[a] = (long)round(((double)p[a] + m.min_spacing) / m.voxel); }
 }
 IMD int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 IMD void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -67,6 +104,38 @@ IMD long long h_find_or_insert(unsigned long long* keys, unsigned long long mask
         h = (h + 1) & mask;
     }
     return -1;
+}
+
+// ---- dedupe grid (m_hashmap_3d_pts): bricked open addressing, see MeshDev::g_ent
+IMD unsigned long long grid_home(const MeshDev& m, long gx, long gy, long gz) {
+    const unsigned long long region = hash64(mkey(gx >> 2, gy >> 2, gz >> 2)) & (m.g_mask >> 6);   // arithmetic shifts: bricks tile negative cells too
+    return (region << 6) | (unsigned long long)(((gx & 3) << 4) | ((gy & 3) << 2) | (gz & 3));
+}
+// continue the linear probe behind a home slot that holds another cell's entry
+IMD long long grid_find_from(const MeshDev& m, unsigned long long slot, unsigned long long key) {
+    for (int probe = 0; probe < 8192; probe++) {
+        slot = (slot + 1) & m.g_mask;
+        const unsigned long long k = m.g_ent[slot].key;
+        if (k == key) return (long long)slot;
+        if (k == MKEY_EMPTY) return -1;
+    }
+    return -1;
+}
+IMD long long grid_insert(const MeshDev& m, long gx, long gy, long gz, unsigned long long key) {
+    unsigned long long h = grid_home(m, gx, gy, gz);
+    for (int probe = 0; probe < 8192; probe++) {
+        const unsigned long long k = m.g_ent[h].key;
+        if (k == key) return (long long)h;
+        if (k == MKEY_EMPTY) {
+            const unsigned long long prev = atomicCAS(&m.g_ent[h].key, (unsigned long long)MKEY_EMPTY, key);
+            if (prev == MKEY_EMPTY || prev == key) return (long long)h;
+        }
+        h = (h + 1) & m.g_mask;
+    }
+    return -1;
+}
+IMD void mkey_unpack(unsigned long long k, long& x, long& y, long& z) {
+    x = (long)((k >> 42) & MKEY_MASK) - MKEY_BIAS; y = (long)((k >> 21) & MKEY_MASK) - MKEY_BIAS; z = (long)(k & MKEY_MASK) - MKEY_BIAS;
 }
 
 // float squared distance exactly as KD_TREE::calc_dist (include/ikd-Tree/ikd_Tree.cpp:1722-1728)
@@ -119,10 +188,25 @@ __global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __res
 // first kernel of a scan: takes the scan's parameters from pinned host memory (no separate copy node), clears the per-scan counters and the
 // candidate-cell table (no separate fill nodes: each of those ran as a ~5 us kernel of its own), and snapshots the vertex count -- the id of the
 // scan's first new vertex is the device's own count, so the host can enqueue a scan before the previous one has reported its size
+#define MV_FIN_CAND 16384
+// Admission order.  A scan's directions are not spatially ordered: in scan order every one of the 27 probes of every candidate was a line miss of its own
+// (32 MB of line traffic for 0.4 MB of entries).  mesh_begin_scan_kernel therefore drops every candidate into the bucket of the 8-cell (0.8 m) cube it
+// falls into -- MV_BIN_BUCKETS buckets of MV_BIN_SLOTS slots, one returning atomic per candidate, no prefix sum, no second pass; what does not fit its
+// bucket goes to an overflow list -- and mesh_append_prepare_kernel walks the slots: the lanes of a wavefront are the candidates of four cubes and
+// probe the SAME lines of the dedupe grid / the mesh-voxel hash.  The order only decides who probes what when; "lowest scan index wins" is settled by the
+// candidate indices themselves.  Offline-sized clouds (> MV_FIN_CAND candidates) keep scan order.
+#define MV_BIN_BUCKETS 2048
+#define MV_BIN_SLOTS 16
+#define MV_BIN_NSLOT (MV_BIN_BUCKETS * MV_BIN_SLOTS)
 __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const MeshDyn* __restrict__ h_dyn, unsigned long long ccap) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t k = i; k < ccap; k += stride) { m.ch_keys[k] = MKEY_EMPTY; m.ch_head[k] = -1; }
-    if (i == 0) {
+    // every candidate starts out rejected: the admission writes a candidate's records only when it survives the test against the map
+    // (n_cand <= ccap / 4 by construction of ccap)
+    for (size_t k = i; k < (size_t)min((unsigned long long)m.cap_cand, ccap >> 2); k += stride) { m.cand_status[k] = ST_REJECT; m.cand_flags[k] = 0; }
+    __shared__ MeshDyn s_dyn;
+    __shared__ int s_late;
+    if (threadIdx.x == 0) {   // every workgroup takes the scan's parameters from pinned host memory itself and waits for the scan itself
         MeshDyn d = *h_dyn;
         bool late = false;
         if (d.wait_flag) {   // the producer was enqueued before this launch; bounded all the same (~1 s) -- reported through the hang guard of the admission
@@ -132,13 +216,32 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
                 if (++spins > (1u << 20)) { late = true; break; }
             }
         }
-        *m.tick0 = __builtin_amdgcn_s_memrealtime();   // (behind the poll: the job's device time does not include waiting for the registration stream)
-        const int base = m.pc[PC_VERTS];
-        d.sp.vtx_base = base;
-        *m.dyn = d;
-        for (int k = 0; k < SC_COUNT; k++) m.sc[k] = 0;
-        m.sc[SC_VTXBASE] = base;
-        if (late) m.sc[SC_UNDECIDED] = 1;
+        s_dyn = d; s_late = late;
+        if (blockIdx.x == 0) {
+            *m.tick0 = __builtin_amdgcn_s_memrealtime();   // (behind the poll: the job's device time does not include waiting for the registration stream)
+            const int base = m.pc[PC_VERTS];
+            d.sp.vtx_base = base;
+            *m.dyn = d;
+            for (int k = 0; k < SC_COUNT; k++) m.sc[k] = 0;
+            m.sc[SC_VTXBASE] = base;
+            if (late) m.sc[SC_UNDECIDED] = 1;
+        }
+    }
+    __syncthreads();
+    const int n = s_dyn.sp.n_cand, step = s_dyn.sp.step;
+    const float* __restrict__ pts = s_dyn.pts;
+    int* __restrict__ cnt = m.bin_cnt + (s_dyn.seq & 1) * (MV_BIN_BUCKETS + 1);
+    int* __restrict__ cnt_next = m.bin_cnt + ((s_dyn.seq & 1) ^ 1) * (MV_BIN_BUCKETS + 1);
+    for (size_t k = i; k <= MV_BIN_BUCKETS; k += stride) cnt_next[k] = 0;   // the next scan's counters (this scan's were cleared by the previous one)
+    if (n > MV_FIN_CAND || pts == nullptr || s_late) return;
+    const float inv_coarse = (float)(1.0 / (8.0 * m.min_spacing));   // (the bucket only decides who sits beside whom in a wavefront: no exact rounding needed)
+    for (size_t c = i; c < (size_t)n; c += stride) {
+        const float4 p = *(const float4*)(pts + 4 * c * step);
+        const int qx = __float2int_rd(p.x * inv_coarse), qy = __float2int_rd(p.y * inv_coarse), qz = __float2int_rd(p.z * inv_coarse);
+        const int bk = (int)(((unsigned int)qx * 73856093u ^ (unsigned int)qy * 19349663u ^ (unsigned int)qz * 83492791u) & (MV_BIN_BUCKETS - 1));
+        const int r = atomicAdd(&cnt[bk], 1);
+        const int pos = r < MV_BIN_SLOTS ? bk * MV_BIN_SLOTS + r : MV_BIN_NSLOT + atomicAdd(&cnt[MV_BIN_BUCKETS], 1);
+        m.cand_pt[pos] = make_float4(p.x, p.y, p.z, __int_as_float((int)c));
     }
 }
 // last launch of a job: the per-scan counters, the job's device time and -- last -- its sequence number go to pinned host memory (the worker thread
@@ -156,80 +259,136 @@ __global__ void mesh_publish_kernel(MeshDev m_in, int32_t* __restrict__ host_sc)
 }
 void launch_mesh_publish(hipStream_t s, const MeshDev& m, int32_t* host_sc) { static_assert(SC_COUNT <= 64, "one wavefront publishes the counters"); KLAUNCH(mesh_publish_kernel, dim3(1), dim3(64), 0, s, m, host_sc); }
 void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dyn_dev, unsigned long long ccap) {
-    KLAUNCH(mesh_begin_scan_kernel, dim3(128), dim3(256), 0, s, m, h_dyn_dev, ccap);
+    KLAUNCH(mesh_begin_scan_kernel, dim3(64), dim3(256), 0, s, m, h_dyn_dev, ccap);
 }
 
 __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
     MESH_DYN(m_in);
     const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sp.n_cand) return;
-    const float* p = pts + 4 * (size_t)i * sp.step;
-    const float px = p[0], py = p[1], pz = p[2];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    // admission order: the slots of the 8-cell cubes, then the overflow list (mesh_begin_scan_kernel); offline-sized clouds: scan order
+    bool live;
+    int i = t;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sp.n_cand <= MV_FIN_CAND) {
+        const int* __restrict__ cnt = m.bin_cnt + (m.seq & 1) * (MV_BIN_BUCKETS + 1);
+        live = t < MV_BIN_NSLOT ? (t & (MV_BIN_SLOTS - 1)) < cnt[t / MV_BIN_SLOTS] : (t - MV_BIN_NSLOT) < min(cnt[MV_BIN_BUCKETS], m.cap_cand);
+        if (live) { pv = m.cand_pt[t]; i = __float_as_int(pv.w); }
+    } else {
+        live = t < sp.n_cand;
+        if (live) pv = *(const float4*)(pts + 4 * (size_t)t * sp.step);
+    }
+    const float px = pv.x, py = pv.y, pz = pv.z;
     const long gx = rnd_cell(px, m.min_spacing), gy = rnd_cell(py, m.min_spacing), gz = rnd_cell(pz, m.min_spacing);
     const long bx = rnd_cell(px, m.voxel), by = rnd_cell(py, m.voxel), bz = rnd_cell(pz, m.voxel);
-    // mesh voxel: find or create, mark visited (m_voxels_recent_visited, pointcloud_rgbd.cpp:480-500)
     const unsigned long long vkey = mkey(bx, by, bz);
-    bool created;
-    const long long vs = h_find_or_insert(m.x_keys, m.x_mask, vkey, &created);
-    int vi = -1;
-    if (vs < 0) { m.sc[SC_OVERFLOW] = 1; }
-    else if (created) {
-        vi = atomicAdd(&m.pc[PC_VOXELS], 1);
-        if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
-        else {
-            m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_stamp[vi] = m.seq;
-            m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
-            m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
-            __threadfence();
-            st_agent(&m.x_vals[vs], vi);
-        }
-    } else {
-        vi = ld_agent(&m.x_vals[vs]);  // -1 while the creating lane of this launch has not published it: the creator marks it visited
-        if (vi >= 0 && atomicExch(&m.vx_stamp[vi], m.seq) != m.seq) m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
-    }
-    m.cand_vox[i] = vi;
     const unsigned long long gkey = mkey(gx, gy, gz);
-    m.cand_cell[i] = gkey;
-    // existing vertices: occupied dedupe cell, or any vertex closer than min_spacing (1-NN test, pointcloud_rgbd.cpp:503-516).
-    // A vertex within min_spacing lies in one of the 27 cells around the candidate's cell and every cell holds at most one vertex
-    // (stored with its position in the hash entry), so the test is 27 independent probes: issued 9 at a time, one latency per batch.
+    // the 27 cells around the candidate lie in at most 2 x 2 x 2 bricks of the dedupe grid: eight brick hashes instead of 27 cell hashes
+    const long rbx = (gx - 1) >> 2, rby = (gy - 1) >> 2, rbz = (gz - 1) >> 2;
+    unsigned int rg[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) rg[q] = (unsigned int)(hash64(mkey(rbx + (q >> 2), rby + ((q >> 1) & 1), rbz + (q & 1))) & (m.g_mask >> 6));
+    auto cell_slot = [&](int dx, int dy, int dz) -> unsigned long long {
+        const long cx = gx + dx, cy = gy + dy, cz = gz + dz;
+        const int sel = (int)((((cx >> 2) - rbx) << 2) | (((cy >> 2) - rby) << 1) | ((cz >> 2) - rbz));
+        unsigned int r = rg[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) r = sel == q ? rg[q] : r;
+        return ((unsigned long long)r << 6) | (unsigned long long)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
+    };
+    // the candidate's own dedupe cell (occupied -> rejected before the 1-NN test, pointcloud_rgbd.cpp:480-500) is requested together with the first
+    // probe of the mesh-voxel hash: one round trip for both
+    const unsigned long long own_slot = cell_slot(0, 0, 0);
+    const unsigned long long own_k = live ? m.g_ent[own_slot].key : gkey;
+    // mesh voxel: find or create, mark visited (m_voxels_recent_visited, pointcloud_rgbd.cpp:480-500)
+    int vi = -1;
+    bool stamp = false;
+    if (live) {
+        bool created;
+        const long long vs = h_find_or_insert(m.x_keys, m.x_mask, vkey, &created);
+        if (vs < 0) { m.sc[SC_OVERFLOW] = 1; }
+        else if (created) {
+            vi = atomicAdd(&m.pc[PC_VOXELS], 1);
+            if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
+            else {
+                m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_stamp[vi] = m.seq;
+                m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
+                m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
+                __threadfence();
+                st_agent(&m.x_vals[vs], vi);
+            }
+        } else {
+            vi = ld_agent(&m.x_vals[vs]);  // -1 while the creating lane of this launch has not published it: the creator marks it visited
+            stamp = vi >= 0;
+        }
+    }
+    // visited mark: the lanes of a wavefront share a handful of voxels now -- one exchange per distinct voxel (not 64 on the same address), all of
+    // them in flight together
+    {
+        bool leader = false;
+        unsigned long long todo = __ballot(stamp);
+        while (todo) {
+            const int l = (int)__builtin_ctzll(todo);
+            const int lead_vi = __builtin_amdgcn_readlane(vi, l);
+            if (lane == l) leader = true;
+            todo &= ~__ballot(stamp && vi == lead_vi);
+        }
+        if (leader && atomicExch(&m.vx_stamp[vi], m.seq) != m.seq) m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
+    }
+    if (!live) return;
+    // sharded admission: every rank marks the voxels of ALL candidates visited (the voxel bookkeeping is replicated: 4 bytes per candidate), but only the
+    // owner of a candidate's mesh-voxel brick tests it against the map and decides it; everybody else hears of it only if it matters (pack / unpack below)
+    int cflags = 0;
+    if (m.shard_world > 1) {
+        if (mesh_owner(m, vkey) != m.shard_rank) return;
+        cflags = CF_OWN;
+    }
+    bool occupied = own_k == gkey;
+    if (!occupied && own_k != MKEY_EMPTY) occupied = grid_find_from(m, own_slot, gkey) >= 0;
+    if (occupied) return;                                    // (cand_status was preset to ST_REJECT by mesh_begin_scan_kernel)
+    // 1-NN test (pointcloud_rgbd.cpp:503-516): a vertex closer than min_spacing lies in one of the 26 other cells around the candidate's cell and every
+    // cell holds at most one vertex, stored with its position in the grid entry.  All 26 keys are requested at once (one round trip; the four cells
+    // of a z-row share a line), the records of the occupied ones in a second, shorter one (same lines).
+    unsigned long long k26[26];
+    unsigned int s26[26];
+#pragma unroll
+    for (int q = 0; q < 26; q++) {
+        const int c = q < 13 ? q : q + 1;   // skip the centre (13)
+        const unsigned long long sl = cell_slot(c / 9 - 1, (c / 3) % 3 - 1, c % 3 - 1);
+        s26[q] = (unsigned int)sl;
+        k26[q] = m.g_ent[sl].key;
+    }
     int status = ST_UNDECIDED;
     int probes = 0;
-    const float4* grec = (const float4*)m.g_rec;
-    for (int dx = -1; dx <= 1 && status == ST_UNDECIDED; dx++) {
-        unsigned long long key9[9], k9[9], h9[9];
-        float4 r9[9];
 #pragma unroll
-        for (int q = 0; q < 9; q++) {
-            key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
-            h9[q] = hash64(key9[q]) & m.g_mask;
-            k9[q] = m.g_keys[h9[q]];
-            r9[q] = grec[h9[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < 9; q++) {
-            float4 r = r9[q];
-            bool hit = (k9[q] == key9[q]);
-            if (!hit && k9[q] != MKEY_EMPTY) {  // displaced entry: continue the linear probe
-                const long long s2 = h_find(m.g_keys, m.g_mask, key9[q]);
-                if (s2 >= 0) { r = grec[s2]; hit = true; }
-            }
-            if (!hit) continue;
-            if (dx == 0 && q == 4) { status = ST_REJECT; continue; }  // the candidate's own cell is occupied
-            probes++;
-            if ((double)sqrtf(dist2f(px, py, pz, r.x, r.y, r.z)) < m.min_spacing) status = ST_REJECT;
-        }
+    for (int q = 0; q < 26; q++) {
+        if (k26[q] == MKEY_EMPTY) continue;
+        const int c = q < 13 ? q : q + 1;
+        const unsigned long long want = mkey(gx + (c / 9 - 1), gy + ((c / 3) % 3 - 1), gz + (c % 3 - 1));
+        long long slot = (long long)s26[q];
+        if (k26[q] != want) slot = grid_find_from(m, s26[q], want);   // displaced entry: continue the linear probe
+        if (slot < 0) continue;
+        const MeshGridEnt e = m.g_ent[slot];
+        probes++;
+        if ((double)sqrtf(dist2f(px, py, pz, e.x, e.y, e.z)) < m.min_spacing) status = ST_REJECT;
     }
     if (probes) atomicAdd(&m.sc[SC_C1], probes);
-    m.cand_next[i] = -1;
-    if (status == ST_UNDECIDED) {  // chain the survivor under its cell for the in-scan conflict resolution
-        bool c2;
-        const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
-        if (cs < 0) m.sc[SC_OVERFLOW] = 3;
-        else m.cand_next[i] = atomicExch(&m.ch_head[cs], i);
+    if (status != ST_UNDECIDED) return;
+    // survivor: its records, and the chain under its cell for the in-scan conflict resolution
+    if (cflags) {
+        long lo[3], hi[3];
+        cand_box(m, px, py, pz, lo, hi);
+        if (box_foreign(m, lo, hi, m.shard_rank)) cflags |= CF_BAND;
+        m.cand_flags[i] = cflags;
     }
-    m.cand_status[i] = status;
+    m.cand_vox[i] = vi;
+    m.cand_cell[i] = gkey;
+    bool c2;
+    const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
+    if (cs < 0) { m.sc[SC_OVERFLOW] = 3; m.cand_next[i] = -1; }
+    else m.cand_next[i] = atomicExch(&m.ch_head[cs], i);
+    st_agent(&m.cand_status[i], ST_UNDECIDED);
 }
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
@@ -238,6 +397,7 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
     MESH_DYN(m_in);
     const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool sharded = m.shard_world > 1;
     // Lanes of one wavefront may depend on each other, so the decision store must happen INSIDE the loop body and the loop must be left
     // by the whole wavefront together (__all): with a per-lane `return` the compiler may sink the store to the loop exit, which the
     // waiting lanes of the same wavefront would then never see.
@@ -245,7 +405,8 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
     float px = 0, py = 0, pz = 0;
     long gx = 0, gy = 0, gz = 0;
     unsigned long long own = 0;
-    if (i < sp.n_cand && ld_agent(&m.cand_status[i]) == ST_UNDECIDED) {
+    // (sharded: a rank decides only its own candidates; the other ranks' band survivors sit in the chains as undecided until their owners report)
+    if (i < sp.n_cand && ld_agent(&m.cand_status[i]) == ST_UNDECIDED && (!sharded || (m.cand_flags[i] & CF_OWN))) {
         my = ST_UNDECIDED;
         const float* p = pts + 4 * (size_t)i * sp.step;
         px = p[0]; py = p[1]; pz = p[2];
@@ -254,7 +415,7 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
     }
     for (int iter = 0; iter < max_iter; iter++) {
         if (my == ST_UNDECIDED) {
-            bool rej = false, blocked = false;
+            bool rej = false, blocked = false, blocked_remote = false;
             for (int dx = -1; dx <= 1 && !rej; dx++) {
                 unsigned long long key9[9], k9[9], h9[9];
                 int hd9[9];
@@ -276,19 +437,94 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
                         const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
                         if (j < i && sj != ST_REJECT) {
                             const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
-                            if (conflict) { if (sj == ST_ACCEPT) rej = true; else blocked = true; }
+                            if (conflict) {
+                                if (sj == ST_ACCEPT) rej = true;
+                                else if (sj == ST_WAIT || (sharded && !(m.cand_flags[j] & CF_OWN))) blocked_remote = true;   // nothing in THIS launch will decide j
+                                else blocked = true;
+                            }
                         }
                         j = nxt;
                     }
                 }
             }
-            if (rej) my = ST_REJECT; else if (!blocked) my = ST_ACCEPT;
+            if (rej) my = ST_REJECT; else if (!blocked && !blocked_remote) my = ST_ACCEPT; else if (!blocked) my = ST_WAIT;
             if (my != ST_UNDECIDED) st_agent(&m.cand_status[i], my);
         }
         if (__all(my != ST_UNDECIDED)) break;
         __builtin_amdgcn_s_sleep(2);
     }
     if (my == ST_UNDECIDED) atomicAdd(&m.sc[SC_UNDECIDED], 1);
+}
+
+// ---- sharded admission: what the ranks tell each other (SURVEY 8(e) "Mesh append": the boundary band) -------------------------------------------------
+// mesh_cand_pack_kernel    this rank's candidates that matter elsewhere and have not been sent yet: band survivors of the test against the map (as
+//                          UNDECIDED: the neighbours chain them), then decisions -- every ACCEPT (the 16-byte vertex commit is replicated on all ranks, so
+//                          ids stay the serial ones: "exclusive scan over ranks in scan-index order" is the prefix sum every rank runs over the same accept
+//                          flags) and the REJECTs of band survivors (they unblock the neighbours).  Rejections against the map and of interior survivors
+//                          never travel.  count[0] += records, count[1] += candidates this rank has still to decide.
+// mesh_cand_unpack_kernel  another rank's records: a band survivor that lies within min_spacing of one of this rank's bricks is chained under its cell;
+//                          decisions overwrite the status.
+__global__ __launch_bounds__(256) void mesh_cand_pack_kernel(MeshDev m_in, MeshCdRec* __restrict__ out, int32_t* __restrict__ count) {
+    MESH_DYN(m_in);
+    const int lane = threadIdx.x & 63;
+    for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < sp.n_cand; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + lane;
+        int send = -1, und = 0;
+        if (i < sp.n_cand) {
+            int f = m.cand_flags[i];
+            if (f & CF_OWN) {
+                int st = m.cand_status[i];
+                if (st == ST_WAIT) { st = ST_UNDECIDED; m.cand_status[i] = ST_UNDECIDED; }
+                if (st == ST_UNDECIDED) {
+                    und = 1;
+                    if ((f & CF_BAND) && !(f & CF_SURV_SENT)) { send = ST_UNDECIDED; f |= CF_SURV_SENT; }
+                } else if (!(f & CF_DEC_SENT) && (st == ST_ACCEPT || (f & CF_BAND))) { send = st; f |= CF_DEC_SENT | CF_SURV_SENT; }
+                if (send >= 0) m.cand_flags[i] = f;
+            }
+        }
+        const unsigned long long mask = __ballot(send >= 0), umask = __ballot(und != 0);
+        int base = 0;
+        if (lane == 0) {
+            if (mask) base = atomicAdd(&count[0], (int)__popcll(mask));
+            if (umask) atomicAdd(&count[1], (int)__popcll(umask));
+        }
+        base = __shfl(base, 0, 64);
+        if (send >= 0) {
+            const int pos = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < m.cap_list) { MeshCdRec r; r.i = i; r.status = send; out[pos] = r; } else m.sc[SC_OVERFLOW] = 14;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void mesh_cand_unpack_kernel(MeshDev m_in, const MeshCdRec* __restrict__ in, int n) {
+    MESH_DYN(m_in);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const MeshCdRec rec = in[k];
+    const int j = rec.i;
+    if (j < 0 || j >= sp.n_cand) return;
+    const float4 p = *(const float4*)(dyn_pts + 4 * (size_t)j * sp.step);
+    const unsigned long long gkey = mkey(rnd_cell(p.x, m.min_spacing), rnd_cell(p.y, m.min_spacing), rnd_cell(p.z, m.min_spacing));
+    const int f = m.cand_flags[j];
+    if (rec.status == ST_UNDECIDED) {
+        if (f & CF_KNOWN) return;
+        long lo[3], hi[3];
+        cand_box(m, p.x, p.y, p.z, lo, hi);
+        if (!box_has(m, lo, hi, m.shard_rank)) return;   // not within min_spacing of anything this rank decides
+        m.cand_flags[j] = CF_KNOWN;
+        m.cand_cell[j] = gkey; m.cand_vox[j] = -1;
+        bool c2;
+        const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
+        if (cs < 0) { m.sc[SC_OVERFLOW] = 3; m.cand_next[j] = -1; }
+        else m.cand_next[j] = atomicExch(&m.ch_head[cs], j);
+        st_agent(&m.cand_status[j], ST_UNDECIDED);
+    } else {
+        if (rec.status == ST_ACCEPT && !(f & CF_KNOWN)) { m.cand_cell[j] = gkey; m.cand_vox[j] = -1; }   // (what the replicated commit reads)
+        st_agent(&m.cand_status[j], rec.status);
+    }
+}
+void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count) { KLAUNCH(mesh_cand_pack_kernel, dim3(64), dim3(256), 0, s, m, out, count); }
+void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const MeshCdRec* in, int n) {
+    if (n > 0) KLAUNCH(mesh_cand_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
 }
 
 __global__ void mesh_append_flags_kernel(MeshDev m_in) {
@@ -324,10 +560,11 @@ __global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m_in, c
     }
     if (vi < 0) { m.sc[SC_OVERFLOW] = 5; return; }
     m.v_voxel[id] = vi;
-    bool created;
-    const long long gs = h_find_or_insert(m.g_keys, m.g_mask, m.cand_cell[i], &created);
+    long cgx, cgy, cgz;
+    mkey_unpack(m.cand_cell[i], cgx, cgy, cgz);
+    const long long gs = grid_insert(m, cgx, cgy, cgz, m.cand_cell[i]);
     if (gs < 0) { m.sc[SC_OVERFLOW] = 6; return; }
-    ((float4*)m.g_rec)[gs] = make_float4(px, py, pz, __int_as_float(id));
+    *(float4*)&m.g_ent[gs] = make_float4(px, py, pz, __int_as_float(id));
     const int pos = atomicAdd(&m.vx_npts[vi], 1);
     if (pos >= MV_VOX_CAP) { m.sc[SC_OVERFLOW] = 7; atomicSub(&m.vx_npts[vi], 1); return; }
     m.vx_pts[(size_t)vi * MV_VOX_CAP + pos] = id;
@@ -358,7 +595,6 @@ __global__ void mesh_select_active_kernel(MeshDev m_in) {
 // the active voxels (bitonic network in LDS) that defines "earlier / later voxel" for the order-dependent parts.  Every one of those launches
 // was a few microseconds of work behind ~5 us of launch latency on the mesher's phase-A chain.
 IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-#define MV_FIN_CAND 16384
 #define MV_FIN_ACT 8192        /* visited voxels whose selection + ordering run in LDS; more than that (sparse far-field scans) take the global arrays */
 // (~100 KB of static LDS for one workgroup: the 160 KB of a gfx950 CU -- the only target of this library, see the Makefile -- is assumed)
 __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
@@ -407,10 +643,11 @@ __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, 
         }
         if (vi < 0) { m.sc[SC_OVERFLOW] = 5; continue; }
         m.v_voxel[id] = vi;
-        bool created;
-        const long long gs = h_find_or_insert(m.g_keys, m.g_mask, m.cand_cell[i], &created);
+        long cgx, cgy, cgz;
+        mkey_unpack(m.cand_cell[i], cgx, cgy, cgz);
+        const long long gs = grid_insert(m, cgx, cgy, cgz, m.cand_cell[i]);
         if (gs < 0) { m.sc[SC_OVERFLOW] = 6; continue; }
-        ((float4*)m.g_rec)[gs] = make_float4(px, py, pz, __int_as_float(id));
+        *(float4*)&m.g_ent[gs] = make_float4(px, py, pz, __int_as_float(id));
         const int pos = atomicAdd(&m.vx_npts[vi], 1);
         if (pos >= MV_VOX_CAP) { m.sc[SC_OVERFLOW] = 7; atomicSub(&m.vx_npts[vi], 1); continue; }
         m.vx_pts[(size_t)vi * MV_VOX_CAP + pos] = id;
@@ -1274,6 +1511,7 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
         if (e & TRI_ADD_BIT) { m.t_flip[t] = fl; list_push(m, m.list_add, SC_ADD, t); }
         else if (m.t_flip[t] != fl) { m.t_flip[t] = fl; list_push(m, m.list_upd, SC_UPD, t); }
     }
+    if (m.shard_world > 1 && mesh_owner(m, m.vx_key[vi]) != m.shard_rank) continue;   // another rank's voxel: what this rank needs of it arrived by all-gather (below)
     const int np = m.rel_nq[r];   // the vertices the voxel held when phase A searched it (phase A of the next scan may be appending already)
     for (int k = lane; k < np; k += 64) {
         const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + k];
@@ -1283,18 +1521,45 @@ __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
         list_push(m, m.list_smooth, SC_SMOOTH, id);
     }
     }
+    if (m.shard_world > 1) {   // smoothed positions received from the other ranks (the band this rank's voxels can reach): committed, not reported
+        const int nrx = min(m.sc[SC_SMOOTH_RX], m.cap_list);
+        for (int k = blockIdx.x * 64 + lane; k < nrx; k += gridDim.x * 64) {
+            const int id = m.list_smooth_rx[k];
+            m.v_smooth[(size_t)id * 3 + 0] = m.v_smooth_new[(size_t)id * 3 + 0];
+            m.v_smooth[(size_t)id * 3 + 1] = m.v_smooth_new[(size_t)id * 3 + 1];
+            m.v_smooth[(size_t)id * 3 + 2] = m.v_smooth_new[(size_t)id * 3 + 2];
+        }
+    }
 }
 
 // =====================================================================================================================
 // sharded mesher: exchange records (see immesh_set_allgather)
 // =====================================================================================================================
+// Only the BOUNDARY BAND travels: what a voxel computes can matter to the voxels within MV_REACH of it, so a rank sends
+//   * the smoothed positions of a voxel it searched only when a brick of another rank lies within MV_REACH of the voxel,
+//   * a triangle mark only when a brick of another rank lies within MV_REACH of the voxel of one of the triangle's vertices
+// and a receiver keeps only what lies within MV_REACH of one of ITS bricks -- its triangle store and smoothed positions cover its bricks + halo.
+IMD bool vertex_near_foreign(const MeshDev& m, int vtx) {
+    long lo[3], hi[3];
+    voxel_box(m.vx_key[m.v_voxel[vtx]], MV_REACH, lo, hi);
+    return box_foreign(m, lo, hi, m.shard_rank);
+}
+IMD bool vertex_near_me(const MeshDev& m, int vtx) {
+    long lo[3], hi[3];
+    voxel_box(m.vx_key[m.v_voxel[vtx]], MV_REACH, lo, hi);
+    return box_has(m, lo, hi, m.shard_rank);
+}
 __global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, MeshSmRec* __restrict__ out, int32_t* __restrict__ count) {
     MESH_DYN(m_in);
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
         const int vi = m.act_vox_s[r];
-        if (mesh_owner(m, m.vx_key[vi]) != m.shard_rank) continue;
+        const unsigned long long vkey = m.vx_key[vi];
+        if (mesh_owner(m, vkey) != m.shard_rank) continue;
+        long lo[3], hi[3];
+        voxel_box(vkey, MV_REACH, lo, hi);
+        if (!box_foreign(m, lo, hi, m.shard_rank)) continue;   // interior voxel: nobody else reads its vertices' smoothed positions
         const int nq = m.rel_nq[r];
         int base = 0;
         if (lane == 0) base = atomicAdd(count, nq);
@@ -1313,7 +1578,9 @@ __global__ void mesh_unpack_smooth_kernel(MeshDev m, const MeshSmRec* __restrict
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const MeshSmRec rec = in[i];
+    if (!vertex_near_me(m, rec.id)) return;
     m.v_smooth_new[(size_t)rec.id * 3 + 0] = rec.x; m.v_smooth_new[(size_t)rec.id * 3 + 1] = rec.y; m.v_smooth_new[(size_t)rec.id * 3 + 2] = rec.z;
+    list_push(m, m.list_smooth_rx, SC_SMOOTH_RX, rec.id);
 }
 // blocks [0, n_active): the touched lists of the voxels this rank triangulated; the blocks after them: its removal marks
 __global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshMkRec* __restrict__ out, int32_t* __restrict__ count) {
@@ -1323,39 +1590,38 @@ __global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshM
     const int n_rem = min(m.sc[SC_REM], m.cap_list);
     const int n_rem_blocks = (n_rem + 63) / 64;
     for (int blk = blockIdx.x; blk < n_active + n_rem_blocks; blk += gridDim.x) {
+        int r = -1, nt = 0;
+        const int* touched = nullptr;
         if (blk < n_active) {
-            const int r = blk;
+            r = blk;
             const int vi = m.act_vox_s[r];
             if (mesh_owner(m, m.vx_key[vi]) != m.shard_rank) continue;
-            const int nt = m.vox_ntris[r];
-            const int* touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(count, nt);
-            base = __shfl(base, 0, 64);
-            for (int k = lane; k < nt; k += 64) {
-                if (base + k >= m.cap_list) { m.sc[SC_OVERFLOW] = 14; break; }
-                const unsigned int e = (unsigned int)touched[k];
-                const int t = (int)(e & 0x7FFFFFFFu);
-                MeshMkRec rec;
+            nt = m.vox_ntris[r];
+            touched = m.vox_tris + (size_t)r * (2 * MV_REL_CAP);
+        } else nt = min(64, n_rem - (blk - n_active) * 64);
+        for (int k0 = 0; k0 < nt; k0 += 64) {
+            const int k = k0 + lane;
+            bool send = false;
+            MeshMkRec rec;
+            rec.a = rec.b = rec.c = 0; rec.rk = -1; rec.word = 0;
+            if (k < nt) {
+                int t;
+                if (r >= 0) {
+                    const unsigned int e = (unsigned int)touched[k];
+                    t = (int)(e & 0x7FFFFFFFu);
+                    rec.rk = (r << 1) | ((e & TRI_ADD_BIT) ? 1 : 0);
+                    rec.word = m.t_word[t];   // this rank's maximum so far; the receivers max it with their own
+                } else t = m.list_rem[(blk - n_active) * 64 + k];
                 rec.a = m.t_v[(size_t)t * 3 + 0]; rec.b = m.t_v[(size_t)t * 3 + 1]; rec.c = m.t_v[(size_t)t * 3 + 2];
-                rec.rk = (r << 1) | ((e & TRI_ADD_BIT) ? 1 : 0);
-                rec.word = m.t_word[t];   // this rank's maximum so far; the receivers max it with their own
-                out[base + k] = rec;
+                send = vertex_near_foreign(m, rec.a) || vertex_near_foreign(m, rec.b) || vertex_near_foreign(m, rec.c);
             }
-        } else {
-            const int i = (blk - n_active) * 64 + lane;
-            const bool has = i < n_rem;
-            const unsigned long long mask = __ballot(has);
+            const unsigned long long mask = __ballot(send);
             int base = 0;
-            if (lane == 0) base = atomicAdd(count, (int)__popcll(mask));
+            if (lane == 0 && mask) base = atomicAdd(count, (int)__popcll(mask));
             base = __shfl(base, 0, 64);
-            if (has && base + lane >= m.cap_list) m.sc[SC_OVERFLOW] = 14;
-            else if (has) {
-                const int t = m.list_rem[i];
-                MeshMkRec rec;
-                rec.a = m.t_v[(size_t)t * 3 + 0]; rec.b = m.t_v[(size_t)t * 3 + 1]; rec.c = m.t_v[(size_t)t * 3 + 2];
-                rec.rk = -1; rec.word = 0;
-                out[base + lane] = rec;
+            if (send) {
+                const int pos = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < m.cap_list) out[pos] = rec; else m.sc[SC_OVERFLOW] = 14;
             }
         }
     }
@@ -1365,6 +1631,7 @@ __global__ void mesh_unpack_marks_kernel(MeshDev m_in, const MeshMkRec* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const MeshMkRec rec = in[i];
+    if (!(vertex_near_me(m, rec.a) || vertex_near_me(m, rec.b) || vertex_near_me(m, rec.c))) return;   // out of this rank's bricks + halo: never queried here
     int spare = -1;
     const int t = tri_find_or_insert(m, rec.a, rec.b, rec.c, &spare);
     if (t < 0) return;
@@ -1516,6 +1783,13 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int 
         out_tri[(size_t)rank * 3 + 0] = (int)(r.k0 >> 32); out_tri[(size_t)rank * 3 + 1] = (int)(unsigned int)(r.k0 & 0xFFFFFFFFull); out_tri[(size_t)rank * 3 + 2] = (int)(r.k1 >> 32);
         if (out_flip) out_flip[rank] = (uint8_t)m.t_flip[t];
         if (job == 1) add_sorted[rank] = t;
+        if (m.shard_world > 1) {
+            // sharded mesher: every rank that holds the triangle commits the change; the rank owning the voxel of its SMALLEST vertex reports it --
+            // the union of the ranks' result lists is the serial list, every entry exactly once
+            const bool mine = mesh_owner(m, m.vx_key[m.v_voxel[(int)(r.k0 >> 32)]]) == m.shard_rank;
+            (job == 0 ? m.out_own_rem : (job == 1 ? m.out_own_add : m.out_own_upd))[rank] = mine ? 1 : 0;
+            if (mine) atomicAdd(&m.sc[job == 0 ? SC_REM_OWN : (job == 1 ? SC_ADD_OWN : SC_UPD_OWN)], 1);
+        }
     } else if (job == 3) {
         const int id = (int)(unsigned int)r.k0;
         m.out_smooth_ids[rank] = id;
@@ -1592,7 +1866,7 @@ void launch_mesh_transform(hipStream_t s, const float* raw_xyzi, float* world_xy
 }
 // n_cand only sizes the grids here; the kernels take every per-scan value from MeshDev::dyn
 void launch_mesh_append_prepare(hipStream_t s, const MeshDev& m, int n_cand, const float* pts) {
-    KLAUNCH(mesh_append_prepare_kernel, g1(n_cand), dim3(256), 0, s, m, pts);
+    KLAUNCH(mesh_append_prepare_kernel, g1(n_cand <= MV_FIN_CAND ? MV_BIN_NSLOT + n_cand : n_cand), dim3(256), 0, s, m, pts);
 }
 void launch_mesh_append_resolve(hipStream_t s, const MeshDev& m, int n_cand, const float* pts, int max_iter) {
     KLAUNCH(mesh_append_resolve_kernel, g1(n_cand), dim3(256), 0, s, m, pts, max_iter);
@@ -1613,7 +1887,7 @@ void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_
 __global__ void mesh_export_faces_kernel(MeshDev m, int32_t* __restrict__ tri_idx, int32_t* __restrict__ count) {
     const int nt = m.pc[PC_TRIS];
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x)
-        if (m.t_live[t]) tri_idx[atomicAdd(count, 1)] = t;
+        if (m.t_live[t] && (m.shard_world <= 1 || mesh_owner(m, m.vx_key[m.v_voxel[m.t_v[(size_t)t * 3]]]) == m.shard_rank)) tri_idx[atomicAdd(count, 1)] = t;
 }
 __global__ void mesh_export_wind_kernel(MeshDev m, const int32_t* __restrict__ tri_sorted, int n, int32_t* __restrict__ faces) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -32,6 +32,8 @@
 enum {
     SC_UNDECIDED = 0, SC_ACCEPTED, SC_RECENT, SC_ACTIVE, SC_ADD, SC_REM, SC_UPD, SC_SMOOTH, SC_OVERFLOW, SC_C1, SC_C20, SC_NV, SC_NU, SC_TV, SC_MAXNU, SC_PASS2,
     SC_VTXBASE,      /* vertex count when the scan started (the id of its first new vertex) */
+    SC_ADD_OWN, SC_REM_OWN, SC_UPD_OWN,   /* sharded mesher: entries of the result lists this rank REPORTS (the lists it commits also hold its halo) */
+    SC_SMOOTH_RX,    /* sharded mesher: smoothed positions received from other ranks this scan */
     SC_COUNT = 24
 };
 // persistent device counters (MeshDev::pc)
@@ -40,6 +42,7 @@ enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
 #define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
 struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; int cs[LS_JOBS]; };   // cs: chunk size of the job
 
+struct MeshGridEnt { float x, y, z; int32_t id; unsigned long long key; unsigned long long pad; };   // 32 B; key == ~0: empty
 struct MeshScanParams {
     double cam[3];
     int32_t n_raw, step, n_cand, vtx_base;
@@ -58,8 +61,10 @@ struct MeshDyn {
 struct MeshDev {
     // vertices
     float* v_pos; double* v_smooth; double* v_smooth_new; int32_t* v_voxel;
-    // dedupe grid hash
-    unsigned long long* g_keys; float* g_rec; uint64_t g_mask;   // g_rec: 16 B per slot = vertex xyz + id (one probe yields the position)
+    // dedupe grid hash: 32-byte entries {vertex xyz + id, cell key}; the home slot of a cell is (hash(brick of 4x4x4 cells) << 6) | (cell within the
+    // brick, z fastest), linear probing from there -- the four cells of a z-row share one 128-byte line, so the 27-cell probe of a candidate touches
+    // ~13 lines instead of 54 (key and record of every cell in lines of their own) and candidates of one neighbourhood touch the SAME lines
+    MeshGridEnt* g_ent; uint64_t g_mask;
     // mesh voxels
     unsigned long long* x_keys; int32_t* x_vals; uint64_t x_mask;
     unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
@@ -72,12 +77,17 @@ struct MeshDev {
     int32_t* sc; int32_t* pc;
     // per-scan scratch
     int32_t* cand_status; int32_t* cand_vox; unsigned long long* cand_cell; int32_t* cand_next; int32_t* cand_rank;
+    int32_t* cand_flags;                                                   // sharded admission (CF_* of mesh_kernels.hip)
+    int32_t* bin_cnt;                                                      // admission order: 2 parities x (bucket fill counts + overflow count)
+    float4* cand_pt;                                                       // the candidates (xyz, scan index in w) in admission order: bucketed by 8-cell cube (mesh_begin_scan_kernel)
     unsigned long long* ch_keys; int32_t* ch_head; uint64_t ch_mask;       // candidate-cell chains
     int32_t* recent;                                                       // voxel indices visited this scan
     unsigned long long* act_key; int32_t* act_vox; unsigned long long* act_key_s; int32_t* act_vox_s;
     int32_t* rel_ids; int32_t* rel_n; int32_t* rel_nq;                     // [n_active][MV_REL_CAP], [n_active], [n_active] (vertices the voxel held when it was searched)
     int32_t* vox_tris; int32_t* vox_ntris;                                 // [n_active][2*MV_REL_CAP] triangle ids touched (bit 31 = add)
     int32_t* list_add; int32_t* list_rem; int32_t* list_upd; int32_t* list_smooth;   // unsorted unique lists
+    int32_t* list_smooth_rx;                                               // sharded mesher: vertices whose smoothed positions arrived from other ranks
+    uint8_t* out_own_add; uint8_t* out_own_rem; uint8_t* out_own_upd;      // sharded mesher: 1 = this rank reports the entry of the sorted list
     // sorted outputs
     int32_t* out_tri_add; uint8_t* out_flip_add; int32_t* out_tri_rem; int32_t* out_tri_upd; uint8_t* out_flip_upd; int32_t* out_smooth_ids;
     double* out_smooth_xyz;
@@ -103,6 +113,7 @@ struct MeshDev {
 // worker thread drives a second HIP stream, strictly in submission order (the sequential-deterministic frame order of the checker).
 // exchange records of the sharded mesher: this scan's smoothed positions of the vertices of the voxels a rank meshed, and the
 // triangle marks its triangulations produced (rk = (voxel rank << 1) | add, word = the rank's current flip word; rk = -1: removal mark)
+struct MeshCdRec { int32_t i, status; };          // sharded admission: candidate (scan index) + ST_UNDECIDED (band survivor) / ST_ACCEPT / ST_REJECT
 struct MeshSmRec { int32_t id, pad; double x, y, z; };
 struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 #define MESH_WORLD_BUFS 4
@@ -110,8 +121,10 @@ struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 #define MESH_PUB_TICKS (SC_COUNT + 2)   /* 64-bit: device time of the job, 100 MHz ticks */
 #define MESH_PUB_WORDS (SC_COUNT + 8)
 struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; const unsigned long long* wait_flag = nullptr; unsigned long long wait_seq = 0; };
-struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz; };
-struct MeshResult { immesh_mesh_sizes_t sizes; int rc = 0; std::string err; float ms = 0.f; long id = 0; const float* d_pts = nullptr; int n_raw = 0; };
+struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz;
+                    uint8_t* own_add; uint8_t* own_rem; uint8_t* own_upd; };
+struct MeshResult { immesh_mesh_sizes_t sizes; int st_add = 0, st_rem = 0, st_upd = 0;   /* sharded: lengths of the committed lists (sizes = the reported parts) */
+                    int rc = 0; std::string err; float ms = 0.f; long id = 0; const float* d_pts = nullptr; int n_raw = 0; };
 
 struct MeshHost {
     int32_t seq = 0;
@@ -172,6 +185,8 @@ struct MeshHost {
     size_t xcap_bytes = 0;
     std::vector<char> h_xsend, h_xrecv;
     int64_t xbytes_sent = 0, xcalls = 0;     // cumulative exchange volume of this rank (payload bytes, collective calls)
+    int64_t x_rounds = 0;                    // cumulative admission exchange rounds (>= 1 per scan; 2 when no dependency chain crosses a brick face twice)
+    int fin_state[3] = {0, 0, 0};            // committed list lengths of the job being finished (sharded: sizes carry the reported parts)
     KProf prof;                              // kernels launched by the worker thread
     std::string err;                         // worker-side error text (moved into the MeshResult of the failing job)
 };
@@ -193,6 +208,8 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
+void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count);   // count: [0] records, [1] candidates still undecided here
+void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const MeshCdRec* in, int n);
 void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count);
 void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const MeshSmRec* in, int n);
 void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count);

@@ -115,21 +115,26 @@ def test_two_rank_register_matches_unsharded():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# sharded mesher: owner-computes kNN + Delaunay per mesh-voxel brick, all-gather of smoothed vertices and triangle marks
+# sharded mesher: owner-computed admission + kNN + Delaunay per mesh-voxel brick; only the boundary band travels (band survivors /
+# decisions of the admission, smoothed positions and triangle marks within reach of another rank's brick); every rank reports the triangles whose
+# smallest vertex lies in its bricks -- the UNION of the ranks' result lists must be the unsharded lists, every entry exactly once
 # ---------------------------------------------------------------------------------------------------------------------
-def _mesh_cfg(rank=0, world=0):
+MESH_KEYS = ("new_vtx", "tri_add", "flip_add", "tri_rem", "tri_upd", "flip_upd", "smooth_ids", "smooth_xyz")
+
+
+def _mesh_cfg(rank=0, world=0, brick_log2=2):
     return capi.avia_config(cap_root_voxels=1 << 14, cap_scan_points=200000, cap_vertices=1 << 17, cap_triangles=1 << 19,
-                            shard_rank=rank, shard_world=world, shard_brick_log2=2, shard_mesh=1 if world > 1 else 0)   # 4-voxel (1.6 m) bricks
+                            shard_rank=rank, shard_world=world, shard_brick_log2=brick_log2, shard_mesh=1 if world > 1 else 0)   # 4-voxel (1.6 m) bricks by default
 
 
-def _mesh_rank_main(rank, world, port, out):
+def _mesh_rank_main(rank, world, port, out, brick_log2, n_scans):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo")
     lib = capi.load_hip_library()
-    h = capi.HotPath(lib, _mesh_cfg(rank, world), "immesh_")
+    h = capi.HotPath(lib, _mesh_cfg(rank, world, brick_log2), "immesh_")
 
     def allgather(send, recv):
         parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
@@ -140,43 +145,72 @@ def _mesh_rank_main(rank, world, port, out):
     ref = capi.HotPath(lib, _mesh_cfg(), "immesh_") if rank == 0 else None
     cfg = _mesh_cfg()
     extT = np.array(list(cfg.extT)); extR = np.array(list(cfg.extR)).reshape(3, 3)
-    same = True
-    n_tri = 0
-    for k in range(4):
+    for k in range(n_scans):
         R, t = synth.trajectory_pose(k)
         raw = synth.livox_scan(k, R, t, n_pts=40000, extT=extT)
         world_pts = raw.copy()
         world_pts[:, :3] = ((raw[:, :3].astype(np.float64) @ extR.T + extT) @ R.T + t).astype(np.float32)
         m = h.mesh_scan(world_pts, t, frame_idx=k)
+        out[(rank, k)] = {key: np.array(m[key]) for key in MESH_KEYS}
         if ref:
             mr = ref.mesh_scan(world_pts, t, frame_idx=k)
-            for key in ("new_vtx", "tri_add", "flip_add", "tri_rem", "tri_upd", "flip_upd", "smooth_ids", "smooth_xyz"):
-                same = same and np.array_equal(m[key], mr[key])
-            n_tri += len(mr["tri_add"])
-        out[(rank, k)] = (len(m["new_vtx"]), len(m["tri_add"]), len(m["tri_rem"]), int(m["tri_add"].sum()) if len(m["tri_add"]) else 0)
+            out[("ref", k)] = {key: np.array(mr[key]) for key in MESH_KEYS}
     cnt = h.counters()
-    out[(rank, "cnt")] = (cnt["n_u"], cnt["n_vertices"], cnt["n_triangles_live"], ref.counters()["n_u"] if ref else 0)
+    out[(rank, "cnt")] = (cnt["n_u"], cnt["n_vertices"], cnt["n_triangles_live"])
+    if ref:
+        rc = ref.counters()
+        out[("ref", "cnt")] = (rc["n_u"], rc["n_vertices"], rc["n_triangles_live"])
     out[(rank, "traffic")] = h.shard_traffic()
-    out[(rank, "same")] = (same, n_tri)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_mesher_matches_unsharded():
+def _lex(tri, flip=None):
+    """rows of tri (n x 3) in lexicographic order, with their flips"""
+    tri = np.asarray(tri).reshape(-1, 3)
+    order = np.lexsort((tri[:, 2], tri[:, 1], tri[:, 0])) if len(tri) else np.zeros(0, int)
+    return tri[order], (np.asarray(flip)[order] if flip is not None else None)
+
+
+@pytest.mark.parametrize("world,brick_log2", [(2, 2), (4, 2), (2, 3)])
+def test_sharded_mesher_union_of_rank_lists_is_the_unsharded_result(world, brick_log2):
     import torch.multiprocessing as mp
-    port = 29900 + (os.getpid() % 90)
+    n_scans = 4
+    port = 29900 + (os.getpid() % 90) + world
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_mesh_rank_main, args=(2, port, out), nprocs=2, join=True)
-    same, n_tri = out[(0, "same")]
-    assert same and n_tri > 5000                                 # rank 0: every result list bit-identical to the unsharded mesher
-    for k in range(4):
-        assert out[(0, k)] == out[(1, k)]                       # both ranks commit the same diff
-    nu0, nv0, nl0, nu_ref = out[(0, "cnt")]
-    nu1, nv1, nl1, _ = out[(1, "cnt")]
-    assert nv0 == nv1 and nl0 == nl1
-    assert nu0 > 0 and nu1 > 0 and nu0 + nu1 == nu_ref            # each rank searched / triangulated only its own voxels; together: all of them
-    assert out[(0, "traffic")]["bytes"] > 0 and out[(1, "traffic")]["bytes"] > 0 and out[(0, "traffic")]["calls"] == 4 * 4
+    mp.spawn(_mesh_rank_main, args=(world, port, out, brick_log2, n_scans), nprocs=world, join=True)
+    n_tri = 0
+    shares = np.zeros(world)
+    for k in range(n_scans):
+        ref = out[("ref", k)]
+        parts = [out[(r, k)] for r in range(world)]
+        for p_ in parts:                                           # the vertex commit is replicated: same ids, same positions on every rank
+            np.testing.assert_array_equal(p_["new_vtx"], ref["new_vtx"], err_msg=f"scan {k} new_vtx")
+        for tri_key, flip_key in (("tri_add", "flip_add"), ("tri_rem", None), ("tri_upd", "flip_upd")):
+            tri = np.concatenate([np.asarray(p_[tri_key]).reshape(-1, 3) for p_ in parts])
+            flip = np.concatenate([np.asarray(p_[flip_key]).reshape(-1) for p_ in parts]) if flip_key else None
+            tri_s, flip_s = _lex(tri, flip)
+            np.testing.assert_array_equal(tri_s, np.asarray(ref[tri_key]).reshape(-1, 3), err_msg=f"scan {k} {tri_key}")   # same triangles, none twice
+            if flip_key:
+                np.testing.assert_array_equal(flip_s, np.asarray(ref[flip_key]).reshape(-1), err_msg=f"scan {k} {flip_key}")
+        ids = np.concatenate([np.asarray(p_["smooth_ids"]).reshape(-1) for p_ in parts])
+        xyz = np.concatenate([np.asarray(p_["smooth_xyz"]).reshape(-1, 3) for p_ in parts])
+        order = np.argsort(ids, kind="stable")
+        np.testing.assert_array_equal(ids[order], ref["smooth_ids"], err_msg=f"scan {k} smooth_ids")
+        np.testing.assert_array_equal(xyz[order], np.asarray(ref["smooth_xyz"]).reshape(-1, 3), err_msg=f"scan {k} smooth_xyz")
+        n_tri += len(ref["tri_add"])
+        shares += [len(p_["tri_add"]) for p_ in parts]
+    assert n_tri > 5000
+    assert (shares > 0).all()                                      # every rank reported part of the mesh
+    nu_ref, nv_ref, nl_ref = out[("ref", "cnt")]
+    cnts = [out[(r, "cnt")] for r in range(world)]
+    assert all(c[1] == nv_ref for c in cnts)                       # every rank knows every vertex (replicated 16-byte commit)
+    assert sum(c[0] for c in cnts) == nu_ref                       # each voxel searched / triangulated on exactly one rank
+    assert sum(c[2] for c in cnts) == nl_ref                       # live triangles: the ranks' reported parts add up
+    for r in range(world):
+        tr = out[(r, "traffic")]
+        assert tr["bytes"] > 0 and tr["calls"] >= 2 * 4 * n_scans   # >= 2 admission rounds + smoothed band + mark band per scan, two calls each
 
 
 def test_rccl_inside_the_library_world_size_one(hip_lib):
