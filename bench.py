@@ -274,11 +274,12 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         cfg = capi.velodyne_config(device=local, cap_root_voxels=1 << 18, cap_scan_points=400_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
     else:
         # sharded map: a rank keeps its bricks plus the one-voxel halo (~20 % at 32^3-voxel bricks) -> capacity per rank, not per job
-        share = (1.5 / world) if sharded else 1.0
+        bv = float(1 << args.brick_log2)
+        share = (max(1.5, 1.25 * ((bv + 2.0) / bv) ** 2) / world) if sharded else 1.0   # owned bricks + their one-voxel halo (surfaces: ~((B + 2) / B)^2)
         cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=2_500_000,
                                cap_vertices=1 << 24, cap_triangles=1 << 25)
     if sharded:
-        cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, 5, 1 if args.mesh else 0
+        cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, args.brick_log2, 1 if args.mesh else 0
     h = capi.HotPath(hip, cfg, "immesh_")
     comm = "none"
     if sharded:
@@ -455,6 +456,15 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
            "cpu_inputs": (cfg, cpu_raws, cpu_downs, R0, t0, seed_cloud) if not (args.gpu_scans and not kitti) else None}
     if sharded:
         res["shard_traffic"] = h.shard_traffic()
+        if rank == 0 and not kitti:
+            # who does how much: the share of every scan's down-sampled points (the matcher's and the map update's work) per rank, for 8^3 / 16^3 / 32^3
+            # voxel bricks -- the job runs at the pace of the rank with the LARGEST share (rank 0's share says nothing)
+            extR_np = np.array(list(cfg.extR)).reshape(3, 3)
+            clouds = []
+            for kk in range(1 + args.warmup, 1 + args.warmup + args.steps):
+                Rk, tk = synth.trajectory_pose(idx[kk])
+                clouds.append((downs[kk][:, :3].astype(np.float64) @ extR_np.T + extT_np) @ Rk.T + tk)
+            res["load_balance"] = D.load_balance(clouds, cfg.voxel_size, world)
 
     # ---- instrumented legs (roofline): the SAME context continues the SAME stream -- same map, same mesh map, scans right after the timed
     # ones.  (a) serial per-stage times, profiler off; (b) HIP events around every launch on the library's own streams.  Run by main() under a
@@ -601,22 +611,34 @@ def dry_run_leg(args, torch, hip, dev, local):
     the data-path collectives stubbed (immesh_stub_collectives).  Reported: the root voxels / HBM bytes of the share and the rank's time per scan: the
     W-rank rate is bounded by the slowest rank's time plus the (latency-bound, < 0.1 ms) collectives -- a prediction until a node exists."""
     W, r = args.dry_run_world, args.dry_run_rank
-    cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * 1.5 / W) + (1 << 16), cap_scan_points=2_500_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
-    cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = r, W, 5, 1 if args.mesh else 0
+    bv = float(1 << args.brick_log2)
+    share = max(1.5, 1.25 * ((bv + 2.0) / bv) ** 2) / W
+    mk = lambda rr_: capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=2_500_000, cap_vertices=1 << 24, cap_triangles=1 << 25,
+                                      shard_rank=max(rr_, 0), shard_world=W, shard_brick_log2=args.brick_log2, shard_mesh=1 if args.mesh else 0)
+    extT = np.array(list(mk(0).extT)); extR = np.array(list(mk(0).extR)).reshape(3, 3)
+    n_total = args.warmup + args.steps
+    # the scan stream first (down-sampled by a plain context): the per-rank shares of its points decide WHICH rank is the slowest one of the job
+    h0 = capi.HotPath(hip, capi.avia_config(device=local, cap_root_voxels=1 << 12, cap_scan_points=2_500_000, cap_vertices=1 << 12, cap_triangles=1 << 12), "immesh_")
+    d_raw, downs_h, n_ds, clouds = [], [], [], []
+    for kk in range(n_total + 1):
+        Rk, tk = synth.trajectory_pose(kk)
+        rr = livox_scan_torch(torch, dev, kk, Rk, tk, args.pts, extT)
+        dn, _ = h0.downsample(rr.data_ptr(), 0.4, n=rr.shape[0], stride=4, to_host=True)
+        d_raw.append(rr); downs_h.append(dn); n_ds.append(len(dn))
+        if kk > args.warmup:
+            clouds.append((dn[:, :3].astype(np.float64) @ extR.T + extT) @ Rk.T + tk)
+    h0.close()
+    balance = D.load_balance(clouds, mk(0).voxel_size, W)
+    if r < 0:
+        r = balance[int(bv)]["busiest_rank"]     # --dry-run-rank -2: the rank with the largest share of the stream's points = the one the job waits for
+    cfg = mk(r)
     h = capi.HotPath(hip, cfg, "immesh_")
     h.stub_collectives()
     side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0
     t0 = time.time()
-    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)      # (a rank keeps ~1.2 / W of the voxels: the loop runs through every strip of the square)
+    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)      # (a rank keeps its bricks + halo: the loop runs through every strip of the square)
     t_map = time.time() - t0
-    extT = np.array(list(cfg.extT))
-    n_total = args.warmup + args.steps
-    d_raw, d_down, n_ds = [], [], []
-    for kk in range(n_total + 1):
-        Rk, tk = synth.trajectory_pose(kk)
-        rr = livox_scan_torch(torch, dev, kk, Rk, tk, args.pts, extT)
-        dn, _ = h.downsample(rr.data_ptr(), 0.4, n=rr.shape[0], stride=4, to_host=True)
-        d_raw.append(rr); d_down.append(torch.from_numpy(dn).to(dev)); n_ds.append(len(dn))
+    d_down = [torch.from_numpy(dn).to(dev) for dn in downs_h]
     R0, t0_ = synth.trajectory_pose(0)
     st = capi.make_state(R=R0, t=t0_)
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
@@ -642,7 +664,8 @@ def dry_run_leg(args, torch, hip, dev, local):
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"ONE rank (rank {r} of {W}) of the sharded job on one GPU, collectives stubbed: {args.pts}-pt scans, {int(args.map_voxels)}-root-voxel survey",
                       "n_raw": int(d_raw[1].shape[0]), "n_ds_mean": round(float(np.mean(n_ds[1:])), 1), "map_root_voxels": int(n_map), "params": "config/avia.yaml",
-                      "parallelism": f"dry run of rank {r} of {W}: brick ownership + 1-voxel halo, sharded mesher; all-reduce / all-gather replaced by local no-ops"},
+                      "parallelism": f"dry run of rank {r} of {W} (the rank with the largest share of the stream's points): {int(bv)}^3-voxel bricks + 1-voxel halo, sharded mesher; all-reduce / all-gather replaced by local no-ops"},
+           "load_balance_point_share_per_brick_size": balance,
            "share": {"root_voxels_kept_by_this_rank": int(n_map), "of_total_surveyed": int(args.map_voxels), "device_bytes_allocated": int(h.device_bytes()),
                      "map_build_seconds": round(t_map, 1), "matches_per_scan_on_this_rank": round(cnt["n_match"] / max(1, cnt["n_iter"]) , 1)},
            "pose_err_m": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))}
@@ -677,6 +700,8 @@ def main():
     ap.add_argument("--nu-scans", type=int, default=5, help="scans after the timed region whose per-voxel neighbourhood sizes n_u are collected (histogram + kernel shares)")
     ap.add_argument("--dry-run-rank", type=int, default=-1, help=">= 0: run ONE rank of a --dry-run-world job alone on this GPU with stubbed collectives (configs[4] capacity / per-rank time)")
     ap.add_argument("--dry-run-world", type=int, default=8)
+    ap.add_argument("--brick-log2", type=int, default=3, help="sharded runs: voxel bricks of 2^k voxels per axis are the unit of ownership (registration map and mesher); 3 = 8^3 (SURVEY 8(e)): "
+                    "a scan's footprint spans hundreds of bricks, so the ranks' shares of a scan stay close to 1/N; 5 = 32^3 (rounds 1-3: a handful of bricks per scan)")
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
     ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
@@ -704,7 +729,7 @@ def main():
     only_sharded = bool(args.shard) and world > 1
     kitti = args.config == "velodyne"
     hip = capi.load_hip_library()
-    if args.dry_run_rank >= 0:
+    if args.dry_run_rank >= 0 or args.dry_run_rank == -2:
         return dry_run_leg(args, torch, hip, dev, local)
 
     res = measure(args, torch, D, dist, hip, rank, world, local, dev, sharded=only_sharded, full=True)
@@ -762,7 +787,7 @@ def main():
             "config": {"workload": (("synthetic KITTI-shaped HDL-64 scan stream (velodyne.yaml), " if kitti else "synthetic Livox-Avia 100k-pt/scan stream, ") +
                                     ("full pipeline (registration + map update + voxel meshing)" if args.mesh else "registration + map update, meshing off")),
                        "n_raw": res["n_raw"], "n_ds_mean": round(res["n_ds_mean"], 1), "map_root_voxels": res["n_map"], "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
-                       "parallelism": (f"one stream; registration map sharded over {world} GPUs (brick ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (replicated vertex admission, owner-computes kNN + Delaunay, all-gather of smoothed vertices and triangle marks); collectives: {res['comm']}" if only_sharded
+                       "parallelism": (f"one stream; registration map sharded over {world} GPUs in {1 << args.brick_log2}^3-voxel bricks (ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (owner-computed vertex admission + kNN + Delaunay; all-gathers of the boundary band only: band candidates / decisions, smoothed positions and triangle marks within reach of another rank's brick; every rank reports its own part of the result lists); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
                        "mesh_map": ("pre-seeded from a dense survey of the stream's corridor (SURVEY 8(d) C3)" if (args.dense_mesh and args.mesh and not kitti and not only_sharded) else "seeded by scan 0 only") if args.mesh else "none",
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
@@ -779,6 +804,9 @@ def main():
             out["collectives"] = res["comm"]
         if res.get("shard_traffic"):
             out["exchange_bytes_per_scan_rank0"] = round(res["shard_traffic"]["bytes"] / max(1, args.steps + args.warmup + 1), 1)
+            out["exchange_calls_per_scan"] = round(res["shard_traffic"]["calls"] / max(1, args.steps + args.warmup + 1), 2)
+        if res.get("load_balance"):
+            out["load_balance_point_share_per_brick_size"] = res["load_balance"]
         if args.profile_scans > 0:   # until the live leg has delivered: the committed rocprofv3 average of the dominant kernel with this run's own counters
             out["roofline"] = add_traffic(roofline_from_committed_profile(args.mesh, cnt, args.steps, args.pts, "not run yet"))
     threading.Thread(target=watchdog, daemon=True).start()
@@ -812,7 +840,7 @@ def main():
                                                                        "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")}
         cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", str(world), "--shard", "1", "--backend", args.backend, "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--pts", str(args.pts), "--map-voxels", str(args.map_voxels), "--mesh", str(args.mesh), "--config", args.config, "--cpu-seconds", "0", "--profile-scans", "0",
-               "--extra-configs", "0"]
+               "--extra-configs", "0", "--brick-log2", str(args.brick_log2)]
         try:
             r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1.5 * args.profile_timeout, text=True)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -820,7 +848,19 @@ def main():
                 d = json.loads(lines[-1])
                 out["sharded"] = {"value": d["value"], "unit": d["unit"], "scaling": d["scaling"], "ms_per_step": d["ms_per_step"], "parallelism": d["config"]["parallelism"],
                                   "collectives": d.get("collectives"), "map_root_voxels_rank0": d["config"]["map_root_voxels"], "exchange_bytes_per_scan_rank0": d.get("exchange_bytes_per_scan_rank0"),
-                                  "pose_err_m": d["pose_err_m"], "how": "child job of the same N ranks, launched by rank 0 after the replica headline"}
+                                  "exchange_calls_per_scan": d.get("exchange_calls_per_scan"), "load_balance_point_share_per_brick_size": d.get("load_balance_point_share_per_brick_size"),
+                                  "pose_err_m": d["pose_err_m"], "how": "child job of the same N ranks, launched by rank 0 after the replica leg"}
+                # THE HEADLINE FOR N > 1 IS THE SHARDED JOB (north star: ONE scan stream, voxels sharded by spatial hash over the GPUs: strong scaling of the
+                # metric's workload); the independent replicas measured above move to `replicas`.  Only if the sharded job fails does the line keep the
+                # replica numbers (then it says so: "scaling": "weak" + `sharded.error`).
+                out["replicas"] = {"value": out["value"], "unit": out["unit"], "scaling": "weak", "ms_per_step": out["ms_per_step"], "parallelism": out["config"]["parallelism"],
+                                   "scan_thread_ms": out["scan_thread_ms"], "pose_err_m": out["pose_err_m"], "mesh_mode": out["config"]["mesh_mode"]}
+                out["value"], out["ms_per_step"], out["scaling"], out["pose_err_m"] = d["value"], d["ms_per_step"], "strong", d["pose_err_m"]
+                out["scan_thread_ms"] = d.get("scan_thread_ms")
+                out["counters_per_scan"] = d.get("counters_per_scan", out["counters_per_scan"])
+                for kk_ in ("parallelism", "mesh_mode", "mesh_map", "map_root_voxels"):
+                    out["config"][kk_] = d["config"][kk_]
+                out["config"]["map_root_voxels_note"] = "rank 0's share (owned bricks + halo) of the 10 M-voxel survey"
             else:
                 out["sharded"] = {"error": f"rc {r.returncode}: " + (r.stderr or "")[-300:]}
         except Exception as e:   # noqa: BLE001
@@ -841,7 +881,7 @@ def main():
                              ("full pipeline THROUGH THE DROP-IN SHIM (what an unchanged ImMesh_node.cpp sees: pcl host clouds in, lists fetched, Triangle_manager / Global_map mirrors applied)", ["--dropin-shim", "1"]),
                              ("full pipeline, mesh map seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)", ["--dense-mesh", "0"]),
                              ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
-                             ("configs[4] dry run: rank 0 of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "0", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
+                             ("configs[4] dry run: the busiest rank of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "-2", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
@@ -856,6 +896,7 @@ def main():
                                                         "reference_threading": cb["reference_threading"], "sample": cb["sample"]}
                     if d.get("share"):
                         extra[label]["share"] = d["share"]
+                        extra[label]["load_balance_point_share_per_brick_size"] = d.get("load_balance_point_share_per_brick_size")
                     if d.get("drop_in_shim"):
                         extra[label]["drop_in_shim"] = d["drop_in_shim"]
                     for kk_ in ("n_u", "mesh_seed", "counters_per_scan"):

@@ -45,14 +45,14 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.v_pos, cap_verts * 3); A(m.v_smooth, cap_verts * 3); A(m.v_smooth_new, cap_verts * 3); A(m.v_voxel, cap_verts);
     const int64_t gcap = np2(cap_verts * 2), xcap = np2(cap_voxels * 2), tcap = np2(cap_tris * 2), ccap = np2(cap_cand * 4);
     A(m.g_ent, gcap); m.g_mask = (uint64_t)gcap - 1;
-    A(m.x_keys, xcap); A(m.x_vals, xcap); m.x_mask = (uint64_t)xcap - 1;
+    A(m.x_ent, xcap); m.x_mask = (uint64_t)xcap - 1;
     A(m.vx_key, cap_voxels); A(m.vx_npts, cap_voxels); A(m.vx_pts, cap_voxels * MV_VOX_CAP); A(m.vx_meshing_times, cap_voxels);
     A(m.vx_new_added, cap_voxels); A(m.vx_stamp, cap_voxels); A(m.vx_rank, cap_voxels); A(m.vx_rank_seq, cap_voxels); A(m.vx_short_axis, cap_voxels * 3);
     A(m.t_v, cap_tris * 3); A(m.t_word, cap_tris); A(m.t_live, cap_tris); A(m.t_rem_seq, cap_tris); A(m.t_flip, cap_tris);
     A(m.th_slots, tcap); m.th_mask = (uint64_t)tcap - 1;
     A(m.a_head, cap_verts); A(m.a_chunks, cap_adj * MV_ADJ_STRIDE);
     A(m.sc, SC_COUNT); A(m.pc, PC_COUNT);
-    A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand); A(m.cand_pt, cap_cand + 32768); A(m.cand_flags, cap_cand); A(m.bin_cnt, 2 * (2048 + 1));
+    A(m.cand_status, cap_cand); A(m.cand_vox, cap_cand); A(m.cand_cell, cap_cand); A(m.cand_next, cap_cand); A(m.cand_rank, cap_cand); A(m.cand_pt, cap_cand + 32768); A(m.cand_flags, cap_cand); A(m.bin_cnt, 2 * (1024 + 1));
     A(m.ch_keys, ccap); A(m.ch_head, ccap);
     A(m.recent, cap_cand);
     int64_t cap_active_p2 = 1; while (cap_active_p2 < cap_active) cap_active_p2 <<= 1;   // mesh_append_finish_kernel's ordering network pads to a power of two
@@ -91,15 +91,14 @@ int mesh_alloc(immesh_ctx* c) {
     m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
     m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
     m.dbg = nullptr;
-    if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 32))) return rc; m.dbg = t; (void)hipMemset(t, 0, 256); }
+    if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 64))) return rc; m.dbg = t; (void)hipMemset(t, 0, 512); }
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemsetAsync(m.g_ent, 0xFF, (size_t)gcap * sizeof(MeshGridEnt), s));   // (key == ~0: empty)
-    launch_fill_u64(s, m.x_keys, ~0ull, (size_t)xcap);
-    HIPCHK(c, hipMemsetAsync(m.x_vals, 0xFF, (size_t)xcap * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.x_ent, 0xFF, (size_t)xcap * sizeof(MeshVoxEnt), s));   // (key == ~0: empty, val == -1)
     HIPCHK(c, hipMemsetAsync(m.th_slots, 0xFF, (size_t)tcap * 4, s));
     HIPCHK(c, hipMemsetAsync(m.a_head, 0xFF, (size_t)cap_verts * 4, s));
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
-    HIPCHK(c, hipMemsetAsync(m.bin_cnt, 0, 2 * (2048 + 1) * 4, s));
+    HIPCHK(c, hipMemsetAsync(m.bin_cnt, 0, 2 * (1024 + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
     if (m.shard_world > 1) {   // exchange staging of the sharded mesher
         h.xcap_bytes = (size_t)cap_list * sizeof(MeshSmRec);
@@ -457,8 +456,13 @@ static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes
     h.n_live += sizes.n_add - sizes.n_rem;   // (sharded: the triangles this rank reports -- the ranks' counts add up to the serial one)
     h.cum[SC_MAXNU] = std::max<int64_t>(h.cum[SC_MAXNU], h.h_sc[SC_MAXNU]); h.cum[SC_PASS2] += h.h_sc[SC_PASS2];
     if (m.dbg) {
-        unsigned long long t[32];
-        (void)hipMemcpy(t, m.dbg, 256, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 256);
+        unsigned long long t[64];
+        (void)hipMemcpy(t, m.dbg, 512, hipMemcpyDeviceToHost); (void)hipMemset(m.dbg, 0, 512);
+        {
+            const unsigned long long nw = std::max(1ull, t[39]);
+            fprintf(stderr, "[append_prepare cycles/wavefront] until candidate %llu | index %llu voxel %llu own+leader %llu 1-NN batches %llu chain %llu | slowest workgroup %llu | wavefront rounds %llu + %llu overflow\n",
+                    t[37] / std::max(1ull, t[40] + t[41]), t[32] / nw, t[33] / nw, t[34] / nw, t[35] / nw, t[36] / nw, t[38], t[40], t[41]);
+        }
         fprintf(stderr, "[delaunay64 cycles/voxel] cavity %llu edges %llu extras %llu inplace %llu filter+emit %llu | sums %llu jacobi %llu proj %llu | points %llu bails %llu\n", t[16] / std::max(1, n_active),
                 t[17] / std::max(1, n_active), t[18] / std::max(1, n_active), t[19] / std::max(1, n_active), t[20] / std::max(1, n_active), t[24] / std::max(1, n_active), t[25] / std::max(1, n_active),
                 t[26] / std::max(1, n_active), t[15], t[7]);

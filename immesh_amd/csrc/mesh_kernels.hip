@@ -111,8 +111,9 @@ IMD unsigned long long grid_home(const MeshDev& m, long gx, long gy, long gz) {
     const unsigned long long region = hash64(mkey(gx >> 2, gy >> 2, gz >> 2)) & (m.g_mask >> 6);   // arithmetic shifts: bricks tile negative cells too
     return (region << 6) | (unsigned long long)(((gx & 3) << 4) | ((gy & 3) << 2) | (gz & 3));
 }
-// continue the linear probe behind a home slot that holds another cell's entry
-IMD long long grid_find_from(const MeshDev& m, unsigned long long slot, unsigned long long key) {
+// continue the linear probe behind a home slot that holds another cell's entry (rare: a real call, not 27 inlined copies of the loop -- the admission
+// kernel is latency-bound code that has to stay in the instruction cache)
+__device__ __noinline__ long long grid_find_from(const MeshDev& m, unsigned long long slot, unsigned long long key) {
     for (int probe = 0; probe < 8192; probe++) {
         slot = (slot + 1) & m.g_mask;
         const unsigned long long k = m.g_ent[slot].key;
@@ -136,6 +137,34 @@ IMD long long grid_insert(const MeshDev& m, long gx, long gy, long gz, unsigned 
 }
 IMD void mkey_unpack(unsigned long long k, long& x, long& y, long& z) {
     x = (long)((k >> 42) & MKEY_MASK) - MKEY_BIAS; y = (long)((k >> 21) & MKEY_MASK) - MKEY_BIAS; z = (long)(k & MKEY_MASK) - MKEY_BIAS;
+}
+
+// ---- mesh-voxel hash (m_hashmap_voxels): 16-byte entries {key, voxel index}: one round trip per lookup
+IMD int vox_find(const MeshDev& m, unsigned long long key) {   // voxel index, or -1 (no such voxel / being created in this launch)
+    unsigned long long h = hash64(key) & m.x_mask;
+    for (int probe = 0; probe < 8192; probe++) {
+        const MeshVoxEnt e = m.x_ent[h];
+        if (e.key == key) return e.val;
+        if (e.key == MKEY_EMPTY) return -1;
+        h = (h + 1) & m.x_mask;
+    }
+    return -1;
+}
+// slot of the key (inserted when absent: *created); *val = the index stored there (-1: not published yet); -1: table full
+IMD long long vox_find_or_insert(const MeshDev& m, unsigned long long key, bool* created, int* val) {
+    unsigned long long h = hash64(key) & m.x_mask;
+    *created = false; *val = -1;
+    for (int probe = 0; probe < 8192; probe++) {
+        const MeshVoxEnt e = m.x_ent[h];
+        if (e.key == key) { *val = e.val; return (long long)h; }
+        if (e.key == MKEY_EMPTY) {
+            const unsigned long long prev = atomicCAS(&m.x_ent[h].key, (unsigned long long)MKEY_EMPTY, key);
+            if (prev == MKEY_EMPTY) { *created = true; return (long long)h; }
+            if (prev == key) { *val = ld_agent(&m.x_ent[h].val); return (long long)h; }
+        }
+        h = (h + 1) & m.x_mask;
+    }
+    return -1;
 }
 
 // float squared distance exactly as KD_TREE::calc_dist (include/ikd-Tree/ikd_Tree.cpp:1722-1728)
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256) void mesh_transform_kernel(const float4* __res
 // bucket goes to an overflow list -- and mesh_append_prepare_kernel walks the slots: the lanes of a wavefront are the candidates of four cubes and
 // probe the SAME lines of the dedupe grid / the mesh-voxel hash.  The order only decides who probes what when; "lowest scan index wins" is settled by the
 // candidate indices themselves.  Offline-sized clouds (> MV_FIN_CAND candidates) keep scan order.
-#define MV_BIN_BUCKETS 2048
+#define MV_BIN_BUCKETS 1024
 #define MV_BIN_SLOTS 16
 #define MV_BIN_NSLOT (MV_BIN_BUCKETS * MV_BIN_SLOTS)
 __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const MeshDyn* __restrict__ h_dyn, unsigned long long ccap) {
@@ -230,9 +259,7 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
     __syncthreads();
     const int n = s_dyn.sp.n_cand, step = s_dyn.sp.step;
     const float* __restrict__ pts = s_dyn.pts;
-    int* __restrict__ cnt = m.bin_cnt + (s_dyn.seq & 1) * (MV_BIN_BUCKETS + 1);
-    int* __restrict__ cnt_next = m.bin_cnt + ((s_dyn.seq & 1) ^ 1) * (MV_BIN_BUCKETS + 1);
-    for (size_t k = i; k <= MV_BIN_BUCKETS; k += stride) cnt_next[k] = 0;   // the next scan's counters (this scan's were cleared by the previous one)
+    int* __restrict__ cnt = m.bin_cnt;   // (zero: cleared by the previous scan's mesh_knn_kernel)
     if (n > MV_FIN_CAND || pts == nullptr || s_late) return;
     const float inv_coarse = (float)(1.0 / (8.0 * m.min_spacing));   // (the bucket only decides who sits beside whom in a wavefront: no exact rounding needed)
     for (size_t c = i; c < (size_t)n; c += stride) {
@@ -262,71 +289,52 @@ void launch_mesh_begin_scan(hipStream_t s, const MeshDev& m, const MeshDyn* h_dy
     KLAUNCH(mesh_begin_scan_kernel, dim3(64), dim3(256), 0, s, m, h_dyn_dev, ccap);
 }
 
-__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
-    MESH_DYN(m_in);
-    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    // admission order: the slots of the 8-cell cubes, then the overflow list (mesh_begin_scan_kernel); offline-sized clouds: scan order
-    bool live;
-    int i = t;
-    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (sp.n_cand <= MV_FIN_CAND) {
-        const int* __restrict__ cnt = m.bin_cnt + (m.seq & 1) * (MV_BIN_BUCKETS + 1);
-        live = t < MV_BIN_NSLOT ? (t & (MV_BIN_SLOTS - 1)) < cnt[t / MV_BIN_SLOTS] : (t - MV_BIN_NSLOT) < min(cnt[MV_BIN_BUCKETS], m.cap_cand);
-        if (live) { pv = m.cand_pt[t]; i = __float_as_int(pv.w); }
-    } else {
-        live = t < sp.n_cand;
-        if (live) pv = *(const float4*)(pts + 4 * (size_t)t * sp.step);
-    }
-    const float px = pv.x, py = pv.y, pz = pv.z;
+// One candidate: mesh voxel found / created + marked visited, test against the map (own dedupe cell, then the 1-NN test over the 26 cells around it),
+// survivors chained under their cell.  Every lane of the wavefront calls it (dead lanes with live = false: the visited marks are agreed wave-wide).
+// Returns the number of vertices the 1-NN test inspected; *visit_new = a voxel this lane is the first to visit this scan (-1: none).
+// The code is kept SMALL on purpose (the dx loop is rolled, the displaced-entry probe is a call): every wavefront runs it exactly once, so what it costs
+// is instruction fetch -- a fully unrolled version (all 26 keys in one round trip, 50 KB of code) took 60 us where this one takes a third of it.
+#define ADBG(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m.dbg[32 + (k)], _t - tprev); tprev = _t; } } while (0)
+IMD int mesh_admit_candidate(const MeshDev& m, bool live, int i, float px, float py, float pz, int lane, int* visit_new) {
+    *visit_new = -1;
+    unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
     const long gx = rnd_cell(px, m.min_spacing), gy = rnd_cell(py, m.min_spacing), gz = rnd_cell(pz, m.min_spacing);
     const long bx = rnd_cell(px, m.voxel), by = rnd_cell(py, m.voxel), bz = rnd_cell(pz, m.voxel);
     const unsigned long long vkey = mkey(bx, by, bz);
     const unsigned long long gkey = mkey(gx, gy, gz);
-    // the 27 cells around the candidate lie in at most 2 x 2 x 2 bricks of the dedupe grid: eight brick hashes instead of 27 cell hashes
-    const long rbx = (gx - 1) >> 2, rby = (gy - 1) >> 2, rbz = (gz - 1) >> 2;
-    unsigned int rg[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) rg[q] = (unsigned int)(hash64(mkey(rbx + (q >> 2), rby + ((q >> 1) & 1), rbz + (q & 1))) & (m.g_mask >> 6));
-    auto cell_slot = [&](int dx, int dy, int dz) -> unsigned long long {
-        const long cx = gx + dx, cy = gy + dy, cz = gz + dz;
-        const int sel = (int)((((cx >> 2) - rbx) << 2) | (((cy >> 2) - rby) << 1) | ((cz >> 2) - rbz));
-        unsigned int r = rg[0];
-#pragma unroll
-        for (int q = 1; q < 8; q++) r = sel == q ? rg[q] : r;
-        return ((unsigned long long)r << 6) | (unsigned long long)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
-    };
-    // the candidate's own dedupe cell (occupied -> rejected before the 1-NN test, pointcloud_rgbd.cpp:480-500) is requested together with the first
-    // probe of the mesh-voxel hash: one round trip for both
-    const unsigned long long own_slot = cell_slot(0, 0, 0);
+    const unsigned long long rmask = m.g_mask >> 6;
+    // round trip 1: the candidate's own dedupe cell (occupied -> rejected before the 1-NN test, pointcloud_rgbd.cpp:480-500) + the first probe of the
+    // mesh-voxel hash
+    const unsigned long long own_slot = ((hash64(mkey(gx >> 2, gy >> 2, gz >> 2)) & rmask) << 6) | (unsigned long long)(((gx & 3) << 4) | ((gy & 3) << 2) | (gz & 3));
     const unsigned long long own_k = live ? m.g_ent[own_slot].key : gkey;
+    ADBG(0);   // index arithmetic
     // mesh voxel: find or create, mark visited (m_voxels_recent_visited, pointcloud_rgbd.cpp:480-500)
     int vi = -1;
     bool stamp = false;
     if (live) {
         bool created;
-        const long long vs = h_find_or_insert(m.x_keys, m.x_mask, vkey, &created);
-        if (vs < 0) { m.sc[SC_OVERFLOW] = 1; }
+        int found;
+        const long long vs = vox_find_or_insert(m, vkey, &created, &found);
+        if (vs < 0) m.sc[SC_OVERFLOW] = 1;
         else if (created) {
             vi = atomicAdd(&m.pc[PC_VOXELS], 1);
             if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
             else {
                 m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_stamp[vi] = m.seq;
                 m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
-                m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
+                *visit_new = vi;
                 __threadfence();
-                st_agent(&m.x_vals[vs], vi);
+                st_agent(&m.x_ent[vs].val, vi);
             }
         } else {
-            vi = ld_agent(&m.x_vals[vs]);  // -1 while the creating lane of this launch has not published it: the creator marks it visited
+            vi = found;  // -1 while the creating lane of this launch has not published it: the creator marks it visited
             stamp = vi >= 0;
         }
     }
-    // visited mark: the lanes of a wavefront share a handful of voxels now -- one exchange per distinct voxel (not 64 on the same address), all of
-    // them in flight together
+    ADBG(1);   // voxel hash: probe + index
+    // visited mark: the lanes of a wavefront share a handful of voxels -- one exchange per distinct voxel (not 64 on the same address), all in flight together
+    bool leader = false;
     {
-        bool leader = false;
         unsigned long long todo = __ballot(stamp);
         while (todo) {
             const int l = (int)__builtin_ctzll(todo);
@@ -334,53 +342,66 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
             if (lane == l) leader = true;
             todo &= ~__ballot(stamp && vi == lead_vi);
         }
-        if (leader && atomicExch(&m.vx_stamp[vi], m.seq) != m.seq) m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vi;
-    }
-    if (!live) return;
-    // sharded admission: every rank marks the voxels of ALL candidates visited (the voxel bookkeeping is replicated: 4 bytes per candidate), but only the
-    // owner of a candidate's mesh-voxel brick tests it against the map and decides it; everybody else hears of it only if it matters (pack / unpack below)
-    int cflags = 0;
-    if (m.shard_world > 1) {
-        if (mesh_owner(m, vkey) != m.shard_rank) return;
-        cflags = CF_OWN;
     }
     bool occupied = own_k == gkey;
     if (!occupied && own_k != MKEY_EMPTY) occupied = grid_find_from(m, own_slot, gkey) >= 0;
-    if (occupied) return;                                    // (cand_status was preset to ST_REJECT by mesh_begin_scan_kernel)
-    // 1-NN test (pointcloud_rgbd.cpp:503-516): a vertex closer than min_spacing lies in one of the 26 other cells around the candidate's cell and every
-    // cell holds at most one vertex, stored with its position in the grid entry.  All 26 keys are requested at once (one round trip; the four cells
-    // of a z-row share a line), the records of the occupied ones in a second, shorter one (same lines).
-    unsigned long long k26[26];
-    unsigned int s26[26];
-#pragma unroll
-    for (int q = 0; q < 26; q++) {
-        const int c = q < 13 ? q : q + 1;   // skip the centre (13)
-        const unsigned long long sl = cell_slot(c / 9 - 1, (c / 3) % 3 - 1, c % 3 - 1);
-        s26[q] = (unsigned int)sl;
-        k26[q] = m.g_ent[sl].key;
-    }
-    int status = ST_UNDECIDED;
+    // (issued behind the call above -- a call waits for everything outstanding -- and looked at behind the 1-NN test: it shares the first batch's round trip)
+    int old_stamp = m.seq;
+    if (leader) old_stamp = atomicExch(&m.vx_stamp[vi], m.seq);
+    ADBG(2);   // leader election + own cell
+    // sharded admission: every rank marks the voxels of ALL candidates visited (the voxel bookkeeping is replicated: 4 bytes per candidate), but only the
+    // owner of a candidate's mesh-voxel brick tests it against the map and decides it; everybody else hears of it only if it matters
+    // (mesh_cand_pack_kernel / mesh_cand_unpack_kernel)
+    const bool probe = live && !occupied && (m.shard_world <= 1 || mesh_owner(m, vkey) == m.shard_rank);
+    int status = probe ? ST_UNDECIDED : ST_REJECT;
     int probes = 0;
+    // 1-NN test (pointcloud_rgbd.cpp:503-516): a vertex closer than min_spacing lies in one of the 26 other cells around the candidate's cell and every
+    // cell holds at most one vertex, stored with its position in the grid entry (key and record in ONE 32-byte entry; the four cells of a z-row share
+    // a line).  Nine cells per round trip; a candidate is out as soon as one is too close.
+    const long rby = (gy - 1) >> 2, rbz = (gz - 1) >> 2;
+    for (int dx = -1; dx <= 1; dx++) {
+        if (!__any(status == ST_UNDECIDED)) break;
+        if (status != ST_UNDECIDED) continue;
+        const long cx = gx + dx;
+        unsigned int rg[4];   // the 3 x 3 cells of this x-layer lie in at most 2 x 2 bricks
 #pragma unroll
-    for (int q = 0; q < 26; q++) {
-        if (k26[q] == MKEY_EMPTY) continue;
-        const int c = q < 13 ? q : q + 1;
-        const unsigned long long want = mkey(gx + (c / 9 - 1), gy + ((c / 3) % 3 - 1), gz + (c % 3 - 1));
-        long long slot = (long long)s26[q];
-        if (k26[q] != want) slot = grid_find_from(m, s26[q], want);   // displaced entry: continue the linear probe
-        if (slot < 0) continue;
-        const MeshGridEnt e = m.g_ent[slot];
-        probes++;
-        if ((double)sqrtf(dist2f(px, py, pz, e.x, e.y, e.z)) < m.min_spacing) status = ST_REJECT;
+        for (int q = 0; q < 4; q++) rg[q] = (unsigned int)(hash64(mkey(cx >> 2, rby + (q >> 1), rbz + (q & 1))) & rmask);
+        unsigned long long k9[9];
+        unsigned int s9[9];
+        float4 r9[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const long cy = gy + (q / 3 - 1), cz = gz + (q % 3 - 1);
+            const int sel = (int)((((cy >> 2) - rby) << 1) | ((cz >> 2) - rbz));
+            const unsigned int r = sel == 3 ? rg[3] : (sel == 2 ? rg[2] : (sel == 1 ? rg[1] : rg[0]));
+            s9[q] = (r << 6) | (unsigned int)(((cx & 3) << 4) | ((cy & 3) << 2) | (cz & 3));
+            k9[q] = m.g_ent[s9[q]].key;
+            r9[q] = *(const float4*)&m.g_ent[s9[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            if (dx == 0 && q == 4) continue;            // the candidate's own cell (found free above)
+            if (k9[q] == MKEY_EMPTY) continue;
+            const unsigned long long want = mkey(cx, gy + (q / 3 - 1), gz + (q % 3 - 1));
+            float4 r = r9[q];
+            if (k9[q] != want) {   // displaced entry: continue the linear probe
+                const long long s2 = grid_find_from(m, s9[q], want);
+                if (s2 < 0) continue;
+                r = *(const float4*)&m.g_ent[s2];
+            }
+            probes++;
+            if ((double)sqrtf(dist2f(px, py, pz, r.x, r.y, r.z)) < m.min_spacing) status = ST_REJECT;
+        }
     }
-    if (probes) atomicAdd(&m.sc[SC_C1], probes);
-    if (status != ST_UNDECIDED) return;
+    ADBG(3);   // the three batches of the 1-NN test
+    if (leader && old_stamp != m.seq) *visit_new = vi;
+    if (m.dbg && lane == 0) atomicAdd(&m.dbg[32 + 7], 1ull);
+    if (status != ST_UNDECIDED) return probes;              // (cand_status was preset to ST_REJECT by mesh_begin_scan_kernel)
     // survivor: its records, and the chain under its cell for the in-scan conflict resolution
-    if (cflags) {
+    if (m.shard_world > 1) {
         long lo[3], hi[3];
         cand_box(m, px, py, pz, lo, hi);
-        if (box_foreign(m, lo, hi, m.shard_rank)) cflags |= CF_BAND;
-        m.cand_flags[i] = cflags;
+        m.cand_flags[i] = CF_OWN | (box_foreign(m, lo, hi, m.shard_rank) ? CF_BAND : 0);
     }
     m.cand_vox[i] = vi;
     m.cand_cell[i] = gkey;
@@ -389,6 +410,53 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
     if (cs < 0) { m.sc[SC_OVERFLOW] = 3; m.cand_next[i] = -1; }
     else m.cand_next[i] = atomicExch(&m.ch_head[cs], i);
     st_agent(&m.cand_status[i], ST_UNDECIDED);
+    ADBG(4);   // survivors: chain insert
+    return probes;
+}
+__global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
+    // (everything a thread needs to find its candidate is requested before anything is waited for: the slot's fill count, the slot, the scan's parameters)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int* __restrict__ cnt = m_in.bin_cnt;
+    const int my_cnt = t < MV_BIN_NSLOT ? cnt[t / MV_BIN_SLOTS] : cnt[MV_BIN_BUCKETS];
+    const float4 slot_pt = m_in.cand_pt[t];   // (allocated for MV_BIN_NSLOT + cap_cand entries: always readable)
+    MESH_DYN(m_in);
+    const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
+    __shared__ int s_c1, s_nvis, s_base;
+    __shared__ int s_vis[1024];
+    if (threadIdx.x == 0) { s_c1 = 0; s_nvis = 0; }
+    __syncthreads();
+    const unsigned long long tk0 = m.dbg ? __builtin_readcyclecounter() : 0;
+    // admission order: the slots of the 8-cell cubes, then -- further workgroups of the same launch -- the overflow list (mesh_begin_scan_kernel);
+    // offline-sized clouds: scan order
+    bool live;
+    int i = t;
+    float4 pv = slot_pt;
+    if (sp.n_cand <= MV_FIN_CAND) {
+        live = t < MV_BIN_NSLOT ? (t & (MV_BIN_SLOTS - 1)) < my_cnt : (t - MV_BIN_NSLOT) < min(my_cnt, m.cap_cand);
+        i = __float_as_int(pv.w);
+    } else {
+        live = t < sp.n_cand;
+        if (live) pv = *(const float4*)(pts + 4 * (size_t)t * sp.step);
+    }
+    if (m.dbg && lane == 0) { atomicAdd(&m.dbg[32 + 5], __builtin_readcyclecounter() - tk0); atomicAdd(&m.dbg[32 + 8], 1ull); }
+    int probes = 0;
+    if (__any(live)) {
+        int vnew;
+        probes = mesh_admit_candidate(m, live, i, pv.x, pv.y, pv.z, lane, &vnew);
+        if (vnew >= 0) { const int k = atomicAdd(&s_nvis, 1); if (k < 1024) s_vis[k] = vnew; else m.recent[atomicAdd(&m.sc[SC_RECENT], 1)] = vnew; }
+    }
+    // one atomic per workgroup on the scan-wide counters (hundreds of wavefronts adding to ONE address serialise at the memory side)
+    if (probes) atomicAdd(&s_c1, probes);
+    __syncthreads();
+    const int nv = min(s_nvis, 1024);
+    if (threadIdx.x == 0) {
+        if (s_c1) atomicAdd(&m.sc[SC_C1], s_c1);
+        s_base = nv ? atomicAdd(&m.sc[SC_RECENT], nv) : 0;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nv; k += 256) m.recent[s_base + k] = s_vis[k];
+    if (m.dbg && threadIdx.x == 0) atomicMax(&m.dbg[32 + 6], __builtin_readcyclecounter() - tk0);   // the slowest workgroup, start to end
 }
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
@@ -555,8 +623,7 @@ __global__ __launch_bounds__(256) void mesh_append_commit_kernel(MeshDev m_in, c
     m.v_smooth[(size_t)id * 3 + 0] = (double)px; m.v_smooth[(size_t)id * 3 + 1] = (double)py; m.v_smooth[(size_t)id * 3 + 2] = (double)pz;
     int vi = m.cand_vox[i];
     if (vi < 0) {
-        const long long vs = h_find(m.x_keys, m.x_mask, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
-        vi = vs >= 0 ? m.x_vals[vs] : -1;
+        vi = vox_find(m, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
     }
     if (vi < 0) { m.sc[SC_OVERFLOW] = 5; return; }
     m.v_voxel[id] = vi;
@@ -638,8 +705,7 @@ __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, 
         m.v_smooth[(size_t)id * 3 + 0] = (double)px; m.v_smooth[(size_t)id * 3 + 1] = (double)py; m.v_smooth[(size_t)id * 3 + 2] = (double)pz;
         int vi = m.cand_vox[i];
         if (vi < 0) {
-            const long long vs = h_find(m.x_keys, m.x_mask, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
-            vi = vs >= 0 ? m.x_vals[vs] : -1;
+            vi = vox_find(m, mkey(rnd_cell(px, m.voxel), rnd_cell(py, m.voxel), rnd_cell(pz, m.voxel)));
         }
         if (vi < 0) { m.sc[SC_OVERFLOW] = 5; continue; }
         m.v_voxel[id] = vi;
@@ -787,6 +853,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     __shared__ long s_box[6];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (!EXPORT && blockIdx.x == 0)   // the admission's bucket fill counts: back to zero for the next scan (mesh_begin_scan_kernel counts, mesh_append_prepare_kernel reads)
+        for (int k = tid; k <= MV_BIN_BUCKETS; k += 256) m.bin_cnt[k] = 0;
     const int n_active = EXPORT ? m.pc[PC_VOXELS] : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
@@ -843,8 +911,8 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
             const int vidx = vstart + tid;
             if (vidx < nvox) {
                 const int iz = vidx % ez, iy = (vidx / ez) % ey, ix = vidx / (ez * ey);
-                const long long s = h_find(m.x_keys, m.x_mask, mkey(bx0 + ix, by0 + iy, bz0 + iz));
-                if (s >= 0) { v2 = m.x_vals[s]; if (v2 >= 0) n2 = min(m.vx_npts[v2], MV_VOX_CAP); }
+                v2 = vox_find(m, mkey(bx0 + ix, by0 + iy, bz0 + iz));
+                if (v2 >= 0) n2 = min(m.vx_npts[v2], MV_VOX_CAP);
             }
             int incl = n2;  // inclusive scan over the 256 threads
 #pragma unroll

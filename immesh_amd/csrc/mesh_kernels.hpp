@@ -42,6 +42,7 @@ enum { PC_VERTS = 0, PC_VOXELS, PC_TRIS, PC_ADJ_CHUNKS, PC_LIVE, PC_COUNT = 8 };
 #define LS_JOBS 5   /* sorted per scan: remove / add / flip-update triangle lists, smoothed vertex ids, active voxels */
 struct LSortPlan { int n[LS_JOBS]; int blk_base[LS_JOBS + 1]; int eblk_base[LS_JOBS + 1]; int rec_off[LS_JOBS]; int cs[LS_JOBS]; };   // cs: chunk size of the job
 
+struct MeshVoxEnt { unsigned long long key; int32_t val; int32_t pad; };   // key == ~0: empty; val == -1: being created
 struct MeshGridEnt { float x, y, z; int32_t id; unsigned long long key; unsigned long long pad; };   // 32 B; key == ~0: empty
 struct MeshScanParams {
     double cam[3];
@@ -66,7 +67,7 @@ struct MeshDev {
     // ~13 lines instead of 54 (key and record of every cell in lines of their own) and candidates of one neighbourhood touch the SAME lines
     MeshGridEnt* g_ent; uint64_t g_mask;
     // mesh voxels
-    unsigned long long* x_keys; int32_t* x_vals; uint64_t x_mask;
+    MeshVoxEnt* x_ent; uint64_t x_mask;                        // 16-byte entries {key, voxel index}: one round trip per lookup
     unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
     int32_t* vx_rank; int32_t* vx_rank_seq; int32_t* vx_rank_seq_alt; double* vx_short_axis;   // (rank, stamp): per job parity; _alt = the other parity's stamps
     // triangles

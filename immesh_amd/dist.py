@@ -83,3 +83,50 @@ def attach_collectives(h, hip, dist, backend, device, world, mesh):
                     recv[r_ * len(send):(r_ + 1) * len(send)] = parts[r_].numpy()
         h.set_allgather(_allgather)
     return f"host callbacks through torch.distributed ({backend})"
+
+
+# ---- host mirror of the kernels' brick ownership (regmap.hpp shard_owner / c_api.cpp immesh_shard_owner), vectorised ----------------------------------
+def _hash64(k):
+    import numpy as np
+    k = k.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(30); k *= np.uint64(0xbf58476d1ce4e5b9)
+        k ^= k >> np.uint64(27); k *= np.uint64(0x94d049bb133111eb)
+        k ^= k >> np.uint64(31)
+    return k
+
+
+def owners_of_root_voxels(keys, brick_log2, world):
+    """keys: n x 3 int64 root-voxel keys -> owning rank per key (same function as the device / immesh_shard_owner)"""
+    import numpy as np
+    b = np.int64(brick_log2)
+    k = np.asarray(keys, np.int64) >> b                         # arithmetic shift: bricks tile negative keys too
+    B, M = np.uint64(1 << 20), np.uint64((1 << 21) - 1)
+    ku = (k.astype(np.uint64) + B) & M
+    packed = ku[:, 0] | (ku[:, 1] << np.uint64(21)) | (ku[:, 2] << np.uint64(42))
+    return (_hash64(packed) % np.uint64(world)).astype(np.int64)
+
+
+def root_voxel_keys(world_xyz, voxel_size):
+    """VOXEL_LOC quantisation of world-frame points (voxel_mapping.cpp:122-128: p / voxel_size, minus one below zero, truncated)"""
+    import numpy as np
+    q = np.asarray(world_xyz, np.float64) / float(voxel_size)   # (the device divides the float coordinate in double as well; a point exactly on a face is measure zero here)
+    q = np.where(q < 0, q - 1.0, q)
+    return np.trunc(q).astype(np.int64)
+
+
+def load_balance(world_clouds, voxel_size, world, brick_log2s=(3, 4, 5)):
+    """Share of the down-sampled scan points (= the matcher's and the map update's work) each rank owns, per scan, for every brick size: the slowest
+    rank of a sharded job is the one with the largest share.  Returns {brick_voxels: {"max_share_mean": ..., "max_share_worst_scan": ..., "min_share_mean": ...,
+    "busiest_rank": r}}; the fair share is 1 / world."""
+    import numpy as np
+    out = {}
+    for b in brick_log2s:
+        mx, mn, tot = [], [], np.zeros(world)
+        for pts in world_clouds:
+            own = owners_of_root_voxels(root_voxel_keys(pts, voxel_size), b, world)
+            sh = np.bincount(own, minlength=world) / max(1, len(own))
+            mx.append(sh.max()); mn.append(sh.min()); tot += sh
+        out[int(1 << b)] = {"max_share_mean": round(float(np.mean(mx)), 4), "max_share_worst_scan": round(float(np.max(mx)), 4), "min_share_mean": round(float(np.mean(mn)), 4),
+                            "busiest_rank": int(np.argmax(tot)), "fair_share": round(1.0 / world, 4)}
+    return out

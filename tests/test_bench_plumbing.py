@@ -73,14 +73,17 @@ def test_gpus_flag_spawns_the_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["sharded"]["scaling"] == "strong" and d["sharded"]["value"] > 0
+    # N > 1: the headline is the SHARDED job (one stream, strong scaling); the independent replicas are reported beside it
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["sharded"]["scaling"] == "strong" and d["value"] == d["sharded"]["value"] > 0
+    assert d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0 and "bricks" in d["config"]["parallelism"]
+    assert set(d["sharded"]["load_balance_point_share_per_brick_size"]) == {"8", "16", "32"}
 
 
 def test_two_rank_replicas_gloo():
     """the N > 1 launch contract (torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, rank 0 prints) with gloo on CPU"""
     port = 29600 + (os.getpid() % 300)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           SHIM, "--gpus", "2", "--backend", "gloo", "--extra-configs", "0"] + ARGS
+           SHIM, "--gpus", "2", "--backend", "gloo", "--extra-configs", "0", "--sharded-leg", "0"] + ARGS   # (the replica leg alone)
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])

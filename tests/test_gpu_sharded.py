@@ -251,7 +251,7 @@ def test_rccl_inside_the_library_world_size_one(hip_lib):
 
 def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
     """`python bench.py --gpus 2 --backend gloo` as ONE command (not under torch.distributed.run): it re-executes itself as two ranks -- both on
-    cuda:0 here, the pool has one GPU per box -- and the line carries the replica headline (n_gpus 2, weak) and the sharded leg (strong)."""
+    cuda:0 here, the pool has one GPU per box -- and the line's headline is the sharded job (n_gpus 2, strong), the replica leg rides along (weak)."""
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--map-voxels", "150000",
@@ -259,5 +259,9 @@ def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["sharded"]["scaling"] == "strong" and d["sharded"]["value"] > 0 and "gloo" in d["sharded"]["collectives"] and d["sharded"]["pose_err_m"] < 0.1
+    # N > 1: the headline is the sharded job (ONE stream, voxel bricks over the ranks, strong scaling); the replica leg is reported beside it
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] == d["sharded"]["value"] > 0 and d["replicas"]["scaling"] == "weak" and d["replicas"]["value"] > 0
+    assert d["sharded"]["scaling"] == "strong" and "gloo" in d["sharded"]["collectives"] and d["sharded"]["pose_err_m"] < 0.1
+    lb = d["sharded"]["load_balance_point_share_per_brick_size"]
+    assert set(lb) == {"8", "16", "32"} and all(0.5 <= v["max_share_mean"] <= 1.0 and v["fair_share"] == 0.5 for v in lb.values())
+    assert d["sharded"]["exchange_calls_per_scan"] >= 8          # >= 2 admission rounds + the two band exchanges, two calls each
