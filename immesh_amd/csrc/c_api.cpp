@@ -80,6 +80,11 @@ static int alloc_all(immesh_ctx* c) {
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
     A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns);
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
+    {   // the VoxelGrid's leaf table: >= 2 entries per point of the largest cloud, all empty (0xFF: key == ~0, chain head == -1)
+        unsigned long long cap = 1024; while (cap < 2ull * (unsigned long long)ns) cap <<= 1;
+        char* t; A(t, cap * 16); c->p_htab = t; c->p_htab_cap = cap;
+        launch_ds_table_reset(c->stream, t, cap);
+    }
     A(c->d_dump_count, 2);
     A(c->d_touched, 2 * ns + 16);
     A(c->d_regstate, 1);
@@ -884,6 +889,29 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     int rc = pre_resolve(c, pts, (size_t)n * stride * 4, stride == 4 ? (void*)c->d_pts_raw : (void*)c->d_pts_down, &d_pts);
     if (rc) return rc;
     const float inv = (float)(1.0 / leaf);   // np.float32(1.0 / leaf)
+    static const bool radix_only = getenv("IMMESH_DS_RADIX") != nullptr;
+    if (!radix_only && !c->ds_skip_hash) {
+        // three launches (ds_kernels.hip: leaf table + chains, leaf sort, per-leaf ordered sums); the radix pipeline below only when that gives up
+        PRE_OUTPUT_FENCE(c);
+        launch_ds_hash_pipeline(s, (const float*)d_pts, n, stride, inv, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->d_ds_out, c->p_nseg + 8);
+        int32_t info[2] = {0, 0};
+        HIPCHK(c, hipMemcpyAsync(info, c->p_nseg + 12, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        if (!info[1]) {
+            const int32_t cnt = info[0];
+            *n_out = cnt;
+            if (out_xyz) {
+                if (cnt > cap_out) { c->err = "output buffer too small"; return IMMESH_E_CAPACITY; }
+                hipPointerAttribute_t attr;
+                const bool dev_out = hipPointerGetAttributes(&attr, out_xyz) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+                if (!dev_out) (void)hipGetLastError();
+                HIPCHK(c, hipMemcpyAsync(out_xyz, c->d_ds_out, (size_t)cnt * 12, dev_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+            }
+            return 0;
+        }
+        launch_ds_table_reset(s, c->p_htab, c->p_htab_cap);   // (a cell outside the key's range, a full table or a leaf above 2048 points: the general path)
+    }
     int32_t* mm = c->p_nseg;                 // 6 ints of scratch: floor(min), floor(max)
     const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     HIPCHK(c, hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, s));
@@ -922,14 +950,8 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
 }
 const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : nullptr; }
 
-// ---- the same pipeline without a host round trip in the middle: everything is enqueued on the pre-processing stream; the radix-sort width comes from
-// the previous cloud's grid extents (consecutive scans of a stream have the same extents to within a leaf or two) and is checked when the job is collected
-static int ds_bits_of(const int32_t* mm) {
-    const unsigned long long total = (unsigned long long)((long long)mm[3] - mm[0] + 1) * (unsigned long long)((long long)mm[4] - mm[1] + 1) * (unsigned long long)((long long)mm[5] - mm[2] + 1);
-    int bits = 1;
-    while (bits < 64 && (total >> bits) != 0) bits++;
-    return bits;
-}
+// ---- the asynchronous pair: the VoxelGrid of scan k+1 enqueued on the pre-processing stream beside scan k's registration, collected later.  The
+// three-launch form needs nothing from the host in between; when it gives up (flag in the job's pinned info) the job is redone synchronously.
 int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     if (c->dsa.active) { c->err = "immesh_downsample_begin: the previous job has not been collected (immesh_downsample_end)"; return IMMESH_E_INVAL; }
@@ -958,19 +980,13 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
         if (is_dev) d_pts = pts;
         else { HIPCHK(c, hipMemcpyAsync(a.stage, pts, (size_t)n * stride * 4, hipMemcpyHostToDevice, s)); d_pts = a.stage; }
     }
-    a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts; a.used_bits = a.pred_bits;
+    a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts;
     const float inv = (float)(1.0 / leaf);
-    int32_t* mm = c->p_nseg;
-    HIPCHK(c, hipMemcpyAsync(mm, a.h_info + 8, 6 * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    launch_ds_minmax(s, (const float*)d_pts, n, stride, inv, mm);
-    launch_ds_index(s, (const float*)d_pts, n, stride, inv, mm, c->p_key_a, c->p_idx_a);
-    sort_pairs_u64(s, c->p_sort_temp, c->sort_temp_bytes, c->p_key_a, c->p_key_b, c->p_idx_a, c->p_idx_b, n, a.used_bits);
-    launch_ds_heads(s, c->p_key_b, n, c->p_idx_c);
-    exclusive_sum_i32(s, c->p_sort_temp, c->sort_temp_bytes, c->p_idx_c, c->p_idx_c, n);
+    // three launches, nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table + chains,
+    // leaf sort, per-leaf ordered sums (ds_kernels.hip)
     PRE_OUTPUT_FENCE(c);   // (the buffer being written was the input of the scan before the one in flight: its point_var has to be through)
-    launch_ds_centroid(s, (const float*)d_pts, n, stride, c->p_key_b, c->p_idx_b, c->p_idx_c, a.out[a.par], c->p_nseg + 8);
-    HIPCHK(c, hipMemcpyAsync(a.h_info, mm, 6 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(a.h_info + 6, c->p_nseg + 8, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    launch_ds_hash_pipeline(s, (const float*)d_pts, n, stride, inv, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, a.out[a.par], c->p_nseg + 8);
+    HIPCHK(c, hipMemcpyAsync(a.h_info, c->p_nseg + 12, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));   // [0] leaves, [1] fall-back wanted
     HIPCHK(c, hipEventRecord(a.ev, s));
     a.active = true;
     return 0;
@@ -982,17 +998,18 @@ int immesh_downsample_end(immesh_ctx* c, int32_t* n_out, const float** dev_xyz) 
     (void)hipSetDevice(c->cfg.device);
     HIPCHK(c, hipEventSynchronize(a.ev));
     a.active = false;
-    const int need = ds_bits_of(a.h_info);
-    a.pred_bits = std::min(64, need + 1);
-    if (need > a.used_bits) {
-        // the cloud spans a larger grid than predicted: its keys were sorted on too few bits -- redo it with the synchronous entry (rare: a jump of the extents)
+    if (a.h_info[1]) {
+        // the three-launch form gave up (a cell outside the key's range, a leaf above 2048 points): the general path, synchronously (it resets the table)
         int32_t cnt = 0;
+        launch_ds_table_reset(c->stream_pre, c->p_htab, c->p_htab_cap);
+        c->ds_skip_hash = true;
         const int rc = immesh_downsample(c, (const float*)a.d_in, a.n, a.stride, a.leaf, nullptr, 0, &cnt);
+        c->ds_skip_hash = false;
         if (rc) return rc;
         HIPCHK(c, hipMemcpy(a.out[a.par], c->d_ds_out, (size_t)cnt * 12, hipMemcpyDeviceToDevice));
-        a.h_info[6] = cnt;
+        a.h_info[0] = cnt;
     }
-    *n_out = a.h_info[6];
+    *n_out = a.h_info[0];
     if (dev_xyz) *dev_xyz = a.out[a.par];
     return 0;
 }

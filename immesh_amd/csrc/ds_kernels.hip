@@ -8,6 +8,7 @@
 //   ds_heads_kernel    run heads -> 0/1 flags        (exclusive scan: rocPRIM)
 //   ds_centroid_kernel one thread per run head: sequential float32 sum of its run, in order -> bit-identical to the CPU spec
 // Bound: HBM streaming (12-16 B per point per pass); the sort dominates.
+#include <algorithm>
 #include "kernels.hpp"
 #include "prof.hpp"
 #include "dev_math.hpp"
@@ -113,6 +114,251 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
         *n_out = last_head_rank;
     }
 }
+
+// =====================================================================================================================
+// The same VoxelGrid in FOUR short launches instead of fifteen (round 4; the radix pipeline above stays as the fall-back and for clouds whose leaves do
+// not fit the single-key form).  The order of the output -- ascending linear leaf index i + j*dx + k*dx*dy -- is the lexicographic order of (k, j, i),
+// and that needs neither the bounding box nor a sort of the POINTS:
+//   ds_hash_kernel       one thread per point: leaf cell (floor(p * inv), the spec's float32 arithmetic) -> packed (k, j, i) key -> find-or-create in an
+//                        open-addressing table; the leaf's point count grows by one atomic; the creator of an entry appends its slot to the leaf list.
+//                        Nobody waits for anybody.
+//   ds_leaf_sort_kernel  the occupied leaves (~8 k for a 100 k-point scan, not 100 k points) sorted by key in chunks of 512 (bitonic network in LDS, one
+//                        workgroup per chunk), and a segment of the point-index pool reserved for every leaf (scan of the counts inside the chunk, one
+//                        atomic per chunk for its base: the pool's order does not matter)
+//   ds_scatter_kernel    one thread per point: its index into its leaf's segment (one atomic: arrival order, i.e. no order)
+//   ds_leaf_emit_kernel  one wavefront per leaf: its output position (own position in its chunk + lower bounds in the other chunks, one lane per chunk),
+//                        its segment ordered by scan index, the float32 sums formed strictly in that order -- the spec's sequential `centroid += pt` --
+//                        and its table entry handed back empty: the table is never cleared as a whole.
+// Bound: latency (one hash round trip per point); HBM traffic ~ 2 x 16 B per point + the leaves' lines.
+// =====================================================================================================================
+#define DSH_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define DSH_BIAS (1 << 20)
+#define DSH_CHUNK 512
+#define DSH_LEAF_CAP 2048          /* points of one leaf ordered in LDS; a leaf holding more sets the fall-back flag */
+struct DsEnt { unsigned long long key; int cnt; int off; };   // 16 B; key == DSH_EMPTY: free (then cnt == 0)
+// info: [0] leaves, [1] fall-back wanted (cell out of the key's range / table full / a leaf above DSH_LEAF_CAP points), [2] pool fill
+__global__ __launch_bounds__(256) void ds_hash_kernel(const float* __restrict__ pts, int n, int stride, float inv, DsEnt* __restrict__ tab, unsigned long long mask,
+                                                       int32_t* __restrict__ pt_slot, int32_t* __restrict__ leaf_slot, int32_t* __restrict__ info) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = pts + (size_t)i * stride;
+    const long long cx = (long long)floorf(p[0] * inv), cy = (long long)floorf(p[1] * inv), cz = (long long)floorf(p[2] * inv);
+    if (cx < -DSH_BIAS || cx >= DSH_BIAS || cy < -DSH_BIAS || cy >= DSH_BIAS || cz < -DSH_BIAS || cz >= DSH_BIAS) { info[1] = 1; pt_slot[i] = -1; return; }
+    const unsigned long long key = ((unsigned long long)(cz + DSH_BIAS) << 42) | ((unsigned long long)(cy + DSH_BIAS) << 21) | (unsigned long long)(cx + DSH_BIAS);
+    unsigned long long h = hash64(key) & mask;
+    for (int probe = 0; probe < 4096; probe++) {
+        unsigned long long k = tab[h].key;
+        if (k == DSH_EMPTY) {
+            k = atomicCAS(&tab[h].key, (unsigned long long)DSH_EMPTY, key);
+            if (k == DSH_EMPTY) { leaf_slot[atomicAdd(&info[0], 1)] = (int)h; k = key; }
+        }
+        if (k == key) { atomicAdd(&tab[h].cnt, 1); pt_slot[i] = (int)h; return; }
+        h = (h + 1) & mask;
+    }
+    info[1] = 1; pt_slot[i] = -1;
+}
+__global__ __launch_bounds__(256) void ds_leaf_sort_kernel(DsEnt* __restrict__ tab, const int32_t* __restrict__ leaf_slot, int32_t* __restrict__ info,
+                                                            unsigned long long* __restrict__ keys_sorted, int32_t* __restrict__ slots_sorted, int32_t* __restrict__ big_list) {
+    __shared__ unsigned long long sk[DSH_CHUNK];
+    __shared__ int sv[DSH_CHUNK];
+    __shared__ unsigned short sc[DSH_CHUNK];   // the leaf's point count, capped (only "above 64?" is needed behind the sort)
+    __shared__ int s_scan[256];
+    __shared__ int s_base;
+    const int nleaf = info[0];
+    const int tid = threadIdx.x;
+    for (int first = blockIdx.x * DSH_CHUNK; first < nleaf; first += gridDim.x * DSH_CHUNK) {
+    const int cnt = min(DSH_CHUNK, nleaf - first);
+    int np2 = 1; while (np2 < cnt) np2 <<= 1;
+    // a segment of the index pool for each of the chunk's leaves (two leaves per thread)
+    int c0 = 0, c1 = 0, sl0 = -1, sl1 = -1;
+    unsigned long long k0 = ~0ull, k1 = ~0ull;
+    if (2 * tid < cnt) { sl0 = leaf_slot[first + 2 * tid]; const DsEnt e = tab[sl0]; k0 = e.key; c0 = e.cnt; }
+    if (2 * tid + 1 < cnt) { sl1 = leaf_slot[first + 2 * tid + 1]; const DsEnt e = tab[sl1]; k1 = e.key; c1 = e.cnt; }
+    if (c0 > DSH_LEAF_CAP || c1 > DSH_LEAF_CAP) info[1] = 1;
+    s_scan[tid] = c0 + c1;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { const int v = tid >= off ? s_scan[tid - off] : 0; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
+    if (tid == 255) s_base = atomicAdd(&info[2], s_scan[255]);
+    __syncthreads();
+    const int excl = s_base + s_scan[tid] - (c0 + c1);
+    if (sl0 >= 0) tab[sl0].off = excl;
+    if (sl1 >= 0) tab[sl1].off = excl + c0;
+    for (int k = tid; k < np2; k += 256) { sk[k] = ~0ull; sv[k] = -1; sc[k] = 0; }
+    __syncthreads();
+    if (sl0 >= 0) { sk[2 * tid] = k0; sv[2 * tid] = sl0; sc[2 * tid] = (unsigned short)min(c0, 65535); }
+    if (sl1 >= 0) { sk[2 * tid + 1] = k1; sv[2 * tid + 1] = sl1; sc[2 * tid + 1] = (unsigned short)min(c1, 65535); }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int lj = 31 - __clz(k >> 1); lj >= 0; lj--) {
+            const int j = 1 << lj;
+            for (int p = tid; p < (np2 >> 1); p += 256) {
+                const int a = ((p >> lj) << (lj + 1)) | (p & (j - 1)), b = a + j;
+                const bool up = ((a & k) == 0);
+                const unsigned long long x = sk[a], y = sk[b];
+                if ((x > y) == up) { sk[a] = y; sk[b] = x; const int t = sv[a]; sv[a] = sv[b]; sv[b] = t; const unsigned short u = sc[a]; sc[a] = sc[b]; sc[b] = u; }
+            }
+            __syncthreads();
+        }
+    for (int k = tid; k < cnt; k += 256) {
+        keys_sorted[first + k] = sk[k]; slots_sorted[first + k] = sv[k];
+        if (sc[k] > 64) big_list[atomicAdd(&info[3], 1)] = first + k;   // leaves above one wavefront's worth of points: ds_leaf_emit_big_kernel
+    }
+    __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void ds_scatter_kernel(int n, DsEnt* __restrict__ tab, const int32_t* __restrict__ pt_slot, int32_t* __restrict__ pool) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int slot = pt_slot[i];
+    if (slot < 0) return;
+    // (the count runs down to zero while the segment fills; ds_leaf_emit_kernel takes the leaf's size from the neighbouring leaves' offsets -- no: it
+    //  is kept in the high half below)
+    const int old = atomicAdd(&tab[slot].cnt, 0x10000 - 1);   // low 16 bits: points still to place (<= DSH_LEAF_CAP), high 16: points placed
+    const int left = old & 0xFFFF;
+    if (left > 0 && left <= DSH_LEAF_CAP) pool[tab[slot].off + left - 1] = i;
+}
+// output position of the leaf at sorted position e: own position in its chunk + the number of smaller keys in every other chunk (keys are unique);
+// one lane per chunk
+IMD int ds_leaf_rank(const unsigned long long* __restrict__ keys_sorted, int nleaf, int e, unsigned long long key, int lane) {
+    const int nchunks = (nleaf + DSH_CHUNK - 1) / DSH_CHUNK;
+    int rank = e % DSH_CHUNK;
+    if (nchunks > 1) {
+        const int own = e / DSH_CHUNK;
+        int lo = 0;
+        for (int c0 = 0; c0 < nchunks; c0 += 64) {
+            const int c = c0 + lane;
+            int l = 0, hgh = (c < nchunks && c != own) ? min(DSH_CHUNK, nleaf - c * DSH_CHUNK) : 0;
+            while (l < hgh) { const int mid = (l + hgh) >> 1; if (keys_sorted[(size_t)c * DSH_CHUNK + mid] < key) l = mid + 1; else hgh = mid; }
+            lo += l;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lo += __shfl_xor(lo, off, 64);
+        rank += lo;
+    }
+    return rank;
+}
+// leaves of <= 64 points (all but a few dozen of a scan's ~8 k): no LDS, one wavefront per leaf
+__global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const float* __restrict__ pts, int stride, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
+                                                            const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ slots_sorted,
+                                                            int32_t* __restrict__ info, float* __restrict__ out, int32_t* __restrict__ n_out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nleaf = info[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = nleaf;
+    for (int e = blockIdx.x * 4 + wv; e < nleaf; e += gridDim.x * 4) {
+        const unsigned long long key = keys_sorted[e];
+        const int slot = slots_sorted[e];
+        const DsEnt ent = tab[slot];
+        const int cnt = ent.cnt >> 16;     // (every point of the leaf has been placed: the low half is zero)
+        if (cnt > 64 || ent.key != key) continue;   // ds_leaf_emit_big_kernel's (it ran first and has handed the entry back already)
+        // the segment and its points first (two dependent round trips), the output position (binary searches) while they are in flight
+        const int mine = lane < cnt ? pool[ent.off + lane] : 0x7FFFFFFF;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (lane < cnt) { const float* q = pts + (size_t)mine * stride; x = q[0]; y = q[1]; z = q[2]; }
+        const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
+        if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }   // the entry goes back empty: the table is never cleared as a whole
+        if (cnt <= 0) { if (lane == 0) info[1] = 1; continue; }
+        // rank by counting (indices are distinct), then the sequential float32 sum in index order: v_readlane from the lane holding rank r
+        int r = 0;
+        for (int l = 0; l < cnt; l++) r += __builtin_amdgcn_readlane(mine, l) < mine ? 1 : 0;
+        int holder = 0;   // holder (in lane q) = the lane whose point has rank q
+        for (int l = 0; l < cnt; l++) { const int rl = __builtin_amdgcn_readlane(r, l); if (rl == lane) holder = l; }
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int q = 0; q < cnt; q++) {
+            const int hl = __builtin_amdgcn_readlane(holder, q);
+            sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), hl));   // (0.f + first, then += : the spec's order)
+            sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), hl));
+            sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), hl));
+        }
+        if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
+    }
+}
+// leaves of 65 .. DSH_LEAF_CAP points (the ground right in front of the sensor): one wavefront per leaf, the segment ordered through a bitmap over the
+// scan's point indices in LDS (set the members' bits, read the words back in order: no sorting network -- a lone wavefront needs ~130 us to sort 2048
+// keys that way) when the scan has at most DSH_BITMAP_PTS points, else by the network
+#define DSH_BITMAP_PTS 131072
+__global__ __launch_bounds__(64) void ds_leaf_emit_big_kernel(const float* __restrict__ pts, int n, int stride, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
+                                                               const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ slots_sorted,
+                                                               const int32_t* __restrict__ big_list, int32_t* __restrict__ info, float* __restrict__ out) {
+    __shared__ unsigned int bm[DSH_BITMAP_PTS / 32];
+    __shared__ int idx[DSH_LEAF_CAP];
+    const int lane = threadIdx.x;
+    const int nleaf = info[0], nbig = info[3];
+    const int nwords = (min(n, DSH_BITMAP_PTS) + 31) / 32;
+    auto lds_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int e = big_list[b];
+        const unsigned long long key = keys_sorted[e];
+        const int slot = slots_sorted[e];
+        const DsEnt ent = tab[slot];
+        const int cnt = ent.cnt >> 16;
+        const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
+        if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }
+        if (cnt > DSH_LEAF_CAP || cnt <= 64) { if (lane == 0) info[1] = 1; continue; }
+        if (n <= DSH_BITMAP_PTS) {
+            for (int w = lane; w < nwords; w += 64) bm[w] = 0u;
+            lds_sync();
+            for (int k = lane; k < cnt; k += 64) { const int p = pool[ent.off + k]; atomicOr(&bm[p >> 5], 1u << (p & 31)); }
+            lds_sync();
+            int base = 0;
+            for (int w0 = 0; w0 < nwords; w0 += 64) {
+                const int w = w0 + lane;
+                unsigned int bits = w < nwords ? bm[w] : 0u;
+                if (!__any(bits != 0u)) continue;
+                const int pc = __popc(bits);
+                int incl = pc;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+                int o = base + incl - pc;
+                while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1; idx[o++] = (w << 5) | bit; }
+                base += __shfl(incl, 63, 64);
+            }
+            lds_sync();
+        } else {
+            int np2 = 128; while (np2 < cnt) np2 <<= 1;
+            for (int k = lane; k < np2; k += 64) idx[k] = k < cnt ? pool[ent.off + k] : 0x7FFFFFFF;
+            lds_sync();
+            for (int k = 2; k <= np2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int p = lane; p < np2; p += 64) {
+                        const int q = p ^ j;
+                        if (q > p) { const bool up = ((p & k) == 0); const int a_ = idx[p], b_ = idx[q]; if ((a_ > b_) == up) { idx[p] = b_; idx[q] = a_; } }
+                    }
+                    lds_sync();
+                }
+        }
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        if (lane < min(64, cnt)) { const float* q = pts + (size_t)idx[lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }
+        for (int b0 = 0; b0 < cnt; b0 += 64) {
+            const int m = min(64, cnt - b0);
+            const float x = nx, y = ny, z = nz;
+            if (b0 + 64 + lane < cnt) { const float* q = pts + (size_t)idx[b0 + 64 + lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }   // next batch in flight
+            for (int l = 0; l < m; l++) {
+                sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+                sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
+                sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
+            }
+        }
+        if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
+        lds_sync();
+    }
+}
+// tab: table of `cap` (power of two, >= 2 n) entries, all empty on entry and on exit.  info: 4 ints, zeroed here.  pool: n ints.
+void launch_ds_hash_pipeline(hipStream_t s, const float* pts, int n, int stride, float inv, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
+                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, float* out, int32_t* n_out) {
+    (void)hipMemsetAsync(info, 0, 16, s);
+    KLAUNCH(ds_hash_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, stride, inv, (DsEnt*)tab, cap - 1, pt_slot, leaf_slot, info);
+    // (big_list: sorted positions of the leaves above 64 points -- at most n / 65 of them)
+    KLAUNCH(ds_leaf_sort_kernel, dim3(std::min(256, (n + DSH_CHUNK - 1) / DSH_CHUNK)), dim3(256), 0, s, (DsEnt*)tab, leaf_slot, info, keys_sorted, slots_sorted, big_list);
+    KLAUNCH(ds_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (DsEnt*)tab, pt_slot, pool);
+    KLAUNCH(ds_leaf_emit_big_kernel, dim3(1024), dim3(64), 0, s, pts, n, stride, (DsEnt*)tab, pool, keys_sorted, slots_sorted, big_list, info, out);   // (first: the long chains)
+    KLAUNCH(ds_leaf_emit_kernel, dim3(2048), dim3(256), 0, s, pts, stride, (DsEnt*)tab, pool, keys_sorted, slots_sorted, info, out, n_out);
+}
+// a fall-back left part of the table occupied: back to all-empty
+__global__ void ds_table_reset_kernel(DsEnt* tab, unsigned long long cap) {
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += (size_t)gridDim.x * blockDim.x) { tab[k].key = DSH_EMPTY; tab[k].cnt = 0; tab[k].off = 0; }
+}
+void launch_ds_table_reset(hipStream_t s, void* tab, unsigned long long cap) { KLAUNCH(ds_table_reset_kernel, dim3(1024), dim3(256), 0, s, (DsEnt*)tab, cap); }
 
 // xyz (3 floats) -> xyzI (4 floats, intensity 0): the mesher consumes pcl::PointXYZI-shaped clouds
 __global__ void ds_expand_xyzi_kernel(const float* __restrict__ xyz, int n, float4* __restrict__ out) {

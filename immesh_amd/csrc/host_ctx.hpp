@@ -102,6 +102,8 @@ struct immesh_ctx {
     int32_t *p_idx_a = nullptr, *p_idx_b = nullptr, *p_idx_c = nullptr, *p_seg = nullptr, *p_nseg = nullptr;
     uint32_t *p_slot = nullptr, *p_slot_s = nullptr;
     void* p_sort_temp = nullptr;
+    bool ds_skip_hash = false;       // immesh_downsample_end's fall-back: straight to the radix pipeline
+    void* p_htab = nullptr; unsigned long long p_htab_cap = 0;   // VoxelGrid leaf table (16-byte entries, all empty between calls)
     char* d_raw_stage = nullptr;     // sensor decode: staging for wire-format clouds handed over as host memory (cap_scan x 64 B, first use)
     float *d_und_in = nullptr, *d_und_out = nullptr; double* d_und_tab = nullptr;   // immesh_undistort staging: n x 5 in, n x 4 out, pose table
     int32_t* d_counters_host = nullptr;   // device view of h_counters

@@ -67,6 +67,34 @@ def test_device_downsample_bit_exact(oracle_lib, hip_lib):
 
 
 @pytest.mark.gpu
+def test_device_downsample_three_launch_form_and_its_fall_backs(hip_lib):
+    """The VoxelGrid as three launches (leaf table + chains, leaf sort, per-leaf ordered sums) against the spec, on the shapes that stress it: more leaves than one
+    sort chunk holds (the merge across chunks), leaves of 65..2048 points (the in-LDS ordering), a leaf above 2048 points and a cell outside the packed key's
+    range (both: the radix pipeline takes over, table handed back clean) -- and an ordinary cloud right after each, through the synchronous entry and the
+    asynchronous pair."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 16, cap_triangles=1 << 18)
+    h = make_hip(hip_lib, cfg)
+    rng = np.random.default_rng(77)
+    extT = np.array(list(cfg.extT))
+    R0, t0 = synth.trajectory_pose(0)
+    ordinary = np.ascontiguousarray(synth.livox_scan(3, R0, t0, n_pts=50000, extT=extT))
+    many_leaves = np.zeros((90000, 4), np.float32); many_leaves[:, :3] = rng.uniform(-60, 60, size=(90000, 3))          # ~90 k leaves of 0.4 m: 11 chunks
+    medium = np.zeros((40000, 4), np.float32); medium[:, :3] = rng.uniform(0, 2.0, size=(40000, 3))                       # 125 leaves of ~320 points
+    crowded = np.zeros((30000, 4), np.float32); crowded[:, :3] = rng.uniform(0.01, 0.39, size=(30000, 3)); crowded[:50, :3] += 5.0   # one leaf holds ~30 k points
+    far = ordinary.copy(); far[7, 0] = np.float32(9.0e5)                                                                 # cell 2.25 M: outside +-2^20
+    for name, cloud in (("ordinary", ordinary), ("many leaves", many_leaves), ("medium", medium), ("crowded", crowded), ("ordinary", ordinary), ("far", far), ("ordinary", ordinary)):
+        ref = synth.voxel_grid_downsample(cloud, 0.4)
+        got, n = h.downsample(cloud, 0.4)
+        assert n == len(ref), name
+        np.testing.assert_array_equal(got, ref, err_msg=name)
+        h.downsample_begin(cloud, 0.4)
+        n_got, ptr = h.downsample_end()
+        assert n_got == len(ref), name
+        np.testing.assert_array_equal(fetch_device(ptr, (n_got, 3)), ref, err_msg=name + " (async pair)")
+    h.close()
+
+
+@pytest.mark.gpu
 def test_async_pair_gives_the_synchronous_result(hip_lib):
     """immesh_downsample_begin / _end: the VoxelGrid of scan k+1 enqueued ahead of time (radix width predicted from the previous cloud's extents) must be
     bit for bit what immesh_downsample returns -- for the first cloud (no prediction), for consecutive scans, and after a jump of the extents (fallback)."""
