@@ -276,8 +276,8 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         # sharded map: a rank keeps its bricks plus the one-voxel halo (~20 % at 32^3-voxel bricks) -> capacity per rank, not per job
         bv = float(1 << args.brick_log2)
         share = (max(1.5, 1.25 * ((bv + 2.0) / bv) ** 2) / world) if sharded else 1.0   # owned bricks + their one-voxel halo (surfaces: ~((B + 2) / B)^2)
-        cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=2_500_000,
-                               cap_vertices=1 << 24, cap_triangles=1 << 25)
+        cfg = capi.avia_config(device=local, cap_root_voxels=int(args.map_voxels * 1.3 * share) + (1 << 16), cap_scan_points=args.cap_scan_points,
+                               cap_vertices=1 << args.mesh_cap_log2, cap_triangles=1 << (args.mesh_cap_log2 + 1))
     if sharded:
         cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, args.brick_log2, 1 if args.mesh else 0
     h = capi.HotPath(hip, cfg, "immesh_")
@@ -700,6 +700,8 @@ def main():
     ap.add_argument("--nu-scans", type=int, default=5, help="scans after the timed region whose per-voxel neighbourhood sizes n_u are collected (histogram + kernel shares)")
     ap.add_argument("--dry-run-rank", type=int, default=-1, help=">= 0: run ONE rank of a --dry-run-world job alone on this GPU with stubbed collectives (configs[4] capacity / per-rank time)")
     ap.add_argument("--dry-run-world", type=int, default=8)
+    ap.add_argument("--mesh-cap-log2", type=int, default=24, help="capacity of the mesh map: 2^k vertices, 2^(k+1) triangles (the hash tables are sized from it)")
+    ap.add_argument("--cap-scan-points", type=int, default=2_500_000, help="largest scan the context accepts (sizes the per-scan scratch and the VoxelGrid's leaf table)")
     ap.add_argument("--brick-log2", type=int, default=3, help="sharded runs: voxel bricks of 2^k voxels per axis are the unit of ownership (registration map and mesher); 3 = 8^3 (SURVEY 8(e)): "
                     "a scan's footprint spans hundreds of bricks, so the ranks' shares of a scan stay close to 1/N; 5 = 32^3 (rounds 1-3: a handful of bricks per scan)")
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
