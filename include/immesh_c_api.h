@@ -65,7 +65,7 @@ typedef struct immesh_config {
     int32_t shard_rank;
     int32_t shard_world;
     int32_t shard_brick_log2;  /* 0 = default 5: 32^3-voxel bricks */
-    int32_t shard_mesh;        /* 1 = the mesher is sharded too (owner-computes per mesh-voxel brick, see immesh_set_allgather); 0 = every context meshes whatever it is handed */
+    int32_t shard_mesh;        /* 1 = the mesher is sharded too (owner-computed admission / kNN / Delaunay per mesh-voxel brick, boundary band by all-gather, see immesh_set_allgather); 0 = every context meshes whatever it is handed */
 } immesh_config;
 
 void immesh_default_config(immesh_config* cfg); /* avia.yaml + mapping_avia.launch values */
@@ -266,11 +266,20 @@ const float* immesh_undistort_result(immesh_ctx* ctx);
  * torch.distributed.all_reduce / ncclAllReduce over xGMI.  The 18-state update then runs identically on every rank. */
 typedef int (*immesh_allreduce_fn)(double* buf, int32_t n, void* user);
 int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
-/* Sharded mesher (shard_world > 1, shard_mesh = 1): every rank is handed the same world-frame scans and admits the same vertices (ids stay
- * the serial ones); the neighbourhood search + per-voxel triangulation of a mesh voxel run only on the rank owning its 2^shard_brick_log2-voxel
- * brick.  Twice per scan the ranks exchange what the others' triangulations need: this scan's smoothed positions of the vertices of the
- * voxels each rank searched (the vertices correct_triangle_index reads across voxel borders), then the triangle marks (add / keep / remove +
- * flip word per voxel) -- after which every rank commits the same diff and immesh_mesh_fetch returns the same lists everywhere.
+/* Sharded mesher (shard_world > 1, shard_mesh = 1; shard_brick_log2 >= 2).  Every rank is handed the same world-frame scans.  Mesh voxels are owned in
+ * bricks of 2^shard_brick_log2 voxels per axis (owner = hash(brick) mod shard_world); the OWNER of a brick tests the candidates falling into it against
+ * the map and decides them (Global_map::append_points_to_global_map, pointcloud_rgbd.cpp:411-552), searches its voxels' neighbourhoods and triangulates
+ * them.  Only the BOUNDARY BAND travels, by all-gather:
+ *   1. admission, in rounds: a rank's candidates that survived the test against the map and lie within min_spacing of another rank's brick, then the
+ *      decisions (every accept; the rejects of band candidates) -- until no rank has an undecided candidate (two rounds unless a dependency chain
+ *      crosses a brick face twice).  Every rank then commits the same new vertices: ids are the serial ones (the prefix sum over the accept flags in
+ *      scan-index order is the same on every rank); the 16 bytes per vertex are the one thing that stays replicated;
+ *   2. this scan's smoothed positions of the voxels that lie within reach (2 voxel indices = 1.25 voxel + rounding) of another rank's brick;
+ *   3. the triangle marks (add / keep / remove + flip word) of triangles with a vertex within reach of another rank's brick.
+ * A rank keeps of what it receives only what lies within reach of ITS bricks: its triangle store and smoothed positions cover its bricks + halo.
+ * immesh_mesh_sizes / immesh_mesh_fetch return THIS RANK'S PART of the result lists: the triangles whose smallest vertex lies in its bricks, the
+ * smoothed vertices of its own voxels (new_vtx: all new vertices, identical on every rank).  The union of the ranks' lists is the unsharded list,
+ * every entry exactly once (tests/test_gpu_sharded.py: 2 and 4 ranks).  n_triangles_live of immesh_counters adds up over the ranks likewise.
  * cb gathers `bytes` bytes from every rank into recv (world x bytes, rank order); equal `bytes` on all ranks.  RCCL: ncclAllGather. */
 typedef int (*immesh_allgather_fn)(const void* send, int64_t bytes, void* recv, void* user);
 int immesh_set_allgather(immesh_ctx* ctx, immesh_allgather_fn cb, void* user);
