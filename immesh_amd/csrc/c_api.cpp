@@ -617,7 +617,12 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         if (rc || rc_prev) { c->ev_par = par; c->pending = true; return rc ? rc : rc_prev; }
         c->ev_par = par;
         long job = 0;
-        if (mesh_mode) job = (epi && !fell_back) ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
+        // IMMESH_SERIAL_SAFE (counter collection: rocprofv3 --pmc runs one kernel at a time, and a mesher kernel polling a flag that a kernel queued
+        // BEHIND it on another stream will store never sees it): the mesher waits for an event behind the map update's launches instead -- same
+        // kernels, same data, a more conservative order
+        static const bool serial_safe = getenv("IMMESH_SERIAL_SAFE") != nullptr;
+        if (mesh_mode && serial_safe && epi && !fell_back) { (void)mesh_record_ready(c); job = mesh_submit(c, world, n_raw, st.t, frame_idx, true); }
+        else if (mesh_mode) job = (epi && !fell_back) ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
         c->timing[3] = 0.f;
         c->pending = true;
         if (nowait) return 0;

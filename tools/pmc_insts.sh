@@ -8,7 +8,7 @@ ARGS="--cpu-seconds 0 --steps 6 --warmup 2 --profile-scans 0 --async-mesh 0 --ex
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"; do
   tag=$(echo $set | tr ' ' '_' | cut -c1-40)
   rm -rf /tmp/pi_$tag
-  timeout 200 rocprofv3 --pmc $set --output-format csv -d /tmp/pi_$tag -- python $R/bench.py $ARGS > /tmp/pi_$tag.log 2>&1
+  IMMESH_SERIAL_SAFE=1 timeout 200 rocprofv3 --pmc $set --output-format csv -d /tmp/pi_$tag -- python $R/bench.py $ARGS > /tmp/pi_$tag.log 2>&1
   f=$(find /tmp/pi_$tag -name '*counter_collection.csv' | head -1)
   python - "$f" <<'PY'
 import csv, sys

@@ -11,7 +11,7 @@ import json; d=json.load(open('$O/$T.json')); print('BENCH', d['value'], d['ms_p
 tail -3 $O/$T.err
 if [ -n "$TRAFFIC" ]; then
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/rp_$ctr; timeout 180 rocprofv3 --pmc $ctr --output-format csv -d /tmp/rp_$ctr -- python $R/bench.py --cpu-seconds 0 --extra-configs 0 --steps 12 --warmup 2 --profile-scans 0 --nu-scans 0 --async-mesh 0 $BENCH_ARGS > /tmp/rp_$ctr.log 2>&1
+    rm -rf /tmp/rp_$ctr; IMMESH_SERIAL_SAFE=1 timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/rp_$ctr -- python $R/bench.py --cpu-seconds 0 --extra-configs 0 --steps 12 --warmup 2 --profile-scans 0 --nu-scans 0 --async-mesh 0 $BENCH_ARGS > /tmp/rp_$ctr.log 2>&1
   done
   python $R/tools/pmc_traffic.py $(find /tmp/rp_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/rp_WRITE_SIZE -name '*counter_collection.csv' | head -1) $O/traffic_$T.json
 fi

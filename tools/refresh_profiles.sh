@@ -12,7 +12,7 @@ cp $(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1) $O/${T}_full_kernel
 grep '^{' /tmp/rp_stats.log | tail -1 > $O/${T}_bench_under_rocprof.json
 # (3) HBM traffic: one counter per pass, the same command in serial mode (per-launch byte counts do not depend on the overlap)
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/rp_$ctr; timeout 180 rocprofv3 --pmc $ctr --output-format csv -d /tmp/rp_$ctr -- python $R/bench.py --cpu-seconds 0 --extra-configs 0 --steps 12 --warmup 2 --profile-scans 0 --nu-scans 0 --async-mesh 0 > /tmp/rp_$ctr.log 2>&1
+  rm -rf /tmp/rp_$ctr; IMMESH_SERIAL_SAFE=1 timeout 300 rocprofv3 --pmc $ctr --output-format csv -d /tmp/rp_$ctr -- python $R/bench.py --cpu-seconds 0 --extra-configs 0 --steps 12 --warmup 2 --profile-scans 0 --nu-scans 0 --async-mesh 0 > /tmp/rp_$ctr.log 2>&1
 done
 python $R/tools/pmc_traffic.py $(find /tmp/rp_FETCH_SIZE -name '*counter_collection.csv' | head -1) $(find /tmp/rp_WRITE_SIZE -name '*counter_collection.csv' | head -1) $O/traffic_${T}.json
 # (4) steady-state kernel timeline (start / duration / queue of every kernel)
