@@ -540,6 +540,12 @@ static void mesh_worker_main(immesh_ctx* c) {
             (void)hipStreamSynchronize(h.stream); (void)hipStreamSynchronize(h.stream_b);
         }
         if (h.prof.on) h.prof.flush();
+        if (f.r.rc) {
+            // a failed job may have stopped between the admission's binning and the kernel that hands the bucket counters back zeroed (mesh_knn_kernel):
+            // the next scan must not find them filled
+            (void)hipStreamSynchronize(h.stream); (void)hipStreamSynchronize(h.stream_b);
+            (void)hipMemsetAsync(c->mesh.bin_cnt, 0, 2 * (1024 + 1) * sizeof(int32_t), h.stream);
+        }
         {
             std::lock_guard<std::mutex> lk(h.mu);
             h.res[f.job.id & 1] = f.r;
