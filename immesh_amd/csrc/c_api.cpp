@@ -85,6 +85,11 @@ static int alloc_all(immesh_ctx* c) {
         char* t; A(t, cap * 16); c->p_htab = t; c->p_htab_cap = cap;
         launch_ds_table_reset(c->stream, t, cap);
     }
+    {   // deep octrees: subtree work items of the map update (regmap.hpp); off for the two-layer avia map, whose general voxels are new or just cut
+        static const char* e = getenv("IMMESH_SPLIT_GENERAL");
+        m.split_general = e ? atoi(e) : (g.max_layer >= 3 ? 1 : 0);
+        A(m.sub_order, ns); A(m.sub_items, 2 * ns);
+    }
     A(c->d_dump_count, 2);
     A(c->d_touched, 2 * ns + 16);
     A(c->d_regstate, 1);

@@ -362,7 +362,7 @@ __device__ __forceinline__ void map_update_tail(const RegMapDev& m, int32_t* __r
     const int base = m.counters[2];
     for (int i = threadIdx.x; i < np; i += 256) m.free_ready[base + i] = m.free_pending[i];
     __syncthreads();
-    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; m.counters[10] = 0; m.counters[11] = 0; }
+    if (threadIdx.x == 0) { m.counters[2] = base + np; m.counters[3] = 0; m.counters[7] = 0; m.counters[9] = 0; m.counters[10] = 0; m.counters[11] = 0; m.counters[12] = 0; }
     __syncthreads();
     if (threadIdx.x < 16) __hip_atomic_store(&host_counters[threadIdx.x], m.counters[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1202,7 +1202,7 @@ __global__ void segment_heads_kernel(const uint32_t* __restrict__ sorted_slot, i
 // =====================================================================================================================
 // wave-cooperative octree maintenance
 // =====================================================================================================================
-struct WaveCtx { int lane; int64_t* stats; int root; };  // stats[0] refits, stats[1] refit points
+struct WaveCtx { int lane; int64_t* stats; int root; bool shared = false; };  // stats[0] refits, stats[1] refit points; shared: other wavefronts work on the same root (replay_sub_kernel)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // OctoTree::init_plane (src/voxel_loc.cpp:47-139) on one wavefront.  The fit is the unit of the map update (one fit used to be 44 k cycles =
@@ -1428,7 +1428,7 @@ __device__ void wave_init_octo_tree(const RegMapDev& m, int node, int* stack, co
             const int f0 = m.nodes[nd].flags;
             int f = f0 | NF_INIT;
             f = planar ? (f | NF_PLANE) : (f & ~NF_PLANE);
-            node_set_flags(m, w.root, nd, f0, f);
+            node_set_flags(m, w.root, nd, f0, f, w.shared);
             m.nodes[nd].newpts = 0;
         }
         if (planar || layer >= m.max_layer) continue;
@@ -1509,7 +1509,7 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (newp > 5) {  // m_update_size_threshold_
                 const bool planar = wave_init_plane(m, nd, n + 1, w);
-                if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE));
+                if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE), w.shared);
                 newp = 0;
             }
             if (w.lane == 0) {
@@ -1546,7 +1546,7 @@ __device__ void wave_update_point(const RegMapDev& m, int root, const double* sr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (newp > 5) {
             const bool planar = wave_init_plane(m, nd, n + 1, w);
-            if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE));
+            if (w.lane == 0) node_set_flags(m, w.root, nd, flags, planar ? (flags | NF_PLANE) : (flags & ~NF_PLANE), w.shared);
             newp = 0;
         }
         if (w.lane == 0) {
@@ -1662,6 +1662,85 @@ __device__ int wave_replay_planar_root(const RegMapDev& m, const int root, const
     }
     if (header_dirty) write_header();
     if (last_refit_n) (void)wave_init_plane(m, root, last_refit_n, wq);
+    if (w.lane == 0 && w.stats && n_ref) { atomicAdd((unsigned long long*)&w.stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n_ref_pts); }
+    return j;
+}
+
+// The same batch treatment for a planar node of ANY size at ANY layer (deep octrees: velodyne.yaml keeps up to 1000 points in a node, and a refit runs over
+// all of them -- six refits of a 37-point batch were 0.25 ms of a lone wavefront): the points are appended through the node's chunk table in memory
+// (wave_push_point), the running per-axis sums decide the intermediate refits by the diagonal bound exactly as above, and only the LAST refit of the batch
+// -- the one the matcher can observe -- is computed, over the points the reference's last refit saw.  Returns the number of points consumed; the node's
+// header in memory is current on return (wave_update_point continues from it when the node turned non-planar or filled up).
+__device__ int wave_replay_planar_node(const RegMapDev& m, const int node, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w) {
+    NodeRec& nd = m.nodes[node];
+    int flags = nd.flags;
+    const int want = NF_INIT | NF_PLANE | NF_UPDATE_EN;
+    if ((flags & want) == (NF_INIT | NF_PLANE)) return cnt;   // a full planar node (m_update_enable_ == false) drops every point
+    if ((flags & want) != want) return 0;
+    int npts = nd.npts, newp = nd.newpts;
+    double s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+    const bool will_refit = newp + cnt > 5;
+    if (will_refit) {
+        for (int i = w.lane; i < npts; i += 64) {
+            const double* q = node_point_ptr(m, node, i);
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double v = q[a]; s1[a] += v; s2[a] += v * v; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { s1[a] = wave_sum(s1[a]); s2[a] = wave_sum(s2[a]); }
+    }
+    WaveCtx wq = w; wq.stats = nullptr;   // refits are counted here (deferred ones included), not by wave_init_plane
+    int last_refit_n = 0, n_ref = 0, j = 0;
+    long long n_ref_pts = 0;
+    auto write_counts = [&]() {
+        if (w.lane == 0) { nd.npts = npts; nd.newpts = newp; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (; j < cnt; j++) {
+        const double* src = pt_data + (size_t)order[j] * IM_PT_DOUBLES;
+        if (!wave_push_point(m, node, npts, src, w)) { write_counts(); return j; }   // pool exhausted (flag raised): stop here
+        if (will_refit) {
+            const double pv = w.lane < IM_PT_DOUBLES ? src[w.lane] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double v = __shfl(pv, a, 64); s1[a] += v; s2[a] += v * v; }
+        }
+        npts++; newp++;
+        if (newp > 5) {   // m_update_size_threshold_: the refit over all retained points falls due
+            n_ref++; n_ref_pts += npts;
+            const double dn = (double)npts;
+            double vmin = 1e300, mag = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { const double mu = s1[a] / dn; const double v = s2[a] / dn - mu * mu; vmin = fmin(vmin, v); mag += s2[a] / dn; }
+            const double err = 1e-7 + 1e-12 * mag;
+            newp = 0;
+            if (vmin + err < (double)m.planer_threshold) last_refit_n = npts;   // certainly still planar: fit later, over these npts points
+            else {
+                write_counts();
+                last_refit_n = 0;
+                const bool planar = wave_init_plane(m, node, npts, wq);
+                if (!planar) {   // the node turns non-planar: later points take the general route (children)
+                    if (w.lane == 0) node_set_flags(m, w.root, node, flags, flags & ~NF_PLANE, w.shared);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    flags &= ~NF_PLANE;
+                    j++;
+                    break;
+                }
+            }
+        }
+        if (npts >= m.max_points_size) {   // the node is full: last fit (if one is pending), then it stops updating and drops its points
+            write_counts();
+            if (last_refit_n) { (void)wave_init_plane(m, node, last_refit_n, wq); last_refit_n = 0; }
+            if (w.lane == 0) { nd.flags = nd.flags & ~NF_UPDATE_EN; node_free_points(m, node); nd.newpts = 0; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            npts = 0; newp = 0;
+            j++;
+            if (w.lane == 0 && w.stats && n_ref) { atomicAdd((unsigned long long*)&w.stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n_ref_pts); }
+            return j;
+        }
+    }
+    write_counts();
+    if (last_refit_n) (void)wave_init_plane(m, node, last_refit_n, wq);
     if (w.lane == 0 && w.stats && n_ref) { atomicAdd((unsigned long long*)&w.stats[0], (unsigned long long)n_ref); atomicAdd((unsigned long long*)&w.stats[1], (unsigned long long)n_ref_pts); }
     return j;
 }
@@ -1882,6 +1961,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
 #undef FEND
 }
 
+__device__ bool replay_split_root(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w);
 // updateVoxelMap without any global sort: one wavefront per root voxel of the work list gathers that voxel's points of this scan from its
 // list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them through the
 // general state machine.  The grid is FIXED and strides over the list (a few dozen voxels per scan on a settled map, every touched voxel while
@@ -1929,7 +2009,10 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            for (int j = wave_replay_planar_root(m, root, big_order + base, cnt, pt_data, w); j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
+            if (replay_split_root(m, root, big_order + base, cnt, pt_data, w)) continue;   // (a subdivided root of a deep octree: its octants go to replay_sub_kernel)
+            int jb = wave_replay_planar_root(m, root, big_order + base, cnt, pt_data, w);
+            if (jb == 0) jb = wave_replay_planar_node(m, root, big_order + base, cnt, pt_data, w);
+            for (int j = jb; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)big_order[base + j] * IM_PT_DOUBLES, stacks[wv], w);
             continue;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1946,8 +2029,10 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // settled planar roots take the register-resident fast path; whatever it does not consume goes through the general state machine
+        if (replay_split_root(m, root, order[wv], cnt, pt_data, w)) continue;   // (a subdivided root of a deep octree: its octants go to replay_sub_kernel)
         const unsigned long long tdbg1 = dbg ? __builtin_readcyclecounter() : 0;
-        const int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
+        int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
+        if (jf == 0) jf = wave_replay_planar_node(m, root, order[wv], cnt, pt_data, w);   // (planar roots that do not fit the register path: deep-octree configurations)
         for (int j = jf; j < cnt; j++) wave_update_point(m, root, pt_data + (size_t)order[wv][j] * IM_PT_DOUBLES, stacks[wv], w);
         if (dbg && w.lane == 0) {   // IMMESH_DEBUG: slowest voxel of each kind (cycles << 16 | points), totals
             const unsigned long long t2 = __builtin_readcyclecounter();
@@ -1959,13 +2044,89 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     }
 }
 
+// Deep octrees (velodyne.yaml: 3 m roots, four layers, ~30 points of a scan per root, up to 60): the general state machine replays a root's points one
+// by one -- descent, push, a refit every sixth point -- and the densest root sets the kernel's time (61 points: 950 k cycles = 0.4 ms of the 0.6 ms scan).
+// A SUBDIVIDED root (initialised, not a plane, below max_layer) only routes: UpdateOctoTree hands the point to the child of its octant (voxel_loc.cpp:
+// 263-288), so the eight octants are independent state machines and only the order of the points WITHIN an octant matters.  replay_list_kernel
+// therefore cuts such a root's ordered list into its octants' lists (replay_split_root) and replay_sub_kernel replays each with a wavefront of its own.
+// What the octants share is the root's flat list of planar descendants: edited under the root's lock (node_set_flags, shared).
+__device__ bool replay_split_root(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w) {
+    const NodeRec& nr = m.nodes[root];
+    const int flags = nr.flags;
+    if (!m.split_general || cnt < 8 || !(flags & NF_INIT) || (flags & NF_PLANE) || nr.layer >= m.max_layer) return false;
+    if (w.lane == 0 && nr.npts != 0) node_free_points(m, root);   // what UpdateOctoTree does on its first visit after the cut (voxel_loc.cpp:263-266)
+    const double ctr[3] = {nr.center[0], nr.center[1], nr.center[2]};
+    int child[8], n_oct[8], base[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { child[k] = nr.child[k]; n_oct[k] = 0; }
+    for (int b0 = 0; b0 < cnt; b0 += 64) {   // counts per octant
+        const int j = b0 + w.lane;
+        const int oct = j < cnt ? octant_of(pt_data + (size_t)order[j] * IM_PT_DOUBLES, ctr) : -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) n_oct[k] += __popcll(__ballot(oct == k));
+    }
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) total += n_oct[k];
+    int seg = 0, item0 = 0, n_items = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) n_items += n_oct[k] > 0 ? 1 : 0;
+    if (w.lane == 0) { seg = atomicAdd(&m.counters[11], total); item0 = atomicAdd(&m.counters[12], n_items); }
+    seg = __shfl(seg, 0, 64); item0 = __shfl(item0, 0, 64);
+    {
+        int run = seg, it = item0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            base[k] = run; run += n_oct[k];
+            if (n_oct[k] > 0) {
+                int c = child[k];
+                if (w.lane == 0 && c < 0) c = make_child(m, root, k);
+                c = __shfl(c, 0, 64);
+                if (c < 0) return true;   // node pool exhausted (flag raised by node_alloc): the update fails as a whole
+                if (w.lane == 0) {
+                    m.sub_items[2 * (size_t)it] = (unsigned long long)(unsigned int)c | ((unsigned long long)(unsigned int)root << 32);
+                    m.sub_items[2 * (size_t)it + 1] = (unsigned long long)(unsigned int)base[k] | ((unsigned long long)(unsigned int)n_oct[k] << 32);
+                }
+                it++;
+            }
+        }
+    }
+    int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b0 = 0; b0 < cnt; b0 += 64) {   // the octants' lists, each in the voxel's replay order
+        const int j = b0 + w.lane;
+        const int id = j < cnt ? order[j] : -1;
+        const int oct = j < cnt ? octant_of(pt_data + (size_t)id * IM_PT_DOUBLES, ctr) : -1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned long long mk = __ballot(oct == k);
+            if (oct == k) m.sub_order[base[k] + fill[k] + __popcll(mk & ((1ull << w.lane) - 1ull))] = id;
+            fill[k] += __popcll(mk);
+        }
+    }
+    return true;
+}
+__global__ __launch_bounds__(256) void replay_sub_kernel(RegMapDev m, const double* __restrict__ pt_data, int64_t* stats) {
+    __shared__ int stacks[4][48];
+    __builtin_amdgcn_s_setprio(1);
+    const int wv = threadIdx.x >> 6;
+    const int n_items = m.counters[12];
+    WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats; w.shared = true;
+    for (int t = blockIdx.x * 4 + wv; t < n_items; t += gridDim.x * 4) {
+        const unsigned long long a = m.sub_items[2 * (size_t)t], b = m.sub_items[2 * (size_t)t + 1];
+        const int child = (int)(unsigned int)a, first = (int)(unsigned int)b, cnt = (int)(unsigned int)(b >> 32);
+        w.root = (int)(unsigned int)(a >> 32);
+        for (int j = wave_replay_planar_node(m, child, m.sub_order + first, cnt, pt_data, w); j < cnt; j++)
+            wave_update_point(m, child, pt_data + (size_t)m.sub_order[first + j] * IM_PT_DOUBLES, stacks[wv], w);
+    }
+}
+
 // merge chunk ids freed by the previous kernel into the ready stack
 __global__ void merge_free_kernel(RegMapDev m) {
     const int np = m.counters[3];
     const int base = m.counters[2];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) m.free_ready[base + i] = m.free_pending[i];
 }
-__global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; m.counters[7] = 0; }
+__global__ void merge_free_finish_kernel(RegMapDev m) { m.counters[2] += m.counters[3]; m.counters[3] = 0; m.counters[7] = 0; m.counters[11] = 0; m.counters[12] = 0; }
 // Tail of the per-scan map update, one launch: chunks freed by the replay kernel join the free list, the per-update counters reset, and the map
 // counters (node / chunk usage, capacity flag) go straight to pinned host memory -- the next scan's residual passes are queued right behind it.
 __global__ __launch_bounds__(256) void merge_free_tail_kernel(RegMapDev m, int32_t* __restrict__ host_counters) { map_update_tail(m, host_counters); }
@@ -2042,6 +2203,7 @@ void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_ne
     const int nb_list = std::min(std::max((n + 127) / 128, 32), 4096);
     KLAUNCH(replay_list_kernel, dim3(nb_list), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
             (const int32_t*)(m.counters + 10));
+    if (m.split_general) KLAUNCH(replay_sub_kernel, dim3(std::min(std::max((n + 63) / 64, 32), 2048)), dim3(256), 0, s, m, pt_data, stats);
     if (with_tail) KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_map_update_tail(hipStream_t s, const RegMapDev& m, int32_t* host_counters) { KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters); }

@@ -34,7 +34,7 @@ struct alignas(64) NodeRec {
     int32_t ext, path;                     // extension table id or -1; child path from the root (3 bits per level)
     unsigned long long key;                // packed root key (for dumps)
     int32_t leaf_head;                     // root nodes: chain of the planar descendants (what build_single_residual's recursion would reach)
-    int32_t pad0;
+    int32_t lock;                          // root nodes: guards leaf_head's chain when several wavefronts update ONE root (replay_sub_kernel); 0 = free
     unsigned long long pad[3];
 };
 static_assert(sizeof(NodeRec) == 384, "NodeRec layout");
@@ -60,6 +60,11 @@ struct RegMapDev {
     // per-update root-voxel point lists (map_incremental_grow): head word per hash slot = (update seq << 32 | last point index), stamped so it never needs clearing
     unsigned long long* slot_head;  // [hcap]
     uint32_t* touched;          // (hash slot, root node) of the voxels touched by the current update (counters[7] pairs)
+    // subtree work items (deep octrees: max_layer >= 3): a subdivided root's points of this scan, split by first-level octant -- the octants are independent
+    // state machines -- and replayed by one wavefront each (replay_sub_kernel).  counters[11] = sub_order fill, counters[12] = items
+    int32_t split_general;      // 1: replay_list_kernel hands the octants of subdivided roots to replay_sub_kernel
+    int32_t* sub_order;         // point indices of the items, each item's in the voxel's replay order
+    unsigned long long* sub_items;   // 2 words per item: child node | root << 32, first index in sub_order | count << 32
     int32_t upd_seq;
     // multi-GPU sharding of the registration map: root voxels are owned in bricks of 2^shard_brick_log2 voxels per axis,
     // owner = hash(brick) mod shard_world; a rank also keeps the 1-voxel halo around its bricks (the near-voxel retry looks one voxel over)
@@ -198,7 +203,7 @@ IMD int node_alloc(const RegMapDev& m, int layer, const double* center, float qu
     nd.flags = NF_UPDATE_EN;
     nd.layer = layer;
     nd.npts = 0; nd.newpts = 0; nd.ext = -1;
-    nd.key = key; nd.path = path; nd.leaf_head = -1;
+    nd.key = key; nd.path = path; nd.leaf_head = -1; nd.lock = 0;
     nd.d = 0.f; nd.radius = 0.f; nd.min_eig = 1.f;
     return id;
 }
@@ -222,10 +227,21 @@ IMD void leaf_remove(const RegMapDev& m, int root, int nd) {
         for (int s = 0; s < IM_LEAF_SLOTS; s++)
             if (m.leaf_chunks[(size_t)ch * 16 + s] == nd) { m.leaf_chunks[(size_t)ch * 16 + s] = -1; return; }
 }
-// write a node's flags; keeps the root's leaf list in step with the plane bit (one lane)
-IMD void node_set_flags(const RegMapDev& m, int root, int nd, int old_flags, int new_flags) {
+// write a node's flags; keeps the root's leaf list in step with the plane bit (one lane).  shared: other wavefronts update other subtrees of the SAME
+// root at the same time (replay_sub_kernel) -- the chain is then edited under the root's lock, with device-scope acquire / release around it
+IMD void node_set_flags(const RegMapDev& m, int root, int nd, int old_flags, int new_flags, bool shared = false) {
     m.nodes[nd].flags = new_flags;
-    if (nd != root && ((old_flags ^ new_flags) & NF_PLANE)) { if (new_flags & NF_PLANE) leaf_add(m, root, nd); else leaf_remove(m, root, nd); }
+    if (nd != root && ((old_flags ^ new_flags) & NF_PLANE)) {
+        if (shared) {
+            while (atomicCAS(&m.nodes[root].lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        if (new_flags & NF_PLANE) leaf_add(m, root, nd); else leaf_remove(m, root, nd);
+        if (shared) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            atomicExch(&m.nodes[root].lock, 0);
+        }
+    }
 }
 // position of a node in the depth-first order of the reference's recursion (child indices, first level most significant)
 IMD unsigned int dfs_key(const RegMapDev& m, int nd) {
