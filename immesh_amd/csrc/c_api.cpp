@@ -84,6 +84,13 @@ static int alloc_all(immesh_ctx* c) {
         unsigned long long cap = 1024; while (cap < 2ull * (unsigned long long)ns) cap <<= 1;
         char* t; A(t, cap * 16); c->p_htab = t; c->p_htab_cap = cap;
         launch_ds_table_reset(c->stream, t, cap);
+        HIPCHK(c, hipHostMalloc((void**)&c->h_ds_dyn, sizeof(DsDyn), hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_ds_dyn, c->h_ds_dyn, 0));
+        std::memset(c->h_ds_dyn, 0, sizeof(DsDyn));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_ds_info, 16 * sizeof(int32_t), hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_ds_info, c->h_ds_info, 0));
+        std::memset(c->h_ds_info, 0, 16 * sizeof(int32_t));
+        HIPCHK(c, hipMemsetAsync(c->p_nseg, 0, 16 * sizeof(int32_t), c->stream));   // (the VoxelGrid's device counters start out zero and are handed back zeroed)
     }
     {   // deep octrees: subtree work items of the map update (regmap.hpp); off for the two-layer avia map, whose general voxels are new or just cut
         static const char* e = getenv("IMMESH_SPLIT_GENERAL");
@@ -166,6 +173,9 @@ void immesh_destroy(immesh_ctx* c) {
     if (c->ev_inputs_free) (void)hipEventDestroy(c->ev_inputs_free);
     if (c->dsa.ev) (void)hipEventDestroy(c->dsa.ev);
     if (c->dsa.h_info) (void)hipHostFree(c->dsa.h_info);
+    if (c->ds_graph) (void)hipGraphExecDestroy(c->ds_graph);
+    if (c->h_ds_dyn) (void)hipHostFree(c->h_ds_dyn);
+    if (c->h_ds_info) (void)hipHostFree(c->h_ds_info);
     mesh_free(c);
     rccl_release(c);
     for (void* p : c->allocs) (void)hipFree(p);
@@ -903,10 +913,11 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     if (!radix_only && !c->ds_skip_hash) {
         // three launches (ds_kernels.hip: leaf table + chains, leaf sort, per-leaf ordered sums); the radix pipeline below only when that gives up
         PRE_OUTPUT_FENCE(c);
-        launch_ds_hash_pipeline(s, (const float*)d_pts, n, stride, inv, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->d_ds_out, c->p_nseg + 8);
-        int32_t info[2] = {0, 0};
-        HIPCHK(c, hipMemcpyAsync(info, c->p_nseg + 12, 8, hipMemcpyDeviceToHost, s));
+        *c->h_ds_dyn = DsDyn{(const float*)d_pts, c->d_ds_out, n, stride, inv, 0};
+        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
+        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info);
         HIPCHK(c, hipStreamSynchronize(s));
+        const int32_t info[2] = {c->h_ds_info[0], c->h_ds_info[1]};
         if (!info[1]) {
             const int32_t cnt = info[0];
             *n_out = cnt;
@@ -995,8 +1006,28 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
     // three launches, nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table + chains,
     // leaf sort, per-leaf ordered sums (ds_kernels.hip)
     PRE_OUTPUT_FENCE(c);   // (the buffer being written was the input of the scan before the one in flight: its point_var has to be through)
-    launch_ds_hash_pipeline(s, (const float*)d_pts, n, stride, inv, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, a.out[a.par], c->p_nseg + 8);
-    HIPCHK(c, hipMemcpyAsync(a.h_info, c->p_nseg + 12, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));   // [0] leaves, [1] fall-back wanted
+    *c->h_ds_dyn = DsDyn{(const float*)d_pts, a.out[a.par], n, stride, inv, 0};   // (pinned: read by thread 0 of every workgroup; the previous job has been collected)
+    auto enqueue = [&]() -> int {
+        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
+        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info);   // [0] leaves, [1] fall-back wanted -> pinned memory; device counters back to zero
+        return 0;
+    };
+    static const bool no_graph = getenv("IMMESH_NO_GRAPH") != nullptr;
+    if (no_graph || c->prof.on) { if ((rc = enqueue())) return rc; }
+    else {
+        // the launches never change (everything cloud-specific is in the pinned block): captured once, replayed with ONE call
+        if (!c->ds_graph) {
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int erc = enqueue();
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (erc || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "hipGraph capture of the VoxelGrid failed"; return IMMESH_E_HIP; }
+            const hipError_t ie = hipGraphInstantiate(&c->ds_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ie != hipSuccess) { c->ds_graph = nullptr; c->err = std::string("hipGraphInstantiate(VoxelGrid): ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
+        }
+        HIPCHK(c, hipGraphLaunch(c->ds_graph, s));
+    }
     HIPCHK(c, hipEventRecord(a.ev, s));
     a.active = true;
     return 0;
@@ -1008,6 +1039,7 @@ int immesh_downsample_end(immesh_ctx* c, int32_t* n_out, const float** dev_xyz) 
     (void)hipSetDevice(c->cfg.device);
     HIPCHK(c, hipEventSynchronize(a.ev));
     a.active = false;
+    a.h_info[0] = c->h_ds_info[0]; a.h_info[1] = c->h_ds_info[1];
     if (a.h_info[1]) {
         // the three-launch form gave up (a cell outside the key's range, a leaf above 2048 points): the general path, synchronously (it resets the table)
         int32_t cnt = 0;

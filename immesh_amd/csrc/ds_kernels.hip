@@ -136,26 +136,36 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
 #define DSH_CHUNK 512
 #define DSH_LEAF_CAP 2048          /* points of one leaf ordered in LDS; a leaf holding more sets the fall-back flag */
 struct DsEnt { unsigned long long key; int cnt; int off; };   // 16 B; key == DSH_EMPTY: free (then cnt == 0)
-// info: [0] leaves, [1] fall-back wanted (cell out of the key's range / table full / a leaf above DSH_LEAF_CAP points), [2] pool fill
-__global__ __launch_bounds__(256) void ds_hash_kernel(const float* __restrict__ pts, int n, int stride, float inv, DsEnt* __restrict__ tab, unsigned long long mask,
+// What changes from cloud to cloud lives in PINNED host memory (DsDyn, kernels.hpp): thread 0 of every workgroup reads it (one PCIe round trip per
+// workgroup) -- so the kernel arguments never change and the five launches + the clearing of `info` + the read-back of the result are ONE hipGraph
+// (immesh_downsample_begin: four API calls on the scan thread instead of nine).
+#define DS_DYN(dynp) __shared__ DsDyn s_dyn_; if (threadIdx.x == 0) s_dyn_ = *(dynp); __syncthreads(); const DsDyn& dyn = s_dyn_
+// info: [0] leaves, [1] fall-back wanted (cell out of the key's range / table full / a leaf above DSH_LEAF_CAP points), [2] pool fill, [3] big leaves
+__global__ __launch_bounds__(256) void ds_hash_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, unsigned long long mask,
                                                        int32_t* __restrict__ pt_slot, int32_t* __restrict__ leaf_slot, int32_t* __restrict__ info) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    DS_DYN(dynp);
+    const float* __restrict__ pts = dyn.pts;
+    const int n = dyn.n, stride = dyn.stride;
+    const float inv = dyn.inv;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float* p = pts + (size_t)i * stride;
     const long long cx = (long long)floorf(p[0] * inv), cy = (long long)floorf(p[1] * inv), cz = (long long)floorf(p[2] * inv);
-    if (cx < -DSH_BIAS || cx >= DSH_BIAS || cy < -DSH_BIAS || cy >= DSH_BIAS || cz < -DSH_BIAS || cz >= DSH_BIAS) { info[1] = 1; pt_slot[i] = -1; return; }
+    if (cx < -DSH_BIAS || cx >= DSH_BIAS || cy < -DSH_BIAS || cy >= DSH_BIAS || cz < -DSH_BIAS || cz >= DSH_BIAS) { info[1] = 1; pt_slot[i] = -1; continue; }
     const unsigned long long key = ((unsigned long long)(cz + DSH_BIAS) << 42) | ((unsigned long long)(cy + DSH_BIAS) << 21) | (unsigned long long)(cx + DSH_BIAS);
     unsigned long long h = hash64(key) & mask;
+    int slot = -1;
     for (int probe = 0; probe < 4096; probe++) {
         unsigned long long k = tab[h].key;
         if (k == DSH_EMPTY) {
             k = atomicCAS(&tab[h].key, (unsigned long long)DSH_EMPTY, key);
             if (k == DSH_EMPTY) { leaf_slot[atomicAdd(&info[0], 1)] = (int)h; k = key; }
         }
-        if (k == key) { atomicAdd(&tab[h].cnt, 1); pt_slot[i] = (int)h; return; }
+        if (k == key) { atomicAdd(&tab[h].cnt, 1); slot = (int)h; break; }
         h = (h + 1) & mask;
     }
-    info[1] = 1; pt_slot[i] = -1;
+    if (slot < 0) info[1] = 1;
+    pt_slot[i] = slot;
+    }
 }
 __global__ __launch_bounds__(256) void ds_leaf_sort_kernel(DsEnt* __restrict__ tab, const int32_t* __restrict__ leaf_slot, int32_t* __restrict__ info,
                                                             unsigned long long* __restrict__ keys_sorted, int32_t* __restrict__ slots_sorted, int32_t* __restrict__ big_list) {
@@ -200,22 +210,25 @@ __global__ __launch_bounds__(256) void ds_leaf_sort_kernel(DsEnt* __restrict__ t
             __syncthreads();
         }
     for (int k = tid; k < cnt; k += 256) {
-        keys_sorted[first + k] = sk[k]; slots_sorted[first + k] = sv[k];
-        if (sc[k] > 64) big_list[atomicAdd(&info[3], 1)] = first + k;   // leaves above one wavefront's worth of points: ds_leaf_emit_big_kernel
+        const bool big = sc[k] > 64;   // leaves above one wavefront's worth of points: marked in the sign bit of their slot and listed for the long-leaf wavefronts
+        keys_sorted[first + k] = sk[k]; slots_sorted[first + k] = big ? (int)((unsigned int)sv[k] | 0x80000000u) : sv[k];
+        if (big) big_list[atomicAdd(&info[3], 1)] = first + k;
     }
     __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void ds_scatter_kernel(int n, DsEnt* __restrict__ tab, const int32_t* __restrict__ pt_slot, int32_t* __restrict__ pool) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(256) void ds_scatter_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const int32_t* __restrict__ pt_slot, int32_t* __restrict__ pool) {
+    DS_DYN(dynp);
+    const int n = dyn.n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int slot = pt_slot[i];
-    if (slot < 0) return;
+    if (slot < 0) continue;
     // (the count runs down to zero while the segment fills; ds_leaf_emit_kernel takes the leaf's size from the neighbouring leaves' offsets -- no: it
     //  is kept in the high half below)
     const int old = atomicAdd(&tab[slot].cnt, 0x10000 - 1);   // low 16 bits: points still to place (<= DSH_LEAF_CAP), high 16: points placed
     const int left = old & 0xFFFF;
     if (left > 0 && left <= DSH_LEAF_CAP) pool[tab[slot].off + left - 1] = i;
+    }
 }
 // output position of the leaf at sorted position e: own position in its chunk + the number of smaller keys in every other chunk (keys are unique);
 // one lane per chunk
@@ -237,25 +250,106 @@ IMD int ds_leaf_rank(const unsigned long long* __restrict__ keys_sorted, int nle
     }
     return rank;
 }
-// leaves of <= 64 points (all but a few dozen of a scan's ~8 k): no LDS, one wavefront per leaf
-__global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const float* __restrict__ pts, int stride, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
+// One launch for both kinds of leaves: wavefront 0 of the first DSH_BIG_BLOCKS workgroups takes the leaves of 65 .. DSH_LEAF_CAP points (the ground right in
+// front of the sensor: a few dozen to a few hundred per scan, each a chain of tens of microseconds), every other wavefront the leaves of <= 64 points --
+// as two launches the short leaves waited 50 us behind the long ones.
+//   <= 64 points: no LDS; the segment's indices in the lanes, ranked by counting, the sums by v_readlane from the lane holding rank r;
+//   65 .. 2048:   the segment ordered through a bitmap over the scan's point indices in LDS (set the members' bits, read the words back in order: no
+//                 sorting network -- a lone wavefront needs ~130 us to sort 2048 keys that way) when the scan has at most DSH_BITMAP_PTS points, else
+//                 by the network.
+#define DSH_BITMAP_PTS 131072
+#define DSH_BIG_BLOCKS 768
+__global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
                                                             const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ slots_sorted,
-                                                            int32_t* __restrict__ info, float* __restrict__ out, int32_t* __restrict__ n_out) {
+                                                            const int32_t* __restrict__ big_list, int32_t* __restrict__ info, int32_t* __restrict__ n_out) {
+    DS_DYN(dynp);
+    __shared__ unsigned int bm[DSH_BITMAP_PTS / 32];
+    __shared__ int idx[DSH_LEAF_CAP];
+    const float* __restrict__ pts = dyn.pts;
+    float* __restrict__ out = dyn.out;
+    const int n = dyn.n, stride = dyn.stride;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nleaf = info[0];
+    const int nleaf = info[0], nbig = info[3];
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = nleaf;
-    for (int e = blockIdx.x * 4 + wv; e < nleaf; e += gridDim.x * 4) {
+    const int n_big_blocks = min((int)gridDim.x, DSH_BIG_BLOCKS);
+    auto lds_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+    if ((int)blockIdx.x < n_big_blocks && wv == 0) {
+        // ---- the long leaves
+        const int nwords = (min(n, DSH_BITMAP_PTS) + 31) / 32;
+        for (int b = blockIdx.x; b < nbig; b += n_big_blocks) {
+            const int e = big_list[b];
+            const unsigned long long key = keys_sorted[e];
+            const int slot = slots_sorted[e] & 0x7FFFFFFF;
+            const DsEnt ent = tab[slot];
+            const int cnt = ent.cnt >> 16;
+            const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
+            if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }   // the entry goes back empty: the table is never cleared as a whole
+            if (cnt > DSH_LEAF_CAP || cnt <= 64) { if (lane == 0) info[1] = 1; continue; }
+            if (n <= DSH_BITMAP_PTS) {
+                for (int w = lane; w < nwords; w += 64) bm[w] = 0u;
+                lds_sync();
+                for (int k = lane; k < cnt; k += 64) { const int p = pool[ent.off + k]; atomicOr(&bm[p >> 5], 1u << (p & 31)); }
+                lds_sync();
+                int base = 0;
+                for (int w0 = 0; w0 < nwords; w0 += 64) {
+                    const int w = w0 + lane;
+                    unsigned int bits = w < nwords ? bm[w] : 0u;
+                    if (!__any(bits != 0u)) continue;
+                    const int pc = __popc(bits);
+                    int incl = pc;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+                    int o = base + incl - pc;
+                    while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1; idx[o++] = (w << 5) | bit; }
+                    base += __shfl(incl, 63, 64);
+                }
+                lds_sync();
+            } else {
+                int np2 = 128; while (np2 < cnt) np2 <<= 1;
+                for (int k = lane; k < np2; k += 64) idx[k] = k < cnt ? pool[ent.off + k] : 0x7FFFFFFF;
+                lds_sync();
+                for (int k = 2; k <= np2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int p = lane; p < np2; p += 64) {
+                            const int q = p ^ j;
+                            if (q > p) { const bool up = ((p & k) == 0); const int a_ = idx[p], b_ = idx[q]; if ((a_ > b_) == up) { idx[p] = b_; idx[q] = a_; } }
+                        }
+                        lds_sync();
+                    }
+            }
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (lane < min(64, cnt)) { const float* q = pts + (size_t)idx[lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }
+            for (int b0 = 0; b0 < cnt; b0 += 64) {
+                const int m = min(64, cnt - b0);
+                const float x = nx, y = ny, z = nz;
+                if (b0 + 64 + lane < cnt) { const float* q = pts + (size_t)idx[b0 + 64 + lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }   // next batch in flight
+                for (int l = 0; l < m; l++) {
+                    sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+                    sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
+                    sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
+                }
+            }
+            if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
+            lds_sync();
+        }
+        return;
+    }
+    // ---- the short leaves: every other wavefront, compactly numbered
+    const int wid = blockIdx.x * 4 + wv - min((int)blockIdx.x, n_big_blocks) - (((int)blockIdx.x < n_big_blocks) ? 1 : 0);
+    const int n_small_waves = gridDim.x * 4 - n_big_blocks;
+    for (int e = wid; e < nleaf; e += n_small_waves) {
         const unsigned long long key = keys_sorted[e];
         const int slot = slots_sorted[e];
+        if (slot < 0) continue;   // a long leaf: its own wavefront's (its table entry may be handed back at any moment -- never looked at here)
         const DsEnt ent = tab[slot];
-        const int cnt = ent.cnt >> 16;     // (every point of the leaf has been placed: the low half is zero)
-        if (cnt > 64 || ent.key != key) continue;   // ds_leaf_emit_big_kernel's (it ran first and has handed the entry back already)
+        const int cnt = ent.cnt >> 16;   // (complete: the scatter launch is behind us)
         // the segment and its points first (two dependent round trips), the output position (binary searches) while they are in flight
         const int mine = lane < cnt ? pool[ent.off + lane] : 0x7FFFFFFF;
         float x = 0.f, y = 0.f, z = 0.f;
         if (lane < cnt) { const float* q = pts + (size_t)mine * stride; x = q[0]; y = q[1]; z = q[2]; }
         const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
-        if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }   // the entry goes back empty: the table is never cleared as a whole
+        if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }
         if (cnt <= 0) { if (lane == 0) info[1] = 1; continue; }
         // rank by counting (indices are distinct), then the sequential float32 sum in index order: v_readlane from the lane holding rank r
         int r = 0;
@@ -272,88 +366,26 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const float* __restri
         if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
     }
 }
-// leaves of 65 .. DSH_LEAF_CAP points (the ground right in front of the sensor): one wavefront per leaf, the segment ordered through a bitmap over the
-// scan's point indices in LDS (set the members' bits, read the words back in order: no sorting network -- a lone wavefront needs ~130 us to sort 2048
-// keys that way) when the scan has at most DSH_BITMAP_PTS points, else by the network
-#define DSH_BITMAP_PTS 131072
-__global__ __launch_bounds__(64) void ds_leaf_emit_big_kernel(const float* __restrict__ pts, int n, int stride, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
-                                                               const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ slots_sorted,
-                                                               const int32_t* __restrict__ big_list, int32_t* __restrict__ info, float* __restrict__ out) {
-    __shared__ unsigned int bm[DSH_BITMAP_PTS / 32];
-    __shared__ int idx[DSH_LEAF_CAP];
-    const int lane = threadIdx.x;
-    const int nleaf = info[0], nbig = info[3];
-    const int nwords = (min(n, DSH_BITMAP_PTS) + 31) / 32;
-    auto lds_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
-    for (int b = blockIdx.x; b < nbig; b += gridDim.x) {
-        const int e = big_list[b];
-        const unsigned long long key = keys_sorted[e];
-        const int slot = slots_sorted[e];
-        const DsEnt ent = tab[slot];
-        const int cnt = ent.cnt >> 16;
-        const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
-        if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }
-        if (cnt > DSH_LEAF_CAP || cnt <= 64) { if (lane == 0) info[1] = 1; continue; }
-        if (n <= DSH_BITMAP_PTS) {
-            for (int w = lane; w < nwords; w += 64) bm[w] = 0u;
-            lds_sync();
-            for (int k = lane; k < cnt; k += 64) { const int p = pool[ent.off + k]; atomicOr(&bm[p >> 5], 1u << (p & 31)); }
-            lds_sync();
-            int base = 0;
-            for (int w0 = 0; w0 < nwords; w0 += 64) {
-                const int w = w0 + lane;
-                unsigned int bits = w < nwords ? bm[w] : 0u;
-                if (!__any(bits != 0u)) continue;
-                const int pc = __popc(bits);
-                int incl = pc;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
-                int o = base + incl - pc;
-                while (bits) { const int bit = __ffs(bits) - 1; bits &= bits - 1; idx[o++] = (w << 5) | bit; }
-                base += __shfl(incl, 63, 64);
-            }
-            lds_sync();
-        } else {
-            int np2 = 128; while (np2 < cnt) np2 <<= 1;
-            for (int k = lane; k < np2; k += 64) idx[k] = k < cnt ? pool[ent.off + k] : 0x7FFFFFFF;
-            lds_sync();
-            for (int k = 2; k <= np2; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int p = lane; p < np2; p += 64) {
-                        const int q = p ^ j;
-                        if (q > p) { const bool up = ((p & k) == 0); const int a_ = idx[p], b_ = idx[q]; if ((a_ > b_) == up) { idx[p] = b_; idx[q] = a_; } }
-                    }
-                    lds_sync();
-                }
-        }
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        if (lane < min(64, cnt)) { const float* q = pts + (size_t)idx[lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }
-        for (int b0 = 0; b0 < cnt; b0 += 64) {
-            const int m = min(64, cnt - b0);
-            const float x = nx, y = ny, z = nz;
-            if (b0 + 64 + lane < cnt) { const float* q = pts + (size_t)idx[b0 + 64 + lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }   // next batch in flight
-            for (int l = 0; l < m; l++) {
-                sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
-                sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
-                sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
-            }
-        }
-        if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
-        lds_sync();
+// tab: table of `cap` (power of two, >= 2 n_max) entries, all empty on entry and on exit.  info: 4 ints, zero on entry (ds_publish_kernel, the last launch of every sequence, hands them back zeroed).  pool: n_max ints.  dyn: the cloud's
+// parameters in pinned, device-mapped memory.  Fixed grids (the kernels stride): the sequence can be captured once and replayed.
+void launch_ds_hash_pipeline(hipStream_t s, const DsDyn* dyn, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
+                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, int32_t* n_out) {
+    KLAUNCH(ds_hash_kernel, dim3(512), dim3(256), 0, s, dyn, (DsEnt*)tab, cap - 1, pt_slot, leaf_slot, info);
+    // (big_list: sorted positions of the leaves above 64 points -- at most n / 65 of them)
+    KLAUNCH(ds_leaf_sort_kernel, dim3(256), dim3(256), 0, s, (DsEnt*)tab, leaf_slot, info, keys_sorted, slots_sorted, big_list);
+    KLAUNCH(ds_scatter_kernel, dim3(512), dim3(256), 0, s, dyn, (DsEnt*)tab, pt_slot, pool);
+    KLAUNCH(ds_leaf_emit_kernel, dim3(2304), dim3(256), 0, s, dyn, (DsEnt*)tab, pool, keys_sorted, slots_sorted, big_list, info, n_out);
+}
+// last launch of the asynchronous form: the leaf count and the fall-back flag go to pinned host memory (a plain kernel, not a copy node: the whole
+// sequence is one hipGraph of kernels + one memset)
+__global__ void ds_publish_kernel(int32_t* __restrict__ info, int32_t* __restrict__ host_info) {
+    if (threadIdx.x < 4) {
+        const int v = info[threadIdx.x];
+        if (threadIdx.x < 2) __hip_atomic_store(&host_info[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        info[threadIdx.x] = 0;   // the counters go back zeroed: the launch sequence holds kernels only (no memset node, no copy node)
     }
 }
-// tab: table of `cap` (power of two, >= 2 n) entries, all empty on entry and on exit.  info: 4 ints, zeroed here.  pool: n ints.
-void launch_ds_hash_pipeline(hipStream_t s, const float* pts, int n, int stride, float inv, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
-                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, float* out, int32_t* n_out) {
-    (void)hipMemsetAsync(info, 0, 16, s);
-    KLAUNCH(ds_hash_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pts, n, stride, inv, (DsEnt*)tab, cap - 1, pt_slot, leaf_slot, info);
-    // (big_list: sorted positions of the leaves above 64 points -- at most n / 65 of them)
-    KLAUNCH(ds_leaf_sort_kernel, dim3(std::min(256, (n + DSH_CHUNK - 1) / DSH_CHUNK)), dim3(256), 0, s, (DsEnt*)tab, leaf_slot, info, keys_sorted, slots_sorted, big_list);
-    KLAUNCH(ds_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, (DsEnt*)tab, pt_slot, pool);
-    KLAUNCH(ds_leaf_emit_big_kernel, dim3(1024), dim3(64), 0, s, pts, n, stride, (DsEnt*)tab, pool, keys_sorted, slots_sorted, big_list, info, out);   // (first: the long chains)
-    KLAUNCH(ds_leaf_emit_kernel, dim3(2048), dim3(256), 0, s, pts, stride, (DsEnt*)tab, pool, keys_sorted, slots_sorted, info, out, n_out);
-}
+void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info) { KLAUNCH(ds_publish_kernel, dim3(1), dim3(64), 0, s, info, host_info); }
 // a fall-back left part of the table occupied: back to all-empty
 __global__ void ds_table_reset_kernel(DsEnt* tab, unsigned long long cap) {
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += (size_t)gridDim.x * blockDim.x) { tab[k].key = DSH_EMPTY; tab[k].cnt = 0; tab[k].off = 0; }

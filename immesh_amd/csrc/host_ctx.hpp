@@ -55,7 +55,7 @@ struct immesh_ctx {
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     // immesh_downsample_begin / _end: two result buffers, the grid extents + leaf count of the running job in pinned memory, its parameters for the fallback
-    struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
+    struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; int32_t* h_info_dev = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
     int rp_max_blocks = 127;         // grid cap of residual_persistent_kernel: half of the device's resident workgroups - 1 (occupancy query at create)
@@ -103,6 +103,9 @@ struct immesh_ctx {
     uint32_t *p_slot = nullptr, *p_slot_s = nullptr;
     void* p_sort_temp = nullptr;
     bool ds_skip_hash = false;       // immesh_downsample_end's fall-back: straight to the radix pipeline
+    int32_t* h_ds_info = nullptr; int32_t* d_ds_info = nullptr;   // the VoxelGrid's result words ([0] leaves, [1] fall-back wanted): pinned + device-side address
+    DsDyn* h_ds_dyn = nullptr; DsDyn* d_ds_dyn = nullptr;   // the VoxelGrid's per-cloud parameters: pinned host memory + its device-side address
+    hipGraphExec_t ds_graph = nullptr;                      // immesh_downsample_begin's launch sequence, captured once
     void* p_htab = nullptr; unsigned long long p_htab_cap = 0;   // VoxelGrid leaf table (16-byte entries, all empty between calls)
     char* d_raw_stage = nullptr;     // sensor decode: staging for wire-format clouds handed over as host memory (cap_scan x 64 B, first use)
     float *d_und_in = nullptr, *d_und_out = nullptr; double* d_und_tab = nullptr;   // immesh_undistort staging: n x 5 in, n x 4 out, pose table

@@ -108,8 +108,11 @@ void launch_decode_velodyne_emit(hipStream_t s, const uint8_t* d, int n, int ste
                                  int32_t* n_out);
 void launch_undistort_keys(hipStream_t s, const float* pts5, int n, uint32_t* key, int32_t* idx);
 void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, int n, const double* poses, int n_poses, const double* fe, float* out_xyzi);
-void launch_ds_hash_pipeline(hipStream_t s, const float* pts, int n, int stride, float inv, void* tab, unsigned long long cap, int32_t* pt_next, int32_t* leaf_slot,
-                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, float* out, int32_t* n_out);
+// the VoxelGrid's per-cloud parameters (pinned, device-mapped host memory: the kernels' arguments stay the same from cloud to cloud -> one hipGraph)
+struct DsDyn { const float* pts; float* out; int32_t n, stride; float inv; int32_t pad; };
+void launch_ds_hash_pipeline(hipStream_t s, const DsDyn* dyn, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
+                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, int32_t* n_out);
+void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info);
 void launch_ds_table_reset(hipStream_t s, void* tab, unsigned long long cap);
 void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xyzi);
 size_t exclusive_sum_temp_bytes(int n);
