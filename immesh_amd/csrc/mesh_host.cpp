@@ -100,11 +100,11 @@ int mesh_alloc(immesh_ctx* c) {
     HIPCHK(c, hipMemsetAsync(m.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.bin_cnt, 0, 2 * (1024 + 1) * 4, s));
     HIPCHK(c, hipMemsetAsync(m.pc, 0, PC_COUNT * 4, s));
-    if (m.shard_world > 1) {   // exchange staging of the sharded mesher
-        h.xcap_bytes = (size_t)cap_list * sizeof(MeshSmRec);
+    if (m.shard_world > 1) {   // exchange staging of the sharded mesher: this rank's block, and every rank's blocks side by side (mesh_exchange)
+        h.xcap_bytes = 16 + (size_t)cap_list * sizeof(MeshSmRec);                               // everything a rank can have to send
+        h.xall_bytes = (size_t)std::min(m.shard_world, 64) * (16 + (size_t)8192 * sizeof(MeshSmRec));   // the first blocks of all ranks (mesh_exchange: XCAP_* x record size)
         { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xsend = t; }
-        { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xrecv = t; }
-        { int32_t* t; if ((rc = c->dalloc(&t, 4))) return rc; h.d_xcount = t; }   // [0] records to send, [1] a number summed over the ranks (admission: candidates still undecided)
+        { char* t; if ((rc = c->dalloc(&t, h.xall_bytes))) return rc; h.d_xall = t; }
     }
     HIPCHK(c, hipMemsetAsync(m1.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
@@ -191,8 +191,9 @@ void mesh_free(immesh_ctx* c) {
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
-    if (h.d_xall) (void)hipFree(h.d_xall);
-    h.d_xall = nullptr; h.xall_bytes = 0;
+    h.d_xall = nullptr; h.xall_bytes = 0;   // (from the context's pool)
+    if (h.d_xbig) (void)hipFree(h.d_xbig);
+    h.d_xbig = nullptr; h.xbig_bytes = 0;
     h.exp_vtx = h.exp_work = h.exp_tmp = nullptr;
     for (int k = 0; k < 2; k++) {
         if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
@@ -260,65 +261,79 @@ static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
     return 0;
 }
 
-// Sharded mesher: all-gather `count` records of `rec` bytes from d_xsend over the ranks and hand every other rank's records to `unpack`.
-// Two collective calls: the counts, then the payload padded to the largest count.  Runs on the worker thread; the stream is idle on return
-// from the device-to-host copies and busy again with the unpack kernels when the function returns.
-static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, const std::function<void(const void*, int)>& unpack, int64_t* aux_sum = nullptr) {
+// Sharded mesher: one exchange = ONE all-gather in the common case.  Every rank packs its records behind a 16-byte header {records, aux, -, -} in
+// d_xsend; the first `cap_small` of them travel with the header in a fixed-size block.  The host reads the gathered headers (one strided copy): the
+// sum of `aux` is the admission's "anybody undecided?", and when a rank had more records than the block holds (a scan over fresh ground, tiny bricks) a
+// second gather carries blocks padded to the largest count.  `unpack(gathered, block bytes, records per block)` -- one launch for all ranks' blocks, the
+// counts read on the device -- is enqueued behind it.
+//   RCCL:      ncclAllGather on the device buffers, in-stream.     callbacks (tests on a gloo group): the blocks are staged through the host.
+static constexpr size_t XHDR = 16;
+static constexpr int XCAP_CAND = 8192;    // admission records (8 B) per rank and round in the first block: a 10 000-candidate scan sends a few hundred
+static constexpr int XCAP_BAND = 4096;    // smoothed positions (32 B) / triangle marks (24 B) per rank and scan in the first block
+static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, int cap_small, const std::function<void(const void*, size_t, int)>& unpack, int64_t* aux_sum = nullptr) {
     MeshHost& h = c->mesh_host;
-    const int world = c->cfg.shard_world, me = c->cfg.shard_rank;
+    const int world = c->cfg.shard_world;
+    const size_t capb = XHDR + (size_t)cap_small * rec;
     if (aux_sum) *aux_sum = 0;
+    if (world > 64 || (size_t)world * capb > h.xall_bytes) { h.err = "sharded mesher: exchange block above the staging buffers"; return IMMESH_E_CAPACITY; }
+    int32_t hdr[64 * 4];
+    int rc;
+    auto big_buffer = [&](size_t need) -> int {
+        if (need <= h.xbig_bytes) return 0;
+        if (h.d_xbig) (void)hipFree(h.d_xbig);
+        h.d_xbig = nullptr; h.xbig_bytes = 0;
+        if (hipMalloc(&h.d_xbig, need + need / 4) != hipSuccess) { h.err = "hipMalloc(exchange buffer)"; return IMMESH_E_NOMEM; }
+        h.xbig_bytes = need + need / 4;
+        return 0;
+    };
     if (c->rccl_comm) {
-        // RCCL on device buffers: all-gather the record counts (the host needs the largest one to size the payload gather), then the payload padded
-        // to it; every other rank's records are unpacked straight from the gathered buffer -- no host staging, one small read-back
-        int rc;
-        if (!h.d_xcounts || world > 64) { h.err = "sharded mesher: RCCL exchange not initialised (immesh_rccl_init)"; return IMMESH_E_INVAL; }
-        if ((rc = rccl_allgather_bytes(c, h.d_xcount, h.d_xcounts, 8, s, &h.err))) return rc;
-        int32_t pairs32[128], counts32[64];
-        MHIPCHK(c, hipMemcpyAsync(pairs32, h.d_xcounts, (size_t)world * 8, hipMemcpyDeviceToHost, s));
-        MHIPCHK(c, hipStreamSynchronize(s));
-        int64_t maxc = 0;
-        for (int r = 0; r < world; r++) { counts32[r] = pairs32[2 * r]; maxc = std::max<int64_t>(maxc, counts32[r]); if (aux_sum) *aux_sum += pairs32[2 * r + 1]; }
+        if ((rc = rccl_allgather_bytes(c, h.d_xsend, h.d_xall, capb, s, &h.err))) return rc;
         h.xcalls++;
-        if (maxc == 0) return 0;
-        if ((size_t)maxc * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
-        const size_t need = (size_t)world * maxc * rec;
-        if (need > h.xall_bytes) {
-            if (h.d_xall) (void)hipFree(h.d_xall);
-            h.d_xall = nullptr; h.xall_bytes = 0;
-            if (hipMalloc(&h.d_xall, need + need / 4) != hipSuccess) { h.err = "hipMalloc(exchange buffer)"; return IMMESH_E_NOMEM; }
-            h.xall_bytes = need + need / 4;
+        MHIPCHK(c, hipMemcpy2DAsync(hdr, XHDR, h.d_xall, capb, XHDR, (size_t)world, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
+    } else {
+        if (!h.allgather) { h.err = "sharded mesher: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
+        int32_t mine[4] = {0, 0, 0, 0};
+        MHIPCHK(c, hipMemcpyAsync(mine, h.d_xsend, XHDR, hipMemcpyDeviceToHost, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
+        const size_t used = (size_t)std::min(std::max(mine[0], 0), cap_small) * rec;
+        h.h_xsend.assign(capb, 0);
+        std::memcpy(h.h_xsend.data(), mine, XHDR);
+        if (used) MHIPCHK(c, hipMemcpy(h.h_xsend.data() + XHDR, (const char*)h.d_xsend + XHDR, used, hipMemcpyDeviceToHost));
+        h.h_xrecv.resize((size_t)world * capb);
+        if (h.allgather(h.h_xsend.data(), (int64_t)capb, h.h_xrecv.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+        h.xcalls++;
+        for (int r = 0; r < world; r++) std::memcpy(hdr + 4 * r, h.h_xrecv.data() + (size_t)r * capb, XHDR);
+    }
+    int64_t maxc = 0;
+    for (int r = 0; r < world; r++) { if (hdr[4 * r] < 0) { h.err = "sharded mesher: corrupt exchange header"; return IMMESH_E_HIP; } maxc = std::max<int64_t>(maxc, hdr[4 * r]); if (aux_sum) *aux_sum += hdr[4 * r + 1]; }
+    if ((size_t)maxc * rec + XHDR > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
+    if (maxc <= cap_small) {
+        if (!c->rccl_comm) {   // (callbacks: the gathered blocks go up; RCCL left them in d_xall)
+            for (int r = 0; r < world; r++)
+                MHIPCHK(c, hipMemcpyAsync((char*)h.d_xall + (size_t)r * capb, h.h_xrecv.data() + (size_t)r * capb, XHDR + (size_t)hdr[4 * r] * rec, hipMemcpyHostToDevice, s));
+            MHIPCHK(c, hipStreamSynchronize(s));   // (the host vector is reused by the next exchange)
         }
-        if ((rc = rccl_allgather_bytes(c, h.d_xsend, h.d_xall, (size_t)maxc * rec, s, &h.err))) return rc;
-        h.xcalls++; h.xbytes_sent += (int64_t)counts32[me] * (int64_t)rec;
-        for (int r = 0; r < world; r++)
-            if (r != me && counts32[r] > 0) unpack((const char*)h.d_xall + (size_t)r * maxc * rec, counts32[r]);
+        unpack(h.d_xall, capb, cap_small);
         return 0;
     }
-    if (!h.allgather) { h.err = "sharded mesher: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
-    int32_t cnt32[2] = {0, 0};
-    MHIPCHK(c, hipMemcpyAsync(cnt32, h.d_xcount, 8, hipMemcpyDeviceToHost, s));
-    MHIPCHK(c, hipStreamSynchronize(s));
-    if ((size_t)cnt32[0] * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
-    const int64_t cnt = cnt32[0];
-    const int64_t mine2[2] = {cnt32[0], cnt32[1]};
-    std::vector<int64_t> pairs((size_t)world * 2, 0), counts((size_t)world, 0);
-    if (h.allgather(mine2, 16, pairs.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
-    int64_t maxc = 0;
-    for (int r = 0; r < world; r++) { counts[r] = pairs[2 * (size_t)r]; maxc = std::max(maxc, counts[r]); if (aux_sum) *aux_sum += pairs[2 * (size_t)r + 1]; }
-    h.xcalls++;
-    if (maxc == 0) return 0;
-    h.h_xsend.assign((size_t)maxc * rec, 0);
-    if (cnt) MHIPCHK(c, hipMemcpy(h.h_xsend.data(), h.d_xsend, (size_t)cnt * rec, hipMemcpyDeviceToHost));
-    h.h_xrecv.resize((size_t)world * maxc * rec);
-    if (h.allgather(h.h_xsend.data(), (int64_t)((size_t)maxc * rec), h.h_xrecv.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
-    h.xcalls++; h.xbytes_sent += cnt * (int64_t)rec;
-    for (int r = 0; r < world; r++) {
-        if (r == me || counts[r] == 0) continue;
-        if ((size_t)counts[r] * rec > h.xcap_bytes) { h.err = "sharded mesher: exchange buffer overflow"; return IMMESH_E_CAPACITY; }
-        MHIPCHK(c, hipMemcpyAsync(h.d_xrecv, h.h_xrecv.data() + (size_t)r * maxc * rec, (size_t)counts[r] * rec, hipMemcpyHostToDevice, s));
-        unpack(h.d_xrecv, (int)counts[r]);
-        MHIPCHK(c, hipStreamSynchronize(s));   // d_xrecv is reused for the next rank's records
+    // ---- a rank had more records than the first block holds: blocks padded to the largest count
+    const size_t bigb = XHDR + (size_t)maxc * rec;
+    if ((rc = big_buffer((size_t)world * bigb))) return rc;
+    if (c->rccl_comm) {
+        if ((rc = rccl_allgather_bytes(c, h.d_xsend, h.d_xbig, bigb, s, &h.err))) return rc;
+        h.xcalls++;
+    } else {
+        h.h_xsend.assign(bigb, 0);
+        MHIPCHK(c, hipMemcpy(h.h_xsend.data(), h.d_xsend, XHDR + (size_t)hdr[4 * c->cfg.shard_rank] * rec, hipMemcpyDeviceToHost));
+        h.h_xrecv.resize((size_t)world * bigb);
+        if (h.allgather(h.h_xsend.data(), (int64_t)bigb, h.h_xrecv.data(), h.allgather_user)) { h.err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+        h.xcalls++;
+        for (int r = 0; r < world; r++)
+            MHIPCHK(c, hipMemcpyAsync((char*)h.d_xbig + (size_t)r * bigb, h.h_xrecv.data() + (size_t)r * bigb, XHDR + (size_t)hdr[4 * r] * rec, hipMemcpyHostToDevice, s));
+        MHIPCHK(c, hipStreamSynchronize(s));
     }
+    unpack(h.d_xbig, bigb, (int)maxc);
     return 0;
 }
 
@@ -371,12 +386,13 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         // ones), searches / triangulates its own voxels, and the band of smoothed positions and triangle marks travels (mesh_pack_*_kernel).
         launch_mesh_begin_scan(sa, m, h.h_dyn_dev[par], (unsigned long long)ccap);
         launch_mesh_append_prepare(sa, m, sp.n_cand, d_pts);
+        char* const xs = (char*)h.d_xsend;
         for (int round = 0;; round++) {
             if (round > 4096) { h.err = "sharded admission did not converge"; return IMMESH_E_HIP; }
-            MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
-            launch_mesh_cand_pack(sa, m, (MeshCdRec*)h.d_xsend, h.d_xcount);
+            MHIPCHK(c, hipMemsetAsync(xs, 0, XHDR, sa));
+            launch_mesh_cand_pack(sa, m, (MeshCdRec*)(xs + XHDR), (int32_t*)xs, (int)((h.xcap_bytes - XHDR) / sizeof(MeshCdRec)));
             int64_t undecided = 0;
-            if ((rc = mesh_exchange(c, sa, sizeof(MeshCdRec), [&](const void* d, int n) { launch_mesh_cand_unpack(sa, m, (const MeshCdRec*)d, n); }, &undecided))) return rc;
+            if ((rc = mesh_exchange(c, sa, sizeof(MeshCdRec), XCAP_CAND, [&](const void* d, size_t capb, int cr) { launch_mesh_cand_unpack(sa, m, d, capb, cr); }, &undecided))) return rc;
             h.x_rounds++;
             if (undecided == 0) break;
             MHIPCHK(c, hipMemsetAsync(m.sc + SC_UNDECIDED, 0, 4, sa));
@@ -384,13 +400,13 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         }
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
         // exchange 1: this scan's smoothed positions (what correct_triangle_index reads across voxels); triangulate own voxels; exchange 2: triangle marks
-        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
-        launch_mesh_pack_smooth(sa, m, (MeshSmRec*)h.d_xsend, h.d_xcount);
-        if ((rc = mesh_exchange(c, sa, sizeof(MeshSmRec), [&](const void* d, int n) { launch_mesh_unpack_smooth(sa, m, (const MeshSmRec*)d, n); }))) return rc;
+        MHIPCHK(c, hipMemsetAsync(xs, 0, XHDR, sa));
+        launch_mesh_pack_smooth(sa, m, (MeshSmRec*)(xs + XHDR), (int32_t*)xs, (int)((h.xcap_bytes - XHDR) / sizeof(MeshSmRec)));
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshSmRec), XCAP_BAND, [&](const void* d, size_t capb, int cr) { launch_mesh_unpack_smooth(sa, m, d, capb, cr); }))) return rc;
         if ((rc = mesh_enqueue_b(c, m, par, sa, 1))) return rc;
-        MHIPCHK(c, hipMemsetAsync(h.d_xcount, 0, 8, sa));
-        launch_mesh_pack_marks(sa, m, (MeshMkRec*)h.d_xsend, h.d_xcount);
-        if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), [&](const void* d, int n) { launch_mesh_unpack_marks(sa, m, (const MeshMkRec*)d, n); }))) return rc;
+        MHIPCHK(c, hipMemsetAsync(xs, 0, XHDR, sa));
+        launch_mesh_pack_marks(sa, m, (MeshMkRec*)(xs + XHDR), (int32_t*)xs, (int)((h.xcap_bytes - XHDR) / sizeof(MeshMkRec)));
+        if ((rc = mesh_exchange(c, sa, sizeof(MeshMkRec), XCAP_BAND, [&](const void* d, size_t capb, int cr) { launch_mesh_unpack_marks(sa, m, d, capb, cr); }))) return rc;
         if ((rc = mesh_enqueue_b(c, m, par, sa, 2))) return rc;
         MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
         return 0;
@@ -448,6 +464,7 @@ static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes
         sizes.n_add = h.h_sc[SC_ADD_OWN]; sizes.n_rem = h.h_sc[SC_REM_OWN]; sizes.n_upd = h.h_sc[SC_UPD_OWN];
     }
     h.fin_state[0] = n_add; h.fin_state[1] = n_rem; h.fin_state[2] = n_upd;
+    if (m.shard_world > 1) h.xbytes_sent += h.h_sc[SC_XBYTES];
     h.n_vertices = sizes.vtx_base + n_new;
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
     h.cum[SC_RECENT] += n_cand;  // n_app: candidates offered

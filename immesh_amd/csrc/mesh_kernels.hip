@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
 //                          never travel.  count[0] += records, count[1] += candidates this rank has still to decide.
 // mesh_cand_unpack_kernel  another rank's records: a band survivor that lies within min_spacing of one of this rank's bricks is chained under its cell;
 //                          decisions overwrite the status.
-__global__ __launch_bounds__(256) void mesh_cand_pack_kernel(MeshDev m_in, MeshCdRec* __restrict__ out, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(256) void mesh_cand_pack_kernel(MeshDev m_in, MeshCdRec* __restrict__ out, int32_t* __restrict__ count, int cap_rec) {
     MESH_DYN(m_in);
     const int lane = threadIdx.x & 63;
     for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < sp.n_cand; i0 += gridDim.x * blockDim.x) {
@@ -559,40 +559,54 @@ __global__ __launch_bounds__(256) void mesh_cand_pack_kernel(MeshDev m_in, MeshC
         base = __shfl(base, 0, 64);
         if (send >= 0) {
             const int pos = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < m.cap_list) { MeshCdRec r; r.i = i; r.status = send; out[pos] = r; } else m.sc[SC_OVERFLOW] = 14;
+            if (pos < cap_rec) { MeshCdRec r; r.i = i; r.status = send; out[pos] = r; }   // (beyond the block's capacity: the count in the header says so to everybody)
         }
     }
 }
-__global__ __launch_bounds__(256) void mesh_cand_unpack_kernel(MeshDev m_in, const MeshCdRec* __restrict__ in, int n) {
+// every rank's block of the gathered buffer: 16-byte header {records, aux, -, -}, then the records.  One launch unpacks all the other ranks' blocks with
+// the counts read on the device (no host look at the gather unless the host has a decision to take)
+IMD int xblock_count(const MeshDev& m, const char* gathered, size_t capb, int r, int cap_rec) {
+    const int n = *(const int32_t*)(gathered + (size_t)r * capb);
+    if (n > cap_rec || n < 0) { m.sc[SC_OVERFLOW] = 14; return 0; }   // a band above the exchange block: every rank sees it and fails the scan
+    return n;
+}
+__global__ __launch_bounds__(256) void mesh_cand_unpack_kernel(MeshDev m_in, const char* __restrict__ gathered, size_t capb, int cap_rec) {
     MESH_DYN(m_in);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const MeshCdRec rec = in[k];
-    const int j = rec.i;
-    if (j < 0 || j >= sp.n_cand) return;
-    const float4 p = *(const float4*)(dyn_pts + 4 * (size_t)j * sp.step);
-    const unsigned long long gkey = mkey(rnd_cell(p.x, m.min_spacing), rnd_cell(p.y, m.min_spacing), rnd_cell(p.z, m.min_spacing));
-    const int f = m.cand_flags[j];
-    if (rec.status == ST_UNDECIDED) {
-        if (f & CF_KNOWN) return;
-        long lo[3], hi[3];
-        cand_box(m, p.x, p.y, p.z, lo, hi);
-        if (!box_has(m, lo, hi, m.shard_rank)) return;   // not within min_spacing of anything this rank decides
-        m.cand_flags[j] = CF_KNOWN;
-        m.cand_cell[j] = gkey; m.cand_vox[j] = -1;
-        bool c2;
-        const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
-        if (cs < 0) { m.sc[SC_OVERFLOW] = 3; m.cand_next[j] = -1; }
-        else m.cand_next[j] = atomicExch(&m.ch_head[cs], j);
-        st_agent(&m.cand_status[j], ST_UNDECIDED);
-    } else {
-        if (rec.status == ST_ACCEPT && !(f & CF_KNOWN)) { m.cand_cell[j] = gkey; m.cand_vox[j] = -1; }   // (what the replicated commit reads)
-        st_agent(&m.cand_status[j], rec.status);
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    if (gtid == 0) atomicAdd(&m.sc[SC_XBYTES], xblock_count(m, gathered, capb, m.shard_rank, cap_rec) * (int)sizeof(MeshCdRec));
+    for (int r = 0; r < m.shard_world; r++) {
+        if (r == m.shard_rank) continue;
+        const int n = xblock_count(m, gathered, capb, r, cap_rec);
+        const MeshCdRec* in = (const MeshCdRec*)(gathered + (size_t)r * capb + 16);
+        for (int k = gtid; k < n; k += gstride) {
+            const MeshCdRec rec = in[k];
+            const int j = rec.i;
+            if (j < 0 || j >= sp.n_cand) continue;
+            const float4 p = *(const float4*)(dyn_pts + 4 * (size_t)j * sp.step);
+            const unsigned long long gkey = mkey(rnd_cell(p.x, m.min_spacing), rnd_cell(p.y, m.min_spacing), rnd_cell(p.z, m.min_spacing));
+            const int f = m.cand_flags[j];
+            if (rec.status == ST_UNDECIDED) {
+                if (f & CF_KNOWN) continue;
+                long lo[3], hi[3];
+                cand_box(m, p.x, p.y, p.z, lo, hi);
+                if (!box_has(m, lo, hi, m.shard_rank)) continue;   // not within min_spacing of anything this rank decides
+                m.cand_flags[j] = CF_KNOWN;
+                m.cand_cell[j] = gkey; m.cand_vox[j] = -1;
+                bool c2;
+                const long long cs = h_find_or_insert(m.ch_keys, m.ch_mask, gkey, &c2);
+                if (cs < 0) { m.sc[SC_OVERFLOW] = 3; m.cand_next[j] = -1; }
+                else m.cand_next[j] = atomicExch(&m.ch_head[cs], j);
+                st_agent(&m.cand_status[j], ST_UNDECIDED);
+            } else {
+                if (rec.status == ST_ACCEPT && !(f & CF_KNOWN)) { m.cand_cell[j] = gkey; m.cand_vox[j] = -1; }   // (what the replicated commit reads)
+                st_agent(&m.cand_status[j], rec.status);
+            }
+        }
     }
 }
-void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count) { KLAUNCH(mesh_cand_pack_kernel, dim3(64), dim3(256), 0, s, m, out, count); }
-void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const MeshCdRec* in, int n) {
-    if (n > 0) KLAUNCH(mesh_cand_unpack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
+void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count, int cap_rec) { KLAUNCH(mesh_cand_pack_kernel, dim3(64), dim3(256), 0, s, m, out, count, cap_rec); }
+void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec) {
+    KLAUNCH(mesh_cand_unpack_kernel, dim3(32), dim3(256), 0, s, m, (const char*)gathered, capb, cap_rec);
 }
 
 __global__ void mesh_append_flags_kernel(MeshDev m_in) {
@@ -1617,7 +1631,7 @@ IMD bool vertex_near_me(const MeshDev& m, int vtx) {
     voxel_box(m.vx_key[m.v_voxel[vtx]], MV_REACH, lo, hi);
     return box_has(m, lo, hi, m.shard_rank);
 }
-__global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, MeshSmRec* __restrict__ out, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, MeshSmRec* __restrict__ out, int32_t* __restrict__ count, int cap_rec) {
     MESH_DYN(m_in);
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
@@ -1633,7 +1647,7 @@ __global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, Mesh
         if (lane == 0) base = atomicAdd(count, nq);
         base = __shfl(base, 0, 64);
         for (int k = lane; k < nq; k += 64) {
-            if (base + k >= m.cap_list) { m.sc[SC_OVERFLOW] = 14; break; }
+            if (base + k >= cap_rec) break;   // (the header's count tells everybody)
             const int id = m.vx_pts[(size_t)vi * MV_VOX_CAP + k];
             MeshSmRec rec;
             rec.id = id; rec.pad = 0;
@@ -1642,16 +1656,23 @@ __global__ __launch_bounds__(64) void mesh_pack_smooth_kernel(MeshDev m_in, Mesh
         }
     }
 }
-__global__ void mesh_unpack_smooth_kernel(MeshDev m, const MeshSmRec* __restrict__ in, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const MeshSmRec rec = in[i];
-    if (!vertex_near_me(m, rec.id)) return;
-    m.v_smooth_new[(size_t)rec.id * 3 + 0] = rec.x; m.v_smooth_new[(size_t)rec.id * 3 + 1] = rec.y; m.v_smooth_new[(size_t)rec.id * 3 + 2] = rec.z;
-    list_push(m, m.list_smooth_rx, SC_SMOOTH_RX, rec.id);
+__global__ __launch_bounds__(256) void mesh_unpack_smooth_kernel(MeshDev m, const char* __restrict__ gathered, size_t capb, int cap_rec) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    if (gtid == 0) atomicAdd(&m.sc[SC_XBYTES], xblock_count(m, gathered, capb, m.shard_rank, cap_rec) * (int)sizeof(MeshSmRec));
+    for (int r = 0; r < m.shard_world; r++) {
+        if (r == m.shard_rank) continue;
+        const int n = xblock_count(m, gathered, capb, r, cap_rec);
+        const MeshSmRec* in = (const MeshSmRec*)(gathered + (size_t)r * capb + 16);
+        for (int i = gtid; i < n; i += gstride) {
+            const MeshSmRec rec = in[i];
+            if (!vertex_near_me(m, rec.id)) continue;
+            m.v_smooth_new[(size_t)rec.id * 3 + 0] = rec.x; m.v_smooth_new[(size_t)rec.id * 3 + 1] = rec.y; m.v_smooth_new[(size_t)rec.id * 3 + 2] = rec.z;
+            list_push(m, m.list_smooth_rx, SC_SMOOTH_RX, rec.id);
+        }
+    }
 }
 // blocks [0, n_active): the touched lists of the voxels this rank triangulated; the blocks after them: its removal marks
-__global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshMkRec* __restrict__ out, int32_t* __restrict__ count) {
+__global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshMkRec* __restrict__ out, int32_t* __restrict__ count, int cap_rec) {
     MESH_DYN(m_in);
     const int lane = threadIdx.x;
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
@@ -1689,37 +1710,44 @@ __global__ __launch_bounds__(64) void mesh_pack_marks_kernel(MeshDev m_in, MeshM
             base = __shfl(base, 0, 64);
             if (send) {
                 const int pos = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < m.cap_list) out[pos] = rec; else m.sc[SC_OVERFLOW] = 14;
+                if (pos < cap_rec) out[pos] = rec;   // (the header's count tells everybody)
             }
         }
     }
 }
-__global__ void mesh_unpack_marks_kernel(MeshDev m_in, const MeshMkRec* __restrict__ in, int n) {
+__global__ __launch_bounds__(256) void mesh_unpack_marks_kernel(MeshDev m_in, const char* __restrict__ gathered, size_t capb, int cap_rec) {
     MESH_DYN(m_in);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const MeshMkRec rec = in[i];
-    if (!(vertex_near_me(m, rec.a) || vertex_near_me(m, rec.b) || vertex_near_me(m, rec.c))) return;   // out of this rank's bricks + halo: never queried here
-    int spare = -1;
-    const int t = tri_find_or_insert(m, rec.a, rec.b, rec.c, &spare);
-    if (t < 0) return;
-    if (rec.rk < 0) {   // removal mark of another rank's voxel: same once-per-scan rule as the local ones
-        if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) list_push(m, m.list_rem, SC_REM, t);
-        return;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    if (gtid == 0) atomicAdd(&m.sc[SC_XBYTES], xblock_count(m, gathered, capb, m.shard_rank, cap_rec) * (int)sizeof(MeshMkRec));
+    for (int rk = 0; rk < m.shard_world; rk++) {
+        if (rk == m.shard_rank) continue;
+        const int n = xblock_count(m, gathered, capb, rk, cap_rec);
+        const MeshMkRec* in = (const MeshMkRec*)(gathered + (size_t)rk * capb + 16);
+        for (int i = gtid; i < n; i += gstride) {
+            const MeshMkRec rec = in[i];
+            if (!(vertex_near_me(m, rec.a) || vertex_near_me(m, rec.b) || vertex_near_me(m, rec.c))) continue;   // out of this rank's bricks + halo: never queried here
+            int spare = -1;
+            const int t = tri_find_or_insert(m, rec.a, rec.b, rec.c, &spare);
+            if (t < 0) continue;
+            if (rec.rk < 0) {   // removal mark of another rank's voxel: same once-per-scan rule as the local ones
+                if (atomicExch(&m.t_rem_seq[t], m.seq) != m.seq) list_push(m, m.list_rem, SC_REM, t);
+                continue;
+            }
+            atomicMax(&m.t_word[t], rec.word);
+            const int r = rec.rk >> 1;
+            const int pos = atomicAdd(&m.vox_ntris[r], 1);
+            if (pos >= 2 * MV_REL_CAP) { m.sc[SC_OVERFLOW] = 12; continue; }
+            m.vox_tris[(size_t)r * (2 * MV_REL_CAP) + pos] = (int)((unsigned int)t | ((rec.rk & 1) ? TRI_ADD_BIT : 0u));
+        }
     }
-    atomicMax(&m.t_word[t], rec.word);
-    const int r = rec.rk >> 1;
-    const int pos = atomicAdd(&m.vox_ntris[r], 1);
-    if (pos >= 2 * MV_REL_CAP) { m.sc[SC_OVERFLOW] = 12; return; }
-    m.vox_tris[(size_t)r * (2 * MV_REL_CAP) + pos] = (int)((unsigned int)t | ((rec.rk & 1) ? TRI_ADD_BIT : 0u));
 }
-void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count) { KLAUNCH(mesh_pack_smooth_kernel, dim3(1024), dim3(64), 0, s, m, out, count); }
-void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const MeshSmRec* in, int n) {
-    if (n > 0) KLAUNCH(mesh_unpack_smooth_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
+void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count, int cap_rec) { KLAUNCH(mesh_pack_smooth_kernel, dim3(1024), dim3(64), 0, s, m, out, count, cap_rec); }
+void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec) {
+    KLAUNCH(mesh_unpack_smooth_kernel, dim3(32), dim3(256), 0, s, m, (const char*)gathered, capb, cap_rec);
 }
-void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count) { KLAUNCH(mesh_pack_marks_kernel, dim3(2048), dim3(64), 0, s, m, out, count); }
-void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const MeshMkRec* in, int n) {
-    if (n > 0) KLAUNCH(mesh_unpack_marks_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, in, n);
+void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count, int cap_rec) { KLAUNCH(mesh_pack_marks_kernel, dim3(2048), dim3(64), 0, s, m, out, count, cap_rec); }
+void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec) {
+    KLAUNCH(mesh_unpack_marks_kernel, dim3(32), dim3(256), 0, s, m, (const char*)gathered, capb, cap_rec);
 }
 
 // =====================================================================================================================

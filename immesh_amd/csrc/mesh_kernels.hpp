@@ -34,6 +34,7 @@ enum {
     SC_VTXBASE,      /* vertex count when the scan started (the id of its first new vertex) */
     SC_ADD_OWN, SC_REM_OWN, SC_UPD_OWN,   /* sharded mesher: entries of the result lists this rank REPORTS (the lists it commits also hold its halo) */
     SC_SMOOTH_RX,    /* sharded mesher: smoothed positions received from other ranks this scan */
+    SC_XBYTES,       /* sharded mesher: payload bytes this rank contributed to the scan's exchanges */
     SC_COUNT = 24
 };
 // persistent device counters (MeshDev::pc)
@@ -184,6 +185,7 @@ struct MeshHost {
     void* d_xsend = nullptr; void* d_xrecv = nullptr; int32_t* d_xcount = nullptr;   // device staging (cap_list records each) + record counter
     int32_t* d_xcounts = nullptr; void* d_xall = nullptr; size_t xall_bytes = 0;     // RCCL path: every rank's record count / records (grow-only)
     size_t xcap_bytes = 0;
+    void* d_xbig = nullptr; size_t xbig_bytes = 0;   // blocks padded to the largest count, when a rank had more records than the first block holds (grow-only)
     std::vector<char> h_xsend, h_xrecv;
     int64_t xbytes_sent = 0, xcalls = 0;     // cumulative exchange volume of this rank (payload bytes, collective calls)
     int64_t x_rounds = 0;                    // cumulative admission exchange rounds (>= 1 per scan; 2 when no dependency chain crosses a brick face twice)
@@ -209,12 +211,14 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
-void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count);   // count: [0] records, [1] candidates still undecided here
-void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const MeshCdRec* in, int n);
-void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count);
-void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const MeshSmRec* in, int n);
-void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count);
-void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const MeshMkRec* in, int n);
+// exchange blocks of the sharded mesher: every rank contributes ONE fixed-size block per exchange -- 16-byte header {records, aux, -, -} + records -- so an
+// exchange is a single all-gather, and the unpack kernels read the counts on the device (cap_rec = records a block holds)
+void launch_mesh_cand_pack(hipStream_t s, const MeshDev& m, MeshCdRec* out, int32_t* count, int cap_rec);   // count: [0] records, [1] candidates still undecided here
+void launch_mesh_cand_unpack(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec);
+void launch_mesh_pack_smooth(hipStream_t s, const MeshDev& m, MeshSmRec* out, int32_t* count, int cap_rec);
+void launch_mesh_unpack_smooth(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec);
+void launch_mesh_pack_marks(hipStream_t s, const MeshDev& m, MeshMkRec* out, int32_t* count, int cap_rec);
+void launch_mesh_unpack_marks(hipStream_t s, const MeshDev& m, const void* gathered, size_t capb, int cap_rec);
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris);
 void launch_mesh_commit_add(hipStream_t s, const MeshDev& m, const int32_t* tris_sorted);
 void launch_mesh_sort_emit(hipStream_t s, const MeshDev& m, int which, void* recs, int32_t* add_sorted);

@@ -280,6 +280,8 @@ int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
  * immesh_mesh_sizes / immesh_mesh_fetch return THIS RANK'S PART of the result lists: the triangles whose smallest vertex lies in its bricks, the
  * smoothed vertices of its own voxels (new_vtx: all new vertices, identical on every rank).  The union of the ranks' lists is the unsharded list,
  * every entry exactly once (tests/test_gpu_sharded.py: 2 and 4 ranks).  n_triangles_live of immesh_counters adds up over the ranks likewise.
+ * Every exchange is ONE all-gather of a fixed-size block per rank (16-byte header {records, aux} + the first records); a second one, padded to the
+ * largest count, only when a rank had more records than the block holds.
  * cb gathers `bytes` bytes from every rank into recv (world x bytes, rank order); equal `bytes` on all ranks.  RCCL: ncclAllGather. */
 typedef int (*immesh_allgather_fn)(const void* send, int64_t bytes, void* recv, void* user);
 int immesh_set_allgather(immesh_ctx* ctx, immesh_allgather_fn cb, void* user);

@@ -210,7 +210,7 @@ def test_sharded_mesher_union_of_rank_lists_is_the_unsharded_result(world, brick
     assert sum(c[2] for c in cnts) == nl_ref                       # live triangles: the ranks' reported parts add up
     for r in range(world):
         tr = out[(r, "traffic")]
-        assert tr["bytes"] > 0 and tr["calls"] >= 2 * 4 * n_scans   # >= 2 admission rounds + smoothed band + mark band per scan, two calls each
+        assert tr["bytes"] > 0 and 4 * n_scans <= tr["calls"] <= 8 * n_scans   # one all-gather per exchange: >= 2 admission rounds + smoothed band + mark band per scan
 
 
 def test_rccl_inside_the_library_world_size_one(hip_lib):
@@ -264,4 +264,4 @@ def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
     assert d["sharded"]["scaling"] == "strong" and "gloo" in d["sharded"]["collectives"] and d["sharded"]["pose_err_m"] < 0.1
     lb = d["sharded"]["load_balance_point_share_per_brick_size"]
     assert set(lb) == {"8", "16", "32"} and all(0.5 <= v["max_share_mean"] <= 1.0 and v["fair_share"] == 0.5 for v in lb.values())
-    assert d["sharded"]["exchange_calls_per_scan"] >= 8          # >= 2 admission rounds + the two band exchanges, two calls each
+    assert 4 <= d["sharded"]["exchange_calls_per_scan"] <= 8      # one all-gather per exchange: >= 2 admission rounds + the two band exchanges
