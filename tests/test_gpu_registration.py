@@ -189,3 +189,40 @@ def test_register_without_overlap(oracle_lib, hip_lib):
     sh, ih = h.register(far, prior, prior)
     assert io["n_match"] == 0 and ih["n_match"] == 0 and ih["n_iter"] == io["n_iter"]
     np.testing.assert_allclose(sh, so, rtol=0, atol=1e-12)
+
+
+def test_plane_decisions_next_to_the_planarity_threshold(oracle_lib, hip_lib, record_property):
+    """the device's plane fit uses cheap reciprocals / reciprocal square roots + Newton steps and regrouped sums where the oracle (and Eigen)
+    divide and take IEEE roots -- differences of ~1e-13 relative, which could flip `min eigenvalue < planer_threshold` for a voxel whose smallest
+    eigenvalue sits on the threshold.  3 000 root voxels whose point clouds are slabs with a thickness variance drawn around the threshold (hundreds of
+    nodes end up with lambda_min within 2 % of it): map build + two updates (refits with the deferred / bounded decisions of the replay kernels), and every
+    is_plane / update_enable / point count must equal the oracle's, the values to 1e-5."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 14, cap_scan_points=400000)
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    rng = np.random.default_rng(20260925)
+    thr = float(cfg.planer_threshold)
+    n_vox, per = 3000, 40
+    centres = np.stack(np.meshgrid(np.arange(60), np.arange(50), indexing="ij"), -1).reshape(-1, 2)[:n_vox] * 1.0   # one slab per 0.5 m voxel, 1 m apart
+    clouds = []
+    for rep in range(3):
+        per = 40 if rep == 0 else 20     # (80 retained points at the end: below max_points_size, every node keeps refitting)
+        pts = np.zeros((n_vox, per, 3))
+        pts[:, :, 0] = centres[:, None, 0] + rng.uniform(0.02, 0.48, (n_vox, per))     # (in-plane variance 0.0176: the smallest eigenvalue is the thickness')
+        pts[:, :, 1] = centres[:, None, 1] + rng.uniform(0.02, 0.48, (n_vox, per))
+        # thickness: uniform in [-w, w] has variance w^2 / 3 -> w = sqrt(3 * thr * (1 + eps)), eps within +-2 %
+        w = np.sqrt(3.0 * thr * (1.0 + rng.uniform(0.03, 0.09, n_vox)))     # (the 1 / n sample variance and the clipping below take ~6 % off)
+        pts[:, :, 2] = 0.25 + np.clip(rng.uniform(-1.0, 1.0, (n_vox, per)) * w[:, None], -0.24, 0.24)
+        clouds.append(np.ascontiguousarray(pts.reshape(-1, 3).astype(np.float32)))
+    st = capi.make_state(R=np.eye(3), t=np.zeros(3))
+    o.map_build(clouds[0], st); h.map_build(clouds[0], st)
+    a, b = o.dump_planes(), h.dump_planes()
+    compare_plane_tables(a, b, TOL)
+    for rep in (1, 2):
+        o.map_update(clouds[rep], st); h.map_update(clouds[rep], st)
+    a, b = o.dump_planes(), h.dump_planes()
+    compare_plane_tables(a, b, TOL)
+    rel = np.abs(a["min_eig"].astype(np.float64) / thr - 1.0)
+    record_property("nodes_within_1e-3_of_threshold", int((rel < 1e-3).sum()))
+    assert (rel < 2e-2).sum() > 100 and a["is_plane"].sum() > 100 and (a["is_plane"] == 0).sum() > 100    # both outcomes, many of them close
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
