@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void mesh_begin_scan_kernel(MeshDev m, const M
             }
         }
         s_dyn = d; s_late = late;
+        if (late) m.bin_cnt[MV_BIN_BUCKETS + 1] = 1;   // (ANY workgroup that gave up: the admission kernel turns it into the scan's hang-guard error)
         if (blockIdx.x == 0) {
             *m.tick0 = __builtin_amdgcn_s_memrealtime();   // (behind the poll: the job's device time does not include waiting for the registration stream)
             const int base = m.pc[PC_VERTS];
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
     __shared__ int s_c1, s_nvis, s_base;
     __shared__ int s_vis[1024];
     if (threadIdx.x == 0) { s_c1 = 0; s_nvis = 0; }
+    if (t == 0 && cnt[MV_BIN_BUCKETS + 1]) m.sc[SC_UNDECIDED] = 1;   // a workgroup of mesh_begin_scan_kernel never saw the scan arrive: its candidates are missing
     __syncthreads();
     const unsigned long long tk0 = m.dbg ? __builtin_readcyclecounter() : 0;
     // admission order: the slots of the 8-cell cubes, then -- further workgroups of the same launch -- the overflow list (mesh_begin_scan_kernel);
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!EXPORT && blockIdx.x == 0)   // the admission's bucket fill counts: back to zero for the next scan (mesh_begin_scan_kernel counts, mesh_append_prepare_kernel reads)
-        for (int k = tid; k <= MV_BIN_BUCKETS; k += 256) m.bin_cnt[k] = 0;
+        for (int k = tid; k <= MV_BIN_BUCKETS + 1; k += 256) m.bin_cnt[k] = 0;
     const int n_active = EXPORT ? m.pc[PC_VOXELS] : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
