@@ -353,11 +353,15 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
                 if ds_state["pending"] is not None:
                     h.downsample_end()
                 h.downsample_begin(d_raw[k].data_ptr(), leaf, n=len(raws[k]), stride=4)
+            t_a = time.perf_counter()
             n_ds, down_ptr = h.downsample_end()
+            t_b = time.perf_counter()
             ds_state["pending"] = None
             if k + 1 < len(d_raw):
                 h.downsample_begin(d_raw[k + 1].data_ptr(), leaf, n=len(raws[k + 1]), stride=4)
                 ds_state["pending"] = k + 1
+            ds_state["end_s"] = ds_state.get("end_s", 0.0) + (t_b - t_a); ds_state["begin_s"] = ds_state.get("begin_s", 0.0) + (time.perf_counter() - t_b)
+            ds_state["calls"] = ds_state.get("calls", 0) + 1
         return h.process_scan(down_ptr, d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mesh_mode if mode is None else mode, n_ds=n_ds, n_raw=len(raws[k]))
 
     k = 1
@@ -412,6 +416,8 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
             st, _ = run(k, st); k += 1
         h.counters(reset=True)
         torch.cuda.synchronize()
+        for key in ("end_s", "begin_s", "calls"):
+            ds_state.pop(key, None)
         gc.collect(); gc.disable()      # a generation-2 collection of the harness's objects inside the loop is a 30 ms stall (seen: one call of 32 ms among 50 of 0.25 ms)
         D.barrier()
         t_begin = time.perf_counter()
@@ -429,6 +435,9 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         gc.enable()
         log(f"[bench] drain after the last scan: mesher {1e3 * (t_d1 - t_d0):.2f} ms, map update {1e3 * (t_d2 - t_d1):.2f} ms, device {1e3 * (time.perf_counter() - t_d2):.2f} ms; "
             f"slowest calls of the timed loop (ms): {np.round(np.sort(np.diff(t_marks))[-3:] * 1e3, 2).tolist()} at scans {np.argsort(np.diff(t_marks))[-3:].tolist()}")
+        if ds_state.get("calls"):
+            log(f"[bench] VoxelGrid on the scan thread, ms per scan: collect (immesh_downsample_end) {1e3 * ds_state['end_s'] / ds_state['calls']:.4f}, "
+                f"enqueue of the next (immesh_downsample_begin) {1e3 * ds_state['begin_s'] / ds_state['calls']:.4f}")
         D.barrier()
         elapsed = D.max_over_ranks(time.perf_counter() - t_begin, dev)
     cnt = h.counters()

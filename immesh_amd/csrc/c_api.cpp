@@ -78,7 +78,7 @@ static int alloc_all(immesh_ctx* c) {
     A(c->d_slot, ns); A(c->d_slot_s, ns); A(c->d_seg_start, ns); A(c->d_nseg, 16); A(c->d_ds_out, ns * 3);
     c->sort_temp_bytes = std::max({sort_pairs_u64_temp_bytes((int)ns), sort_pairs_u32_temp_bytes((int)ns), exclusive_sum_temp_bytes((int)ns)}) + 256;
     { char* t; A(t, c->sort_temp_bytes); c->d_sort_temp = t; }
-    A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns);
+    A(c->p_key_a, ns); A(c->p_key_b, ns); A(c->p_idx_a, ns); A(c->p_idx_b, ns); A(c->p_idx_c, ns); A(c->p_seg, ns); A(c->p_nseg, 16); A(c->p_slot, ns); A(c->p_slot_s, ns); A(c->p_pool4, ns * 4);
     { char* t; A(t, c->sort_temp_bytes); c->p_sort_temp = t; }
     {   // the VoxelGrid's leaf table: >= 2 entries per point of the largest cloud, all empty (0xFF: key == ~0, chain head == -1)
         unsigned long long cap = 1024; while (cap < 2ull * (unsigned long long)ns) cap <<= 1;
@@ -401,6 +401,7 @@ int immesh_register(immesh_ctx* c, const float* pts, int32_t n_ds, const double*
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state_prior || !state_inout) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    c->ds_gate_ok = false;
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
@@ -456,6 +457,7 @@ int immesh_residuals(immesh_ctx* c, const float* pts, int32_t n_ds, const double
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state || !HTH36 || !HTz6) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    c->ds_gate_ok = false;
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
@@ -543,6 +545,7 @@ int immesh_map_update(immesh_ctx* c, const float* pts, int32_t n_ds, const doubl
     if (!c || !pts || n_ds <= 0 || n_ds > c->cap_scan || !state) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    c->ds_gate_ok = false;
     if (const int s_rc = settle(c)) return s_rc;
     const void* d_pts;
     int rc = resolve_input(c, pts, (size_t)n_ds * 12, c->d_pts_down, &d_pts);
@@ -563,6 +566,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
+    c->ds_gate_ok = false;
     const void *d_down, *d_raw = nullptr;
     int rc = resolve_input(c, pts_down, (size_t)n_ds * 12, c->d_pts_down, &d_down);
     if (rc) return rc;
@@ -640,6 +644,7 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
         else if (mesh_mode) job = (epi && !fell_back) ? mesh_submit(c, world, n_raw, st.t, frame_idx, true, (const unsigned long long*)(c->d_epi + 2), c->epi_seq) : mesh_submit(c, world, n_raw, st.t, frame_idx, true);
         c->timing[3] = 0.f;
         c->pending = true;
+        c->ds_gate_ok = nowait && epi && !fell_back;
         if (nowait) return 0;
         if ((rc = settle(c))) return rc;
         if (mesh_mode == IMMESH_MESH_SYNC && (rc = mesh_wait(c, job))) return rc;
@@ -913,9 +918,9 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     if (!radix_only && !c->ds_skip_hash) {
         // three launches (ds_kernels.hip: leaf table + chains, leaf sort, per-leaf ordered sums); the radix pipeline below only when that gives up
         PRE_OUTPUT_FENCE(c);
-        *c->h_ds_dyn = DsDyn{(const float*)d_pts, c->d_ds_out, n, stride, inv, 0};
-        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
-        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info);
+        *c->h_ds_dyn = DsDyn{(const float*)d_pts, c->d_ds_out, n, stride, inv, 0, nullptr, 0, 0};
+        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_pool4, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
+        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info, c->d_ds_dyn);
         HIPCHK(c, hipStreamSynchronize(s));
         const int32_t info[2] = {c->h_ds_info[0], c->h_ds_info[1]};
         if (!info[1]) {
@@ -973,6 +978,34 @@ const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : 
 
 // ---- the asynchronous pair: the VoxelGrid of scan k+1 enqueued on the pre-processing stream beside scan k's registration, collected later.  The
 // three-launch form needs nothing from the host in between; when it gives up (flag in the job's pinned info) the job is redone synchronously.
+// the asynchronous VoxelGrid's launch sequence (parameters are in the pinned block already)
+static int ds_job_launch(immesh_ctx* c) {
+    hipStream_t s = c->stream_pre;
+    auto enqueue = [&]() -> int {
+        launch_ds_gate(s, c->d_ds_dyn);
+        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_pool4, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
+        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info, c->d_ds_dyn);   // [0] leaves, [1] fall-back wanted, [2] the job's ticket -> pinned memory; device counters back to zero
+        return 0;
+    };
+    static const bool no_graph = getenv("IMMESH_NO_GRAPH") != nullptr;
+    int rc;
+    if (no_graph || c->prof.on) { if ((rc = enqueue())) return rc; }
+    else {
+        // the launches never change (everything cloud-specific is in the pinned block): captured once, replayed with ONE call
+        if (!c->ds_graph) {
+            hipGraph_t g = nullptr;
+            HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            const int erc = enqueue();
+            const hipError_t ce = hipStreamEndCapture(s, &g);
+            if (erc || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "hipGraph capture of the VoxelGrid failed"; return IMMESH_E_HIP; }
+            const hipError_t ie = hipGraphInstantiate(&c->ds_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ie != hipSuccess) { c->ds_graph = nullptr; c->err = std::string("hipGraphInstantiate(VoxelGrid): ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
+        }
+        HIPCHK(c, hipGraphLaunch(c->ds_graph, s));
+    }
+    return 0;
+}
 int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
     if (c->dsa.active) { c->err = "immesh_downsample_begin: the previous job has not been collected (immesh_downsample_end)"; return IMMESH_E_INVAL; }
@@ -1003,32 +1036,15 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
     }
     a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts;
     const float inv = (float)(1.0 / leaf);
-    // three launches, nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table + chains,
-    // leaf sort, per-leaf ordered sums (ds_kernels.hip)
+    // five launches, nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table, leaf sort,
+    // point scatter + output positions, per-leaf ordered sums, publish (ds_kernels.hip)
     PRE_OUTPUT_FENCE(c);   // (the buffer being written was the input of the scan before the one in flight: its point_var has to be through)
-    *c->h_ds_dyn = DsDyn{(const float*)d_pts, a.out[a.par], n, stride, inv, 0};   // (pinned: read by thread 0 of every workgroup; the previous job has been collected)
-    auto enqueue = [&]() -> int {
-        launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_seg, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
-        launch_ds_publish(s, c->p_nseg + 12, c->d_ds_info);   // [0] leaves, [1] fall-back wanted -> pinned memory; device counters back to zero
-        return 0;
-    };
-    static const bool no_graph = getenv("IMMESH_NO_GRAPH") != nullptr;
-    if (no_graph || c->prof.on) { if ((rc = enqueue())) return rc; }
-    else {
-        // the launches never change (everything cloud-specific is in the pinned block): captured once, replayed with ONE call
-        if (!c->ds_graph) {
-            hipGraph_t g = nullptr;
-            HIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            const int erc = enqueue();
-            const hipError_t ce = hipStreamEndCapture(s, &g);
-            if (erc || ce != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "hipGraph capture of the VoxelGrid failed"; return IMMESH_E_HIP; }
-            const hipError_t ie = hipGraphInstantiate(&c->ds_graph, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (ie != hipSuccess) { c->ds_graph = nullptr; c->err = std::string("hipGraphInstantiate(VoxelGrid): ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
-        }
-        HIPCHK(c, hipGraphLaunch(c->ds_graph, s));
-    }
-    HIPCHK(c, hipEventRecord(a.ev, s));
+    if (++a.ticket <= 0) a.ticket = 1;
+    // a scan loop (the last scan was an asynchronous immesh_process_scan): the sequence is held at its gate until the NEXT registration launch is running
+    static const bool no_gate = getenv("IMMESH_DS_NO_GATE") != nullptr || getenv("IMMESH_SERIAL_SAFE") != nullptr;
+    const bool gate = c->ds_gate_ok && !no_gate && !c->prof.on;
+    *c->h_ds_dyn = DsDyn{(const float*)d_pts, a.out[a.par], n, stride, inv, a.ticket, gate ? &c->d_regstate->started : nullptr, gate ? (int32_t)(long long)(c->res_ticket + 1) : 0, 0};   // (pinned: read by thread 0 of every workgroup; the previous job has been collected)
+    if ((rc = ds_job_launch(c))) return rc;
     a.active = true;
     return 0;
 }
@@ -1037,7 +1053,18 @@ int immesh_downsample_end(immesh_ctx* c, int32_t* n_out, const float** dev_xyz) 
     immesh_ctx::DsAsync& a = c->dsa;
     if (!a.active) { c->err = "immesh_downsample_end: no job in flight"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
-    HIPCHK(c, hipEventSynchronize(a.ev));
+    {
+        // the publishing kernel's ticket in pinned memory (bounded spin, then the stream)
+        volatile int32_t* flag = c->h_ds_info + 2;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*flag != a.ticket) {
+            if ((++spins & 0x3FF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+        if (*flag != a.ticket || c->prof.on) HIPCHK(c, hipStreamSynchronize(c->stream_pre));
+        if (*flag != a.ticket) { a.active = false; c->err = "immesh_downsample_end: the VoxelGrid launches did not complete"; return IMMESH_E_HIP; }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     a.active = false;
     a.h_info[0] = c->h_ds_info[0]; a.h_info[1] = c->h_ds_info[1];
     if (a.h_info[1]) {

@@ -123,12 +123,12 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
 //                        open-addressing table; the leaf's point count grows by one atomic; the creator of an entry appends its slot to the leaf list.
 //                        Nobody waits for anybody.
 //   ds_leaf_sort_kernel  the occupied leaves (~8 k for a 100 k-point scan, not 100 k points) sorted by key in chunks of 512 (bitonic network in LDS, one
-//                        workgroup per chunk), and a segment of the point-index pool reserved for every leaf (scan of the counts inside the chunk, one
+//                        workgroup per chunk), and a segment of the point pool reserved for every leaf (scan of the counts inside the chunk, one
 //                        atomic per chunk for its base: the pool's order does not matter)
-//   ds_scatter_kernel    one thread per point: its index into its leaf's segment (one atomic: arrival order, i.e. no order)
-//   ds_leaf_emit_kernel  one wavefront per leaf: its output position (own position in its chunk + lower bounds in the other chunks, one lane per chunk),
-//                        its segment ordered by scan index, the float32 sums formed strictly in that order -- the spec's sequential `centroid += pt` --
-//                        and its table entry handed back empty: the table is never cleared as a whole.
+//   ds_scatter_kernel    one thread per point: the point (x, y, z, scan index) into its leaf's segment (one atomic: arrival order, i.e. no order); then every leaf's output
+//                        position (own position in its chunk + lower bounds in the other chunks, one lane per chunk)
+//   ds_leaf_emit_kernel  one wavefront per leaf: its segment ordered by scan index, the float32 sums formed strictly in that order -- the spec's
+//                        sequential `centroid += pt` -- and its table entry handed back empty: the table is never cleared as a whole.
 // Bound: latency (one hash round trip per point); HBM traffic ~ 2 x 16 B per point + the leaves' lines.
 // =====================================================================================================================
 #define DSH_EMPTY 0xFFFFFFFFFFFFFFFFull
@@ -140,6 +140,23 @@ struct DsEnt { unsigned long long key; int cnt; int off; };   // 16 B; key == DS
 // workgroup) -- so the kernel arguments never change and the five launches + the clearing of `info` + the read-back of the result are ONE hipGraph
 // (immesh_downsample_begin: four API calls on the scan thread instead of nine).
 #define DS_DYN(dynp) __shared__ DsDyn s_dyn_; if (threadIdx.x == 0) s_dyn_ = *(dynp); __syncthreads(); const DsDyn& dyn = s_dyn_
+// First launch of the asynchronous sequence: one thread that waits until the registration launch named by the job has started (DsDyn::gate_word) -- or
+// for DS_GATE_TICKS, whichever comes first: it is a scheduling hint, nothing depends on it.  Measured (round 4, meshing off, period 145 us without the
+// VoxelGrid): enqueued right behind a scan's pose the sequence ran beside that scan's MAP UPDATE and stretched its two kernels by 20 + 30 us (period
+// 203 us); beside the next scan's registration launch it stretches that one by 30 us and the update by 10 (period 184 us).  Whatever runs beside these
+// 100 k random accesses pays in memory latency (CU masks, stream priorities and smaller grids change nothing: profiles/README.md).
+#define DS_GATE_TICKS 15000ull   /* 150 us of s_memrealtime (100 MHz) */
+__global__ void ds_gate_kernel(const DsDyn* __restrict__ dynp) {
+    const int32_t* const w = dynp->gate_word;
+    if (!w) return;
+    const int want = dynp->gate_val;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > DS_GATE_TICKS) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+void launch_ds_gate(hipStream_t s, const DsDyn* dyn) { KLAUNCH(ds_gate_kernel, dim3(1), dim3(1), 0, s, dyn); }
 // info: [0] leaves, [1] fall-back wanted (cell out of the key's range / table full / a leaf above DSH_LEAF_CAP points), [2] pool fill, [3] big leaves
 __global__ __launch_bounds__(256) void ds_hash_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, unsigned long long mask,
                                                        int32_t* __restrict__ pt_slot, int32_t* __restrict__ leaf_slot, int32_t* __restrict__ info) {
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(256) void ds_leaf_sort_kernel(DsEnt* __restrict__ t
     for (int first = blockIdx.x * DSH_CHUNK; first < nleaf; first += gridDim.x * DSH_CHUNK) {
     const int cnt = min(DSH_CHUNK, nleaf - first);
     int np2 = 1; while (np2 < cnt) np2 <<= 1;
-    // a segment of the index pool for each of the chunk's leaves (two leaves per thread)
+    // a segment of the point pool for each of the chunk's leaves (two leaves per thread)
     int c0 = 0, c1 = 0, sl0 = -1, sl1 = -1;
     unsigned long long k0 = ~0ull, k1 = ~0ull;
     if (2 * tid < cnt) { sl0 = leaf_slot[first + 2 * tid]; const DsEnt e = tab[sl0]; k0 = e.key; c0 = e.cnt; }
@@ -217,38 +234,50 @@ __global__ __launch_bounds__(256) void ds_leaf_sort_kernel(DsEnt* __restrict__ t
     __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void ds_scatter_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const int32_t* __restrict__ pt_slot, int32_t* __restrict__ pool) {
+__global__ __launch_bounds__(256) void ds_scatter_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const int32_t* __restrict__ pt_slot, float4* __restrict__ pool4,
+                                                          const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ info, int32_t* __restrict__ leaf_rank) {
     DS_DYN(dynp);
-    const int n = dyn.n;
+    // the sequence has given up already (a cell outside the key's range, a full table, a leaf above DSH_LEAF_CAP points -- flagged by the two launches in
+    // front): nothing of this launch's work will be looked at, and the counts below are only sure to stay inside their fields when no leaf is above the cap
+    if (info[1]) return;
+    const float* __restrict__ pts = dyn.pts;
+    const int n = dyn.n, stride = dyn.stride;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int slot = pt_slot[i];
     if (slot < 0) continue;
-    // (the count runs down to zero while the segment fills; ds_leaf_emit_kernel takes the leaf's size from the neighbouring leaves' offsets -- no: it
-    //  is kept in the high half below)
-    const int old = atomicAdd(&tab[slot].cnt, 0x10000 - 1);   // low 16 bits: points still to place (<= DSH_LEAF_CAP), high 16: points placed
-    const int left = old & 0xFFFF;
-    if (left > 0 && left <= DSH_LEAF_CAP) pool[tab[slot].off + left - 1] = i;
+    const float* p = pts + (size_t)i * stride;
+    const float x = p[0], y = p[1], z = p[2];
+    // ONE returning atomic on the entry's (count, segment offset) word: low 16 bits of the count = points still to place (<= DSH_LEAF_CAP), high 16 =
+    // points placed; the offset rides back in the upper half (a second random read per point otherwise).  The point itself goes into the pool, not its
+    // index: ds_leaf_emit_kernel reads a leaf's segment as consecutive 16-byte records instead of gathering 100 k points one line each
+    const unsigned long long old = atomicAdd((unsigned long long*)&tab[slot].cnt, 0xFFFFull);
+    const int left = (int)(old & 0xFFFFull), off = (int)(old >> 32);
+    if (left > 0 && left <= DSH_LEAF_CAP) pool4[off + left - 1] = make_float4(x, y, z, __int_as_float(i));
     }
-}
-// output position of the leaf at sorted position e: own position in its chunk + the number of smaller keys in every other chunk (keys are unique);
-// one lane per chunk
-IMD int ds_leaf_rank(const unsigned long long* __restrict__ keys_sorted, int nleaf, int e, unsigned long long key, int lane) {
+    // ---- the output position of every leaf (its rank among all keys): own position in its chunk + the number of smaller keys in every other chunk
+    // (keys are unique).  L lanes per leaf, one lane per chunk -- nine dependent reads that used to head every wavefront of ds_leaf_emit_kernel; here
+    // they ride behind the scatter's single round trip
+    const int nleaf = info[0];
     const int nchunks = (nleaf + DSH_CHUNK - 1) / DSH_CHUNK;
-    int rank = e % DSH_CHUNK;
-    if (nchunks > 1) {
+    int L = 1;
+    while (L < nchunks && L < 64) L <<= 1;
+    const int per_wave = 64 / L, lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = (gridDim.x * blockDim.x) >> 6;
+    const int sub = lane / L, sl = lane % L;
+    for (int e0 = gw * per_wave; e0 < nleaf; e0 += nw * per_wave) {
+        const int e = e0 + sub;
+        const bool live = e < nleaf;
+        const unsigned long long key = live ? keys_sorted[e] : 0ull;
         const int own = e / DSH_CHUNK;
         int lo = 0;
-        for (int c0 = 0; c0 < nchunks; c0 += 64) {
-            const int c = c0 + lane;
-            int l = 0, hgh = (c < nchunks && c != own) ? min(DSH_CHUNK, nleaf - c * DSH_CHUNK) : 0;
+        for (int c = sl; c < nchunks; c += L) {
+            int l = 0, hgh = (live && c != own) ? min(DSH_CHUNK, nleaf - c * DSH_CHUNK) : 0;
             while (l < hgh) { const int mid = (l + hgh) >> 1; if (keys_sorted[(size_t)c * DSH_CHUNK + mid] < key) l = mid + 1; else hgh = mid; }
             lo += l;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) lo += __shfl_xor(lo, off, 64);
-        rank += lo;
+        for (int off = L >> 1; off > 0; off >>= 1) lo += __shfl_xor(lo, off, 64);
+        if (live && sl == 0) leaf_rank[e] = e % DSH_CHUNK + lo;
     }
-    return rank;
 }
 // One launch for both kinds of leaves: wavefront 0 of the first DSH_BIG_BLOCKS workgroups takes the leaves of 65 .. DSH_LEAF_CAP points (the ground right in
 // front of the sensor: a few dozen to a few hundred per scan, each a chain of tens of microseconds), every other wavefront the leaves of <= 64 points --
@@ -259,11 +288,15 @@ IMD int ds_leaf_rank(const unsigned long long* __restrict__ keys_sorted, int nle
 //                 by the network.
 #define DSH_BITMAP_PTS 131072
 #define DSH_BIG_BLOCKS 768
-__global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const int32_t* __restrict__ pool,
+__global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restrict__ dynp, DsEnt* __restrict__ tab, const float4* __restrict__ pool4,
                                                             const unsigned long long* __restrict__ keys_sorted, const int32_t* __restrict__ slots_sorted,
-                                                            const int32_t* __restrict__ big_list, int32_t* __restrict__ info, int32_t* __restrict__ n_out) {
+                                                            const int32_t* __restrict__ big_list, const int32_t* __restrict__ leaf_rank, int32_t* __restrict__ info,
+                                                            int32_t* __restrict__ n_out) {
     DS_DYN(dynp);
-    __shared__ unsigned int bm[DSH_BITMAP_PTS / 32];
+    // one region, two lives: the bitmap over the scan's point indices while a long leaf is being ordered, then the leaf's coordinates by component
+    __shared__ __attribute__((aligned(16))) unsigned int bm[3 * DSH_LEAF_CAP];
+    static_assert(3 * DSH_LEAF_CAP >= DSH_BITMAP_PTS / 32, "the coordinate table covers the bitmap");
+    float* const c3 = (float*)bm;
     __shared__ int idx[DSH_LEAF_CAP];
     const float* __restrict__ pts = dyn.pts;
     float* __restrict__ out = dyn.out;
@@ -278,17 +311,16 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restri
         const int nwords = (min(n, DSH_BITMAP_PTS) + 31) / 32;
         for (int b = blockIdx.x; b < nbig; b += n_big_blocks) {
             const int e = big_list[b];
-            const unsigned long long key = keys_sorted[e];
             const int slot = slots_sorted[e] & 0x7FFFFFFF;
             const DsEnt ent = tab[slot];
             const int cnt = ent.cnt >> 16;
-            const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
+            const int rank = leaf_rank[e];
             if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }   // the entry goes back empty: the table is never cleared as a whole
             if (cnt > DSH_LEAF_CAP || cnt <= 64) { if (lane == 0) info[1] = 1; continue; }
             if (n <= DSH_BITMAP_PTS) {
                 for (int w = lane; w < nwords; w += 64) bm[w] = 0u;
                 lds_sync();
-                for (int k = lane; k < cnt; k += 64) { const int p = pool[ent.off + k]; atomicOr(&bm[p >> 5], 1u << (p & 31)); }
+                for (int k = lane; k < cnt; k += 64) { const int p = __float_as_int(pool4[ent.off + k].w); atomicOr(&bm[p >> 5], 1u << (p & 31)); }
                 lds_sync();
                 int base = 0;
                 for (int w0 = 0; w0 < nwords; w0 += 64) {
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restri
                 lds_sync();
             } else {
                 int np2 = 128; while (np2 < cnt) np2 <<= 1;
-                for (int k = lane; k < np2; k += 64) idx[k] = k < cnt ? pool[ent.off + k] : 0x7FFFFFFF;
+                for (int k = lane; k < np2; k += 64) idx[k] = k < cnt ? __float_as_int(pool4[ent.off + k].w) : 0x7FFFFFFF;
                 lds_sync();
                 for (int k = 2; k <= np2; k <<= 1)
                     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -317,20 +349,23 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restri
                         lds_sync();
                     }
             }
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            if (lane < min(64, cnt)) { const float* q = pts + (size_t)idx[lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }
-            for (int b0 = 0; b0 < cnt; b0 += 64) {
-                const int m = min(64, cnt - b0);
-                const float x = nx, y = ny, z = nz;
-                if (b0 + 64 + lane < cnt) { const float* q = pts + (size_t)idx[b0 + 64 + lane] * stride; nx = q[0]; ny = q[1]; nz = q[2]; }   // next batch in flight
-                for (int l = 0; l < m; l++) {
-                    sx += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
-                    sy += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), l));
-                    sz += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), l));
-                }
+            // the coordinates in index order, one table per component (all gathers in flight at once), then the spec's sequential `centroid += pt` with
+            // lane c adding component c: one 16-byte LDS read per four terms and nothing but dependent v_add_f32 between them (as v_readlane from the
+            // lanes holding a batch it was ~40 cycles a term: the long pole of the launch for a leaf of 2 000 points)
+            for (int k = lane; k < cnt; k += 64) {
+                const float* q = pts + (size_t)idx[k] * stride;
+                c3[k] = q[0]; c3[DSH_LEAF_CAP + k] = q[1]; c3[2 * DSH_LEAF_CAP + k] = q[2];
             }
-            if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
+            lds_sync();
+            {
+                const float* const col = c3 + min(lane, 2) * DSH_LEAF_CAP;
+                float sum = 0.f;
+                int k = 0;
+#pragma unroll 4
+                for (; k + 4 <= cnt; k += 4) { const float4 v = *(const float4*)(col + k); sum += v.x; sum += v.y; sum += v.z; sum += v.w; }
+                for (; k < cnt; k++) sum += col[k];
+                if (lane < 3) out[(size_t)rank * 3 + lane] = sum / (float)cnt;
+            }
             lds_sync();
         }
         return;
@@ -339,16 +374,15 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restri
     const int wid = blockIdx.x * 4 + wv - min((int)blockIdx.x, n_big_blocks) - (((int)blockIdx.x < n_big_blocks) ? 1 : 0);
     const int n_small_waves = gridDim.x * 4 - n_big_blocks;
     for (int e = wid; e < nleaf; e += n_small_waves) {
-        const unsigned long long key = keys_sorted[e];
         const int slot = slots_sorted[e];
         if (slot < 0) continue;   // a long leaf: its own wavefront's (its table entry may be handed back at any moment -- never looked at here)
         const DsEnt ent = tab[slot];
         const int cnt = ent.cnt >> 16;   // (complete: the scatter launch is behind us)
-        // the segment and its points first (two dependent round trips), the output position (binary searches) while they are in flight
-        const int mine = lane < cnt ? pool[ent.off + lane] : 0x7FFFFFFF;
+        // the segment holds the points themselves (one round trip behind the entry); the output position comes ready from ds_scatter_kernel
+        int mine = 0x7FFFFFFF;
         float x = 0.f, y = 0.f, z = 0.f;
-        if (lane < cnt) { const float* q = pts + (size_t)mine * stride; x = q[0]; y = q[1]; z = q[2]; }
-        const int rank = ds_leaf_rank(keys_sorted, nleaf, e, key, lane);
+        if (lane < cnt) { const float4 v = pool4[ent.off + lane]; x = v.x; y = v.y; z = v.z; mine = __float_as_int(v.w); }
+        const int rank = leaf_rank[e];
         if (lane == 0) { tab[slot].key = DSH_EMPTY; tab[slot].cnt = 0; }
         if (cnt <= 0) { if (lane == 0) info[1] = 1; continue; }
         // rank by counting (indices are distinct), then the sequential float32 sum in index order: v_readlane from the lane holding rank r
@@ -366,26 +400,29 @@ __global__ __launch_bounds__(256) void ds_leaf_emit_kernel(const DsDyn* __restri
         if (lane == 0) { const float c = (float)cnt; out[(size_t)rank * 3 + 0] = sx / c; out[(size_t)rank * 3 + 1] = sy / c; out[(size_t)rank * 3 + 2] = sz / c; }
     }
 }
-// tab: table of `cap` (power of two, >= 2 n_max) entries, all empty on entry and on exit.  info: 4 ints, zero on entry (ds_publish_kernel, the last launch of every sequence, hands them back zeroed).  pool: n_max ints.  dyn: the cloud's
+// tab: table of `cap` (power of two, >= 2 n_max) entries, all empty on entry and on exit.  info: 4 ints, zero on entry (ds_publish_kernel, the last launch of every sequence, hands them back zeroed).  pool4: n_max float4.  dyn: the cloud's
 // parameters in pinned, device-mapped memory.  Fixed grids (the kernels stride): the sequence can be captured once and replayed.
 void launch_ds_hash_pipeline(hipStream_t s, const DsDyn* dyn, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
-                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, int32_t* n_out) {
+                             unsigned long long* keys_sorted, int32_t* slots_sorted, float* pool4, int32_t* big_list, int32_t* info, int32_t* n_out) {
     KLAUNCH(ds_hash_kernel, dim3(512), dim3(256), 0, s, dyn, (DsEnt*)tab, cap - 1, pt_slot, leaf_slot, info);
     // (big_list: sorted positions of the leaves above 64 points -- at most n / 65 of them)
     KLAUNCH(ds_leaf_sort_kernel, dim3(256), dim3(256), 0, s, (DsEnt*)tab, leaf_slot, info, keys_sorted, slots_sorted, big_list);
-    KLAUNCH(ds_scatter_kernel, dim3(512), dim3(256), 0, s, dyn, (DsEnt*)tab, pt_slot, pool);
-    KLAUNCH(ds_leaf_emit_kernel, dim3(2304), dim3(256), 0, s, dyn, (DsEnt*)tab, pool, keys_sorted, slots_sorted, big_list, info, n_out);
+    // (leaf_slot has done its job once the leaves are sorted: the scatter launch hands it on holding every sorted leaf's output position)
+    KLAUNCH(ds_scatter_kernel, dim3(512), dim3(256), 0, s, dyn, (DsEnt*)tab, pt_slot, (float4*)pool4, keys_sorted, info, leaf_slot);
+    KLAUNCH(ds_leaf_emit_kernel, dim3(2304), dim3(256), 0, s, dyn, (DsEnt*)tab, (const float4*)pool4, keys_sorted, slots_sorted, big_list, leaf_slot, info, n_out);
 }
 // last launch of the asynchronous form: the leaf count and the fall-back flag go to pinned host memory (a plain kernel, not a copy node: the whole
 // sequence is one hipGraph of kernels + one memset)
-__global__ void ds_publish_kernel(int32_t* __restrict__ info, int32_t* __restrict__ host_info) {
-    if (threadIdx.x < 4) {
-        const int v = info[threadIdx.x];
-        if (threadIdx.x < 2) __hip_atomic_store(&host_info[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        info[threadIdx.x] = 0;   // the counters go back zeroed: the launch sequence holds kernels only (no memset node, no copy node)
+__global__ void ds_publish_kernel(int32_t* __restrict__ info, int32_t* __restrict__ host_info, const DsDyn* __restrict__ dynp) {
+    if (threadIdx.x == 0) {
+        const int ticket = dynp->pad;   // (the job number the host waits for: the host polls host_info[2] -- no event packet behind the sequence)
+        __hip_atomic_store(&host_info[0], info[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_info[1], info[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_info[2], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (threadIdx.x < 4) info[threadIdx.x] = 0;   // the counters go back zeroed: the launch sequence holds kernels only (no memset node, no copy node)
 }
-void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info) { KLAUNCH(ds_publish_kernel, dim3(1), dim3(64), 0, s, info, host_info); }
+void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info, const DsDyn* dyn) { KLAUNCH(ds_publish_kernel, dim3(1), dim3(64), 0, s, info, host_info, dyn); }
 // a fall-back left part of the table occupied: back to all-empty
 __global__ void ds_table_reset_kernel(DsEnt* tab, unsigned long long cap) {
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < cap; k += (size_t)gridDim.x * blockDim.x) { tab[k].key = DSH_EMPTY; tab[k].cnt = 0; tab[k].off = 0; }

@@ -55,7 +55,7 @@ struct immesh_ctx {
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
     // immesh_downsample_begin / _end: two result buffers, the grid extents + leaf count of the running job in pinned memory, its parameters for the fallback
-    struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t* h_info = nullptr; int32_t* h_info_dev = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
+    struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t ticket = 0; int32_t* h_info = nullptr; int32_t* h_info_dev = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials
     int rp_parity = 0;
     int rp_max_blocks = 127;         // grid cap of residual_persistent_kernel: half of the device's resident workgroups - 1 (occupancy query at create)
@@ -101,8 +101,10 @@ struct immesh_ctx {
     unsigned long long *p_key_a = nullptr, *p_key_b = nullptr;
     int32_t *p_idx_a = nullptr, *p_idx_b = nullptr, *p_idx_c = nullptr, *p_seg = nullptr, *p_nseg = nullptr;
     uint32_t *p_slot = nullptr, *p_slot_s = nullptr;
+    float* p_pool4 = nullptr;   // the VoxelGrid's point pool: (x, y, z, scan index) of every point, grouped by leaf
     void* p_sort_temp = nullptr;
     bool ds_skip_hash = false;       // immesh_downsample_end's fall-back: straight to the radix pipeline
+    bool ds_gate_ok = false;   // the last scan went through immesh_process_scan's asynchronous path on the resident registration grid: a scan loop -- the next VoxelGrid job is scheduled beside the next registration launch (ds_gate_kernel)
     int32_t* h_ds_info = nullptr; int32_t* d_ds_info = nullptr;   // the VoxelGrid's result words ([0] leaves, [1] fall-back wanted): pinned + device-side address
     DsDyn* h_ds_dyn = nullptr; DsDyn* d_ds_dyn = nullptr;   // the VoxelGrid's per-cloud parameters: pinned host memory + its device-side address
     hipGraphExec_t ds_graph = nullptr;                      // immesh_downsample_begin's launch sequence, captured once

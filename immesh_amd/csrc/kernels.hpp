@@ -40,7 +40,7 @@ struct RegState {
     double p11inv[36];        // inverse of the pose block P11 of the prior covariance (state.cov is the prior for every iteration of a scan)
     double tmat[72];          // P21 P11^-1 (12 x 6): with X = (H^T R^-1 H + P11^-1)^-1 the gain's six columns are [X; tmat X]
     double tot[4];            // cumulative over the passes: n_plane_tests, n_extra_probe, passes run, n_match
-    int rematch, done, pad0, pad1;
+    int rematch, done, started, pad1;   // started: low bits of the ticket of the last residual_persistent_kernel launch whose workgroups are running (a scheduling hint: ds_gate_kernel)
 };
 // argument block of one residual pass (kernel arguments are limited to 4 KB: RegMapDev + this + a dozen pointers stay below)
 #define REG_MODE_HOST 0       /* legacy: parameters by value, the 48 sums + ticket go to pinned host memory, the host runs the EKF step */
@@ -109,10 +109,11 @@ void launch_decode_velodyne_emit(hipStream_t s, const uint8_t* d, int n, int ste
 void launch_undistort_keys(hipStream_t s, const float* pts5, int n, uint32_t* key, int32_t* idx);
 void launch_undistort(hipStream_t s, const float* pts5, const int32_t* order, int n, const double* poses, int n_poses, const double* fe, float* out_xyzi);
 // the VoxelGrid's per-cloud parameters (pinned, device-mapped host memory: the kernels' arguments stay the same from cloud to cloud -> one hipGraph)
-struct DsDyn { const float* pts; float* out; int32_t n, stride; float inv; int32_t pad; };
+struct DsDyn { const float* pts; float* out; int32_t n, stride; float inv; int32_t pad; const int32_t* gate_word; int32_t gate_val, gate_pad; };   // pad: the job's ticket (ds_publish_kernel hands it to the host); gate_word != nullptr: ds_gate_kernel holds the sequence back until *gate_word has reached gate_val
 void launch_ds_hash_pipeline(hipStream_t s, const DsDyn* dyn, void* tab, unsigned long long cap, int32_t* pt_slot, int32_t* leaf_slot,
-                             unsigned long long* keys_sorted, int32_t* slots_sorted, int32_t* pool, int32_t* big_list, int32_t* info, int32_t* n_out);
-void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info);
+                             unsigned long long* keys_sorted, int32_t* slots_sorted, float* pool4, int32_t* big_list, int32_t* info, int32_t* n_out);
+void launch_ds_publish(hipStream_t s, int32_t* info, int32_t* host_info, const DsDyn* dyn);
+void launch_ds_gate(hipStream_t s, const DsDyn* dyn);
 void launch_ds_table_reset(hipStream_t s, void* tab, unsigned long long cap);
 void launch_ds_expand_xyzi(hipStream_t s, const float* xyz, int n, float* out_xyzi);
 size_t exclusive_sum_temp_bytes(int n);

@@ -813,7 +813,12 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     const unsigned long long t_entry = sp.dbg ? __builtin_amdgcn_s_memrealtime() : 0;   // (trace: [4] of the pass-0 record = kernel entry, [5] = block 0 finished)
     // re-arm the other parity's slots for the next scan (fire-and-forget: the kernel boundary publishes them)
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n_slots_next; e += gridDim.x * 256) ((unsigned long long*)slots_next)[e] = RP_SENTINEL;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ((unsigned long long*)slots_next)[RP_TAIL_WORD] = RP_SENTINEL; ((unsigned long long*)slots_next)[RP_ABORT_WORD] = RP_SENTINEL; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((unsigned long long*)slots_next)[RP_TAIL_WORD] = RP_SENTINEL; ((unsigned long long*)slots_next)[RP_ABORT_WORD] = RP_SENTINEL;
+        // "this scan's registration is running": what the next cloud's VoxelGrid waits for (ds_gate_kernel) so that it shares the chip with this launch,
+        // which does not mind, and not with the map update in front of it, which does
+        __hip_atomic_store(&rs->started, (int)(long long)ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // the previous scan's map update left its tail to this launch (a.pad): nothing of it is read by the passes below.  It gets a workgroup of its
     // own (the launcher adds one): inside a working block it delayed that block's first partial sums, i.e. everybody's first gather
     const int G = (int)gridDim.x - 1;
