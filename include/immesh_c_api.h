@@ -315,8 +315,10 @@ int immesh_downsample(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stri
 const float* immesh_downsample_result(immesh_ctx* ctx);
 /* The same VoxelGrid as an asynchronous pair: _begin enqueues the whole down-sampling of scan k+1 on the pre-processing stream and returns at once, so it
  * runs beside scan k's registration; _end waits for it and hands back the leaf count and the device-resident result (n_out x 3 floats, valid until the
- * second _begin after it: the results alternate between two buffers).  The radix-sort width of _begin is predicted from the previous cloud's grid
- * extents; a cloud that needs more bits is redone synchronously inside _end -- the result is always the one immesh_downsample gives. */
+ * second _begin after it: the results alternate between two buffers).  A cloud the hashed form gives up on (a leaf above 2048 points, a leaf index
+ * beyond +-2^20) is redone by the radix pipeline inside _end -- the result is always the one immesh_downsample gives.  Call _begin(k+1) BEFORE
+ * immesh_process_scan(k): behind an asynchronous immesh_process_scan the sequence is held (on the device, at most 150 us) until the next registration
+ * launch is running, so that it keeps the registration company and not the map update of the scan before. */
 int immesh_downsample_begin(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf);
 int immesh_downsample_end(immesh_ctx* ctx, int32_t* n_out, const float** dev_xyz);
 /* The device buffers handed to an ASYNCHRONOUS immesh_process_scan (pts_down, pts_raw) are still read for a few microseconds after the call has

@@ -152,3 +152,46 @@ def test_async_pair_with_host_clouds_beside_host_input_scans(hip_lib):
         np.testing.assert_array_equal(got, want)
     h.mesh_wait()
     h.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_async_pair_behind_an_asynchronous_scan_with_and_without_a_next_registration(hip_lib):
+    """Behind an asynchronous immesh_process_scan the library takes the caller for a scan loop and holds the next VoxelGrid job at a gate until the NEXT
+    registration launch is running (ds_gate_kernel: a scheduling hint).  The job must give the synchronous result both when that registration comes
+    (begin before immesh_process_scan, the loop's order) and when it never does (the gate's own time-out lets the sequence through)."""
+    torch = pytest.importorskip("torch")
+    import time
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000)
+    h, ref = make_hip(hip_lib, cfg), make_hip(hip_lib, cfg)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(5):
+        R, t = synth.trajectory_pose(k)
+        scans.append(np.ascontiguousarray(synth.livox_scan(k, R, t, n_pts=100000, extT=extT)))
+    d_raw = [torch.from_numpy(s).cuda() for s in scans]
+    downs = [synth.voxel_grid_downsample(s, 0.4) for s in scans]
+    d_down = [torch.from_numpy(np.ascontiguousarray(d[:, :3], np.float32)).cuda() for d in downs]
+    R0, t0 = synth.trajectory_pose(0)
+    st = capi.make_state(R=R0, t=t0)
+    h.map_build(np.ascontiguousarray(scans[0][:, :3]), st)
+    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+    NOWAIT = 0x10
+
+    def check(k, n_got, ptr):
+        want, n_want = ref.downsample(scans[k], 0.4)
+        assert n_got == n_want == len(downs[k])
+        np.testing.assert_array_equal(fetch_device(ptr, (n_got, 3)), want)
+
+    for k in range(1, 4):
+        h.downsample_begin(d_raw[k + 1].data_ptr(), 0.4, n=len(scans[k + 1]), stride=4)      # (from the second round on: held until scan k's registration runs)
+        prior = synth.forward_without_imu(st)
+        st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=NOWAIT, n_ds=len(downs[k]), n_raw=len(scans[k]))
+        n_got, ptr = h.downsample_end()
+        check(k + 1, n_got, ptr)
+    # the loop stops: one more job, no registration behind it -- the gate gives up after its bound (150 us), the result is the same
+    t0_ = time.perf_counter()
+    h.downsample_begin(d_raw[2].data_ptr(), 0.4, n=len(scans[2]), stride=4)
+    n_got, ptr = h.downsample_end()
+    assert time.perf_counter() - t0_ < 0.05
+    check(2, n_got, ptr)
+    h.close(); ref.close()
