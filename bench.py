@@ -412,13 +412,16 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         elapsed = D.max_over_ranks(float(ms[1]) * 1e-3, dev)
         t_marks = []
     else:
+        # (before the warm-up, not between it and the timed region: a generation-2 collection of the harness's objects inside the loop is a 30 ms stall
+        #  -- seen: one call of 32 ms among 50 of 0.25 ms --, and tens of milliseconds of idle device in front of the first timed scan cost that scan
+        #  0.2 ms of clock ramp: its call took 0.36 ms against 0.17 for the others)
+        gc.collect(); gc.disable()
         for _ in range(args.warmup):
             st, _ = run(k, st); k += 1
         h.counters(reset=True)
         torch.cuda.synchronize()
         for key in ("end_s", "begin_s", "calls"):
             ds_state.pop(key, None)
-        gc.collect(); gc.disable()      # a generation-2 collection of the harness's objects inside the loop is a 30 ms stall (seen: one call of 32 ms among 50 of 0.25 ms)
         D.barrier()
         t_begin = time.perf_counter()
         t_marks = [t_begin]
