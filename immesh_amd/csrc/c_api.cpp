@@ -916,7 +916,7 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
     const float inv = (float)(1.0 / leaf);   // np.float32(1.0 / leaf)
     static const bool radix_only = getenv("IMMESH_DS_RADIX") != nullptr;
     if (!radix_only && !c->ds_skip_hash) {
-        // three launches (ds_kernels.hip: leaf table + chains, leaf sort, per-leaf ordered sums); the radix pipeline below only when that gives up
+        // the hashed form (ds_kernels.hip: leaf table, leaf sort, point scatter + output positions, per-leaf ordered sums, publish); the radix pipeline below only when that gives up
         PRE_OUTPUT_FENCE(c);
         *c->h_ds_dyn = DsDyn{(const float*)d_pts, c->d_ds_out, n, stride, inv, 0, nullptr, 0, 0};
         launch_ds_hash_pipeline(s, c->d_ds_dyn, c->p_htab, c->p_htab_cap, c->p_idx_a, c->p_idx_b, c->p_key_b, c->p_idx_c, c->p_pool4, (int32_t*)c->p_slot, c->p_nseg + 12, c->p_nseg + 8);
@@ -977,7 +977,7 @@ int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride
 const float* immesh_downsample_result(immesh_ctx* c) { return c ? c->d_ds_out : nullptr; }
 
 // ---- the asynchronous pair: the VoxelGrid of scan k+1 enqueued on the pre-processing stream beside scan k's registration, collected later.  The
-// three-launch form needs nothing from the host in between; when it gives up (flag in the job's pinned info) the job is redone synchronously.
+// hashed form needs nothing from the host in between; when it gives up (flag in the job's pinned info) the job is redone synchronously.
 // the asynchronous VoxelGrid's launch sequence (parameters are in the pinned block already)
 static int ds_job_launch(immesh_ctx* c) {
     hipStream_t s = c->stream_pre;
@@ -1014,13 +1014,12 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
     immesh_ctx::DsAsync& a = c->dsa;
     int rc;
     if (!a.ready) {   // first use: all or nothing (a failed allocation leaves the job state untouched; what was allocated stays in the context's pool)
-        hipEvent_t ev = nullptr; int32_t* info = nullptr; float* o0 = nullptr; float* o1 = nullptr; float* stg = nullptr;
+        int32_t* info = nullptr; float* o0 = nullptr; float* o1 = nullptr; float* stg = nullptr;
         if ((rc = c->dalloc(&o0, (size_t)c->cap_scan * 3)) || (rc = c->dalloc(&o1, (size_t)c->cap_scan * 3)) || (rc = c->dalloc(&stg, (size_t)c->cap_scan * 4))) return rc;
         if (hipHostMalloc((void**)&info, 16 * sizeof(int32_t)) != hipSuccess) { c->err = "hipHostMalloc(downsample job)"; return IMMESH_E_NOMEM; }
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(info); c->err = "hipEventCreate(downsample job)"; return IMMESH_E_HIP; }
         const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
         std::memcpy(info + 8, init, sizeof(init));   // (pinned: the source of the asynchronous initialisation below)
-        a.ev = ev; a.h_info = info; a.out[0] = o0; a.out[1] = o1; a.stage = stg; a.ready = true;
+        a.h_info = info;   // (completion is the ticket ds_publish_kernel stores to pinned memory: no event) a.out[0] = o0; a.out[1] = o1; a.stage = stg; a.ready = true;
     }
     hipStream_t s = c->stream_pre;
     const void* d_pts;
@@ -1068,7 +1067,7 @@ int immesh_downsample_end(immesh_ctx* c, int32_t* n_out, const float** dev_xyz) 
     a.active = false;
     a.h_info[0] = c->h_ds_info[0]; a.h_info[1] = c->h_ds_info[1];
     if (a.h_info[1]) {
-        // the three-launch form gave up (a cell outside the key's range, a leaf above 2048 points): the general path, synchronously (it resets the table)
+        // the hashed form gave up (a cell outside the key's range, a leaf above 2048 points): the general path, synchronously (it resets the table)
         int32_t cnt = 0;
         launch_ds_table_reset(c->stream_pre, c->p_htab, c->p_htab_cap);
         c->ds_skip_hash = true;

@@ -68,7 +68,7 @@ def test_device_downsample_bit_exact(oracle_lib, hip_lib):
 
 @pytest.mark.gpu
 def test_device_downsample_three_launch_form_and_its_fall_backs(hip_lib):
-    """The VoxelGrid as three launches (leaf table + chains, leaf sort, per-leaf ordered sums) against the spec, on the shapes that stress it: more leaves than one
+    """The hashed VoxelGrid (leaf table, leaf sort, point scatter, per-leaf ordered sums) against the spec, on the shapes that stress it: more leaves than one
     sort chunk holds (the merge across chunks), leaves of 65..2048 points (the in-LDS ordering), a leaf above 2048 points and a cell outside the packed key's
     range (both: the radix pipeline takes over, table handed back clean) -- and an ordinary cloud right after each, through the synchronous entry and the
     asynchronous pair."""
