@@ -1019,7 +1019,7 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
         if (hipHostMalloc((void**)&info, 16 * sizeof(int32_t)) != hipSuccess) { c->err = "hipHostMalloc(downsample job)"; return IMMESH_E_NOMEM; }
         const int init[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
         std::memcpy(info + 8, init, sizeof(init));   // (pinned: the source of the asynchronous initialisation below)
-        a.h_info = info;   // (completion is the ticket ds_publish_kernel stores to pinned memory: no event) a.out[0] = o0; a.out[1] = o1; a.stage = stg; a.ready = true;
+        a.h_info = info; a.out[0] = o0; a.out[1] = o1; a.stage = stg; a.ready = true;   // (completion is the ticket ds_publish_kernel stores to pinned memory: no event)
     }
     hipStream_t s = c->stream_pre;
     const void* d_pts;
