@@ -1035,7 +1035,7 @@ int immesh_downsample_begin(immesh_ctx* c, const float* pts, int32_t n, int32_t 
     }
     a.par ^= 1; a.n = n; a.stride = stride; a.leaf = leaf; a.d_in = d_pts;
     const float inv = (float)(1.0 / leaf);
-    // five launches, nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table, leaf sort,
+    // six launches (a gate in front of the five that do the work), nothing the host has to look at in between (the radix pipeline needed the grid extents for its sort width): leaf table, leaf sort,
     // point scatter + output positions, per-leaf ordered sums, publish (ds_kernels.hip)
     PRE_OUTPUT_FENCE(c);   // (the buffer being written was the input of the scan before the one in flight: its point_var has to be through)
     if (++a.ticket <= 0) a.ticket = 1;
