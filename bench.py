@@ -223,14 +223,20 @@ COMMITTED_TRAFFIC = "traffic_r04.json"          # profiles/: PMC-derived HBM byt
 
 
 def kernel_sources_sha():
-    """fingerprint of everything that is compiled into the kernels: a PMC traffic file measured on other sources is stale by construction"""
+    """fingerprint of everything that is compiled into the kernels: a PMC traffic file measured on other sources is stale by construction.  Comments and
+    layout are not compiled: the text is hashed without them ('c2:' scheme; a file stamped by the older whole-text scheme simply does not match)."""
     import hashlib
+    import re
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "immesh_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".inc", ".hpp")):
-            hsh.update(name.encode()); hsh.update(open(os.path.join(d, name), "rb").read())
-    return hsh.hexdigest()[:16]
+            text = open(os.path.join(d, name), "r", errors="replace").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+            text = re.sub(r"//[^\n]*", " ", text)                   # line comments (a '//' inside a string literal goes too: the hash only has to be stable)
+            text = " ".join(text.split())
+            hsh.update(name.encode()); hsh.update(text.encode())
+    return "c2:" + hsh.hexdigest()[:16]
 
 
 def roofline_from_committed_profile(mesh, cnt, n_scans, n_raw, note):

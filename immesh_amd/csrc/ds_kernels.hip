@@ -116,12 +116,12 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
 }
 
 // =====================================================================================================================
-// The same VoxelGrid in FOUR short launches instead of fifteen (round 4; the radix pipeline above stays as the fall-back and for clouds whose leaves do
+// The same VoxelGrid in FIVE short launches (+ a one-thread gate and a one-thread publish) instead of fifteen (round 4; the radix pipeline above stays as the fall-back and for clouds whose leaves do
 // not fit the single-key form).  The order of the output -- ascending linear leaf index i + j*dx + k*dx*dy -- is the lexicographic order of (k, j, i),
 // and that needs neither the bounding box nor a sort of the POINTS:
 //   ds_hash_kernel       one thread per point: leaf cell (floor(p * inv), the spec's float32 arithmetic) -> packed (k, j, i) key -> find-or-create in an
 //                        open-addressing table; the leaf's point count grows by one atomic; the creator of an entry appends its slot to the leaf list.
-//                        Nobody waits for anybody.
+//                        Nobody waits for anybody.  (count and segment offset share ONE 64-bit word of the entry)
 //   ds_leaf_sort_kernel  the occupied leaves (~8 k for a 100 k-point scan, not 100 k points) sorted by key in chunks of 512 (bitonic network in LDS, one
 //                        workgroup per chunk), and a segment of the point pool reserved for every leaf (scan of the counts inside the chunk, one
 //                        atomic per chunk for its base: the pool's order does not matter)
@@ -129,16 +129,17 @@ __global__ __launch_bounds__(256) void ds_centroid_kernel(const float* __restric
 //                        position (own position in its chunk + lower bounds in the other chunks, one lane per chunk)
 //   ds_leaf_emit_kernel  one wavefront per leaf: its segment ordered by scan index, the float32 sums formed strictly in that order -- the spec's
 //                        sequential `centroid += pt` -- and its table entry handed back empty: the table is never cleared as a whole.
-// Bound: latency (one hash round trip per point); HBM traffic ~ 2 x 16 B per point + the leaves' lines.
+// Bound: latency (one hash round trip per point in ds_hash_kernel, one returning atomic + one 16-byte write in ds_scatter_kernel); HBM traffic ~ 3 x 16 B
+// per point + the leaves' lines.
 // =====================================================================================================================
 #define DSH_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define DSH_BIAS (1 << 20)
 #define DSH_CHUNK 512
 #define DSH_LEAF_CAP 2048          /* points of one leaf ordered in LDS; a leaf holding more sets the fall-back flag */
-struct DsEnt { unsigned long long key; int cnt; int off; };   // 16 B; key == DSH_EMPTY: free (then cnt == 0)
+struct DsEnt { unsigned long long key; int cnt; int off; };   // 16 B; key == DSH_EMPTY: free (then cnt == 0).  (cnt, off) = one 64-bit word for ds_scatter_kernel's atomic
 // What changes from cloud to cloud lives in PINNED host memory (DsDyn, kernels.hpp): thread 0 of every workgroup reads it (one PCIe round trip per
-// workgroup) -- so the kernel arguments never change and the five launches + the clearing of `info` + the read-back of the result are ONE hipGraph
-// (immesh_downsample_begin: four API calls on the scan thread instead of nine).
+// workgroup) -- so the kernel arguments never change and the whole sequence (gate, five working launches, publish: the counters are handed back zeroed and
+// the result goes to pinned memory by kernels, not by memset / copy nodes) is ONE hipGraph: one API call per cloud on the scan thread.
 #define DS_DYN(dynp) __shared__ DsDyn s_dyn_; if (threadIdx.x == 0) s_dyn_ = *(dynp); __syncthreads(); const DsDyn& dyn = s_dyn_
 // First launch of the asynchronous sequence: one thread that waits until the registration launch named by the job has started (DsDyn::gate_word) -- or
 // for DS_GATE_TICKS, whichever comes first: it is a scheduling hint, nothing depends on it.  Measured (round 4, meshing off, period 145 us without the
@@ -412,7 +413,7 @@ void launch_ds_hash_pipeline(hipStream_t s, const DsDyn* dyn, void* tab, unsigne
     KLAUNCH(ds_leaf_emit_kernel, dim3(2304), dim3(256), 0, s, dyn, (DsEnt*)tab, (const float4*)pool4, keys_sorted, slots_sorted, big_list, leaf_slot, info, n_out);
 }
 // last launch of the asynchronous form: the leaf count and the fall-back flag go to pinned host memory (a plain kernel, not a copy node: the whole
-// sequence is one hipGraph of kernels + one memset)
+// sequence is one hipGraph of kernels only)
 __global__ void ds_publish_kernel(int32_t* __restrict__ info, int32_t* __restrict__ host_info, const DsDyn* __restrict__ dynp) {
     if (threadIdx.x == 0) {
         const int ticket = dynp->pad;   // (the job number the host waits for: the host polls host_info[2] -- no event packet behind the sequence)
