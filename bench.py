@@ -890,8 +890,10 @@ def main():
             out["sharded"] = {"error": str(e)[:200]}
 
     # ---- CPU baseline leg (rank 0, N = 1 semantics: the oracle on this box's host cores)
-    if rank == 0 and args.cpu_seconds > 0 and not args.gpu_scans:
+    if rank == 0 and args.cpu_seconds > 0 and not args.gpu_scans and world == 1:
         out["cpu_baseline"] = cpu_baseline_leg(args, res["cpu_inputs"], args.cpu_seconds)
+    elif rank == 0 and world > 1:
+        out["cpu_baseline_note"] = "timed at N = 1 only (the same host cores, the same oracle: nothing about it changes with the number of GPUs)"
 
     # ---- BASELINE configs[1] and configs[3] as short child runs of this script (N = 1 headline runs only)
     want_extra = args.extra_configs if args.extra_configs >= 0 else int(world == 1 and args.mesh == 1 and args.config == "avia" and not args.device_downsample and args.pts == 100000 and args.map_voxels >= 10e6)

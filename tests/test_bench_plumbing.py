@@ -88,7 +88,9 @@ def test_two_rank_replicas_gloo():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     d = json.loads(lines[0])
-    _check_line_n = dict(d); _check_line_n["n_gpus"] = 1
+    assert d["cpu_baseline"] is None and "N = 1 only" in d["cpu_baseline_note"]      # the CPU leg belongs to the N = 1 line
+    d1 = _run(SHIM, ["--extra-configs", "0"])
+    _check_line_n = dict(d); _check_line_n["n_gpus"] = 1; _check_line_n["cpu_baseline"] = d1["cpu_baseline"]
     _check_line(_check_line_n)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 independent scan streams" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]      # whole-job throughput = all ranks' scans / slowest rank's time
