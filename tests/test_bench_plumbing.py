@@ -94,3 +94,32 @@ def test_two_rank_replicas_gloo():
     _check_line(_check_line_n)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "2 independent scan streams" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-2 * d["value"]      # whole-job throughput = all ranks' scans / slowest rank's time
+
+
+def test_kernel_source_fingerprint_ignores_comments_and_the_committed_traffic_file_is_current(tmp_path, monkeypatch):
+    """roofline.traffic is only reported from a PMC file measured on THESE kernel sources (bench.kernel_sources_sha: the compiled text, comments and
+    layout removed).  A comment or blank line must not move the fingerprint, a token must; and the file under profiles/ should be the current one
+    (a stale file is not an error -- bench.py then reports traffic: null and says why -- but it is worth a visible skip)."""
+    import shutil
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    src = os.path.join(ROOT, "immesh_amd", "csrc")
+    work = tmp_path / "immesh_amd" / "csrc"
+    work.mkdir(parents=True)
+    for name in os.listdir(src):
+        if name.endswith((".hip", ".inc", ".hpp")):
+            shutil.copy(os.path.join(src, name), work / name)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    base = bench.kernel_sources_sha()
+    victim = work / "ds_kernels.hip"
+    text = victim.read_text()
+    victim.write_text("// a remark\n\n" + text.replace("\n", "\n   ", 3) + "\n/* another\n   one */\n")
+    assert bench.kernel_sources_sha() == base
+    victim.write_text(text.replace("#define DSH_CHUNK 512", "#define DSH_CHUNK 256"))
+    assert bench.kernel_sources_sha() != base
+    monkeypatch.setattr(bench, "ROOT", ROOT)
+    assert bench.kernel_sources_sha() == base
+    meta = json.load(open(os.path.join(ROOT, "profiles", bench.COMMITTED_TRAFFIC)))["_meta"]
+    if meta["kernel_sources_sha16"] != base:
+        pytest.skip(f"profiles/{bench.COMMITTED_TRAFFIC} was measured on {meta['kernel_sources_sha16']}, the kernels are {base}: tools/r04_traffic.sh regenerates it")
