@@ -86,6 +86,37 @@ int orc_register(void* p, const float* pts, int32_t n_ds, const double* state_pr
     if (eff_norm_dis && M) std::memcpy(eff_norm_dis, o->last_eff_nd.data(), (size_t)M * 16);
     return 0;
 }
+// orc_register with what every iteration held when it ended (RegDebug): HTH 36, HTz 6, solution 18, G 324, state 24, covariance 324, matches,
+// mean residual, {converged, stopped} per iteration, at most `cap_iters` of them; the test tap of tests/test_ref_lio.py
+int orc_register_trace(void* p, const float* pts, int32_t n_ds, const double* state_prior, double* state_inout, int32_t cap_iters, double* HTH, double* HTz,
+                       double* sol, double* G, double* state24, double* cov, int32_t* n_match, double* res_mean, int32_t* flags2, float* eff_pts_body,
+                       float* eff_norm_dis, double* rinv_last) {
+    OrcCtx* o = (OrcCtx*)p;
+    State prior, st;
+    load_state(state_prior, prior); load_state(state_inout, st);
+    RegDebug dbg;
+    const int it = o->reg.run(pts, n_ds, prior, st, &dbg);
+    store_state(st, state_inout);
+    for (int k = 0; k < it && k < cap_iters; k++) {
+        if (HTH) std::memcpy(HTH + k * 36, &dbg.HTH[(size_t)k * 36], 36 * 8);
+        if (HTz) std::memcpy(HTz + k * 6, &dbg.HTz[(size_t)k * 6], 6 * 8);
+        if (sol) std::memcpy(sol + k * 18, &dbg.sol[(size_t)k * 18], 18 * 8);
+        if (G) std::memcpy(G + k * 324, &dbg.G[(size_t)k * 324], 324 * 8);
+        if (state24) std::memcpy(state24 + k * 24, &dbg.state24[(size_t)k * 24], 24 * 8);
+        if (cov) std::memcpy(cov + k * 324, &dbg.cov[(size_t)k * 324], 324 * 8);
+        if (n_match) n_match[k] = dbg.n_match[k];
+        if (res_mean) res_mean[k] = dbg.res_mean[k];
+        if (flags2) { flags2[k * 2] = dbg.converged[k]; flags2[k * 2 + 1] = dbg.stopped[k]; }
+    }
+    const int M = dbg.n_match.empty() ? 0 : dbg.n_match.back();
+    for (int i = 0; i < M; i++) {
+        const int j = dbg.match_idx_last[i];
+        if (eff_pts_body) for (int k = 0; k < 3; k++) eff_pts_body[i * 3 + k] = pts[j * 3 + k];
+        if (eff_norm_dis) { for (int k = 0; k < 3; k++) eff_norm_dis[i * 4 + k] = (float)dbg.normals_last[i * 3 + k]; eff_norm_dis[i * 4 + 3] = dbg.dis_last[i]; }
+        if (rinv_last) rinv_last[i] = dbg.rinv_last[i];
+    }
+    return it;
+}
 int orc_last_matches(void* p, float* eff_pts_body, float* eff_norm_dis, int32_t cap, int32_t* n_out) {
     OrcCtx* o = (OrcCtx*)p;
     const int32_t M = (int32_t)(o->last_eff_pts.size() / 3);

@@ -434,6 +434,9 @@ struct RegDebug {  // per-iteration intermediates exposed for parity tests
     std::vector<float> dis_last;
     std::vector<double> rinv_last;
     double res_mean_last = 0;
+    // per iteration, as it ended (tests/test_ref_lio.py compares them with the reference's own lio_state_estimation, oracle/ref_lio)
+    std::vector<double> sol, G, state24, cov, res_mean;   // 18 / 324 / 24 (R, t, vel, bg, ba, g) / 324 / 1
+    std::vector<int> converged, stopped;
 };
 
 struct Registration {
@@ -605,13 +608,28 @@ struct Registration {
             const double tn = std::sqrt(sol[3] * sol[3] + sol[4] * sol[4] + sol[5] * sol[5]);
             const bool converged = (rn * 57.3 < 0.01) && (tn * 100 < 0.015);
             if (converged || ((rematch_num == 0) && (it == (c.max_iter - 2)))) rematch_num++;
-            if (rematch_num >= 2 || (it == c.max_iter - 1)) {
+            const bool stop_now = rematch_num >= 2 || (it == c.max_iter - 1);
+            auto tap_iteration = [&]() {
+                if (!dbg) return;
+                dbg->sol.insert(dbg->sol.end(), sol, sol + 18);
+                dbg->G.insert(dbg->G.end(), G, G + 324);
+                dbg->state24.insert(dbg->state24.end(), state.R, state.R + 9);
+                const double* parts[5] = {state.t, state.vel, state.bg, state.ba, state.g};
+                for (const double* q : parts) dbg->state24.insert(dbg->state24.end(), q, q + 3);
+                dbg->cov.insert(dbg->cov.end(), state.cov, state.cov + 324);
+                dbg->res_mean.push_back(M ? total_residual / M : 0);
+                dbg->converged.push_back(converged ? 1 : 0);
+                dbg->stopped.push_back(stop_now ? 1 : 0);
+            };
+            if (!stop_now) tap_iteration();
+            if (stop_now) {
                 double IG[324], nc[324];
                 for (int r = 0; r < 18; r++)
                     for (int cc = 0; cc < 18; cc++) IG[r * 18 + cc] = ((r == cc) ? 1.0 : 0.0) - G[r * 18 + cc];
                 for (int r = 0; r < 18; r++)
                     for (int cc = 0; cc < 18; cc++) { double s = 0; for (int k = 0; k < 18; k++) s += IG[r * 18 + k] * state.cov[k * 18 + cc]; nc[r * 18 + cc] = s; }
                 std::memcpy(state.cov, nc, sizeof(nc));
+                tap_iteration();
                 break;
             }
         }

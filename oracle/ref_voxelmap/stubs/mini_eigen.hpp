@@ -10,6 +10,9 @@
 #include <cstddef>
 #include <vector>
 #include <memory>
+#include <cstdlib>
+#include <ostream>
+#include <type_traits>
 #include "../../orc_linalg.hpp"
 
 namespace Eigen {
@@ -27,13 +30,32 @@ template <typename T, int R, int C> struct CommaInit {
 };
 template <typename T, int R, int C, int BR, int BC> struct BlockRef {   // writable view
     Matrix<T, R, C>& m; int r0, c0;
+    Matrix<T, BR, BC> eval() const { Matrix<T, BR, BC> o; for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) o(i, j) = m(r0 + i, c0 + j); return o; }
     template <int SR, int SC> BlockRef& operator=(const Matrix<T, SR, SC>& s) {
         static_assert(SR * SC == BR * BC, "block assignment: size mismatch");
         // same shape, or a vector assigned to a vector-shaped block of the other orientation (Eigen transposes vectors on assignment)
         for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) m(r0 + i, c0 + j) = (SR == BR) ? s.a[i * SC + j] : s.a[j * SC + i];
         return *this;
     }
-    operator Matrix<T, BR, BC>() const { Matrix<T, BR, BC> o; for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) o(i, j) = m(r0 + i, c0 + j); return o; }
+    // a dynamic-size right-hand side (MatrixXd below): anything that says so with a `dyn_tag`
+    template <typename D, typename = typename D::dyn_tag> BlockRef& operator=(const D& s) {
+        if (s.rows() != BR || s.cols() != BC) std::abort();
+        for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) m(r0 + i, c0 + j) = s(i, j);
+        return *this;
+    }
+    operator Matrix<T, BR, BC>() const { return eval(); }
+    template <int K> Matrix<T, BR, K> operator*(const Matrix<T, BC, K>& b) const { return eval() * b; }
+    template <int R2, int C2, int K> Matrix<T, BR, K> operator*(const BlockRef<T, R2, C2, BC, K>& b) const { return eval() * b.eval(); }
+    template <typename D, typename = typename D::dynvec_tag> Matrix<T, BR, 1> operator*(const D& v) const {   // fixed block * VectorXd
+        if (v.size() != BC) std::abort();
+        Matrix<T, BR, 1> o;
+        for (int i = 0; i < BR; i++) { T s = T(0); for (int k = 0; k < BC; k++) s += m(r0 + i, c0 + k) * v(k); o.a[i] = s; }
+        return o;
+    }
+    typename real_of<T>::type norm() const { return eval().norm(); }
+    void setZero() { for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) m(r0 + i, c0 + j) = T(0); }
+    // (only inside the reference's `if ( 0 )` degeneracy print, voxel_mapping.cpp:1601-1607: has to compile, never runs)
+    Matrix<std::complex<T>, BR, 1> eigenvalues() const { std::abort(); }
 };
 template <typename T, int R, int C> struct Rowwise { const Matrix<T, R, C>& m; Matrix<T, R, 1> sum() const { Matrix<T, R, 1> o; for (int i = 0; i < R; i++) { T s = T(0); for (int j = 0; j < C; j++) s += m(i, j); o.a[i] = s; } return o; } };
 
@@ -70,6 +92,9 @@ template <typename T, int R, int C> struct Matrix {
         for (int i = 0; i < R; i++) for (int j = 0; j < K; j++) { T s = T(0); for (int k = 0; k < C; k++) s += (*this)(i, k) * b(k, j); o(i, j) = s; }
         return o;
     }
+    template <int R2, int C2, int K> Matrix<T, R, K> operator*(const BlockRef<T, R2, C2, C, K>& b) const { return (*this) * b.eval(); }
+    template <int R2, int C2> Matrix operator+(const BlockRef<T, R2, C2, R, C>& b) const { return (*this) + b.eval(); }
+    template <int R2, int C2> Matrix operator-(const BlockRef<T, R2, C2, R, C>& b) const { return (*this) - b.eval(); }
     Matrix<T, R, 1> col(Index j) const { Matrix<T, R, 1> o; for (int i = 0; i < R; i++) o.a[i] = (*this)(i, (int)j); return o; }
     BlockRef<T, R, C, 1, C> row(Index i) { return BlockRef<T, R, C, 1, C>{*this, (int)i, 0}; }
     Matrix<T, 1, C> row(Index i) const { Matrix<T, 1, C> o; for (int j = 0; j < C; j++) o.a[j] = (*this)((int)i, j); return o; }
@@ -89,6 +114,10 @@ template <typename T, int R, int C> struct Matrix {
     Matrix<typename real_of<T>::type, R, C> real() const { Matrix<typename real_of<T>::type, R, C> o; for (int i = 0; i < R * C; i++) o.a[i] = std::real(a[i]); return o; }
     template <typename U> Matrix<U, R, C> cast() const { Matrix<U, R, C> o; for (int i = 0; i < R * C; i++) o.a[i] = (U)a[i]; return o; }
     void setZero() { for (int i = 0; i < R * C; i++) a[i] = T(0); }
+    void setIdentity() { setZero(); for (int i = 0; i < R && i < C; i++) (*this)(i, i) = T(1); }
+    T trace() const { T s = T(0); for (int i = 0; i < R && i < C; i++) s += (*this)(i, i); return s; }
+    // Matrix<double, 18, 18>::inverse() (voxel_mapping.cpp:1588): Eigen's LU is not restated -- Gauss-Jordan with partial pivoting (orc_linalg.hpp) stands in
+    Matrix inverse() const { static_assert(R == C, "inverse of a square matrix"); Matrix o; if (!orc::inv_gauss_jordan(a, o.a, R)) std::abort(); return o; }
     T* data() { return a; } const T* data() const { return a; }
 };
 template <typename T, int R, int C> Matrix<T, R, C> operator*(T s, const Matrix<T, R, C>& m) { return m * s; }
@@ -130,21 +159,41 @@ template <> struct SelfAdjointEigenSolver<Matrix3d> {
     const Vector3d& eigenvalues() const { return L; }
 };
 
-// the handful of dynamic-size operations delaunay_triangulation (mesh_rec_geometry.cpp:174-213) performs on its n x 3 point matrix
+// the handful of dynamic-size operations the compiled excerpts perform: delaunay_triangulation (mesh_rec_geometry.cpp:174-213) on its n x 3 point
+// matrix; lio_state_estimation (voxel_mapping.cpp:1487-1587) on Hsub (M x 6), Hsub_T_R_inv (6 x M), R_inv / meas_vec (M)
+inline std::vector<double>& last_dyn_matvec() { static thread_local std::vector<double> v; return v; }   // test tap: the newest MatrixXd * VectorXd (HTz)
+struct VectorXd {
+    typedef void dynvec_tag;
+    std::vector<double> a;
+    VectorXd() {}
+    explicit VectorXd(int n) : a((size_t)n, 0.0) {}
+    int size() const { return (int)a.size(); } int rows() const { return (int)a.size(); } int cols() const { return 1; }
+    void setZero() { std::fill(a.begin(), a.end(), 0.0); }
+    double& operator()(int i) { return a[(size_t)i]; } double operator()(int i) const { return a[(size_t)i]; }
+    double& operator[](int i) { return a[(size_t)i]; } double operator[](int i) const { return a[(size_t)i]; }
+};
 struct MatrixXd;
 struct MatrixXdT { const MatrixXd& m; };
 struct MatrixXd {
+    typedef void dyn_tag;
     int r = 0, c = 0; std::vector<double> a;
+    MatrixXd() {}
+    MatrixXd(int rr, int cc) { resize(rr, cc); }
     void resize(int rr, int cc) { r = rr; c = cc; a.assign((size_t)rr * cc, 0.0); }
     int rows() const { return r; } int cols() const { return c; }
     double& operator()(int i, int j) { return a[(size_t)i * c + j]; }
     double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+    // `row(i) << a, b, ...` / `col(j) << a, b, ...` (voxel_mapping.cpp:1564-1566): values in order, floats widen to double
+    struct CommaDyn { MatrixXd& m; int i, j, di, dj; CommaDyn& operator,(double v) { m(i, j) = v; i += di; j += dj; return *this; } };
     struct RowRef {
         MatrixXd& m; int i;
         RowRef& operator=(const Matrix<double, 3, 1>& v) { for (int j = 0; j < 3; j++) m(i, j) = v.a[j]; return *this; }
         double dot(const Matrix<double, 3, 1>& v) const { double s = 0; for (int j = 0; j < 3; j++) s += m(i, j) * v.a[j]; return s; }
+        CommaDyn operator<<(double v) { m(i, 0) = v; return CommaDyn{m, i, 1, 0, 1}; }
     };
+    struct ColRef { MatrixXd& m; int j; CommaDyn operator<<(double v) { m(0, j) = v; return CommaDyn{m, 1, j, 1, 0}; } };
     RowRef row(int i) { return RowRef{*this, i}; }
+    ColRef col(int j) { return ColRef{*this, j}; }
     struct Colwise { const MatrixXd& m; Matrix<double, 1, 3> mean() const { Matrix<double, 1, 3> o; for (int j = 0; j < 3; j++) { double s = 0; for (int i = 0; i < m.r; i++) s += m(i, j); o.a[j] = s / (double)m.r; } return o; } };
     Colwise colwise() const { return Colwise{*this}; }
     struct RowwiseX { const MatrixXd& m; MatrixXd operator-(const Matrix<double, 1, 3>& v) const { MatrixXd o; o.resize(m.r, m.c); for (int i = 0; i < m.r; i++) for (int j = 0; j < m.c; j++) o(i, j) = m(i, j) - v.a[j]; return o; } };
@@ -158,4 +207,20 @@ inline MatrixXd operator*(const MatrixXdT& at, const MatrixXd& b) {   // (A^T B)
     for (int p = 0; p < at.m.c; p++) for (int q = 0; q < b.c; q++) { double s = 0; for (int i = 0; i < b.r; i++) s += at.m(i, p) * b(i, q); o(p, q) = s; }
     return o;
 }
+inline MatrixXd operator*(const MatrixXd& x, const MatrixXd& y) {     // inner index ascending: for (6 x M)(M x 6) that is the sum over the matches in list order
+    if (x.c != y.r) std::abort();
+    MatrixXd o; o.resize(x.r, y.c);
+    for (int p = 0; p < x.r; p++) for (int q = 0; q < y.c; q++) { double s = 0; for (int k = 0; k < x.c; k++) s += x(p, k) * y(k, q); o(p, q) = s; }
+    return o;
+}
+inline VectorXd operator*(const MatrixXd& x, const VectorXd& v) {
+    if (x.c != v.size()) std::abort();
+    VectorXd o(x.r);
+    for (int p = 0; p < x.r; p++) { double s = 0; for (int k = 0; k < x.c; k++) s += x(p, k) * v(k); o(p) = s; }
+    last_dyn_matvec() = o.a;
+    return o;
+}
+template <typename T, int R, int C> std::ostream& operator<<(std::ostream& os, const Matrix<T, R, C>& m) { for (int i = 0; i < R; i++) { for (int j = 0; j < C; j++) os << m(i, j) << ' '; if (R > 1) os << '\n'; } return os; }
+// Eigen::Quaterniond( rotation matrix ) (voxel_mapping.cpp:1246, ImMesh_mesh_reconstruction.cpp:416): carried along, never read by the compiled excerpts
+struct Quaterniond { Matrix3d R; Quaterniond() {} Quaterniond(const Matrix3d& r) : R(r) {} };
 }  // namespace Eigen

@@ -6,5 +6,14 @@
 namespace pcl {
 struct PointXYZINormal { float x = 0, y = 0, z = 0, intensity = 0, normal_x = 0, normal_y = 0, normal_z = 0, curvature = 0; };
 struct PointXYZI { float x = 0, y = 0, z = 0, intensity = 0; };
-template <typename T> struct PointCloud { typedef std::shared_ptr<PointCloud<T>> Ptr; std::vector<T> points; size_t size() const { return points.size(); } };
+template <typename T> struct PointCloud {
+    typedef std::shared_ptr<PointCloud<T>> Ptr;
+    std::vector<T> points;
+    PointCloud() {}
+    PointCloud(unsigned w, unsigned h) : points((size_t)w * h) {}
+    size_t size() const { return points.size(); }
+    void clear() { points.clear(); }
+    void push_back(const T& p) { points.push_back(p); }
+    Ptr makeShared() const { return Ptr(new PointCloud<T>(*this)); }
+};
 }  // namespace pcl
