@@ -66,6 +66,7 @@ template <typename T, int R, int C> struct Matrix {
     Matrix() { for (int i = 0; i < R * C; i++) a[i] = T(0); }
     Matrix(T x, T y, T z) { static_assert(R * C == 3, "3-vector constructor"); a[0] = x; a[1] = y; a[2] = z; }
     Matrix(T x, T y) { static_assert(R * C == 2, "2-vector constructor"); a[0] = x; a[1] = y; }
+    Matrix(T x, T y, T z, T w) { static_assert(R * C == 4, "4-vector constructor"); a[0] = x; a[1] = y; a[2] = z; a[3] = w; }
     static Matrix Zero() { return Matrix(); }
     static Matrix Identity() { Matrix m; for (int i = 0; i < R && i < C; i++) m(i, i) = T(1); return m; }
     T& operator()(int i, int j) { return a[i * C + j]; }
@@ -100,6 +101,14 @@ template <typename T, int R, int C> struct Matrix {
     Matrix<T, 1, C> row(Index i) const { Matrix<T, 1, C> o; for (int j = 0; j < C; j++) o.a[j] = (*this)((int)i, j); return o; }
     template <int BR, int BC> BlockRef<T, R, C, BR, BC> block(int r0, int c0) { return BlockRef<T, R, C, BR, BC>{*this, r0, c0}; }
     template <int BR, int BC> Matrix<T, BR, BC> block(int r0, int c0) const { Matrix<T, BR, BC> o; for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) o(i, j) = (*this)(r0 + i, c0 + j); return o; }
+    template <int N> BlockRef<T, R, C, N, 1> head() { static_assert(C == 1, "head of a column vector"); return BlockRef<T, R, C, N, 1>{*this, 0, 0}; }
+    // block( r0, c0, rows, cols ) with run-time extents (ImMesh_mesh_reconstruction.cpp:100, 199): a view that is assigned from / converts to a fixed matrix
+    struct DynBlock {
+        Matrix& m; int r0, c0, nr, nc;
+        template <int SR, int SC> DynBlock& operator=(const Matrix<T, SR, SC>& s) { if (SR != nr || SC != nc) std::abort(); for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) m(r0 + i, c0 + j) = s(i, j); return *this; }
+        template <int BR, int BC> operator Matrix<T, BR, BC>() const { if (BR != nr || BC != nc) std::abort(); Matrix<T, BR, BC> o; for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) o(i, j) = m(r0 + i, c0 + j); return o; }
+    };
+    DynBlock block(int r0, int c0, int nr, int nc) { return DynBlock{*this, r0, c0, nr, nc}; }
     Matrix<T, (R < C ? R : C), 1> diagonal() const { Matrix<T, (R < C ? R : C), 1> o; for (int i = 0; i < R && i < C; i++) o.a[i] = (*this)(i, i); return o; }
     typename real_of<T>::type squaredNorm() const { typename real_of<T>::type s = 0; for (int i = 0; i < R * C; i++) s += std::norm(a[i]); return s; }
     typename real_of<T>::type norm() const { return std::sqrt(squaredNorm()); }
@@ -222,5 +231,19 @@ inline VectorXd operator*(const MatrixXd& x, const VectorXd& v) {
 }
 template <typename T, int R, int C> std::ostream& operator<<(std::ostream& os, const Matrix<T, R, C>& m) { for (int i = 0; i < R; i++) { for (int j = 0; j < C; j++) os << m(i, j) << ' '; if (R > 1) os << '\n'; } return os; }
 // Eigen::Quaterniond( rotation matrix ) (voxel_mapping.cpp:1246, ImMesh_mesh_reconstruction.cpp:416): carried along, never read by the compiled excerpts
-struct Quaterniond { Matrix3d R; Quaterniond() {} Quaterniond(const Matrix3d& r) : R(r) {} };
+struct Quaterniond {
+    Matrix3d R; double q[4] = {0, 0, 0, 1};   // x, y, z, w
+    Quaterniond() {}
+    Quaterniond(const Matrix3d& m) : R(m) {   // (the usual trace / largest-diagonal conversion)
+        const double t = m(0, 0) + m(1, 1) + m(2, 2);
+        if (t > 0) { double s = std::sqrt(t + 1.0); q[3] = 0.5 * s; s = 0.5 / s; q[0] = (m(2, 1) - m(1, 2)) * s; q[1] = (m(0, 2) - m(2, 0)) * s; q[2] = (m(1, 0) - m(0, 1)) * s; }
+        else {
+            int i = 0; if (m(1, 1) > m(0, 0)) i = 1; if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            double s = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0); q[i] = 0.5 * s; s = 0.5 / s;
+            q[3] = (m(k, j) - m(j, k)) * s; q[j] = (m(j, i) + m(i, j)) * s; q[k] = (m(k, i) + m(i, k)) * s;
+        }
+    }
+    Matrix<double, 4, 1> coeffs() const { return Matrix<double, 4, 1>(q[0], q[1], q[2], q[3]); }
+};
 }  // namespace Eigen
