@@ -223,20 +223,24 @@ COMMITTED_TRAFFIC = "traffic_r04.json"          # profiles/: PMC-derived HBM byt
 
 
 def kernel_sources_sha():
-    """fingerprint of everything that is compiled into the kernels: a PMC traffic file measured on other sources is stale by construction.  Comments and
-    layout are not compiled: the text is hashed without them ('c2:' scheme; a file stamped by the older whole-text scheme simply does not match)."""
+    """fingerprint of everything that decides which kernels run on what: the kernel sources AND the host layer that picks and sequences them (c_api.cpp's
+    hashed-vs-radix VoxelGrid choice, mesh_host.cpp's launch / exchange sequence change per-launch HBM traffic just as a kernel edit does).
+    A PMC traffic file measured on other sources is stale by construction.  Comments and layout are not compiled: every line is hashed without comments
+    and with its blanks collapsed, line ends kept (a #define must not merge with the code that follows) -- 'c3:' scheme; a file stamped by an older
+    scheme simply does not match."""
     import hashlib
     import re
     hsh = hashlib.sha256()
     d = os.path.join(ROOT, "immesh_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".inc", ".hpp")):
+        if name.endswith((".hip", ".inc", ".hpp", ".cpp")):
             text = open(os.path.join(d, name), "r", errors="replace").read()
             text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
             text = re.sub(r"//[^\n]*", " ", text)                   # line comments (a '//' inside a string literal goes too: the hash only has to be stable)
-            text = " ".join(text.split())
+            lines = [" ".join(ln.split()) for ln in text.split("\n")]
+            text = "\n".join(ln for ln in lines if ln)
             hsh.update(name.encode()); hsh.update(text.encode())
-    return "c2:" + hsh.hexdigest()[:16]
+    return "c3:" + hsh.hexdigest()[:16]
 
 
 def roofline_from_committed_profile(mesh, cnt, n_scans, n_raw, note):

@@ -96,6 +96,7 @@ static int alloc_all(immesh_ctx* c) {
         static const char* e = getenv("IMMESH_SPLIT_GENERAL");
         m.split_general = e ? atoi(e) : (g.max_layer >= 3 ? 1 : 0);
         A(m.sub_order, ns); A(m.sub_items, 2 * ns);
+        HIPCHK(c, hipMemsetAsync(m.sub_items, 0, (size_t)2 * ns * sizeof(unsigned long long), c->stream));   // (a zero item = child 0, no points: harmless if ever read unwritten)
     }
     A(c->d_dump_count, 2);
     A(c->d_touched, 2 * ns + 16);
@@ -207,8 +208,8 @@ static int check_overflow(immesh_ctx* c) {  // after a stream sync
         static const char* why[] = {"", "point-chunk pool exhausted (cap_point_chunks)", "node exceeds 32896 retained points", "extension-table pool exhausted",
                                     "node pool exhausted (cap_nodes)", "root-voxel hash full (cap_root_voxels)",
                                     "(unused)",
-                                    "leaf-list pool exhausted (cap_nodes)"};
-        c->err = std::string("registration map capacity: ") + why[f < 8 ? f : 0];
+                                    "leaf-list pool exhausted (cap_nodes)", "a root's leaf-list lock was not released (device hang guard)"};
+        c->err = std::string("registration map capacity: ") + why[f < 9 ? f : 0];
         return IMMESH_E_CAPACITY;
     }
     return 0;
@@ -907,6 +908,9 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
 // pcl::VoxelGrid stand-in on the device (the stage before lio_state_estimation, src/voxel_mapping.cpp:1888-1891)
 int immesh_downsample(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out) {
     if (!c || !pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4) || leaf <= 0 || !n_out) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    // the synchronous call and an asynchronous job share the pinned parameter block, the leaf table, the counters and the ticket word: between
+    // immesh_downsample_begin and immesh_downsample_end the job's kernels still read them
+    if (c->dsa.active) { c->err = "immesh_downsample: an asynchronous job is in flight (collect it with immesh_downsample_end first)"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     ProfBind _pb(c);
     hipStream_t s = c->stream_pre;

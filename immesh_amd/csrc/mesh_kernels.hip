@@ -705,6 +705,9 @@ __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, 
     const int total = sscan[1023];
     int rank = sscan[tid] - local;
     if (tid == 0) { m.sc[SC_ACCEPTED] = total; m.pc[PC_VERTS] = sp.vtx_base + total; }
+    // the hang guard's "a workgroup never saw the scan arrive" survives the sharded admission's rounds (which zero SC_UNDECIDED before every resolve,
+    // ADVICE r04): candidates are missing, the job has to fail
+    if (tid == 0 && m.bin_cnt[MV_BIN_BUCKETS + 1]) m.sc[SC_UNDECIDED] = 1;
     // the accepted candidates, compacted in scan order (accepted candidates cluster: a thread's own 11 may hold several, and each commit is a chain
     // of dependent global round trips -- so the commits are dealt out one per thread from the compacted list)
     int* clist = (int*)skey;   // MV_FIN_CAND ints == the key array's bytes; the keys are not in use yet

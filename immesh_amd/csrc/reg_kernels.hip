@@ -1649,6 +1649,13 @@ __device__ int wave_replay_planar_root(const RegMapDev& m, const int root, const
                     if (w.lane == 0) node_set_flags(m, w.root, root, flags, flags & ~NF_PLANE);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     flags &= ~NF_PLANE;
+                    if (npts >= m.max_points_size) {   // the fullness test of the same UpdateOctoTree call still runs (voxel_loc.cpp:245-250)
+                        flags &= ~NF_UPDATE_EN;
+                        write_header();
+                        if (w.lane == 0) { node_free_points(m, root); nd.newpts = 0; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        npts = 0; newp = 0;
+                    }
                     j++;
                     break;
                 }
@@ -1728,6 +1735,14 @@ __device__ int wave_replay_planar_node(const RegMapDev& m, const int node, const
                     if (w.lane == 0) node_set_flags(m, w.root, node, flags, flags & ~NF_PLANE, w.shared);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     flags &= ~NF_PLANE;
+                    // the fullness test of the same UpdateOctoTree call still runs (voxel_loc.cpp:245-250): a node that goes non-planar exactly when it
+                    // fills up stops updating and drops its points -- at max_layer it would otherwise keep refitting
+                    if (npts >= m.max_points_size) {
+                        write_counts();
+                        if (w.lane == 0) { nd.flags = nd.flags & ~NF_UPDATE_EN; node_free_points(m, node); nd.newpts = 0; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        npts = 0; newp = 0;
+                    }
                     j++;
                     break;
                 }
@@ -2076,6 +2091,18 @@ __device__ bool replay_split_root(const RegMapDev& m, const int root, const int*
     int seg = 0, item0 = 0, n_items = 0;
 #pragma unroll
     for (int k = 0; k < 8; k++) n_items += n_oct[k] > 0 ? 1 : 0;
+    // every child the octants need exists BEFORE anything is reserved: a failed make_child (node pool exhausted) must not leave reserved work items
+    // that replay_sub_kernel would read unwritten
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (n_oct[k] > 0) {
+            int c = child[k];
+            if (w.lane == 0 && c < 0) c = make_child(m, root, k);
+            c = __shfl(c, 0, 64);
+            if (c < 0) return true;   // node pool exhausted (flag raised by node_alloc): the update fails as a whole
+            child[k] = c;
+        }
+    }
     if (w.lane == 0) { seg = atomicAdd(&m.counters[11], total); item0 = atomicAdd(&m.counters[12], n_items); }
     seg = __shfl(seg, 0, 64); item0 = __shfl(item0, 0, 64);
     {
@@ -2084,10 +2111,7 @@ __device__ bool replay_split_root(const RegMapDev& m, const int root, const int*
         for (int k = 0; k < 8; k++) {
             base[k] = run; run += n_oct[k];
             if (n_oct[k] > 0) {
-                int c = child[k];
-                if (w.lane == 0 && c < 0) c = make_child(m, root, k);
-                c = __shfl(c, 0, 64);
-                if (c < 0) return true;   // node pool exhausted (flag raised by node_alloc): the update fails as a whole
+                const int c = child[k];
                 if (w.lane == 0) {
                     m.sub_items[2 * (size_t)it] = (unsigned long long)(unsigned int)c | ((unsigned long long)(unsigned int)root << 32);
                     m.sub_items[2 * (size_t)it + 1] = (unsigned long long)(unsigned int)base[k] | ((unsigned long long)(unsigned int)n_oct[k] << 32);

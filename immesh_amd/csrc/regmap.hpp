@@ -233,7 +233,14 @@ IMD void node_set_flags(const RegMapDev& m, int root, int nd, int old_flags, int
     m.nodes[nd].flags = new_flags;
     if (nd != root && ((old_flags ^ new_flags) & NF_PLANE)) {
         if (shared) {
-            while (atomicCAS(&m.nodes[root].lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(4);
+            // bounded like every other poll of the library: the lock is held for a list edit of a few hundred cycles by wavefronts
+            // that are RUNNING (replay_sub_kernel's grid is resident), so 2^20 tries (~0.1 s) mean something is wrong -- the update fails as a whole
+            // (flag 8) instead of hanging the device
+            int tries = 0;
+            while (atomicCAS(&m.nodes[root].lock, 0, 1) != 0) {
+                if (++tries > (1 << 20)) { m.counters[5] = 8; return; }
+                __builtin_amdgcn_s_sleep(4);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         if (new_flags & NF_PLANE) leaf_add(m, root, nd); else leaf_remove(m, root, nd);

@@ -310,7 +310,8 @@ int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3);
 /* pcl::VoxelGrid (m_downSizeFilterSurf.filter, src/voxel_mapping.cpp:1888-1891) on the device: pts = n points of `stride` (3 or 4) floats, host or
  * device; result = one float32 centroid per occupied leaf, ordered by linear leaf index (SURVEY A.15 spec).  *n_out = number of leaves.  out_xyz
  * (host or device, may be NULL) receives n_out x 3 floats; the result also stays on the device (immesh_downsample_result) so that it can be fed
- * to immesh_register / immesh_process_scan without leaving HBM. */
+ * to immesh_register / immesh_process_scan without leaving HBM.  Not between immesh_downsample_begin and immesh_downsample_end of the same context
+ * (IMMESH_E_INVAL: the two share the leaf table and the parameter block). */
 int immesh_downsample(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, double leaf, float* out_xyz, int32_t cap_out, int32_t* n_out);
 const float* immesh_downsample_result(immesh_ctx* ctx);
 /* The same VoxelGrid as an asynchronous pair: _begin enqueues the whole down-sampling of scan k+1 on the pre-processing stream and returns at once, so it

@@ -108,7 +108,7 @@ def test_kernel_source_fingerprint_ignores_comments_and_the_committed_traffic_fi
     work = tmp_path / "immesh_amd" / "csrc"
     work.mkdir(parents=True)
     for name in os.listdir(src):
-        if name.endswith((".hip", ".inc", ".hpp")):
+        if name.endswith((".hip", ".inc", ".hpp", ".cpp")):
             shutil.copy(os.path.join(src, name), work / name)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     base = bench.kernel_sources_sha()
@@ -117,6 +117,12 @@ def test_kernel_source_fingerprint_ignores_comments_and_the_committed_traffic_fi
     victim.write_text("// a remark\n\n" + text.replace("\n", "\n   ", 3) + "\n/* another\n   one */\n")
     assert bench.kernel_sources_sha() == base
     victim.write_text(text.replace("#define DSH_CHUNK 512", "#define DSH_CHUNK 256"))
+    assert bench.kernel_sources_sha() != base
+    victim.write_text(text)
+    host = work / "mesh_host.cpp"                       # the host layer decides which kernels run on what: part of the fingerprint
+    host.write_text(host.read_text().replace("round > 4096", "round > 4097"))
+    assert bench.kernel_sources_sha() != base
+    victim.write_text(text.replace("#define DSH_CHUNK 512\n", "#define DSH_CHUNK 512 \\\n"))   # a line end that ends a #define is not layout
     assert bench.kernel_sources_sha() != base
     monkeypatch.setattr(bench, "ROOT", ROOT)
     assert bench.kernel_sources_sha() == base

@@ -112,6 +112,8 @@ def test_async_pair_gives_the_synchronous_result(hip_lib):
         d = torch.from_numpy(raw).cuda()
         want, n_want = h.downsample(d.data_ptr(), 0.4, n=len(raw), stride=4, to_host=True)
         h.downsample_begin(d.data_ptr(), 0.4, n=len(raw), stride=4)
+        with pytest.raises(RuntimeError):           # the synchronous call shares the job's table / parameter block: refused while a job is in flight
+            h.downsample(d.data_ptr(), 0.4, n=len(raw), stride=4, to_host=True)
         n_got, ptr = h.downsample_end()
         assert n_got == n_want
         got = fetch_device(ptr, (n_got, 3))         # the result stays in HBM

@@ -123,6 +123,43 @@ def test_update_state_machine_freeze(oracle_lib, hip_lib):
     compare_plane_tables(a, b, TOL)
 
 
+@pytest.mark.parametrize("max_layer", [0, 2, 4])
+def test_node_that_turns_nonplanar_exactly_when_it_fills(oracle_lib, hip_lib, max_layer):
+    """ADVICE r04: OctoTree::UpdateOctoTree's planar branch (voxel_loc.cpp:233-251) runs the fullness test in the SAME call in which a refit turned the
+    node non-planar: the node stops updating and drops its points.  One root voxel, max_points_size = 12: six coplanar points (planar at the 6th),
+    then six points off the plane -- the 12th point triggers the refit (non-planar) and fills the node --, then more points (a max-layer node must
+    ignore them; a shallower one routes them to children)."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 10, cap_scan_points=10000, max_layer=max_layer, max_points_size=12)
+    for i in range(3):
+        cfg.extT[i] = 0.0
+    o, h = _both(oracle_lib, hip_lib, cfg)
+    rng = np.random.default_rng(7)
+    st = capi.make_state(cov_diag=1e-8)
+    def pts(n, z_sigma, z0=0.2):
+        return np.stack([10.0 + rng.uniform(0.03, 0.47, n), 10.0 + rng.uniform(0.03, 0.47, n), z0 + rng.normal(0, z_sigma, n)], axis=1).astype(np.float32)
+    first = pts(6, 0.002, z0=0.04)
+    o.map_build(first, st); h.map_build(first, st)
+    a = o.dump_planes()
+    assert len(a) == 1 and a[0]["is_plane"] == 1 and a[0]["n_points"] == 6
+    second = pts(6, 0.002, z0=0.46)                      # a second sheet 42 cm above the first: lambda_min ~ 0.016 > 0.01 in every direction
+    o.map_update(second, st); h.map_update(second, st)
+    a, b = o.dump_planes(), h.dump_planes()
+    root = a[[i for i, r in enumerate(a) if r["layer"] == 0][0]]
+    assert root["is_plane"] == 0 and root["update_enable"] == 0, (root["is_plane"], root["update_enable"])   # non-planar AND frozen in one call
+    compare_plane_tables(a, b, TOL)
+    for _ in range(3):
+        more = pts(7, 0.003, z0=0.04)
+        o.map_update(more, st); h.map_update(more, st)
+        a, b = o.dump_planes(), h.dump_planes()
+        compare_plane_tables(a, b, TOL)
+    if max_layer == 0:
+        assert len(a) == 1                              # a max-layer node that stopped updating ignores everything
+    else:
+        assert len(a) > 1                               # a shallower one routed the later points to children, which initialised
+    co, ch = o.counters(), h.counters()
+    assert ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+
+
 def test_edge_cases(oracle_lib, hip_lib):
     cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000)
     o, h = _both(oracle_lib, hip_lib, cfg)
