@@ -68,3 +68,74 @@ def test_hip_admission_matches_reference_tree(hip_lib):
         np.testing.assert_allclose(sm[int(q)], pos[ref_ids[keep]].mean(axis=0), rtol=0, atol=1e-9)
         checked += 1
     assert checked > 20
+
+
+# ---- deliberate distance ties (tools/make_golden_ikdtree_ties.py): a cubic lattice of exactly representable points ---------------------------------
+GT = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ikdtree_ties_r05.npz"))
+
+
+def _cfg_ties():
+    return capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=100000, cap_vertices=1 << 16, cap_triangles=1 << 19, mesh_append_budget=1600)
+
+
+def _replay_ties(h):
+    got = []
+    cam = np.array([7.5, 0.0, 3.0])
+    for k, w in enumerate(GT["scans"]):
+        out = h.mesh_scan(np.ascontiguousarray(w), cam, frame_idx=k)
+        assert len(out["new_vtx"]) == GT["accepted_per_scan"][k], k        # incl. the two scans that add nothing (own cell occupied; two vertices at 0.0625 m)
+        got.append(out["new_vtx"])
+    return np.concatenate(got)
+
+
+def test_oracle_knn_under_exact_distance_ties_matches_reference_tree(oracle_lib):
+    """once its heap is full the tree accepts a candidate only if dist < top.dist (strict, ikd_Tree.cpp:1096-1279), so the ids AT the
+    cut distance depend on its traversal order -- the 20 distances do not, nor do the ids below the cut.  255 of the 256 golden queries have more
+    equidistant points at the cut than the cut admits.  The checker's rule there is "ascending id" (a choice the reference does not define); everything
+    the reference does define must match exactly."""
+    o = make_oracle(oracle_lib, _cfg_ties())
+    V = _replay_ties(o)
+    np.testing.assert_array_equal(V, GT["accepted"])
+    ids, d2 = np.zeros(20, np.int32), np.zeros(20, np.float32)
+    Vf = GT["accepted"].astype(np.float32)
+    n_cut_ties = n_same_choice = 0
+    for qi, q in enumerate(GT["q_ids"]):
+        n_ref = int(GT["nn_cnt"][qi]); ref_ids = GT["nn_ids"][qi, :n_ref]; ref_d2 = GT["nn_d2"][qi, :n_ref]
+        assert n_ref == 20
+        p = np.ascontiguousarray(GT["accepted"][q])
+        n = oracle_lib.orc_mesh_knn(o.ctx, p.ctypes.data_as(C.c_void_p), 20, C.c_double(1.0), ids.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
+        assert n == 20
+        np.testing.assert_array_equal(d2, ref_d2)                                   # the 20 distances, bit for bit, ascending
+        cut = ref_d2[-1]
+        below = ref_d2 < cut
+        for dist in np.unique(ref_d2[below]):                                       # every complete shell: the same id set (order inside a shell is the tree's)
+            assert set(ids[d2 == dist].tolist()) == set(ref_ids[ref_d2 == dist].tolist()), (qi, dist)
+        dq = (Vf - Vf[q]) ** 2
+        dq = (dq[:, 0] + dq[:, 1]) + dq[:, 2]                                       # calc_dist's float grouping (ikd_Tree.cpp:1722)
+        at_cut = set(np.nonzero(dq == cut)[0].tolist())
+        assert set(ref_ids[ref_d2 == cut].tolist()) <= at_cut and set(ids[d2 == cut].tolist()) <= at_cut
+        if len(at_cut) > int((ref_d2 == cut).sum()):
+            n_cut_ties += 1
+            want = sorted(at_cut)[:int((d2 == cut).sum())]
+            assert ids[d2 == cut].tolist() == want                                  # the checker's own rule: ascending id
+            n_same_choice += int(set(ref_ids[ref_d2 == cut].tolist()) == set(want))
+    assert n_cut_ties > 200
+    print(f"{n_cut_ties} queries with a tie at the cut; the tree's traversal picked the ascending-id subset in {n_same_choice} of them")
+
+
+@pytest.mark.gpu
+def test_hip_admission_under_ties_matches_reference_tree(hip_lib, oracle_lib):
+    """The HIP path admits exactly the vertices the real tree admitted on the tie lattice (ids = order, positions bit-exact; the repeat scan and the
+    half-spacing sheet add nothing), and its per-scan lists equal the checker's on the same scans (the checker's tie rule is the HIP path's)."""
+    h = make_hip(hip_lib, _cfg_ties())
+    V = _replay_ties(h)
+    np.testing.assert_array_equal(V, GT["accepted"])
+    o = make_oracle(oracle_lib, _cfg_ties())
+    h2 = make_hip(hip_lib, _cfg_ties())
+    cam = np.array([7.5, 0.0, 3.0])
+    for k, w in enumerate(GT["scans"]):
+        mo = o.mesh_scan(np.ascontiguousarray(w), cam, frame_idx=k)
+        mh = h2.mesh_scan(np.ascontiguousarray(w), cam, frame_idx=k)
+        for key in ("new_vtx", "tri_add", "flip_add", "tri_rem", "tri_upd", "flip_upd", "smooth_ids"):
+            np.testing.assert_array_equal(mh[key], mo[key], err_msg=f"scan {k} {key}")
+        np.testing.assert_allclose(mh["smooth_xyz"], mo["smooth_xyz"], rtol=0, atol=1e-9)

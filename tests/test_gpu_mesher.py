@@ -312,3 +312,43 @@ def test_more_active_voxels_than_the_lds_stage_holds(oracle_lib, hip_lib):
         mh = h.mesh_scan(pts, cam, frame_idx=k)
         _compare_scan(mo, mh, f"scan {k}")
     assert mo["n_voxels_meshed"] > 8192 and len(mo["tri_add"]) > 8192
+
+
+@pytest.mark.parametrize("spacing", [0.25, 0.125])
+def test_exact_ties_lattice_cloud(oracle_lib, hip_lib, spacing):
+    """exact ties, not avoided.  A REGULAR lattice on exactly representable coordinates (binary fractions): every 20-NN query
+    has equal distances at the cut (shells of 4 / 4 / 4 / 8 neighbours: the 20th falls inside the shell of eight), every lattice square is a cocircular
+    quadruple (in-circle determinant exactly zero), the PCA of a neighbourhood has a repeated eigenvalue.  The checker's rules (ties by ascending id in
+    the kNN, insertion order in the triangulation) must be the HIP path's, bit for bit -- spacing 0.25 m keeps the neighbourhoods on the
+    register-resident triangulation (n_u <= 64), 0.125 m puts them on the general kernel (65..256)."""
+    cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    nx = int(6.0 / spacing)
+    gx, gy = np.meshgrid(np.arange(nx), np.arange(nx), indexing="ij")
+    cam = np.array([8.0, 0.0, 3.0])
+
+    def sheet(x0, y0, z0):
+        p = np.stack([x0 + gx.ravel() * spacing, y0 + gy.ravel() * spacing, np.full(gx.size, z0)], axis=1).astype(np.float32)
+        assert np.array_equal(p.astype(np.float64), np.stack([x0 + gx.ravel() * spacing, y0 + gy.ravel() * spacing, np.full(gx.size, z0)], axis=1))   # exact
+        return np.ascontiguousarray(np.concatenate([p, np.ones((len(p), 1), np.float32)], axis=1))
+
+    scans = [sheet(5.0, -3.0, 0.0),                    # the lattice
+             sheet(5.0, -3.0, 0.0)]                    # the same points again: every candidate meets its own dedupe cell
+    if spacing >= 0.25:
+        scans.append(sheet(5.0 + spacing / 2, -3.0 + spacing / 2, 0.0))                 # face centres: four corners at the same distance
+    else:
+        scans += [sheet(5.0, -3.0, 0.125), sheet(5.0, -3.0, 0.25)]                      # two more sheets above: a cubic lattice, neighbourhoods of ~90 vertices
+    scans.append(sheet(11.0, -3.0, 0.0))               # an adjacent lattice: neighbourhoods that straddle the seam
+    n_u_max = 0
+    for k, pts in enumerate(scans):
+        mo = o.mesh_scan(pts, cam, frame_idx=k)
+        mh = h.mesh_scan(pts, cam, frame_idx=k)
+        _compare_scan(mo, mh, f"lattice {spacing} scan {k}")
+        nu = o.mesh_neighbourhood_sizes()
+        np.testing.assert_array_equal(h.mesh_neighbourhood_sizes(), nu)
+        n_u_max = max(n_u_max, int(nu.max()) if len(nu) else 0)
+    assert (n_u_max <= 64) if spacing >= 0.25 else (n_u_max > 64), n_u_max
+    co, ch = o.counters(), h.counters()
+    for key in ("n_app", "n_new", "v_act", "n_v", "n_u", "t_v", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
+        assert ch[key] == co[key], key
+    assert co["n_triangles_live"] > 500
