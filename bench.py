@@ -295,8 +295,10 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     if sharded:
         comm = D.attach_collectives(h, hip, dist, args.backend, dev, world, bool(args.mesh))
     n_extra = (2 * args.profile_scans if full else 0) + (args.nu_scans if args.mesh else 0)
-    n_total = args.warmup + args.steps + n_extra
+    n_pre = max(0, args.map_scans - 1) if kitti else 0      # C4: scans 1 .. map_scans-1 build the map before the warm-up
+    n_total = n_pre + args.warmup + args.steps + n_extra
     n_cpu = int(min(260, 24 + args.cpu_seconds * 12)) if (full and args.cpu_seconds > 0 and rank == 0 and not args.gpu_scans) else 0   # the CPU-baseline leg replays the stream from scan 1: 20 + 200 + the all-cores sample
+    n_cpu += n_pre if n_cpu else 0
     extT_np = np.array(list(cfg.extT))
     if args.gpu_scans and not kitti:
         # scans ray-cast on the GPU (harness), down-sampled by the library's own VoxelGrid BEFORE the timed region: the long steady-state leg
@@ -320,7 +322,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         raws, downs = [raws[i] for i in idx], [downs[i] for i in idx]
         d_raw = [torch.from_numpy(r).to(dev) for r in raws]
         d_down = [torch.from_numpy(d).to(dev) for d in downs]
-    n_ds_mean = float(np.mean([len(d) for d in downs[1:1 + args.warmup + args.steps]]))
+    n_ds_mean = float(np.mean([len(d) for d in downs[1 + n_pre:1 + n_pre + args.warmup + args.steps]]))
     mesh_seed, seed_cloud = None, None
     if args.dense_mesh and args.mesh and not kitti and not sharded:
         # the mesh map pre-seeded from the survey, capped at the stream's corridor.  The cloud goes through the mesher in
@@ -377,10 +379,26 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
     k = 1
     import gc
     shim_info = None
+    if n_pre:
+        # SURVEY 8(d) C4 "map built from first 50 scans": the stream's own first scans through the full pipeline, untimed
+        t_pre = time.time()
+        for _ in range(n_pre):
+            st, _ = run(k, st); k += 1
+        if mesh_mode == 2:
+            h.mesh_wait()
+        n_map = h.counters()["n_root_voxels"]
+        log(f"[bench] C4 map: {n_pre + 1} scans -> {n_map} root voxels, {h.counters()['n_vertices']} mesh vertices ({time.time() - t_pre:.1f} s)")
     if args.dropin_shim:
         # ---- the same stream THROUGH THE DROP-IN: two threads as the reference runs them, host clouds, lists fetched, mirrors applied
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "libimmesh_dropin_async.so"], stdout=subprocess.DEVNULL)
-        sl = ctypes.CDLL(os.path.join(ROOT, "drop_in", "libimmesh_dropin_async.so"))
+        # the host mirror behind the shim: the REFERENCE'S OWN Triangle_manager (drop_in/_ref/libimmesh_dropin_async_refmirror.so: triangle.hpp / .cpp compiled from
+        # where they lie, built where /root/reference exists and carried to the GPU box) when it is there, else the hash-map stand-in of drop_in/stubs
+        ref_so = os.path.join(ROOT, "drop_in", "_ref", "libimmesh_dropin_async_refmirror.so")
+        use_ref = args.dropin_mirror == "ref" or (args.dropin_mirror == "auto" and os.path.exists(ref_so))
+        if use_ref and not os.path.exists(ref_so):
+            raise SystemExit("--dropin-mirror ref: drop_in/_ref/libimmesh_dropin_async_refmirror.so is not built (make -C drop_in refmirror, needs /root/reference)")
+        if not use_ref:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "libimmesh_dropin_async.so"], stdout=subprocess.DEVNULL)
+        sl = ctypes.CDLL(ref_so if use_ref else os.path.join(ROOT, "drop_in", "libimmesh_dropin_async.so"))
         sl.dropin_create.restype = ctypes.c_void_p; sl.dropin_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         sl.dropin_destroy.argtypes = [ctypes.c_void_p, ctypes.c_int]; sl.dropin_seed_mirror.argtypes = [ctypes.c_void_p]
         sl.dropin_mirror_sizes.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -412,10 +430,14 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
         sl.dropin_mirror_sizes(drv, ctypes.byref(nvm), ctypes.byref(nlm))
         sl.dropin_destroy(drv, 0)
         cm = h.counters()
-        shim_info = {"ms_until_last_pose": round(float(ms[0]), 3), "ms_until_mirrors_current": round(float(ms[1]), 3), "mirror_vertices": int(nvm.value), "mirror_live_triangles": int(nlm.value),
+        shim_info = {"host_mirror": ("the reference's own Triangle_manager (src/meshing/r3live/triangle.hpp / triangle.cpp compiled from where they lie: per-vertex adjacency sets, region buckets, a mutex per operation)"
+                                     if use_ref else "stand-in of drop_in/stubs (a hash map + a hash set)"),
+                     "threads": "scan thread (immesh_process_scan per scan) / service thread (wait for the frame's job, fetch its lists, enqueue) / mirror thread (apply the lists; host queue 256 frames deep)",
+                     "scans_per_s_until_last_pose": round(1e3 * args.steps / float(ms[0]), 1), "scans_per_s_until_mirrors_current": round(1e3 * args.steps / float(ms[1]), 1),
+                     "ms_until_last_pose": round(float(ms[0]), 3), "ms_until_mirrors_current": round(float(ms[1]), 3), "mirror_vertices": int(nvm.value), "mirror_live_triangles": int(nlm.value),
                      "host_ms_per_scan": {"scan_thread_pack_pcl_clouds": round(stage5[0] / args.steps, 4), "scan_thread_immesh_process_scan": round(stage5[1] / args.steps, 4),
                                           "service_thread_wait_for_job": round(stage5[2] / args.steps, 4), "service_thread_fetch": round(stage5[3] / args.steps, 4),
-                                          "service_thread_mirror_update": round(stage5[4] / args.steps, 4)},
+                                          "mirror_thread_update": round(stage5[4] / args.steps, 4)},
                      "mirror_equals_device": bool(nvm.value == cm["n_vertices"] and nlm.value == cm["n_triangles_live"])}
         log(f"[bench] through the drop-in shim: {shim_info}")
         D.barrier()
@@ -562,7 +584,16 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
             o.mesh_scan(np.ascontiguousarray(seed_cloud[a:a + pkg]), cam0, frame_idx=0, fetch=False)
     if args.mesh:
         o.process_scan(downs[0], raws[0], so, so, frame_idx=0, do_mesh=True)
-    cursor = {"kk": 1, "so": so}
+    kk0 = 1
+    if args.config == "velodyne" and args.map_scans > 1:   # the map (registration + mesh) from the first map_scans scans, as on the GPU leg
+        o.set_threads(ncores if ncores < 16 else ncores // 2, min(4, ncores))
+        for kk0 in range(1, min(args.map_scans, len(raws) - 8)):
+            prior = synth.forward_without_imu(so)
+            so, _ = o.process_scan(downs[kk0], raws[kk0], prior, prior, frame_idx=kk0, do_mesh=bool(args.mesh))
+        kk0 += 1
+        n_map = int(o.counters()["n_root_voxels"])
+        log(f"[bench] CPU baseline: C4 map from the first {kk0} scans: {n_map} root voxels")
+    cursor = {"kk": kk0, "so": so}
 
     def cpu_pass(mesher_threads, matcher_threads, budget, warm, max_scans):
         """one variant of the threading on the next scans of the stream (the context, its map and its mesh map carry on: one map build for both)"""
@@ -729,6 +760,10 @@ def main():
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
     ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
+    ap.add_argument("--dropin-mirror", choices=["auto", "ref", "stub"], default="auto", help="--dropin-shim 1: the host mirror the shim applies the lists to: ref = the reference's own Triangle_manager "
+                    "(drop_in/_ref/libimmesh_dropin_async_refmirror.so), stub = the stand-in of drop_in/stubs, auto = ref when it is built")
+    ap.add_argument("--map-scans", type=int, default=50, help="--config velodyne (BASELINE configs[3] = SURVEY 8(d) C4): the map -- registration map AND mesh map -- is built from the first "
+                    "this many scans of the stream (scan 0 through immesh_map_build, the rest through the full pipeline, untimed), then the stream is timed; 1 = scan 0 only (the variant of rounds 1-4)")
     ap.add_argument("--extra-configs", type=int, default=-1, help="1 = also run BASELINE configs[1] (--mesh 0) and configs[3] (--config velodyne) as short child runs and report them under "
                     "`extra`; default: on for the plain N=1 headline run")
     args = ap.parse_args()
@@ -816,7 +851,8 @@ def main():
                        "n_raw": res["n_raw"], "n_ds_mean": round(res["n_ds_mean"], 1), "map_root_voxels": res["n_map"], "params": "config/velodyne.yaml" if kitti else "config/avia.yaml",
                        "parallelism": (f"one stream; registration map sharded over {world} GPUs in {1 << args.brick_log2}^3-voxel bricks (ownership + 1-voxel halo, all-reduce of 46 doubles per EKF iteration); mesher sharded by mesh-voxel bricks (owner-computed vertex admission + kNN + Delaunay; all-gathers of the boundary band only: band candidates / decisions, smoothed positions and triangle marks within reach of another rank's brick; every rank reports its own part of the result lists); collectives: {res['comm']}" if only_sharded
                                        else f"{world} independent scan streams, one per GPU" if world > 1 else "1 GPU"),
-                       "mesh_map": ("pre-seeded from a dense survey of the stream's corridor (SURVEY 8(d) C3)" if (args.dense_mesh and args.mesh and not kitti and not only_sharded) else "seeded by scan 0 only") if args.mesh else "none",
+                       "mesh_map": ("pre-seeded from a dense survey of the stream's corridor (SURVEY 8(d) C3)" if (args.dense_mesh and args.mesh and not kitti and not only_sharded) else (f"built by the first {args.map_scans} scans of the stream, like the registration map (SURVEY 8(d) C4)" if (kitti and args.map_scans > 1) else "seeded by scan 0 only")) if args.mesh else "none",
+                       "registration_map": (f"built from the first {args.map_scans} scans of the stream (SURVEY 8(d) C4)" if (kitti and args.map_scans > 1) else "scan 0 only") if kitti else "dense survey (SURVEY 8(d) C2/C3)",
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device, inside the timed region (asynchronous: scan k+1's VoxelGrid on the pre-processing stream beside scan k's registration)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
                        "inputs": ("pcl-shaped host clouds through the drop-in shim (packed + staged over PCIe inside the timed region; result lists fetched, host mirrors applied)" if args.dropin_shim else
@@ -904,10 +940,12 @@ def main():
     if rank == 0 and want_extra:
         extra = {}
         env = {kk_: v for kk_, v in os.environ.items() if kk_ not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped", ["--config", "velodyne", "--steps", str(min(args.steps, 20)), "--cpu-seconds", "8"]),
+        for label, flags in (("configs[1] registration only", ["--mesh", "0"]), ("configs[3] velodyne.yaml, KITTI-shaped, map built from the first 50 scans (SURVEY 8(d) C4)", ["--config", "velodyne", "--steps", str(min(args.steps, 20)), "--cpu-seconds", "8"]),
+                             ("configs[3] variant of rounds 1-4: map from scan 0 only (every timed scan creates root voxels)", ["--config", "velodyne", "--map-scans", "1", "--steps", str(min(args.steps, 20))]),
                              ("full pipeline, VoxelGrid of the raw scan on the device inside the timed region", ["--device-downsample", "1"]),
                              ("full pipeline, scans handed over as host buffers (PCIe-inclusive)", ["--host-inputs", "1"]),
                              ("full pipeline THROUGH THE DROP-IN SHIM (what an unchanged ImMesh_node.cpp sees: pcl host clouds in, lists fetched, Triangle_manager / Global_map mirrors applied)", ["--dropin-shim", "1"]),
+                             ("through the drop-in shim, host mirror = the stand-in of drop_in/stubs (round 4's leg)", ["--dropin-shim", "1", "--dropin-mirror", "stub"]),
                              ("full pipeline, mesh map seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)", ["--dense-mesh", "0"]),
                              ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
                              ("configs[4] dry run: the busiest rank of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "-2", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):

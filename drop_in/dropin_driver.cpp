@@ -42,14 +42,14 @@ void store_state(const StatesGroup& s, double* o) {
 void after_frame(int frame_idx) {   // service thread, mirrors of `frame_idx` applied
     Driver* d = g_drv;
     if (!d) return;
-    FrameStat st{(int32_t)g_map_rgb_pts_mesh.m_rgb_pts_vec.size(), (int32_t)g_triangles_manager.m_live.size(), 0ull};
+    FrameStat st{(int32_t)g_map_rgb_pts_mesh.m_rgb_pts_vec.size(), (int32_t)immesh_mirror_live_count(g_triangles_manager), 0ull};
     if (d->record_hash) {
         unsigned long long h = 0;
-        for (auto& t : g_triangles_manager.m_live) {
+        immesh_mirror_for_each_live(g_triangles_manager, [&](const Triangle_ptr& t) {
             unsigned long long x = ((unsigned long long)(unsigned)t->m_tri_pts_id[0] * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(unsigned)t->m_tri_pts_id[1] << 21) ^ ((unsigned long long)(unsigned)t->m_tri_pts_id[2] << 42) ^ (unsigned long long)(t->m_index_flip & 1);
             x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
             h += x;
-        }
+        });
         st.hash = h;
     }
     std::lock_guard<std::mutex> lk(d->mu);
@@ -74,7 +74,7 @@ void* dropin_create(immesh_ctx* adopt, const double* extT3, int record_hash) {
     d->vm.m_hip = adopt;
     g_immesh_service_stop = false; g_immesh_frames_meshed = 0; g_frame_idx = 0;
     g_map_rgb_pts_mesh.m_rgb_pts_vec.clear();
-    g_triangles_manager = Triangle_manager();
+    immesh_mirror_reset(g_triangles_manager, &g_map_rgb_pts_mesh, d->vm.m_meshing_region_size * d->vm.m_meshing_distance_scale);   // (ImMesh_node.cpp:268-271 in the node)
     d->vm.immesh_shim_init();
     g_drv = d;
     g_immesh_after_frame = after_frame;
@@ -159,7 +159,7 @@ int dropin_seed_mirror(void* p) {
     std::vector<int32_t> f((size_t)nf * 3);
     if ((rc = immesh_mesh_export_fetch(d->vm.m_hip, v.data(), f.data()))) return rc;
     g_map_rgb_pts_mesh.m_rgb_pts_vec.clear();
-    g_triangles_manager = Triangle_manager();
+    immesh_mirror_reset(g_triangles_manager, &g_map_rgb_pts_mesh, d->vm.m_meshing_region_size * d->vm.m_meshing_distance_scale);
     for (int64_t i = 0; i < nv; i++) {
         auto pt = std::make_shared<RGB_pts>();
         pt->set_pos(vec_3(v[3 * i], v[3 * i + 1], v[3 * i + 2]));
@@ -178,7 +178,7 @@ int dropin_stage_ms(void* p, double* ms5) {
 }
 int dropin_mirror_sizes(void* p, int64_t* nv, int64_t* nl) {
     (void)p;
-    *nv = (int64_t)g_map_rgb_pts_mesh.m_rgb_pts_vec.size(); *nl = (int64_t)g_triangles_manager.m_live.size();
+    *nv = (int64_t)g_map_rgb_pts_mesh.m_rgb_pts_vec.size(); *nl = immesh_mirror_live_count(g_triangles_manager);
     return 0;
 }
 int dropin_wait_meshed(void* p, long n_frames, int timeout_ms) {

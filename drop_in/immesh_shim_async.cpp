@@ -9,6 +9,12 @@
 //                    incremental_mesh_reconstruction(..)     = immesh_mesh_collect_begin (wait for that scan's job) + immesh_mesh_sizes / _fetch + the host
 //                                                              mirrors (Global_map::m_rgb_pts_vec, Triangle_manager: all removes, then all adds, :228-244)
 //                                                              + immesh_mesh_collect_end
+//   mirror thread    (round 5) started by service_reconstruct_mesh itself: the lists of a frame are APPLIED to the host mirrors by a third thread, fed by
+//                    the service thread through a host-side queue (256 frames deep).  The device-side result buffers are double-buffered, so while
+//                    the service thread applied the lists itself (0.8 ms of host containers per frame against 0.2 ms of device time) the scan thread
+//                    spent its calls waiting for it; now the service thread only waits, fetches and enqueues (0.15 ms), and immesh_process_scan returns at
+//                    the device's pace.  The mirrors lag the device by the queue -- the renderer polls them at 10 Hz (mesh_rec_display.cpp:262-271)
+//                    and the sensor delivers 10 scans a second; nothing is dropped, and a full queue blocks the service thread as before.
 // Same signatures, classes and globals as the reference (compiled here against drop_in/stubs; -DIMMESH_SHIM_REAL_HEADERS inside the reference tree);
 // immesh_shim.cpp is the synchronous three-call variant of the same bodies.  Nothing is dropped: a scan whose mesh job would overwrite results the
 // service thread has not collected yet blocks in immesh_process_scan (immesh_mesh_collect_enable).
@@ -19,8 +25,10 @@
 #endif
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <list>
 #include <mutex>
 #include <thread>
@@ -137,6 +145,49 @@ void Voxel_mapping::map_incremental_grow() {
     g_frame_idx++;
 }
 
+// ---- the lists of one frame, fetched, on their way to the host mirrors -------------------------------------------------------------------------
+struct MirrorJob {
+    int frame_idx = 0;
+    immesh_mesh_sizes_t z;
+    std::vector<float> vtx; std::vector<int32_t> add, rem, upd, sid; std::vector<uint8_t> fadd, fupd; std::vector<double> sxyz;
+};
+int g_immesh_mirror_queue_depth = 256;          // frames between the service thread and the mirror thread; 0 = apply on the service thread
+static std::mutex g_mirror_mu;
+static std::condition_variable g_mirror_cv;
+static std::deque<MirrorJob> g_mirror_queue;
+// Global_map::m_rgb_pts_vec (index == vertex id, pointcloud_rgbd.cpp:518-527) and the Triangle_manager: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244)
+static void apply_to_mirrors(const MirrorJob& j) {
+    const long long t_c = now_ns();
+    const immesh_mesh_sizes_t& z = j.z;
+    for (int i = 0; i < z.n_new_vtx; i++) {
+        auto pt = std::make_shared<RGB_pts>();
+        pt->set_pos(vec_3(j.vtx[3 * i], j.vtx[3 * i + 1], j.vtx[3 * i + 2]));
+        pt->m_pt_index = (int)g_map_rgb_pts_mesh.m_rgb_pts_vec.size();
+        g_map_rgb_pts_mesh.m_rgb_pts_vec.push_back(pt);
+    }
+    for (int i = 0; i < z.n_smooth; i++) g_map_rgb_pts_mesh.m_rgb_pts_vec[j.sid[i]]->set_smooth_pos(vec_3(j.sxyz[3 * i], j.sxyz[3 * i + 1], j.sxyz[3 * i + 2]));
+    Triangle_set to_rem;
+    for (int i = 0; i < z.n_rem; i++) to_rem.insert(g_triangles_manager.find_triangle(j.rem[3 * i], j.rem[3 * i + 1], j.rem[3 * i + 2]));
+    g_triangles_manager.remove_triangle_list(to_rem, j.frame_idx);
+    for (int i = 0; i < z.n_add; i++) g_triangles_manager.insert_triangle(j.add[3 * i], j.add[3 * i + 1], j.add[3 * i + 2], 1, j.frame_idx)->m_index_flip = j.fadd[i];
+    for (int i = 0; i < z.n_upd; i++) { Triangle_ptr t = g_triangles_manager.find_triangle(j.upd[3 * i], j.upd[3 * i + 1], j.upd[3 * i + 2]); if (t) t->m_index_flip = j.fupd[i]; }
+    g_immesh_shim_ns[4] += now_ns() - t_c;
+    if (g_immesh_after_frame) g_immesh_after_frame(j.frame_idx);
+    g_immesh_frames_meshed.fetch_add(1);
+}
+static void service_apply_mirrors() {   // the mirror thread: frames in order, until the service thread stops and the queue is empty
+    for (;;) {
+        std::unique_lock<std::mutex> lk(g_mirror_mu);
+        g_mirror_cv.wait(lk, [] { return !g_mirror_queue.empty() || g_immesh_service_stop.load(); });
+        if (g_mirror_queue.empty()) return;
+        MirrorJob j = std::move(g_mirror_queue.front());
+        g_mirror_queue.pop_front();
+        lk.unlock();
+        g_mirror_cv.notify_all();
+        apply_to_mirrors(j);
+    }
+}
+
 // ---- void incremental_mesh_reconstruction(cloud, q, t, frame_idx)   src/ImMesh_mesh_reconstruction.cpp:92-267 ------------------------------
 // frame_pts == nullptr: the frame's job was queued by immesh_process_scan; collect it (jobs are handed out in submission order, one per package)
 void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_pts, Eigen::Quaterniond, Eigen::Vector3d pose_t, int frame_idx) {
@@ -158,28 +209,24 @@ void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_
     (void)immesh_mesh_collect_end(c);     // the lists are on the host: the device buffers may be reused
     if (rc) { fail(c, "immesh_mesh_fetch", rc); return; }
     const long long t_c = now_ns();
-    // ---- host mirrors: Global_map::m_rgb_pts_vec (index == vertex id, pointcloud_rgbd.cpp:518-527) and the Triangle_manager
-    for (int i = 0; i < z.n_new_vtx; i++) {
-        auto pt = std::make_shared<RGB_pts>();
-        pt->set_pos(vec_3(vtx[3 * i], vtx[3 * i + 1], vtx[3 * i + 2]));
-        pt->m_pt_index = (int)g_map_rgb_pts_mesh.m_rgb_pts_vec.size();
-        g_map_rgb_pts_mesh.m_rgb_pts_vec.push_back(pt);
-    }
-    for (int i = 0; i < z.n_smooth; i++) g_map_rgb_pts_mesh.m_rgb_pts_vec[sid[i]]->set_smooth_pos(vec_3(sxyz[3 * i], sxyz[3 * i + 1], sxyz[3 * i + 2]));
-    Triangle_set to_rem;   // all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244)
-    for (int i = 0; i < z.n_rem; i++) to_rem.insert(g_triangles_manager.find_triangle(rem[3 * i], rem[3 * i + 1], rem[3 * i + 2]));
-    g_triangles_manager.remove_triangle_list(to_rem, frame_idx);
-    for (int i = 0; i < z.n_add; i++) g_triangles_manager.insert_triangle(add[3 * i], add[3 * i + 1], add[3 * i + 2], 1, frame_idx)->m_index_flip = fadd[i];
-    for (int i = 0; i < z.n_upd; i++) { Triangle_ptr t = g_triangles_manager.find_triangle(upd[3 * i], upd[3 * i + 1], upd[3 * i + 2]); if (t) t->m_index_flip = fupd[i]; }
-    g_immesh_shim_ns[2] += t_b - t_a; g_immesh_shim_ns[3] += t_c - t_b; g_immesh_shim_ns[4] += now_ns() - t_c;
-    if (g_immesh_after_frame) g_immesh_after_frame(frame_idx);
-    g_immesh_frames_meshed.fetch_add(1);
+    g_immesh_shim_ns[2] += t_b - t_a; g_immesh_shim_ns[3] += t_c - t_b;
+    MirrorJob job;
+    job.frame_idx = frame_idx; job.z = z;
+    job.vtx.swap(vtx); job.add.swap(add); job.rem.swap(rem); job.upd.swap(upd); job.sid.swap(sid); job.fadd.swap(fadd); job.fupd.swap(fupd); job.sxyz.swap(sxyz);
+    if (g_immesh_mirror_queue_depth <= 0) { apply_to_mirrors(job); return; }   // (0: the lists are applied right here, on the service thread, as in round 4)
+    std::unique_lock<std::mutex> lk(g_mirror_mu);
+    g_mirror_cv.wait(lk, [] { return (int)g_mirror_queue.size() < g_immesh_mirror_queue_depth || g_immesh_service_stop.load(); });
+    g_mirror_queue.push_back(std::move(job));
+    lk.unlock();
+    g_mirror_cv.notify_all();
 }
 
 // ---- void service_reconstruct_mesh()   src/ImMesh_mesh_reconstruction.cpp:272-310 ------------------------------------------------------------
 // The reference commits each package to a 12-thread pool whose tasks serialise on g_mutex_reconstruct_mesh; here the frame's work already runs on the
 // device, so the service thread itself collects the results, in order.
 void service_reconstruct_mesh() {
+    std::thread mirror;
+    if (g_immesh_mirror_queue_depth > 0) mirror = std::thread(service_apply_mirrors);
     while (!g_immesh_service_stop.load()) {
         g_mutex_data_package_lock.lock();
         if (g_rec_mesh_data_package_list.empty()) {
@@ -192,6 +239,8 @@ void service_reconstruct_mesh() {
         g_mutex_data_package_lock.unlock();
         incremental_mesh_reconstruction(pk.m_frame_pts, pk.m_pose_q, pk.m_pose_t, pk.m_frame_idx);
     }
+    g_mirror_cv.notify_all();
+    if (mirror.joinable()) mirror.join();
 }
 
 // ---- void save_to_ply_file(std::string, double smooth_factor, double knn)   src/meshing/mesh_rec_geometry.cpp:71-131 -----------------------

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <new>
 #include <set>
 #include <string>
 #include <vector>
@@ -42,6 +43,14 @@ struct StatesGroup {   // include/common_lib.h:199-288
     Eigen::MatrixNd<18> cov;
 };
 
+#ifdef IMMESH_SHIM_REF_MIRROR
+// the host mirrors are THE REFERENCE'S OWN: triangle.hpp (Triangle, Triangle_manager; with triangle.cpp linked in) over ref_mirror/pointcloud_rgbd.hpp
+// (drop_in/Makefile: _ref/libimmesh_dropin_async_refmirror.so, built where /root/reference exists)
+#include "triangle.hpp"
+inline int64_t immesh_mirror_live_count(Triangle_manager& m) { return (int64_t)m.get_triangle_list_size(); }
+template <typename F> inline void immesh_mirror_for_each_live(Triangle_manager& m, F f) { for (auto* s : m.m_triangle_set_vector) for (auto& t : *s->get_triangle_set_ptr()) f(t); }
+inline void immesh_mirror_reset(Triangle_manager& m, Global_map* map, double region_size) { m.~Triangle_manager(); new (&m) Triangle_manager(); m.m_pointcloud_map = map; m.m_region_size = region_size; }   // ImMesh_node.cpp:268-271
+#else
 // ---- src/meshing/r3live/pointcloud_rgbd.hpp:77-140, 234-298 and triangle.hpp:9-34, 115-395 (the host mirrors the renderer / PLY export read) --------
 struct vec_3 { double v[3]; vec_3(double x = 0, double y = 0, double z = 0) : v{x, y, z} {} double operator()(int i) const { return v[i]; } };
 class RGB_pts {
@@ -70,6 +79,10 @@ class Triangle_manager {   // same three entry points and semantics as triangle.
         return t;
     }
 };
+inline int64_t immesh_mirror_live_count(Triangle_manager& m) { return (int64_t)m.m_live.size(); }
+template <typename F> inline void immesh_mirror_for_each_live(Triangle_manager& m, F f) { for (auto& t : m.m_live) f(t); }
+inline void immesh_mirror_reset(Triangle_manager& m, Global_map*, double) { m = Triangle_manager(); }
+#endif
 extern Global_map g_map_rgb_pts_mesh;           // src/ImMesh_mesh_reconstruction.cpp:40
 extern Triangle_manager g_triangles_manager;    // :41
 

@@ -1244,6 +1244,8 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
     __shared__ __attribute__((aligned(16))) unsigned short tri_l[LT * 4];
     __shared__ unsigned short cav[DT_CAV_CAP];
     __shared__ unsigned short ea[DT_CAV_CAP * 3], eb[DT_CAV_CAP * 3];
+    __shared__ unsigned char bdf[DT_CAV_CAP * 3];     // boundary flag of every directed edge of the cavity
+    __shared__ unsigned char cmem[DT_CAV_CAP];        // degenerate input: membership in the connected part of the cavity
     __shared__ unsigned int fresh_l[LT];
     __shared__ unsigned char fhit_l[LT];
     __shared__ double sm_l[LC * 3];   // smoothed positions as this voxel's turn in the sequential loop would see them
@@ -1392,27 +1394,125 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
                 if (ncav == 0) continue;  // duplicate / on every circle: not inserted
                 if (ncav > DT_CAV_CAP) { fail = true; break; }
                 __syncthreads();
-                const int ne = 3 * ncav;
-                // boundary edges (twin not in the cavity) -> fan of new triangles (a, b, p), reusing the cavity slots first
-                int nb = 0;
-                for (int base = 0; base < ne; base += 64) {
-                    const int e = base + lane;
-                    bool bd = false;
-                    unsigned short a = 0, b = 0;
-                    if (e < ne) { a = ea[e]; b = eb[e]; bd = true; }
-                    if (ne <= 64) {  // one edge per lane: the twin search runs on registers (v_readlane), no LDS round trips
-                        const unsigned int key = ((unsigned int)a << 16) | (unsigned int)b, twin = ((unsigned int)b << 16) | (unsigned int)a;
-                        for (int f = 0; f < ne; f++) if ((unsigned int)__builtin_amdgcn_readlane((int)key, f) == twin) bd = false;
-                    } else if (e < ne) {
-                        for (int f = 0; f < ne; f++) if (ea[f] == b && eb[f] == a) { bd = false; break; }
+                int ne = 3 * ncav;
+                // boundary edges (twin not in the cavity): flags first, the fan afterwards
+                auto mark_boundary = [&]() -> int {
+                    int nbq = 0;
+                    for (int base = 0; base < ne; base += 64) {
+                        const int e = base + lane;
+                        bool bd = false;
+                        unsigned short a = 0, b = 0;
+                        if (e < ne) { a = ea[e]; b = eb[e]; bd = true; }
+                        if (ne <= 64) {  // one edge per lane: the twin search runs on registers (v_readlane), no LDS round trips
+                            const unsigned int key = ((unsigned int)a << 16) | (unsigned int)b, twin = ((unsigned int)b << 16) | (unsigned int)a;
+                            for (int f = 0; f < ne; f++) if ((unsigned int)__builtin_amdgcn_readlane((int)key, f) == twin) bd = false;
+                        } else if (e < ne) {
+                            for (int f = 0; f < ne; f++) if (ea[f] == b && eb[f] == a) { bd = false; break; }
+                        }
+                        if (e < ne) bdf[e] = bd ? 1 : 0;
+                        nbq += __popcll(__ballot(bd));
                     }
-                    const unsigned long long mask = __ballot(bd);
-                    if (bd) {
-                        const int j = nb + __popcll(mask & ((1ull << lane) - 1ull));
-                        const int slot = j < ncav ? (int)cav[j] : nt + (j - ncav);
-                        if (slot < TCAP) { tri[slot * 4 + 0] = a; tri[slot * 4 + 1] = b; tri[slot * 4 + 2] = (unsigned short)pi; }
+                    return nbq;
+                };
+                int nb = mark_boundary();
+                if (nb != ncav + 2) {
+                    // DEGENERATE INPUT (cocircular / collinear points: the in-circle determinants are rounding noise around zero).  The triangles that
+                    // tested in-disk are not ONE disk (Euler: a disk of c triangles has c + 2 boundary edges, ghosts included) -- a far-away triangle
+                    // tested positive, or one next to p negative.  The checker's rule (oracle/orc_delaunay.hpp, header), literally: the cavity is the
+                    // part of the set that is edge-connected to the START SET = its finite triangles that contain p (all three orientations >= 0);
+                    // none (p outside the hull) -> its ghost that sees p best (largest orient2d(a, b, p), ties: smallest sorted vertex triple); no
+                    // ghost either -> its triangle with the smallest sorted vertex triple.  Never reached on points in general position.
+                    __syncthreads();
+                    bool any = false;
+                    for (int base = 0; base < ncav; base += 64) {   // start set: the finite triangles of the set that contain p (closed)
+                        const int cidx = base + lane;
+                        bool cont = false;
+                        if (cidx < ncav) {
+                            const unsigned v0 = ea[cidx * 3 + 2], v1 = ea[cidx * 3 + 0], v2 = ea[cidx * 3 + 1];
+                            cont = v0 != DT_INF && v1 != DT_INF && v2 != DT_INF &&
+                                   orient2d(xy + 2 * v0, xy + 2 * v1, p) >= 0 && orient2d(xy + 2 * v1, xy + 2 * v2, p) >= 0 && orient2d(xy + 2 * v2, xy + 2 * v0, p) >= 0;
+                            cmem[cidx] = cont ? 1 : 0;
+                        }
+                        any = any || (__ballot(cont) != 0ull);
                     }
-                    nb += __popcll(mask);
+                    if (!any) {   // p outside the hull: the ghost that sees it best (largest orient2d(a, b, p); ties: smallest sorted vertex triple); no ghost: smallest triple
+                        double best_o = -1.0;                 // (a ghost of the set has o >= 0)
+                        unsigned long long best_k = ~0ull;    // sorted triple << 16 | cavity index
+                        bool have_ghost = false;
+                        for (int pass = 0; pass < 2 && !have_ghost; pass++) {   // pass 0: ghosts by (o desc, key asc); pass 1 (no ghost at all): every triangle by key
+                            for (int cidx = lane; cidx < ncav; cidx += 64) {
+                                unsigned v0 = ea[cidx * 3 + 2], v1 = ea[cidx * 3 + 0], v2 = ea[cidx * 3 + 1];
+                                const int gi = v0 == DT_INF ? 0 : (v1 == DT_INF ? 1 : (v2 == DT_INF ? 2 : -1));
+                                if (pass == 0 && gi < 0) continue;
+                                double o = 0.0;
+                                if (pass == 0) { const unsigned a = gi == 0 ? v1 : (gi == 1 ? v2 : v0), b = gi == 0 ? v2 : (gi == 1 ? v0 : v1); o = orient2d(xy + 2 * a, xy + 2 * b, p); }
+                                if (v0 > v1) { const unsigned x = v0; v0 = v1; v1 = x; }
+                                if (v1 > v2) { const unsigned x = v1; v1 = v2; v2 = x; }
+                                if (v0 > v1) { const unsigned x = v0; v0 = v1; v1 = x; }
+                                const unsigned long long key = ((((unsigned long long)v0 << 32) | ((unsigned long long)v1 << 16) | (unsigned long long)v2) << 16) | (unsigned long long)cidx;
+                                if (o > best_o || (o == best_o && key < best_k)) { best_o = o; best_k = key; }
+                            }
+                            for (int off = 32; off > 0; off >>= 1) {
+                                const double oo = __shfl_xor(best_o, off, 64); const unsigned long long ok = __shfl_xor(best_k, off, 64);
+                                if (oo > best_o || (oo == best_o && ok < best_k)) { best_o = oo; best_k = ok; }
+                            }
+                            have_ghost = best_k != ~0ull;
+                            if (!have_ghost) best_o = -1.0;
+                        }
+                        if (lane == 0) cmem[(int)(best_k & 0xFFFFull)] = 1;
+                    }
+                    __syncthreads();
+                    for (bool changed = true; changed;) {
+                        bool ch = false;
+                        for (int base = 0; base < ncav; base += 64) {
+                            const int cidx = base + lane;
+                            bool join = false;
+                            if (cidx < ncav && !cmem[cidx])
+                                for (int f = 0; f < ncav && !join; f++) {
+                                    if (!cmem[f]) continue;
+                                    for (int i = 0; i < 3 && !join; i++)
+                                        for (int j = 0; j < 3; j++)
+                                            if (ea[cidx * 3 + i] == eb[f * 3 + j] && eb[cidx * 3 + i] == ea[f * 3 + j]) { join = true; break; }
+                                }
+                            ch = ch || (__ballot(join) != 0ull);
+                            __syncthreads();
+                            if (join) cmem[cidx] = 1;
+                            __syncthreads();
+                        }
+                        changed = ch;
+                    }
+                    if (lane == 0) {   // compact the member triangles to the front (cavity order kept)
+                        int j = 0;
+                        for (int cidx = 0; cidx < ncav; cidx++)
+                            if (cmem[cidx]) {
+                                cav[j] = cav[cidx];
+                                for (int k = 0; k < 3; k++) { ea[j * 3 + k] = ea[cidx * 3 + k]; eb[j * 3 + k] = eb[cidx * 3 + k]; }
+                                j++;
+                            }
+                        s_cnt[1] = j;
+                    }
+                    __syncthreads();
+                    ncav = s_cnt[1];
+                    __syncthreads();
+                    if (lane == 0) s_cnt[1] = 0;
+                    ne = 3 * ncav;
+                    nb = mark_boundary();
+                }
+                __syncthreads();
+                // the fan of new triangles (a, b, p) over the boundary edges, reusing the cavity slots first
+                {
+                    int nbw = 0;
+                    for (int base = 0; base < ne; base += 64) {
+                        const int e = base + lane;
+                        const bool bd = e < ne && bdf[e];
+                        const unsigned long long mask = __ballot(bd);
+                        if (bd) {
+                            const int j = nbw + __popcll(mask & ((1ull << lane) - 1ull));
+                            const int slot = j < ncav ? (int)cav[j] : nt + (j - ncav);
+                            if (slot < TCAP) { tri[slot * 4 + 0] = ea[e]; tri[slot * 4 + 1] = eb[e]; tri[slot * 4 + 2] = (unsigned short)pi; }
+                        }
+                        nbw += __popcll(mask);
+                    }
                 }
                 if (nb >= ncav) { nt += nb - ncav; if (nt > TCAP) { fail = true; break; } }
                 else {  // inconsistent predicates left fewer new triangles than holes: close the holes from the back
@@ -1460,6 +1560,24 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
         for (int k = lane; k < nf; k += 64) fhit[k] = 0;
         __syncthreads();
         lds_bitonic_sort<unsigned int, 64>(fresh, nfp, lane);
+        {   // the faces are a SET (triangle_compare keys them by sorted triplet, mesh_rec_geometry.cpp:137-172): on degenerate input the triangulation can
+            // hold the same face twice -- keep one (in place: a chunk is read into registers before anything of it is overwritten, and the write
+            // positions never run ahead of the read positions)
+            int nu = 0;
+            for (int base = 0; base < nf; base += 64) {
+                const int k = base + lane;
+                __syncthreads();
+                const unsigned int v = k < nf ? fresh[k] : 0u;
+                const bool keep = k < nf && (k == 0 || fresh[k - 1] != v);
+                const unsigned long long mask = __ballot(keep);
+                __syncthreads();
+                if (keep) fresh[nu + __popcll(mask & ((1ull << lane) - 1ull))] = v;
+                nu += __popcll(mask);
+            }
+            __syncthreads();
+            for (int k = nu + lane; k < nf; k += 64) fresh[k] = 0xFFFFFFFFu;
+            nf = nu;
+        }
         DBG_T(4);
     }
     __syncthreads();

@@ -452,8 +452,11 @@ void orc_key(const double* p3, double voxel_size, int64_t* key3) {
     key3[0] = k.x; key3[1] = k.y; key3[2] = k.z;
 }
 // 2-D Delaunay of n points -> triangles (local indices); returns triangle count, writes up to cap triangles
+static bool g_dt_link_free = false;
+void orc_delaunay_force_link_free(int on) { g_dt_link_free = on != 0; }   // tests: see Delaunay2D::force_link_free
 int orc_delaunay2d(const double* xy, int n, int32_t* tris, int cap) {
     Delaunay2D dt;
+    dt.force_link_free = g_dt_link_free;
     std::vector<int> f;
     dt.run(xy, n, f);
     const int nt = (int)f.size() / 3;

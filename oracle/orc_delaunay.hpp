@@ -7,8 +7,24 @@
 // an "infinite vertex" closing the hull.  Predicates are the plain-double Simple_cartesian formulas
 // (SURVEY.md A.14): no filtering, no exact fallback.
 // For points in general position the Delaunay triangulation is unique, so the face set equals CGAL's; exact
-// co-circular/collinear ties are resolved differently (CGAL: symbolic perturbation) -- tests use jittered data and
-// cross-check against scipy.spatial.Delaunay (Qhull).
+// co-circular/collinear ties are resolved differently (CGAL: symbolic perturbation) -- cross-checks against
+// scipy.spatial.Delaunay (Qhull) use jittered data.
+// DEGENERATE INPUT (round 5: regular lattices are tested, not avoided).  On cocircular / collinear points the plain-double determinants are
+// rounding noise around zero: a far-away triangle may test in-disk, one next to p may not, the orientation tests of an edge p lies on may disagree
+// from its two sides.  (CGAL with Simple_cartesian< double > is no better off -- the reference is not robust here; what the checker fixes is a
+// DETERMINISTIC rule that keeps the triangulation usable and that the HIP path reproduces bit for bit.)  The rule, on the bare SET of live triangles:
+//   G = every live triangle with in_disk(t, p); empty -> the point is not inserted.
+//   If G's boundary (directed edges whose twin is not an edge of G) has |G| + 2 edges, G is one disk: cavity = G.
+//   Otherwise cavity = the part of G that is edge-connected to the START SET: the finite triangles of G that contain p (all three orientations
+//   >= 0); if there is none (p outside the hull) the ghost of G that sees p best (largest orient2d(a, b, p); ties: smallest sorted vertex
+//   triple); if G has neither, its triangle with the smallest sorted vertex triple.
+//   Cavity out, one new triangle (a, b, p) per boundary edge of the cavity in.
+// The HIP path does exactly this at every insertion (it keeps nothing but the set).  The checker normally runs the usual linked algorithm -- walk to
+// the containing triangle, flood over the neighbour links -- which gives the same cavity whenever every determinant it evaluated was decisively
+// non-zero: then the flood's result C is the true cavity, anything else in G is a stray piece not adjacent to C, so G is either C or fails the
+// |G| + 2 test, and the start set lies in C.  As soon as one evaluated determinant is within rounding of zero (|det| <= 1e-11 x the sum of the
+// absolute values of its terms -- four orders of magnitude above the rounding error, so never on real, noisy scans) the checker leaves the linked
+// mode for this point set and applies the rule above literally.
 #pragma once
 #include <vector>
 #include <cstdint>
@@ -33,15 +49,23 @@ struct Delaunay2D {
     std::vector<T> tris;
     std::vector<int> free_list;
     int last = 0;
+    bool force_link_free = false;   // tests: every insertion by the link-free rule (what the HIP path does throughout) -- the result must not depend on it
 
     const double* P(int i) const { return xy + 2 * i; }
+    mutable bool suspect = false;   // a determinant evaluated since the flag was cleared was within rounding of zero (see the header)
+    double orient_s(const double* p, const double* q, const double* r) const {
+        const double t1 = (q[0] - p[0]) * (r[1] - p[1]), t2 = (r[0] - p[0]) * (q[1] - p[1]);
+        const double o = t1 - t2;
+        if (std::fabs(o) <= 1e-11 * (std::fabs(t1) + std::fabs(t2))) suspect = true;
+        return o;
+    }
 
     // does the (possibly infinite) triangle's "circumdisk" contain point p ?
     bool in_disk(const T& t, const double* p) const {
         for (int i = 0; i < 3; i++)
             if (t.v[i] == INF) {  // ghost (a,b,INF) with a->b a hull edge seen from outside: half-plane test
                 const int a = t.v[(i + 1) % 3], b = t.v[(i + 2) % 3];
-                const double o = orient2d(P(a), P(b), p);
+                const double o = orient_s(P(a), P(b), p);
                 if (o > 0) return true;
                 if (o < 0) return false;
                 // collinear with the hull edge: inside iff strictly between a and b
@@ -50,7 +74,16 @@ struct Delaunay2D {
                 const double l = (B[0] - A[0]) * (B[0] - A[0]) + (B[1] - A[1]) * (B[1] - A[1]);
                 return d > 0 && d < l;
             }
-        return incircle2d(P(t.v[0]), P(t.v[1]), P(t.v[2]), p) > 0;
+        {   // incircle2d with the magnitude of its two terms alongside (same expression, same bits)
+            const double* a = P(t.v[0]); const double* q = P(t.v[1]); const double* r = P(t.v[2]);
+            const double qpx = q[0] - a[0], qpy = q[1] - a[1], rpx = r[0] - a[0], rpy = r[1] - a[1], tpx = p[0] - a[0], tpy = p[1] - a[1];
+            const double m1 = (qpx * tpy - qpy * tpx) * (rpx * (r[0] - q[0]) + rpy * (r[1] - q[1])), m2 = (tpx * (p[0] - q[0]) + tpy * (p[1] - q[1])) * (qpx * rpy - qpy * rpx);
+            const double val = m1 - m2;
+            const double mag = (std::fabs(qpx * tpy) + std::fabs(qpy * tpx)) * (std::fabs(rpx * (r[0] - q[0])) + std::fabs(rpy * (r[1] - q[1]))) +
+                               (std::fabs(tpx * (p[0] - q[0])) + std::fabs(tpy * (p[1] - q[1]))) * (std::fabs(qpx * rpy) + std::fabs(qpy * rpx));
+            if (std::fabs(val) <= 1e-11 * mag) suspect = true;
+            return val > 0;
+        }
     }
     int new_tri(int a, int b, int c) {
         int id;
@@ -77,13 +110,22 @@ struct Delaunay2D {
             bool moved = false;
             for (int i = 0; i < 3; i++) {
                 const int a = t.v[(i + 1) % 3], b = t.v[(i + 2) % 3];
-                if (orient2d(P(a), P(b), p) < 0) { cur = t.n[i]; moved = true; break; }
+                if (orient_s(P(a), P(b), p) < 0) { cur = t.n[i]; moved = true; break; }
             }
             if (!moved) return cur;  // inside or on the boundary of a finite triangle
         }
-        // fallback: brute force
-        for (int i = 0; i < (int)tris.size(); i++) if (tris[i].alive && in_disk(tris[i], p)) return i;
-        return -1;
+        return -2;   // the walk did not settle (degenerate input): the caller chooses the start set by the canonical rule
+    }
+    // closed containment of p in a live triangle of G (see the header): ghosts count as containing
+    bool contains(const T& t, const double* p) const {
+        if (t.v[0] == INF || t.v[1] == INF || t.v[2] == INF) return true;
+        return orient2d(P(t.v[0]), P(t.v[1]), p) >= 0 && orient2d(P(t.v[1]), P(t.v[2]), p) >= 0 && orient2d(P(t.v[2]), P(t.v[0]), p) >= 0;
+    }
+    static unsigned long long canon_key(const T& t) {   // sorted vertex triple, the infinite vertex last
+        unsigned v[3];
+        for (int i = 0; i < 3; i++) v[i] = t.v[i] == INF ? 0xFFFFu : (unsigned)t.v[i];
+        std::sort(v, v + 3);
+        return ((unsigned long long)v[0] << 32) | ((unsigned long long)v[1] << 16) | (unsigned long long)v[2];
     }
 
     // triangulate n points; out = finite faces as local index triples (ccw)
@@ -133,67 +175,138 @@ struct Delaunay2D {
         std::vector<char> incav;
         struct BE { int a, b, outer; };  // boundary edge a->b (ccw around the cavity), triangle outside
         std::vector<BE> boundary;
+        // LINKED mode (the normal case): walk to the containing triangle, flood over the neighbour links, fan, re-link.  It is left for good -- for the
+        // rest of this point set -- the first time a determinant comes out within rounding of zero, the walk does not end in a triangle whose disk
+        // holds p, or the cavity is not a disk; from then on every insertion follows the header's rule literally, on the bare set of triangles.
+        bool linked = !force_link_free;
+        auto edge_key = [](int x, int y) { return ((unsigned long long)(unsigned)(x + 1) << 32) | (unsigned long long)(unsigned)(y + 1); };
         for (int oi = 0; oi < n; oi++) {
             const int pi = order[oi].second;
             if (used[pi]) continue;
             const double* p = P(pi);
-            const int seed = locate(p);
-            if (seed < 0) continue;
-            // duplicate of an existing vertex -> skip (CGAL keeps one vertex; info() of the later one. Jittered data has none.)
-            bool dup = false;
-            for (int i = 0; i < 3; i++) { int v = tris[seed].v[i]; if (v != INF && P(v)[0] == p[0] && P(v)[1] == p[1]) dup = true; }
-            if (dup) continue;
-            if (!in_disk(tris[seed], p)) {
-                // p lies on the boundary of `seed` but not in its open disk (degenerate); look for any containing disk nearby
-                int alt = -1;
-                for (int i = 0; i < 3 && alt < 0; i++) { int nb = tris[seed].n[i]; if (nb >= 0 && tris[nb].alive && in_disk(tris[nb], p)) alt = nb; }
-                if (alt < 0) for (int i = 0; i < (int)tris.size() && alt < 0; i++) if (tris[i].alive && in_disk(tris[i], p)) alt = i;
-                if (alt < 0) continue;
-                cavity.clear(); stack.clear(); stack.push_back(alt);
-            } else { cavity.clear(); stack.clear(); stack.push_back(seed); }
-            incav.assign(tris.size(), 0);
-            incav[stack[0]] = 1;
-            boundary.clear();
-            while (!stack.empty()) {
-                const int c = stack.back(); stack.pop_back();
-                cavity.push_back(c);
-                for (int i = 0; i < 3; i++) {
-                    const int nb = tris[c].n[i];
-                    if (incav[nb]) continue;
-                    if (in_disk(tris[nb], p)) { incav[nb] = 1; stack.push_back(nb); }
-                    else boundary.push_back(BE{tris[c].v[(i + 1) % 3], tris[c].v[(i + 2) % 3], nb});
-                }
-            }
-            // boundary edges found while a neighbour was not yet in the cavity may later be absorbed: filter
-            {
-                std::vector<BE> b2;
-                for (auto& e : boundary) if (!incav[e.outer]) b2.push_back(e);
-                boundary.swap(b2);
-            }
-            for (int c : cavity) { tris[c].alive = false; free_list.push_back(c); }
-            // fan: new triangle (a,b,p) per boundary edge; link to outer and to each other
-            std::vector<int> created(boundary.size());
-            for (size_t k = 0; k < boundary.size(); k++) {
-                const BE& e = boundary[k];
-                const int nt = new_tri(e.a, e.b, pi);
-                created[k] = nt;
-                tris[nt].n[2] = e.outer;
-                T& o = tris[e.outer];
-                for (int i = 0; i < 3; i++) {  // outer's edge (b,a)
-                    const int oa = o.v[(i + 1) % 3], ob = o.v[(i + 2) % 3];
-                    if (oa == e.b && ob == e.a) o.n[i] = nt;
-                }
-            }
-            if (incav.size() < tris.size()) incav.resize(tris.size(), 0);
-            for (size_t k = 0; k < boundary.size(); k++)
-                for (size_t m = 0; m < boundary.size(); m++) {
-                    if (boundary[k].b == boundary[m].a) {  // triangle k's edge (b,p) [opp a = n[0]] meets triangle m's edge (p,a) [opp b = n[1]]
-                        tris[created[k]].n[0] = created[m];
-                        tris[created[m]].n[1] = created[k];
+            if (linked) {
+                suspect = false;
+                const int seed = locate(p);
+                if (seed >= 0 && in_disk(tris[seed], p)) {
+                    cavity.clear(); stack.clear(); stack.push_back(seed);
+                    incav.assign(tris.size(), 0);
+                    incav[seed] = 1;
+                    boundary.clear();
+                    while (!stack.empty()) {
+                        const int c = stack.back(); stack.pop_back();
+                        cavity.push_back(c);
+                        for (int i = 0; i < 3; i++) {
+                            const int nb = tris[c].n[i];
+                            if (incav[nb]) continue;
+                            if (in_disk(tris[nb], p)) { incav[nb] = 1; stack.push_back(nb); }
+                            else boundary.push_back(BE{tris[c].v[(i + 1) % 3], tris[c].v[(i + 2) % 3], nb});
+                        }
+                    }
+                    // boundary edges found while a neighbour was not yet in the cavity may later be absorbed: filter
+                    {
+                        std::vector<BE> b2;
+                        for (auto& e : boundary) if (!incav[e.outer]) b2.push_back(e);
+                        boundary.swap(b2);
+                    }
+                    bool disk = !suspect && boundary.size() == cavity.size() + 2;
+                    if (disk) {   // one simple loop: every vertex starts exactly one boundary edge
+                        std::vector<int> starts;
+                        for (auto& e : boundary) starts.push_back(e.a);
+                        std::sort(starts.begin(), starts.end());
+                        for (size_t k = 1; k < starts.size(); k++) if (starts[k] == starts[k - 1]) disk = false;
+                    }
+                    if (disk) {
+                        for (int c : cavity) { tris[c].alive = false; free_list.push_back(c); }
+                        // fan: new triangle (a,b,p) per boundary edge; link to outer and to each other
+                        std::vector<int> created(boundary.size());
+                        for (size_t k = 0; k < boundary.size(); k++) {
+                            const BE& e = boundary[k];
+                            const int nt = new_tri(e.a, e.b, pi);
+                            created[k] = nt;
+                            tris[nt].n[2] = e.outer;
+                            T& o = tris[e.outer];
+                            for (int i = 0; i < 3; i++) {  // outer's edge (b,a)
+                                const int oa = o.v[(i + 1) % 3], ob = o.v[(i + 2) % 3];
+                                if (oa == e.b && ob == e.a) o.n[i] = nt;
+                            }
+                        }
+                        for (size_t k = 0; k < boundary.size(); k++)
+                            for (size_t m = 0; m < boundary.size(); m++) {
+                                if (boundary[k].b == boundary[m].a) {  // triangle k's edge (b,p) [opp a = n[0]] meets triangle m's edge (p,a) [opp b = n[1]]
+                                    tris[created[k]].n[0] = created[m];
+                                    tris[created[m]].n[1] = created[k];
+                                }
+                            }
+                        used[pi] = 1;
+                        last = created.empty() ? last : created[0];
+                        continue;
                     }
                 }
+                linked = false;   // nothing has been changed for this point yet: it is inserted link-free below
+            }
+            // ---- link-free insertion on the set of live triangles
+            std::vector<int> G;
+            for (int i = 0; i < (int)tris.size(); i++) if (tris[i].alive && in_disk(tris[i], p)) G.push_back(i);
+            if (G.empty()) continue;                       // duplicate of a vertex / on every circle: not inserted
+            auto boundary_of = [&](const std::vector<int>& S, std::vector<std::pair<int, int>>& bd) {
+                std::vector<unsigned long long> ek;
+                for (int t : S) for (int i = 0; i < 3; i++) ek.push_back(edge_key(tris[t].v[(i + 1) % 3], tris[t].v[(i + 2) % 3]));
+                std::sort(ek.begin(), ek.end());
+                bd.clear();
+                for (int t : S) for (int i = 0; i < 3; i++) {
+                    const int x = tris[t].v[(i + 1) % 3], y = tris[t].v[(i + 2) % 3];
+                    if (!std::binary_search(ek.begin(), ek.end(), edge_key(y, x))) bd.push_back({x, y});
+                }
+            };
+            std::vector<std::pair<int, int>> bd;
+            boundary_of(G, bd);
+            std::vector<int> cav = G;
+            if (bd.size() != G.size() + 2) {
+                std::vector<char> mem(G.size(), 0);
+                bool any = false;
+                for (size_t g = 0; g < G.size(); g++) {
+                    const T& t = tris[G[g]];
+                    if (t.v[0] != INF && t.v[1] != INF && t.v[2] != INF && contains(t, p)) { mem[g] = 1; any = true; }
+                }
+                if (!any) {   // p outside the hull: the ghost that sees it best; no ghost either: the smallest vertex triple
+                    long best = -1; double best_o = 0;
+                    for (size_t g = 0; g < G.size(); g++) {
+                        const T& t = tris[G[g]];
+                        int gi = -1;
+                        for (int i = 0; i < 3; i++) if (t.v[i] == INF) gi = i;
+                        if (gi < 0) continue;
+                        const double o = orient2d(P(t.v[(gi + 1) % 3]), P(t.v[(gi + 2) % 3]), p);
+                        if (best < 0 || o > best_o || (o == best_o && canon_key(t) < canon_key(tris[G[best]]))) { best = (long)g; best_o = o; }
+                    }
+                    if (best < 0) {
+                        best = 0;
+                        for (size_t g = 1; g < G.size(); g++) if (canon_key(tris[G[g]]) < canon_key(tris[G[best]])) best = (long)g;
+                    }
+                    mem[best] = 1;
+                }
+                for (bool changed = true; changed;) {
+                    changed = false;
+                    for (size_t g = 0; g < G.size(); g++) {
+                        if (mem[g]) continue;
+                        const T& t = tris[G[g]];
+                        bool join = false;
+                        for (size_t f = 0; f < G.size() && !join; f++) {
+                            if (!mem[f]) continue;
+                            const T& u = tris[G[f]];
+                            for (int i = 0; i < 3 && !join; i++)
+                                for (int j = 0; j < 3; j++)
+                                    if (t.v[(i + 1) % 3] == u.v[(j + 2) % 3] && t.v[(i + 2) % 3] == u.v[(j + 1) % 3]) { join = true; break; }
+                        }
+                        if (join) { mem[g] = 1; changed = true; }
+                    }
+                }
+                cav.clear();
+                for (size_t g = 0; g < G.size(); g++) if (mem[g]) cav.push_back(G[g]);
+                boundary_of(cav, bd);
+            }
+            for (int c : cav) { tris[c].alive = false; free_list.push_back(c); }
+            for (auto& e : bd) new_tri(e.first, e.second, pi);
             used[pi] = 1;
-            last = created.empty() ? last : created[0];
         }
         for (const T& t : tris)
             if (t.alive && t.v[0] != INF && t.v[1] != INF && t.v[2] != INF) { out.push_back(t.v[0]); out.push_back(t.v[1]); out.push_back(t.v[2]); }

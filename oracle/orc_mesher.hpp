@@ -259,7 +259,7 @@ struct Mesher {
             const std::vector<int>& tri_ids = w.tri_ids;
             const std::set<long> rel(ids.begin(), ids.end());
             out.n_u_list.push_back((int)ids.size());
-            if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); cnt->t_v += (long)tri_ids.size() / 3; }
+            if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); }
             // a21 find_relative_triangulation_combination, triangle.hpp:223-246
             std::set<Tri> old;
             for (int id : ids) {
@@ -275,6 +275,7 @@ struct Mesher {
                 std::sort(t.begin(), t.end());
                 fresh.insert(t);
             }
+            if (cnt) cnt->t_v += (long)fresh.size();   // (the faces are a set: on degenerate input the triangulation may hold one twice)
             for (const Tri& t : old) if (!fresh.count(t)) all_rem.insert(t);
             for (const Tri& t : fresh) {
                 const int fl = flip_of(t, sensor_pos, vox.short_axis);

@@ -28,3 +28,9 @@ def test_async_shim_against_the_oracle_build(oracle_lib):
 def test_async_shim_links_against_the_product_library():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "libimmesh_dropin_async.so"])
     assert os.path.exists(os.path.join(ROOT, "drop_in", "libimmesh_dropin_async.so"))
+
+
+def test_async_shim_with_the_reference_triangle_manager_against_the_oracle_build(oracle_lib):
+    """the same shim with THE REFERENCE'S OWN Triangle_manager as the host mirror (drop_in/Makefile `refmirror`: triangle.hpp / triangle.cpp /
+    tools_kd_hash.hpp compiled from where they lie), linked against the oracle: the real manager's live set and flips per frame equal the direct calls'"""
+    run_drop_in_async(lambda cfg: make_oracle(oracle_lib, cfg), "_ref/libimmesh_dropin_async_refmirror_oracle.so", lockstep=True)

@@ -116,7 +116,13 @@ def run_drop_in(oracle_lib, make_direct, target, tmp_path, expect_ply=True):
 # ---- the SERVICE-LEVEL (asynchronous) drop-in: drop_in/immesh_shim_async.cpp behind drop_in/dropin_driver.cpp (two threads, as the reference runs them) ----------
 def _dropin_lib(name):
     import ctypes as C
-    subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), name])
+    if name.startswith("_ref/"):   # the variants with the reference's own Triangle_manager as the host mirror: built only where /root/reference exists
+        if os.path.exists("/root/reference/src/meshing/r3live/triangle.hpp"):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), "refmirror"])
+        elif not os.path.exists(os.path.join(ROOT, "drop_in", name)):
+            pytest.skip(f"drop_in/{name} not built and /root/reference absent")
+    else:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drop_in"), name])
     lib = C.CDLL(os.path.join(ROOT, "drop_in", name))
     lib.dropin_create.restype = C.c_void_p; lib.dropin_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.dropin_destroy.argtypes = [C.c_void_p, C.c_int]
@@ -204,6 +210,13 @@ def run_drop_in_async(make_direct, libname, lockstep, shadow=None):
 
 def test_async_drop_in_matches_direct_calls_and_the_oracle(oracle_lib, hip_lib):
     run_drop_in_async(lambda cfg: make_hip(hip_lib, cfg), "libimmesh_dropin_async.so", lockstep=False, shadow=make_oracle(oracle_lib, capi.avia_config()))
+
+
+def test_async_drop_in_with_the_reference_triangle_manager_as_the_mirror(oracle_lib, hip_lib):
+    """The same asynchronous shim compiled against THE REFERENCE'S OWN Triangle_manager (triangle.hpp / triangle.cpp / tools_kd_hash.hpp from where they lie,
+    drop_in/Makefile `refmirror`): per frame the real manager's live set -- walked through its region buckets, m_triangle_set_vector -- and its flips hash
+    to the direct calls' and the shadow oracle's.  This is the mirror bench.py's drop-in leg pays for."""
+    run_drop_in_async(lambda cfg: make_hip(hip_lib, cfg), "_ref/libimmesh_dropin_async_refmirror.so", lockstep=False, shadow=make_oracle(oracle_lib, capi.avia_config()))
 
 
 def test_async_drop_in_stream_runner(hip_lib):

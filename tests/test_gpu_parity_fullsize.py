@@ -191,6 +191,48 @@ def test_hdl64_full_width_scans(oracle_lib, hip_lib, record_property):
     assert o2.counters()["n_vertices"] > 5000
 
 
+def test_hdl64_map_built_from_the_first_50_scans(oracle_lib, hip_lib, record_property, tmp_path):
+    """BASELINE configs[3] as SURVEY 8(d) C4 words it: the map -- registration map AND mesh map -- is what the first 50 full-width HDL-64 scans of the
+    stream leave behind (scan 0 through map_build, scans 1..49 through the full pipeline, each side on its own poses).  Then: every initialised node of
+    the two plane tables, and four more composed scans (poses <= 1e-5, lists against the shadow oracle bit for bit).  This is the map bench.py's
+    configs[3] leg times its stream on (velodyne.yaml:40-50: 3 m roots, max_layer 4, 1000 points per node)."""
+    import bench                                          # (the scan cache: worker processes ray-cast the 54 scans in parallel)
+    caps = dict(cap_root_voxels=1 << 16, cap_scan_points=400_000, cap_vertices=1 << 22, cap_triangles=1 << 24)
+    cfg = capi.velodyne_config(**caps)
+    raws, downs = bench.make_scans(54, 0, cfg, str(tmp_path / "scans"), kitti=True)
+    o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
+    o.set_threads(12, 4)
+    R0, t0 = synth.trajectory_pose(0)
+    st = capi.make_state(R=R0, t=t0)
+    p0 = np.ascontiguousarray(raws[0][:, :3])
+    o.map_build(p0, st); h.map_build(p0, st)
+    so = st.copy(); so[12:15] = [1.0, 0, 0]; so[15:18] = [0, 0, np.deg2rad(2.0)]
+    sh = so.copy()
+    chk = ComposedRunChecker(make_oracle(oracle_lib, capi.velodyne_config(**caps)), cfg.mesh_append_budget, _compare_scan)
+    chk.shadow.set_threads(12, 4)
+    worst = 0.0
+    for k in range(1, 54):
+        po, ph = synth.forward_without_imu(so), synth.forward_without_imu(sh)
+        so, io = o.process_scan(downs[k], raws[k], po, po, frame_idx=k, do_mesh=True)
+        sh, ih = h.process_scan(downs[k], raws[k], ph, ph, frame_idx=k, do_mesh=1)
+        assert ih == io, (k, ih, io)
+        worst = max(worst, float(np.abs(sh[:24] - so[:24]).max()))
+        np.testing.assert_allclose(sh[:24], so[:24], rtol=0, atol=TOL)
+        mo, mh = o.mesh_fetch(), h.mesh_fetch()
+        chk.check_scan(k, o, h, sh, mo, mh, pose_o=so, lever=float(np.abs(raws[k][:, :3]).max()) + 1.0)   # every scan of the build, too: the shadow follows the device
+        if k == 49:   # the C4 map
+            a, b = o.dump_planes(), h.dump_planes()
+            n_pl = compare_plane_tables_fast(a, b, TOL)
+            co, ch = o.counters(), h.counters()
+            assert ch["n_root_voxels"] == co["n_root_voxels"] and ch["n_refits"] == co["n_refits"] and ch["n_refit_pts"] == co["n_refit_pts"]
+            assert n_pl > 2000 and int(a["layer"].max()) >= 2 and int((a["update_enable"] == 0).sum()) > 0       # deep, with frozen nodes: a map that has lived
+            record_property("c4_map", str({"root_voxels": co["n_root_voxels"], "initialised_nodes": len(a), "planar": n_pl, "frozen": int((a["update_enable"] == 0).sum()),
+                                            "mesh_vertices": co["n_vertices"], "live_triangles": co["n_triangles_live"]}))
+    assert chk.summary()["scans_equal_to_shadow_oracle"] == 53
+    assert compare_plane_tables_fast(o.dump_planes(), h.dump_planes(), TOL) > 2000
+    print(f"[parity] C4 map from 50 scans + 4 composed scans: worst pose / state difference {worst:.2e}; {chk.summary()['first_divergence']=}")
+
+
 def test_one_500k_point_scan(oracle_lib, hip_lib):
     """configs[4]'s scan size on one GPU: a 500 000-pt scan registered against the map of a first 500 000-pt scan, then meshed"""
     caps = dict(cap_root_voxels=1 << 18, cap_scan_points=600_000, cap_vertices=1 << 21, cap_triangles=1 << 23)

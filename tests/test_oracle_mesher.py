@@ -152,3 +152,47 @@ def test_append_step_rule(oracle_lib):
     out = hp.mesh_scan(pts, np.zeros(3))
     assert len(out["new_vtx"]) == 12000
     np.testing.assert_array_equal(out["new_vtx"][:, 0], pts[::2, 0])
+
+
+def test_delaunay_on_exact_lattices_linked_equals_link_free(oracle_lib):
+    """Exactly degenerate input (regular lattices, rotated / thinned: every square a cocircular quadruple, every row collinear; the in-circle determinants
+    are rounding noise around zero).  oracle/orc_delaunay.hpp's deterministic rule: (1) the checker's usual linked algorithm (walk + flood, leaving the
+    linked mode as soon as a determinant is within rounding of zero) gives the same faces as the rule applied literally from the first insertion on
+    (force_link_free: what the HIP path does throughout); (2) the result never has a face of negative area, and its faces never cover more than the hull
+    (no overlaps); (3) in general position nothing changes (test_delaunay_vs_qhull)."""
+    from scipy.spatial import ConvexHull
+    f = oracle_lib.orc_delaunay2d; f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]; f.restype = C.c_int
+    oracle_lib.orc_delaunay_force_link_free.argtypes = [C.c_int]
+
+    def run(xy, link_free):
+        oracle_lib.orc_delaunay_force_link_free(link_free)
+        tr = np.zeros((4 * len(xy) + 16, 3), np.int32)
+        n = f(xy.ctypes.data_as(C.c_void_p), len(xy), tr.ctypes.data_as(C.c_void_p), len(tr))
+        oracle_lib.orc_delaunay_force_link_free(0)
+        return tr[:n]
+
+    rng = np.random.default_rng(0)
+    n_cases = n_full = 0
+    for trial in range(600):
+        nx, ny = rng.integers(3, 10, 2)
+        rot = rng.choice([0.0, 0.3, np.pi / 4, 1.1, rng.random() * 3])
+        gx, gy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+        xy = np.stack([gx.ravel() * 0.125, gy.ravel() * 0.125], axis=1)
+        xy = xy[rng.random(len(xy)) < rng.choice([1.0, 0.8, 0.6])]
+        if len(xy) < 3:
+            continue
+        xy = xy - xy.mean(axis=0) * rng.choice([0, 1])
+        R = np.array([[np.cos(rot), -np.sin(rot)], [np.sin(rot), np.cos(rot)]])
+        xy = np.ascontiguousarray(xy @ R.T)
+        ta, tb = run(xy, 0), run(xy, 1)
+        assert set(map(tuple, np.sort(ta, axis=1).tolist())) == set(map(tuple, np.sort(tb, axis=1).tolist())), trial
+        a, b, c = xy[ta[:, 0]], xy[ta[:, 1]], xy[ta[:, 2]]
+        area = 0.5 * ((b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1]))
+        assert area.min() > -1e-12, trial
+        try:
+            hull = ConvexHull(xy).volume
+        except Exception:
+            continue
+        assert area.sum() <= hull + 1e-9, trial            # no overlapping faces
+        n_cases += 1; n_full += int(abs(area.sum() - hull) <= 1e-9)
+    assert n_cases > 400 and n_full > 0.9 * n_cases          # (a few per cent of these inputs leave a lattice cell uncovered: a point that no disk claimed)
