@@ -290,6 +290,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
                                cap_vertices=1 << args.mesh_cap_log2, cap_triangles=1 << (args.mesh_cap_log2 + 1))
     if sharded:
         cfg.shard_rank, cfg.shard_world, cfg.shard_brick_log2, cfg.shard_mesh = rank, world, args.brick_log2, 1 if args.mesh else 0
+        cfg.shard_scheme = args.shard_scheme
     h = capi.HotPath(hip, cfg, "immesh_")
     comm = "none"
     if sharded:
@@ -508,7 +509,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
             for kk in range(1 + args.warmup, 1 + args.warmup + args.steps):
                 Rk, tk = synth.trajectory_pose(idx[kk])
                 clouds.append((downs[kk][:, :3].astype(np.float64) @ extR_np.T + extT_np) @ Rk.T + tk)
-            res["load_balance"] = D.load_balance(clouds, cfg.voxel_size, world)
+            res["load_balance"] = D.load_balance(clouds, cfg.voxel_size, world, scheme=args.shard_scheme)
 
     # ---- instrumented legs (roofline): the SAME context continues the SAME stream -- same map, same mesh map, scans right after the timed
     # ones.  (a) serial per-stage times, profiler off; (b) HIP events around every launch on the library's own streams.  Run by main() under a
@@ -681,48 +682,63 @@ def dry_run_leg(args, torch, hip, dev, local):
         if kk > args.warmup:
             clouds.append((dn[:, :3].astype(np.float64) @ extR.T + extT) @ Rk.T + tk)
     h0.close()
-    balance = D.load_balance(clouds, mk(0).voxel_size, W)
-    if r < 0:
-        r = balance[int(bv)]["busiest_rank"]     # --dry-run-rank -2: the rank with the largest share of the stream's points = the one the job waits for
-    cfg = mk(r)
-    h = capi.HotPath(hip, cfg, "immesh_")
-    h.stub_collectives()
+    balance = {"lattice colouring (bx + 3 by + 5 bz) mod W [scheme 0, the default]": D.load_balance(clouds, mk(0).voxel_size, W, scheme=0),
+               "hash(brick) mod W [scheme 1, rounds 1-4]": D.load_balance(clouds, mk(0).voxel_size, W, scheme=1)}
+    bal_now = balance[[k_ for k_ in balance if f"scheme {args.shard_scheme}" in k_][0]]
+    ranks = list(range(W)) if r < 0 else [r]     # --dry-run-rank -2 (default): EVERY rank's share in turn; the job waits for the slowest one
     side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0
-    t0 = time.time()
-    n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)      # (a rank keeps its bricks + halo: the loop runs through every strip of the square)
-    t_map = time.time() - t0
     d_down = [torch.from_numpy(dn).to(dev) for dn in downs_h]
-    R0, t0_ = synth.trajectory_pose(0)
-    st = capi.make_state(R=R0, t=t0_)
-    st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
-    mode = 1 if args.mesh else 0          # the sharded mesher runs serial per scan (its exchanges must not interleave with the next scan's all-reduces)
-    if mode:
-        h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1, n_ds=n_ds[0], n_raw=d_raw[0].shape[0])
-    k = 1
-    for _ in range(args.warmup):
-        prior = capi.forward_without_imu_native(hip, st)
-        st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
-    h.counters(reset=True)
-    torch.cuda.synchronize()
-    tb = time.perf_counter()
-    for _ in range(args.steps):
-        prior = capi.forward_without_imu_native(hip, st)
-        st, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
-    h.last_timing()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - tb
-    cnt = h.counters()
-    out = {"metric": f"scans/sec of ONE rank's share (rank {r} of {W}; collectives stubbed), 500k-pt scan into 50M-voxel map" if args.pts >= 400000 else f"scans/sec of rank {r} of {W} alone (collectives stubbed)",
-           "value": round(args.steps / el, 4), "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
+    per_rank = []
+    for r in ranks:
+        cfg = mk(r)
+        cfg.shard_scheme = args.shard_scheme
+        h = capi.HotPath(hip, cfg, "immesh_")
+        h.stub_collectives()
+        t0 = time.time()
+        n_map = build_big_map(h, cfg, torch, dev, args.map_voxels, side)      # (a rank keeps its bricks + halo: the loop runs through every strip of the square)
+        t_map = time.time() - t0
+        R0, t0_ = synth.trajectory_pose(0)
+        st = capi.make_state(R=R0, t=t0_)
+        st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+        mode = 1 if args.mesh else 0          # the sharded mesher runs serial per scan (its exchanges must not interleave with the next scan's all-reduces)
+        if mode:
+            h.process_scan(d_down[0].data_ptr(), d_raw[0].data_ptr(), st, st, frame_idx=0, do_mesh=1, n_ds=n_ds[0], n_raw=d_raw[0].shape[0])
+        k = 1
+        for _ in range(args.warmup):
+            prior = capi.forward_without_imu_native(hip, st)
+            st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+        h.counters(reset=True)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            prior = capi.forward_without_imu_native(hip, st)
+            st, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+        h.last_timing()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - tb
+        cnt = h.counters()
+        per_rank.append({"rank": r, "ms_per_scan": round(1e3 * el / args.steps, 4), "root_voxels_kept": int(n_map), "device_bytes_allocated": int(h.device_bytes()), "map_build_seconds": round(t_map, 1),
+                         "matches_per_scan": round(cnt["n_match"] / max(1, cnt["n_iter"]), 1), "new_vertices_per_scan": round(cnt["n_new"] / args.steps, 1),
+                         "pose_err_m": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))})
+        log(f"[bench] dry run, rank {r} of {W}: {per_rank[-1]}")
+        h.close()
+        del h
+        import gc as _gc
+        _gc.collect()
+    slow = max(per_rank, key=lambda q_: q_["ms_per_scan"])
+    el_ms = slow["ms_per_scan"]
+    who = f"rank {slow['rank']} of {W}, the slowest of {'all ' + str(W) + ' ranks run in turn' if len(ranks) > 1 else 'the one rank run'}"
+    out = {"metric": f"scans/sec bound of the {W}-rank job = the slowest rank's share ({who}; collectives stubbed), 500k-pt scan into 50M-voxel map" if args.pts >= 400000 else f"scans/sec of {who} alone (collectives stubbed)",
+           "value": round(1e3 / el_ms, 4), "unit": "scans/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el_ms,
            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": f"ONE rank (rank {r} of {W}) of the sharded job on one GPU, collectives stubbed: {args.pts}-pt scans, {int(args.map_voxels)}-root-voxel survey",
-                      "n_raw": int(d_raw[1].shape[0]), "n_ds_mean": round(float(np.mean(n_ds[1:])), 1), "map_root_voxels": int(n_map), "params": "config/avia.yaml",
-                      "parallelism": f"dry run of rank {r} of {W} (the rank with the largest share of the stream's points): {int(bv)}^3-voxel bricks + 1-voxel halo, sharded mesher; all-reduce / all-gather replaced by local no-ops"},
+           "config": {"workload": f"every rank's share of the {W}-rank sharded job in turn on one GPU, collectives stubbed: {args.pts}-pt scans, {int(args.map_voxels)}-root-voxel survey",
+                      "n_raw": int(d_raw[1].shape[0]), "n_ds_mean": round(float(np.mean(n_ds[1:])), 1), "map_root_voxels": int(slow["root_voxels_kept"]), "params": "config/avia.yaml",
+                      "parallelism": f"dry run: {int(bv)}^3-voxel bricks (ownership scheme {args.shard_scheme}) + 1-voxel halo, sharded mesher; all-reduce / all-gather replaced by local no-ops"},
            "load_balance_point_share_per_brick_size": balance,
-           "share": {"root_voxels_kept_by_this_rank": int(n_map), "of_total_surveyed": int(args.map_voxels), "device_bytes_allocated": int(h.device_bytes()),
-                     "map_build_seconds": round(t_map, 1), "matches_per_scan_on_this_rank": round(cnt["n_match"] / max(1, cnt["n_iter"]) , 1)},
-           "pose_err_m": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))}
-    h.close()
+           "share": {"per_rank": per_rank, "slowest_rank": slow["rank"], "fastest_ms_per_scan": min(q_["ms_per_scan"] for q_ in per_rank),
+                     "root_voxels_kept_by_this_rank": int(slow["root_voxels_kept"]), "of_total_surveyed": int(args.map_voxels), "device_bytes_allocated": int(slow["device_bytes_allocated"]),
+                     "busiest_point_share_mean": bal_now[int(bv)]["max_share_mean"], "fair_share": round(1.0 / W, 4)},
+           "pose_err_m": slow["pose_err_m"]}
     print(json.dumps(out), flush=True)
 
 
@@ -760,6 +776,7 @@ def main():
     ap.add_argument("--profile-inproc", type=int, default=0, help="sharded runs only: 1 = also run the HIP-event leg (every rank takes part)")
     ap.add_argument("--profile-timeout", type=float, default=120.0, help="watchdog of the instrumented legs + extra configurations (seconds)")
     ap.add_argument("--sharded-leg", type=int, default=1, help="N>1: after the replica headline also measure the sharded split (ONE stream over N ranks) and report it as `sharded`")
+    ap.add_argument("--shard-scheme", type=int, default=0, choices=[0, 1], help="brick ownership of the sharded map / mesher: 0 = lattice colouring (bx + 3 by + 5 bz) mod W (default), 1 = hash(brick) mod W (rounds 1-4)")
     ap.add_argument("--dropin-mirror", choices=["auto", "ref", "stub"], default="auto", help="--dropin-shim 1: the host mirror the shim applies the lists to: ref = the reference's own Triangle_manager "
                     "(drop_in/_ref/libimmesh_dropin_async_refmirror.so), stub = the stand-in of drop_in/stubs, auto = ref when it is built")
     ap.add_argument("--map-scans", type=int, default=50, help="--config velodyne (BASELINE configs[3] = SURVEY 8(d) C4): the map -- registration map AND mesh map -- is built from the first "
@@ -948,7 +965,7 @@ def main():
                              ("through the drop-in shim, host mirror = the stand-in of drop_in/stubs (round 4's leg)", ["--dropin-shim", "1", "--dropin-mirror", "stub"]),
                              ("full pipeline, mesh map seeded by scan 0 only (the stream meshes unexplored ground: the headline of rounds 1-2)", ["--dense-mesh", "0"]),
                              ("full pipeline, steady state: 500 scans after 20 warm-up scans", ["--gpu-scans", "1", "--steps", "500", "--warmup", "20", "--nu-scans", "0"]),
-                             ("configs[4] dry run: the busiest rank of 8 alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed", ["--dry-run-rank", "-2", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
+                             ("configs[4] dry run: every rank of 8 in turn, alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed (the job waits for the slowest)", ["--dry-run-rank", "-2", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)

@@ -21,6 +21,7 @@ class Config(C.Structure):
         ("device", C.c_int32), ("cap_root_voxels", C.c_int64), ("cap_nodes", C.c_int64), ("cap_point_chunks", C.c_int64),
         ("cap_vertices", C.c_int64), ("cap_triangles", C.c_int64), ("cap_scan_points", C.c_int64),
         ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_brick_log2", C.c_int32), ("shard_mesh", C.c_int32),
+        ("shard_scheme", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

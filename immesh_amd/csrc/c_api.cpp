@@ -59,6 +59,7 @@ static int alloc_all(immesh_ctx* c) {
     m.voxel_size_d = g.voxel_size;
     m.shard_rank = g.shard_world > 1 ? g.shard_rank : 0; m.shard_world = g.shard_world > 1 ? g.shard_world : 1;
     m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
+    m.shard_scheme = g.shard_scheme == 1 ? 1 : 0;
     HIPCHK(c, hipMemsetAsync(m.counters, 0, 16 * sizeof(int32_t), c->stream));
     HIPCHK(c, hipMemsetAsync(m.htab, 0xFF, hcap * sizeof(HashEnt), c->stream));   // key = IM_KEY_EMPTY, root = -1
     HIPCHK(c, hipMemsetAsync(m.slot_head, 0, hcap * sizeof(unsigned long long), c->stream));
@@ -1127,7 +1128,9 @@ int immesh_shard_owner(const immesh_config* cfg, const int64_t* key3) {
     if (!cfg || !key3) return IMMESH_E_INVAL;
     if (cfg->shard_world <= 1) return 0;
     const int b = cfg->shard_brick_log2 > 0 ? cfg->shard_brick_log2 : 5;
-    return (int)(h_hash64(h_pack(key3[0] >> b, key3[1] >> b, key3[2] >> b)) % (uint64_t)cfg->shard_world);
+    if (cfg->shard_scheme == 1) return (int)(h_hash64(h_pack(key3[0] >> b, key3[1] >> b, key3[2] >> b)) % (uint64_t)cfg->shard_world);
+    const int64_t col = ((key3[0] >> b) + 3 * (key3[1] >> b) + 5 * (key3[2] >> b)) % (int64_t)cfg->shard_world;   // lattice colouring (immesh_config::shard_scheme)
+    return (int)(col < 0 ? col + cfg->shard_world : col);
 }
 
 int immesh_registration_fallbacks(immesh_ctx* c, int64_t* n) {

@@ -89,7 +89,7 @@ int mesh_alloc(immesh_ctx* c) {
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
     m.min_spacing = g.mesh_min_spacing; m.voxel = g.mesh_voxel; m.accept = g.mesh_voxel * 1.25;
-    m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5;
+    m.shard_rank = shard_mesh ? g.shard_rank : 0; m.shard_world = shard_mesh ? g.shard_world : 1; m.shard_brick_log2 = g.shard_brick_log2 > 0 ? g.shard_brick_log2 : 5; m.shard_scheme = g.shard_scheme == 1 ? 1 : 0;
     m.dbg = nullptr;
     if (getenv("IMMESH_DEBUG")) { unsigned long long* t; if ((rc = c->dalloc(&t, 64))) return rc; m.dbg = t; (void)hipMemset(t, 0, 512); }
     hipStream_t s = c->stream;

@@ -41,10 +41,12 @@ IMD unsigned long long mkey(long x, long y, long z) {
            ((unsigned long long)(z + MKEY_BIAS) & MKEY_MASK);
 }
 IMD long rnd_cell(float p, double cell) { return (long)(int)round((double)p / cell); }  // std::round of the f64 quotient, pointcloud_rgbd.cpp:467-472
-// sharded mesher: mesh voxels are owned in bricks of 2^shard_brick_log2 voxels per axis, owner = hash(brick) mod world
+// sharded mesher: mesh voxels are owned in bricks of 2^shard_brick_log2 voxels per axis; the owner function is the registration map's (regmap.hpp brick_owner)
 IMD int mesh_owner_xyz(const MeshDev& m, long x, long y, long z) {
-    const int b = m.shard_brick_log2;
-    return (int)(hash64(mkey(x >> b, y >> b, z >> b)) % (unsigned long long)m.shard_world);   // arithmetic shifts: bricks tile negative cells too
+    const int b = m.shard_brick_log2;   // arithmetic shifts: bricks tile negative cells too
+    if (m.shard_scheme == 1) return (int)(hash64(mkey(x >> b, y >> b, z >> b)) % (unsigned long long)m.shard_world);
+    const long c = ((x >> b) + 3 * (y >> b) + 5 * (z >> b)) % (long)m.shard_world;
+    return (int)(c < 0 ? c + m.shard_world : c);
 }
 IMD int mesh_owner(const MeshDev& m, unsigned long long vkey) {
     const long x = (long)((vkey >> 42) & MKEY_MASK) - MKEY_BIAS, y = (long)((vkey >> 21) & MKEY_MASK) - MKEY_BIAS, z = (long)(vkey & MKEY_MASK) - MKEY_BIAS;

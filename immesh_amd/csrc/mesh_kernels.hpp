@@ -99,7 +99,7 @@ struct MeshDev {
     double min_spacing, voxel, accept;   // accept = voxel * 1.25 (g_kd_tree_accept_pt_dis, mesh_rec_geometry.cpp:343)
     unsigned long long* tick0;   // s_memrealtime of the job's first kernel (per parity); mesh_publish_kernel turns it into the job's device time
     unsigned char* dv_scratch;   // mesh_delaunay_general_kernel: per-block tables of the neighbourhoods above 256 vertices (MV_GEN_BLOCKS x MV_GEN_SCRATCH bytes)
-    int32_t shard_rank, shard_world, shard_brick_log2;   // sharded mesher: owner-computes per mesh-voxel brick (shard_world <= 1: off)
+    int32_t shard_rank, shard_world, shard_brick_log2, shard_scheme;   // sharded mesher: owner-computes per mesh-voxel brick (shard_world <= 1: off)
     int32_t seq;                         // scan sequence number (>= 1); kernels take it (and ch_mask) from *dyn
     MeshDyn* dyn;                        // per-scan parameters (device memory)
     unsigned long long* dbg;             // optional phase timers (IMMESH_DEBUG): [16] sums of s_memtime deltas, nullptr = off

@@ -67,8 +67,8 @@ struct RegMapDev {
     unsigned long long* sub_items;   // 2 words per item: child node | root << 32, first index in sub_order | count << 32
     int32_t upd_seq;
     // multi-GPU sharding of the registration map: root voxels are owned in bricks of 2^shard_brick_log2 voxels per axis,
-    // owner = hash(brick) mod shard_world; a rank also keeps the 1-voxel halo around its bricks (the near-voxel retry looks one voxel over)
-    int32_t shard_rank, shard_world, shard_brick_log2;
+    // owner = brick_owner() below; a rank also keeps the 1-voxel halo around its bricks (the near-voxel retry looks one voxel over)
+    int32_t shard_rank, shard_world, shard_brick_log2, shard_scheme;
     int32_t cap_nodes, cap_chunks, cap_ext;
     // parameters
     int32_t max_layer, max_points_size, init_size[5];
@@ -84,9 +84,16 @@ IMD int sym21_index(int r, int c) {  // r <= c, 6x6 upper triangle row-major
 }
 
 // ---- sharding ---------------------------------------------------------------------------------------------------
+// owner of brick (bx, by, bz) -- ONE function for the registration map, the mesher and the host mirror (immesh_shard_owner): scheme 0 = lattice colouring
+// (bx + 3 by + 5 bz) mod P, scheme 1 = hash(brick) mod P (immesh_config::shard_scheme)
+IMD int brick_owner(int scheme, int world, int64_t bx, int64_t by, int64_t bz, uint64_t packed) {
+    if (scheme == 1) return (int)(hash64(packed) % (uint64_t)world);
+    const int64_t c = (bx + 3 * by + 5 * bz) % (int64_t)world;
+    return (int)(c < 0 ? c + world : c);
+}
 IMD int shard_owner(const RegMapDev& m, int64_t kx, int64_t ky, int64_t kz) {
-    const int b = m.shard_brick_log2;
-    return (int)(hash64(pack_key(kx >> b, ky >> b, kz >> b)) % (uint64_t)m.shard_world);   // arithmetic shift: bricks tile negative keys too
+    const int b = m.shard_brick_log2;   // arithmetic shift: bricks tile negative keys too
+    return brick_owner(m.shard_scheme, m.shard_world, kx >> b, ky >> b, kz >> b, pack_key(kx >> b, ky >> b, kz >> b));
 }
 // does this rank keep voxel k ?  (owned, or within one voxel of an owned brick)
 IMD bool shard_keeps(const RegMapDev& m, int64_t kx, int64_t ky, int64_t kz) {

@@ -96,11 +96,14 @@ def _hash64(k):
     return k
 
 
-def owners_of_root_voxels(keys, brick_log2, world):
-    """keys: n x 3 int64 root-voxel keys -> owning rank per key (same function as the device / immesh_shard_owner)"""
+def owners_of_root_voxels(keys, brick_log2, world, scheme=0):
+    """keys: n x 3 int64 root-voxel keys -> owning rank per key (same function as the device / immesh_shard_owner).  scheme 0 = lattice colouring
+    (bx + 3 by + 5 bz) mod world, 1 = hash(brick) mod world (immesh_config::shard_scheme)"""
     import numpy as np
     b = np.int64(brick_log2)
     k = np.asarray(keys, np.int64) >> b                         # arithmetic shift: bricks tile negative keys too
+    if scheme != 1:
+        return np.mod(k[:, 0] + 3 * k[:, 1] + 5 * k[:, 2], np.int64(world)).astype(np.int64)   # (numpy's mod is non-negative for a positive modulus)
     B, M = np.uint64(1 << 20), np.uint64((1 << 21) - 1)
     ku = (k.astype(np.uint64) + B) & M
     packed = ku[:, 0] | (ku[:, 1] << np.uint64(21)) | (ku[:, 2] << np.uint64(42))
@@ -115,7 +118,7 @@ def root_voxel_keys(world_xyz, voxel_size):
     return np.trunc(q).astype(np.int64)
 
 
-def load_balance(world_clouds, voxel_size, world, brick_log2s=(3, 4, 5)):
+def load_balance(world_clouds, voxel_size, world, brick_log2s=(3, 4, 5), scheme=0):
     """Share of the down-sampled scan points (= the matcher's and the map update's work) each rank owns, per scan, for every brick size: the slowest
     rank of a sharded job is the one with the largest share.  Returns {brick_voxels: {"max_share_mean": ..., "max_share_worst_scan": ..., "min_share_mean": ...,
     "busiest_rank": r}}; the fair share is 1 / world."""
@@ -124,7 +127,7 @@ def load_balance(world_clouds, voxel_size, world, brick_log2s=(3, 4, 5)):
     for b in brick_log2s:
         mx, mn, tot = [], [], np.zeros(world)
         for pts in world_clouds:
-            own = owners_of_root_voxels(root_voxel_keys(pts, voxel_size), b, world)
+            own = owners_of_root_voxels(root_voxel_keys(pts, voxel_size), b, world, scheme)
             sh = np.bincount(own, minlength=world) / max(1, len(own))
             mx.append(sh.max()); mn.append(sh.min()); tot += sh
         out[int(1 << b)] = {"max_share_mean": round(float(np.mean(mx)), 4), "max_share_worst_scan": round(float(np.max(mx)), 4), "min_share_mean": round(float(np.mean(mn)), 4),

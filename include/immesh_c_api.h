@@ -66,6 +66,11 @@ typedef struct immesh_config {
     int32_t shard_world;
     int32_t shard_brick_log2;  /* 0 = default 5: 32^3-voxel bricks */
     int32_t shard_mesh;        /* 1 = the mesher is sharded too (owner-computed admission / kNN / Delaunay per mesh-voxel brick, boundary band by all-gather, see immesh_set_allgather); 0 = every context meshes whatever it is handed */
+    /* which rank owns brick (bx, by, bz): 0 = LATTICE COLOURING, owner = (bx + 3 by + 5 bz) mod shard_world -- along every axis consecutive bricks cycle
+     * through all ranks (1, 3, 5 are units mod 2 / 4 / 8), so any axis-aligned surface patch a scan touches is dealt out evenly and neighbouring bricks never
+     * share an owner (round 5: the busiest of 8 ranks owns 0.137 of a configs[4] scan instead of 0.170, the idlest 0.117 instead of 0.083); 1 = hash(brick) mod shard_world (rounds 1-4) */
+    int32_t shard_scheme;
+    int32_t reserved_;
 } immesh_config;
 
 void immesh_default_config(immesh_config* cfg); /* avia.yaml + mapping_avia.launch values */
@@ -267,7 +272,7 @@ const float* immesh_undistort_result(immesh_ctx* ctx);
 typedef int (*immesh_allreduce_fn)(double* buf, int32_t n, void* user);
 int immesh_set_allreduce(immesh_ctx* ctx, immesh_allreduce_fn fn, void* user);
 /* Sharded mesher (shard_world > 1, shard_mesh = 1; shard_brick_log2 >= 2).  Every rank is handed the same world-frame scans.  Mesh voxels are owned in
- * bricks of 2^shard_brick_log2 voxels per axis (owner = hash(brick) mod shard_world); the OWNER of a brick tests the candidates falling into it against
+ * bricks of 2^shard_brick_log2 voxels per axis (owner: immesh_config::shard_scheme); the OWNER of a brick tests the candidates falling into it against
  * the map and decides them (Global_map::append_points_to_global_map, pointcloud_rgbd.cpp:411-552), searches its voxels' neighbourhoods and triangulates
  * them.  Only the BOUNDARY BAND travels, by all-gather:
  *   1. admission, in rounds: a rank's candidates that survived the test against the map and lie within min_spacing of another rank's brick, then the

@@ -61,3 +61,18 @@ def test_shard_owner_partitions_bricks():
             base = (k >> 5) << 5
             assert capi.shard_owner(lib, cfg, base) == o and capi.shard_owner(lib, cfg, base + 31) == o
     assert capi.shard_owner(lib, capi.avia_config(), np.array([5, -7, 9])) == 0     # sharding off
+    # both ownership schemes (immesh_config::shard_scheme): the numpy mirror bench.py's load-balance report uses (immesh_amd/dist.py) is the library's function;
+    # lattice colouring (scheme 0, the default): along every axis consecutive bricks cycle through all ranks, neighbours never share an owner
+    from immesh_amd import dist as D
+    for scheme in (0, 1):
+        for world in (2, 4, 8):
+            cfg = capi.avia_config(shard_rank=0, shard_world=world, shard_brick_log2=3, shard_scheme=scheme)
+            keys = rng.integers(-3000, 3000, size=(1500, 3))
+            lib_owner = np.array([capi.shard_owner(lib, cfg, k) for k in keys])
+            np.testing.assert_array_equal(D.owners_of_root_voxels(keys, 3, world, scheme), lib_owner)
+            if scheme == 0:
+                for axis in range(3):
+                    k = np.zeros((world, 3), np.int64); k[:, axis] = np.arange(world) * 8 - 24
+                    assert sorted(D.owners_of_root_voxels(k, 3, world, 0).tolist()) == list(range(world))
+                    step = np.zeros(3, np.int64); step[axis] = 8
+                    assert (D.owners_of_root_voxels(keys, 3, world, 0) != D.owners_of_root_voxels(keys + step, 3, world, 0)).all()
