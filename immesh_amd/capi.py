@@ -555,6 +555,18 @@ class HotPath:
         f = self._f("set_allgather"); f.argtypes = [C.c_void_p, proto, C.c_void_p]; f.restype = C.c_int
         self._check(f(self.ctx, self._allgather_cb, None), "set_allgather")
 
+    def broadcast_scan(self, pts, root=0, stride=None, n=None):
+        """immesh_broadcast_scan: collective; the root passes the scan (ndarray n x 3 / n x 4 or a device pointer with n and stride), the others None.
+        Returns (device pointer, points) of the scan in this context's memory."""
+        f = self._f("broadcast_scan"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        if pts is not None and not isinstance(pts, (int, np.integer)):
+            pts = np.ascontiguousarray(pts, np.float32)
+            n, stride = len(pts), pts.shape[1]
+        out, n_out = C.c_void_p(0), C.c_int32(0)
+        self._check(f(self.ctx, _ptr(pts), int(n or 0), int(stride or 0), int(root), C.byref(out), C.byref(n_out)), "broadcast_scan")
+        return int(out.value), int(n_out.value)
+
     def shard_traffic(self):
         f = self._f("shard_traffic"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; f.restype = C.c_int
         b, n = C.c_int64(0), C.c_int64(0)

@@ -17,6 +17,7 @@ typedef int (*fn_comm_init_rank)(void**, int, rcclUniqueId, int);
 typedef int (*fn_comm_destroy)(void*);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_all_gather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef const char* (*fn_error_string)(int);
 struct RcclApi {
     void* lib = nullptr;
@@ -25,6 +26,7 @@ struct RcclApi {
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_reduce all_reduce = nullptr;
     fn_all_gather all_gather = nullptr;
+    fn_broadcast broadcast = nullptr;
     fn_error_string error_string = nullptr;
     std::string err;
 };
@@ -43,8 +45,9 @@ bool rccl_load() {
     g_rccl.comm_destroy = (fn_comm_destroy)dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.all_reduce = (fn_all_reduce)dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.all_gather = (fn_all_gather)dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.broadcast = (fn_broadcast)dlsym(g_rccl.lib, "ncclBroadcast");
     g_rccl.error_string = (fn_error_string)dlsym(g_rccl.lib, "ncclGetErrorString");
-    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather) {
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.all_gather || !g_rccl.broadcast) {
         g_rccl.err = "librccl.so lacks an expected entry point"; dlclose(g_rccl.lib); g_rccl.lib = nullptr; return false;
     }
     return true;
@@ -109,6 +112,63 @@ int immesh_rccl_init(immesh_ctx* c, const uint8_t id_in[128]) {
     const int rc = g_rccl.comm_init_rank(&c->rccl_comm, world, id, rank);
     if (rc) { c->rccl_comm = nullptr; c->err = "ncclCommInitRank: " + rccl_why(rc); return IMMESH_E_HIP; }
     c->allreduce = nullptr; c->mesh_host.allgather = nullptr;   // the library's own collectives replace the host callbacks
+    return 0;
+}
+
+// SURVEY 8(e), first row: "Scan (<= 0.5 M x 12 B = 6 MB) broadcast once per scan" -- the library distributes the scan, not the harness.  Collective over
+// the ranks of the sharded job, on the context's registration stream (whatever is enqueued there next -- immesh_process_scan -- is ordered behind it):
+//   RCCL     a 16-byte header {points, stride} (ncclBroadcast + one host read: the payload's size is a host-side argument of the collective), then
+//            ncclBroadcast of the points, device to device;
+//   callbacks (gloo tests)   the same two messages through the registered all-gather (the root's block carries the data, the others' are ignored).
+int immesh_broadcast_scan(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, int32_t root, const float** dev_out, int32_t* n_out) {
+    if (!c || !dev_out || !n_out) return IMMESH_E_INVAL;
+    const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1, me = c->cfg.shard_world > 1 ? c->cfg.shard_rank : 0;
+    if (root < 0 || root >= world) { c->err = "immesh_broadcast_scan: root outside the job"; return IMMESH_E_INVAL; }
+    const bool am_root = me == root;
+    if (am_root && (!pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4))) { c->err = "immesh_broadcast_scan: the root's scan is empty, too large (cap_scan_points) or not 3 / 4 floats per point"; return IMMESH_E_INVAL; }
+    (void)hipSetDevice(c->cfg.device);
+    hipStream_t s = c->stream;
+    for (int k = 0; k < 2; k++)
+        if (!c->d_bcast[k]) { const int arc = c->dalloc(&c->d_bcast[k], (size_t)c->cap_scan * (k ? 4 : 3)); if (arc) return arc; }
+    if (!c->d_bcast_hdr) { const int arc = c->dalloc(&c->d_bcast_hdr, 4); if (arc) return arc; }
+    int32_t hdr[4] = {am_root ? n : 0, am_root ? stride : 0, 0, 0};
+    const bool use_rccl = c->rccl_comm && c->rccl_comm != RCCL_STUB;
+    std::vector<char> gathered;
+    if (world > 1 && !use_rccl && c->rccl_comm != RCCL_STUB) {
+        if (!c->mesh_host.allgather) { c->err = "immesh_broadcast_scan: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
+        gathered.resize((size_t)world * 16);
+        if (c->mesh_host.allgather(hdr, 16, gathered.data(), c->mesh_host.allgather_user)) { c->err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+        std::memcpy(hdr, gathered.data() + (size_t)root * 16, 16);
+    } else if (use_rccl) {
+        HIPCHK(c, hipMemcpyAsync(c->d_bcast_hdr, hdr, 16, hipMemcpyHostToDevice, s));
+        const int rc = g_rccl.broadcast(c->d_bcast_hdr, c->d_bcast_hdr, 16, RCCL_INT8, root, c->rccl_comm, s);
+        if (rc) { c->err = "ncclBroadcast: " + rccl_why(rc); return IMMESH_E_HIP; }
+        c->rccl_calls++;
+        HIPCHK(c, hipMemcpyAsync(hdr, c->d_bcast_hdr, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    const int32_t np = hdr[0], st = hdr[1];
+    if (np <= 0 || np > c->cap_scan || (st != 3 && st != 4)) { c->err = "immesh_broadcast_scan: bad header from the root (its scan exceeds this rank's cap_scan_points?)"; return IMMESH_E_CAPACITY; }
+    float* buf = c->d_bcast[st == 4 ? 1 : 0];
+    const size_t bytes = (size_t)np * st * sizeof(float);
+    if (am_root) {
+        hipPointerAttribute_t attr;
+        const bool dev_in = hipPointerGetAttributes(&attr, pts) == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+        if (!dev_in) (void)hipGetLastError();
+        if ((const void*)pts != (const void*)buf) HIPCHK(c, hipMemcpyAsync(buf, pts, bytes, dev_in ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    }
+    if (use_rccl) {
+        const int rc = g_rccl.broadcast(buf, buf, bytes, RCCL_INT8, root, c->rccl_comm, s);
+        if (rc) { c->err = "ncclBroadcast: " + rccl_why(rc); return IMMESH_E_HIP; }
+        c->rccl_calls++;
+    } else if (world > 1 && c->rccl_comm != RCCL_STUB) {
+        std::vector<char> send(bytes, 0);
+        if (am_root) { HIPCHK(c, hipMemcpyAsync(send.data(), buf, bytes, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s)); }
+        gathered.resize((size_t)world * bytes);
+        if (c->mesh_host.allgather(send.data(), (int64_t)bytes, gathered.data(), c->mesh_host.allgather_user)) { c->err = "all-gather callback failed"; return IMMESH_E_INVAL; }
+        if (!am_root) { HIPCHK(c, hipMemcpyAsync(buf, gathered.data() + (size_t)root * bytes, bytes, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
+    }
+    *dev_out = buf; *n_out = np;
     return 0;
 }
 

@@ -298,6 +298,12 @@ int immesh_set_allgather(immesh_ctx* ctx, immesh_allgather_fn cb, void* user);
 int immesh_rccl_unique_id(uint8_t id_out[128]);
 int immesh_rccl_init(immesh_ctx* ctx, const uint8_t id[128]);
 const char* immesh_rccl_error(void);
+/* SURVEY 8(e) "Scan ... broadcast once per scan": the rank that holds the scan (root: pts = n points of `stride` = 3 or 4 floats, host or device) hands it
+ * to every rank of the sharded job; the other ranks pass pts = NULL.  Collective -- every rank calls it, in the same order.  On return *dev_out points at the
+ * scan in THIS context's device memory (one buffer per stride, valid until the next broadcast of that stride) and *n_out is its length: feed them to
+ * immesh_process_scan / immesh_mesh_scan, which take device pointers as they are.  RCCL (immesh_rccl_init): ncclBroadcast on the registration stream;
+ * otherwise through the all-gather callback (immesh_set_allgather).  Unsharded context: a plain copy into the buffer. */
+int immesh_broadcast_scan(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, int32_t root, const float** dev_out, int32_t* n_out);
 /* payload bytes this rank has contributed to the mesher's all-gathers, and the number of collective calls, since create */
 int immesh_shard_traffic(immesh_ctx* ctx, int64_t* bytes, int64_t* calls);
 

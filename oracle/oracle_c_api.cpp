@@ -308,6 +308,7 @@ int orc_set_threads(void* p, int32_t mesher_threads, int32_t matcher_threads) {
     return 0;
 }
 int orc_set_allgather(void*, immesh_allgather_fn, void*) { return 0; }
+int orc_broadcast_scan(void*, const float* pts, int32_t n, int32_t, int32_t, const float** out, int32_t* n_out) { if (out) *out = pts; if (n_out) *n_out = n; return 0; }   // the checker is single-process: the scan is where it is
 int orc_shard_traffic(void*, int64_t* bytes, int64_t* calls) { if (bytes) *bytes = 0; if (calls) *calls = 0; return 0; }
 int orc_shard_owner(const immesh_config*, const int64_t*) { return 0; }
 int orc_mesh_wait(void* p) { (void)p; return 0; }

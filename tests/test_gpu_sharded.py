@@ -78,6 +78,13 @@ def _rank_main(rank, world, port, out):
     lib = capi.load_hip_library()
     h = capi.HotPath(lib, _cfg(rank, world), "immesh_")
     h.set_allreduce(lambda buf: dist.all_reduce(torch.from_numpy(buf)))          # in place on the library's buffer
+
+    def allgather(send, recv):
+        parts = [torch.empty(len(send), dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(send))
+        for r in range(world):
+            recv[r * len(send):(r + 1) * len(send)] = parts[r].numpy()
+    h.set_allgather(allgather)                                                    # (carries immesh_broadcast_scan here; RCCL: ncclBroadcast)
     ref = capi.HotPath(lib, _cfg(), "immesh_") if rank == 0 else None
     scans = _scans(5)
     R0, t0, raw0, _ = scans[0]
@@ -88,11 +95,17 @@ def _rank_main(rank, world, port, out):
     st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
     sr = st.copy()
     err = 0.0
+    from conftest import fetch_device
     for k in range(1, 5):
         down = scans[k][3]
+        # the scan is DISTRIBUTED BY THE LIBRARY -- only the root holds it (every other rank passes nothing), every rank registers
+        # and grows its shard from the copy the broadcast left in its own device memory
+        d_down, n_down = h.broadcast_scan(down if rank == 0 else None, root=0)
+        assert n_down == len(down)
+        np.testing.assert_array_equal(fetch_device(d_down, (n_down, 3)), down)      # (the test generates the stream on every rank: it can look)
         prior = synth.forward_without_imu(st)
-        st, info = h.register(down, prior, prior)
-        h.map_update(down, st)
+        st, info = h.register(d_down, prior, prior, n=n_down)
+        h.map_update(d_down, st, n=n_down)
         if ref:
             pr = synth.forward_without_imu(sr)
             sr, ir = ref.register(down, pr, pr)
@@ -104,13 +117,16 @@ def _rank_main(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_register_matches_unsharded():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_register_matches_unsharded(world):
+    """2 ranks, and configs[4]'s 8 (eight processes on the one GPU of the box; gloo carries the all-reduce and the scan broadcast)"""
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 300)
+    port = 29600 + (os.getpid() % 300) + world
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_rank_main, args=(2, port, out), nprocs=2, join=True)
-    np.testing.assert_array_equal(out[0][0], out[1][0])       # the ranks stay in lock step (identical all-reduced sums -> identical states)
+    mp.spawn(_rank_main, args=(world, port, out), nprocs=world, join=True)
+    for r in range(1, world):
+        np.testing.assert_array_equal(out[0][0], out[r][0])   # the ranks stay in lock step (identical all-reduced sums -> identical states)
     assert out[0][1] < 1e-9                                    # and agree with the unsharded run up to summation order
 
 
@@ -172,7 +188,7 @@ def _lex(tri, flip=None):
     return tri[order], (np.asarray(flip)[order] if flip is not None else None)
 
 
-@pytest.mark.parametrize("world,brick_log2", [(2, 2), (4, 2), (2, 3)])
+@pytest.mark.parametrize("world,brick_log2", [(2, 2), (4, 2), (2, 3), (8, 3)])   # (8, 3): configs[4]'s rank count and brick size, eight processes on the one GPU
 def test_sharded_mesher_union_of_rank_lists_is_the_unsharded_result(world, brick_log2):
     import torch.multiprocessing as mp
     n_scans = 4
