@@ -248,7 +248,9 @@ def test_rccl_inside_the_library_world_size_one(hip_lib):
     for k in range(1, 4):
         down, raw = scans[k][3], scans[k][2]
         prior, pr = synth.forward_without_imu(st), synth.forward_without_imu(sr)
-        st, info = h.process_scan(down, raw, prior, prior, frame_idx=k, do_mesh=1)
+        d_down, n_down = h.broadcast_scan(down, root=0)            # ncclBroadcast (header + points) inside the library; one rank: a copy
+        assert n_down == len(down)
+        st, info = h.process_scan(d_down, raw, prior, prior, frame_idx=k, do_mesh=1, n_ds=n_down)
         sr, ir = ref.process_scan(down, raw, pr, pr, frame_idx=k, do_mesh=1)
         assert info == ir
         np.testing.assert_allclose(st[:24], sr[:24], rtol=0, atol=1e-9)

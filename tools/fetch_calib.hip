@@ -31,6 +31,24 @@ __global__ void gather_node(const float4* __restrict__ t, size_t n_nodes, size_t
     const float4 a = p[0], b = p[8], c = p[16];   // one 16-byte piece in each of three 128-byte-apart lines
     if (a.x + b.x + c.x == 123456.f) sink[0] = a.y;
 }
+// ---- WRITE_SIZE (round 5): what a SMALL SCATTERED STORE costs.  The mesher's result kernels (mesh_merge_emit: every record goes to its
+// global rank -- 12 + 1 + 4 bytes per triangle, 4 + 24 per smoothed vertex --, mesh_chunk_sort, the table clears of mesh_begin_scan) write a few bytes
+// per thread at addresses that are not neighbours.  N threads, each storing `bytes` bytes into a 64-byte line of its own; stream_write for comparison.
+__global__ void stream_write(float4* __restrict__ t, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+}
+template <int BYTES>
+__global__ void scatter_store(unsigned char* __restrict__ t, size_t n_lines, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t line = (i * 0x9E3779B97F4A7C15ull + 12345) & (n_lines - 1);
+    unsigned char* p = t + line * 64;
+    if (BYTES == 1) p[0] = (unsigned char)i;
+    else if (BYTES == 4) *(int*)p = (int)i;
+    else if (BYTES == 12) { int* q = (int*)p; q[0] = (int)i; q[1] = (int)i + 1; q[2] = (int)i + 2; }   // (three dword stores of one thread: out_tri[rank * 3 + 0..2])
+    else if (BYTES == 24) { double* q = (double*)p; q[0] = (double)i; q[1] = 1.0; q[2] = 2.0; }         // (out_smooth_xyz[rank * 3 + 0..2])
+}
 int main() {
     const size_t bytes = 1ull << 30, n4 = bytes / 16, n_lines = bytes / 64, n_nodes = bytes / 384;
     float4* t; float* sink;
@@ -42,8 +60,15 @@ int main() {
         hipLaunchKernelGGL(stream_read, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, 0, t, n_stream, sink);
         hipLaunchKernelGGL(gather16, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, t, n_lines, n_g, sink);
         hipLaunchKernelGGL(gather_node, dim3((unsigned)((n_node + 255) / 256)), dim3(256), 0, 0, t, n_nodes, n_node, sink);
+        hipLaunchKernelGGL(stream_write, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, t, n_g);
+        hipLaunchKernelGGL(scatter_store<1>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
+        hipLaunchKernelGGL(scatter_store<4>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
+        hipLaunchKernelGGL(scatter_store<12>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
+        hipLaunchKernelGGL(scatter_store<24>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
         hipDeviceSynchronize();
     }
+    printf("write side, per launch: stream_write %zu bytes (coalesced); scatter_store<1|4|12|24> %zu threads, each 1 / 4 / 12 / 24 bytes into a 64-byte line of its own (useful bytes %zu / %zu / %zu / %zu)\n",
+           n_g * 16, n_g, n_g * 1, n_g * 4, n_g * 12, n_g * 24);
     printf("expected per launch: stream_read %zu bytes; gather16 %zu useful bytes in %zu distinct 64-byte lines (%zu bytes of lines); gather_node %zu useful bytes in %zu lines (%zu bytes of lines)\n",
            n_stream * 16, n_g * 16, n_g, n_g * 64, n_node * 48, n_node * 3, n_node * 3 * 64);
     return 0;
