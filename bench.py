@@ -624,7 +624,7 @@ def cpu_baseline_leg(args, hip_cfg_inputs, budget_s):
     warm = 2 if budget_s < 5 else 20
     ref_thr = (min(12, ncores), min(4, ncores))
     phys = max(1, ncores // 2) if ncores >= 16 else ncores
-    avail = len(raws) - 1                      # the stream is shared by the two variants
+    avail = len(raws) - kk0                    # the stream (what the map build left of it) is shared by the two variants
     n_all = min(24, max(4, avail // 8)) if ncores > 1 else 0
     v_ref = cpu_pass(ref_thr[0], ref_thr[1], budget_s * 0.75, min(warm, max(0, avail - n_all - 3)), min(avail - n_all, warm + 200))
     v_all = cpu_pass(phys, phys, budget_s * 0.25, 1, n_all) if ncores > 1 else v_ref

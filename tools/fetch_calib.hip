@@ -49,6 +49,14 @@ __global__ void scatter_store(unsigned char* __restrict__ t, size_t n_lines, siz
     else if (BYTES == 12) { int* q = (int*)p; q[0] = (int)i; q[1] = (int)i + 1; q[2] = (int)i + 2; }   // (three dword stores of one thread: out_tri[rank * 3 + 0..2])
     else if (BYTES == 24) { double* q = (double*)p; q[0] = (double)i; q[1] = 1.0; q[2] = 2.0; }         // (out_smooth_xyz[rank * 3 + 0..2])
 }
+// ---- which kernel is charged for a write-back?  small_dirty writes 2 MiB (coalesced: fits the 4 MB L2 of every XCD many times over, so the lines can stay
+// dirty in L2 when the kernel ends), noop_after touches nothing.  If WRITE_SIZE of noop_after is not zero, write-backs are charged to the kernel during
+// which they happen, not to the one that dirtied the lines.
+__global__ void small_dirty(float4* __restrict__ t, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = make_float4(4.f, 3.f, 2.f, (float)i);
+}
+__global__ void noop_after(float* __restrict__ sink) { if (threadIdx.x == 12345) sink[1] = 1.f; }
 int main() {
     const size_t bytes = 1ull << 30, n4 = bytes / 16, n_lines = bytes / 64, n_nodes = bytes / 384;
     float4* t; float* sink;
@@ -60,6 +68,8 @@ int main() {
         hipLaunchKernelGGL(stream_read, dim3((unsigned)((n_stream + 255) / 256)), dim3(256), 0, 0, t, n_stream, sink);
         hipLaunchKernelGGL(gather16, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, t, n_lines, n_g, sink);
         hipLaunchKernelGGL(gather_node, dim3((unsigned)((n_node + 255) / 256)), dim3(256), 0, 0, t, n_nodes, n_node, sink);
+        hipLaunchKernelGGL(small_dirty, dim3((unsigned)(((1u << 17) + 255) / 256)), dim3(256), 0, 0, t + (size_t)rep * (1u << 17), (size_t)(1u << 17));   // 2 MiB, a fresh region per repetition
+        hipLaunchKernelGGL(noop_after, dim3(1), dim3(64), 0, 0, sink);
         hipLaunchKernelGGL(stream_write, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, t, n_g);
         hipLaunchKernelGGL(scatter_store<1>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
         hipLaunchKernelGGL(scatter_store<4>, dim3((unsigned)((n_g + 255) / 256)), dim3(256), 0, 0, (unsigned char*)t, n_lines, n_g);
