@@ -1906,11 +1906,21 @@ IMD void lds_sort_recs(SortRec* a, int np2, int tid) {
 // binary searches per record); long lists (offline clouds) keep 1024 -- the merge is linear in the number of chunks.
 #define LS_CHUNK_SMALL 256
 #define LS_SMALL_LIST 4096
-IMD void lsort_locate(const LSortPlan& pl, int blk, const int* base, int& job, int& local) {
-    job = 0;
+// element `j` of a small plan array BY VALUE (a chain of selects over compile-time indices): `a[j]` with a run-time j sends the whole LSortPlan to scratch
+// memory -- 112 bytes per lane, written by EVERY lane of the launch: mesh_merge_emit_kernel's 6.2 MB and mesh_chunk_sort_kernel's 1.8 MB of WRITE_SIZE per
+// launch in traffic_r04.json (for ~0.1 MB of records) were exactly that, plus a scratch round trip on the mesher's longest chain (round 5)
+template <int N> IMD int pick(const int (&a)[N], int j) {
+    int v = a[0];
 #pragma unroll
-    for (int j = 1; j < LS_JOBS; j++) if (blk >= base[j]) job = j;
-    local = blk - base[job];
+    for (int k = 1; k < N; k++) { const int ak = a[k]; v = (j == k) ? ak : v; }   // (by value: `c ? a[k] : v` on lvalues selects ADDRESSES and pins the array to memory)
+    return v;
+}
+template <int N> IMD void lsort_locate(const int (&base)[N], int blk, int& job, int& local) {
+    job = 0;
+    int b = base[0];
+#pragma unroll
+    for (int j = 1; j < LS_JOBS; j++) { const int bj = base[j]; const bool ge = blk >= bj; job = ge ? j : job; b = ge ? bj : b; }
+    local = blk - b;
 }
 // which 0: the active-voxel list; which 1: the four result lists.  Lengths are read from the device counters, so the launch needs no host sync.
 IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
@@ -1937,9 +1947,10 @@ __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int 
     const int tid = threadIdx.x;
     for (int blk = blockIdx.x; blk < pl.blk_base[LS_JOBS]; blk += gridDim.x) {
         int job, chunk;
-        lsort_locate(pl, blk, pl.blk_base, job, chunk);
-        const int n = pl.n[job];
-        const int cs = pl.cs[job];
+        lsort_locate(pl.blk_base, blk, job, chunk);
+        const int n = pick(pl.n, job);
+        const int cs = pick(pl.cs, job);
+        const int rec_off = pick(pl.rec_off, job);
         const int first = chunk * cs, cnt = min(cs, n - first);
         const int32_t* list = job == 0 ? m.list_rem : (job == 1 ? m.list_add : (job == 2 ? m.list_upd : (job == 3 ? m.list_smooth : nullptr)));
         const int np2 = next_pow2_i(cnt);
@@ -1957,7 +1968,7 @@ __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int 
         }
         __syncthreads();
         lds_sort_recs<256>(recs, np2, tid);
-        for (int i = tid; i < cnt; i += 256) recs_out[(size_t)pl.rec_off[job] + first + i] = recs[i];
+        for (int i = tid; i < cnt; i += 256) recs_out[(size_t)rec_off + first + i] = recs[i];
         __syncthreads();
     }
 }
@@ -1973,13 +1984,13 @@ __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int 
     lsort_plan_dev(m, which, pl);
     for (int eblk = blockIdx.x; eblk < pl.eblk_base[LS_JOBS]; eblk += gridDim.x) {
     int job, lb;
-    lsort_locate(pl, eblk, pl.eblk_base, job, lb);
+    lsort_locate(pl.eblk_base, eblk, job, lb);
     const int i = lb * 256 + threadIdx.x;
-    const int n = pl.n[job];
+    const int n = pick(pl.n, job);
     if (i >= n) continue;
-    const SortRec* base = recs + (size_t)pl.rec_off[job];
+    const SortRec* base = recs + (size_t)pick(pl.rec_off, job);
     const SortRec r = base[i];
-    const int cs = pl.cs[job];
+    const int cs = pick(pl.cs, job);
     const int own = i / cs, nchunks = (n + cs - 1) / cs;
     int rank = i - own * cs;
     for (int c0 = 0; c0 < nchunks; c0 += 4) {  // four independent binary searches in flight
