@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; T=${1:-r03}; O=$R/gpurun_out/profiles_new; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 line() { grep '^{' | tail -1; }
 # (1) the default command, as the driver runs it
-if [ -z "$SKIP_FULL" ]; then timeout 500 python $R/bench.py --gpus 1 --steps 20 --warmup 5 2>$O/${T}_bench_full.err | line > $O/${T}_bench_full.json; fi
+if [ -z "$SKIP_FULL" ]; then timeout 900 python $R/bench.py --gpus 1 --steps 20 --warmup 5 2>$O/${T}_bench_full.err | line > $O/${T}_bench_full.json; fi
 # (2) rocprofv3 kernel stats of the default command (CPU leg and child runs skipped: they launch nothing of interest)
 rm -rf /tmp/rp_stats; timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_stats -- python $R/bench.py --cpu-seconds 0 --extra-configs 0 > /tmp/rp_stats.log 2>&1
 cp $(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1) $O/${T}_full_kernel_stats.csv
