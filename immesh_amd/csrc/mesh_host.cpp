@@ -188,6 +188,7 @@ void mesh_free(immesh_ctx* c) {
     if (h.stream) { (void)hipStreamSynchronize(h.stream); (void)hipStreamDestroy(h.stream); h.stream = nullptr; }
     if (h.stream_b) { (void)hipStreamSynchronize(h.stream_b); (void)hipStreamDestroy(h.stream_b); h.stream_b = nullptr; }
     if (h.stream_fetch) { (void)hipStreamSynchronize(h.stream_fetch); (void)hipStreamDestroy(h.stream_fetch); h.stream_fetch = nullptr; }
+    if (h.h_fetch) { (void)hipHostFree(h.h_fetch); h.h_fetch = nullptr; h.h_fetch_bytes = 0; }
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
@@ -814,15 +815,33 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
         HIPCHK(c, hipStreamSynchronize(s));
         return 0;
     }
-    if (new_vtx_xyz && z.n_new_vtx) HIPCHK(c, hipMemcpyAsync(new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12, hipMemcpyDeviceToHost, s));
-    if (tri_add && z.n_add) HIPCHK(c, hipMemcpyAsync(tri_add, o.tri_add, (size_t)z.n_add * 12, hipMemcpyDeviceToHost, s));
-    if (flip_add && z.n_add) HIPCHK(c, hipMemcpyAsync(flip_add, o.flip_add, (size_t)z.n_add, hipMemcpyDeviceToHost, s));
-    if (tri_rem && z.n_rem) HIPCHK(c, hipMemcpyAsync(tri_rem, o.tri_rem, (size_t)z.n_rem * 12, hipMemcpyDeviceToHost, s));
-    if (tri_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(tri_upd, o.tri_upd, (size_t)z.n_upd * 12, hipMemcpyDeviceToHost, s));
-    if (flip_upd && z.n_upd) HIPCHK(c, hipMemcpyAsync(flip_upd, o.flip_upd, (size_t)z.n_upd, hipMemcpyDeviceToHost, s));
-    if (smooth_ids && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_ids, o.smooth_ids, (size_t)z.n_smooth * 4, hipMemcpyDeviceToHost, s));
-    if (smooth_xyz && z.n_smooth) HIPCHK(c, hipMemcpyAsync(smooth_xyz, o.smooth_xyz, (size_t)z.n_smooth * 24, hipMemcpyDeviceToHost, s));
+    // Eight lists, each a few KB to a few hundred KB, into the caller's (pageable) buffers: a device-to-pageable copy is staged and waited for by the runtime one
+    // at a time (0.3-0.65 ms for the eight: the drop-in's service thread spent its frame on it).  They go to ONE pinned staging block instead -- eight DMA
+    // copies in flight together, one wait -- and from there by memcpy (round 5).
+    struct Part { void* dst; const void* src; size_t bytes; };
+    const Part parts[8] = {{new_vtx_xyz, m.v_pos + (size_t)z.vtx_base * 3, (size_t)z.n_new_vtx * 12}, {tri_add, o.tri_add, (size_t)z.n_add * 12}, {flip_add, o.flip_add, (size_t)z.n_add},
+                           {tri_rem, o.tri_rem, (size_t)z.n_rem * 12}, {tri_upd, o.tri_upd, (size_t)z.n_upd * 12}, {flip_upd, o.flip_upd, (size_t)z.n_upd},
+                           {smooth_ids, o.smooth_ids, (size_t)z.n_smooth * 4}, {smooth_xyz, o.smooth_xyz, (size_t)z.n_smooth * 24}};
+    size_t total = 0;
+    for (const Part& q : parts) if (q.dst && q.bytes) total += (q.bytes + 63) & ~(size_t)63;
+    if (total == 0) return 0;
+    {
+        std::lock_guard<std::mutex> lk(h.mu);   // (one fetch at a time uses the staging block: the service thread's)
+        if (total > h.h_fetch_bytes) {
+            if (h.h_fetch) (void)hipHostFree(h.h_fetch);
+            h.h_fetch = nullptr; h.h_fetch_bytes = 0;
+            const size_t want = total + total / 2 + (1 << 16);
+            if (hipHostMalloc((void**)&h.h_fetch, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc(fetch staging)"; return IMMESH_E_NOMEM; }
+            h.h_fetch_bytes = want;
+        }
+    }
+    size_t off = 0;
+    for (const Part& q : parts)
+        if (q.dst && q.bytes) { HIPCHK(c, hipMemcpyAsync(h.h_fetch + off, q.src, q.bytes, hipMemcpyDeviceToHost, s)); off += (q.bytes + 63) & ~(size_t)63; }
     HIPCHK(c, hipStreamSynchronize(s));
+    off = 0;
+    for (const Part& q : parts)
+        if (q.dst && q.bytes) { std::memcpy(q.dst, h.h_fetch + off, q.bytes); off += (q.bytes + 63) & ~(size_t)63; }
     return 0;
 }
 

@@ -163,6 +163,7 @@ struct MeshHost {
     // overwrite the result buffers of a job not yet collected (id - 2) waits -- nothing is dropped
     bool collect_on = false;
     long collected = 0;
+    char* h_fetch = nullptr; size_t h_fetch_bytes = 0;   // immesh_mesh_fetch: pinned staging (the lists land here by DMA, all copies in flight together, then one memcpy each into the caller's pageable buffers)
     hipStream_t stream_fetch = nullptr;      // immesh_mesh_fetch's copies: a stream of their own, so that a service thread can fetch while the scan thread enqueues
     bool stop = false;
     // per-scan parameters + graph replay
