@@ -218,8 +218,8 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     return None
 
 
-COMMITTED_STATS = "r04_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
-COMMITTED_TRAFFIC = "traffic_r04.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+COMMITTED_STATS = "r05_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
+COMMITTED_TRAFFIC = "traffic_r05.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
 
 
 def kernel_sources_sha():
@@ -710,14 +710,19 @@ def dry_run_leg(args, torch, hip, dev, local):
         h.counters(reset=True)
         torch.cuda.synchronize()
         tb = time.perf_counter()
+        marks = [tb]
         for _ in range(args.steps):
             prior = capi.forward_without_imu_native(hip, st)
             st, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
-        h.last_timing()
+            h.last_timing()                 # (serial per scan in this leg: the scan's map update has finished)
+            marks.append(time.perf_counter())
         torch.cuda.synchronize()
         el = time.perf_counter() - tb
         cnt = h.counters()
-        per_rank.append({"rank": r, "ms_per_scan": round(1e3 * el / args.steps, 4), "root_voxels_kept": int(n_map), "device_bytes_allocated": int(h.device_bytes()), "map_build_seconds": round(t_map, 1),
+        per = np.diff(marks) * 1e3
+        # the median scan, not the mean: a rank's ten scans follow the allocation of its 90 GB context, and one stalled call (a 6 ms hiccup seen on one rank
+        # of one run) would otherwise decide which rank "the job waits for"
+        per_rank.append({"rank": r, "ms_per_scan": round(float(np.median(per)), 4), "ms_per_scan_mean": round(1e3 * el / args.steps, 4), "ms_per_scan_max": round(float(per.max()), 4), "root_voxels_kept": int(n_map), "device_bytes_allocated": int(h.device_bytes()), "map_build_seconds": round(t_map, 1),
                          "matches_per_scan": round(cnt["n_match"] / max(1, cnt["n_iter"]), 1), "new_vertices_per_scan": round(cnt["n_new"] / args.steps, 1),
                          "pose_err_m": float(np.linalg.norm(st[9:12] - synth.trajectory_pose(k - 1)[1]))})
         log(f"[bench] dry run, rank {r} of {W}: {per_rank[-1]}")
