@@ -6,10 +6,44 @@ exports the identical entry points.  Nothing here computes anything.
 """
 import ctypes as C
 import os
+import sys
 import numpy as np
 
 STATE_DOUBLES = 348
 _HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def one_hip_runtime():
+    """ONE HIP / HSA runtime in a test or bench process, and it is the one the product library is linked against (/opt/rocm).
+
+    The torch wheel bundles its own copies of libamdhip64 / libhsa-runtime64 and its libraries ask for them by the bare file names
+    ``libamdhip64.so`` / ``libhsa-runtime64.so``.  The loader reuses an object that is already mapped under the name asked for, so mapping the
+    system copies under exactly those names BEFORE torch is imported makes torch run on them too (measured on an MI355X box: device ops, a GEMM,
+    a world-1 RCCL all-reduce -- tools/r05_one_runtime.py).  In the reference's process there is no torch and therefore one runtime; the harness
+    now has the same shape.  When torch was imported first, its copy already is the process's runtime and the library binds to it by soname
+    (still one runtime, but torch's): nothing to do then.  Returns the runtime files mapped."""
+    if "torch" not in sys.modules:
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            try:
+                C.CDLL(name, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass                      # no ROCm in the loader's cache (a CPU-only box): the library load below fails loudly on its own
+    return mapped_hip_runtimes()
+
+
+def mapped_hip_runtimes():
+    out = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln or "libhsa-runtime64" in ln:
+                    out.add(ln.split()[-1])
+    except OSError:
+        pass
+    return sorted(out)
+
+
+one_hip_runtime()
 
 
 class Config(C.Structure):

@@ -96,16 +96,12 @@ def make_hip(hip_lib, cfg):
 
 
 def fetch_device(ptr, shape, dtype=np.float32):
-    """Copy a device buffer the HIP library handed out (e.g. immesh_downsample_end) into a host array, with the HIP runtime THE LIBRARY is linked
-    against (libamdhip64.so.7 of /opt/rocm -- torch bundles a second copy of the runtime, which does not know the library's allocations)."""
+    """Copy a device buffer the HIP library handed out (e.g. immesh_downsample_end) into a host array.  The process holds ONE HIP runtime
+    (capi.one_hip_runtime: the system copy the library is linked against, mapped before torch), so the soname resolves to it."""
     import ctypes
-    rt = None
-    with open("/proc/self/maps") as f:
-        for ln in f:
-            if "libamdhip64.so" in ln and "/torch/" not in ln:
-                rt = ctypes.CDLL(ln.split()[-1]); break
-    if rt is None:
-        rt = ctypes.CDLL("libamdhip64.so.7")
+    rts = [r for r in capi.mapped_hip_runtimes() if "libamdhip64" in r]
+    assert len(rts) == 1, f"expected one HIP runtime in the process, found {rts}"
+    rt = ctypes.CDLL(rts[0])
     rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     rt.hipMemcpy.restype = ctypes.c_int
     out = np.zeros(shape, dtype)

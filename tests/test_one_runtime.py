@@ -1,0 +1,67 @@
+"""ONE HIP / HSA runtime in a test or bench process: the system copy the product library is linked against, with torch as
+its guest -- not the copies the torch wheel bundles, and never both.  Loading libraries needs no GPU, so this runs in the CPU tier; the device
+side of the claim (torch ops, a GEMM and an RCCL all-reduce on the system runtime) is tools/r05_one_runtime.py and the GPU test below."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_PROBE = r"""
+import sys
+sys.path.insert(0, {root!r})
+{first}
+{second}
+from immesh_amd import capi
+lib = capi.load_hip_library()
+import torch
+rts = capi.mapped_hip_runtimes()
+print("RUNTIMES", "|".join(rts))
+"""
+
+
+def _probe(first, second=""):
+    out = subprocess.run([sys.executable, "-c", _PROBE.format(root=ROOT, first=first, second=second)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("RUNTIMES")][-1]
+    return [r for r in line.split(" ", 1)[1].split("|") if r]
+
+
+def _need_lib():
+    from immesh_amd import capi
+    if not os.path.exists(capi.hip_library_path()):
+        pytest.skip("libimmesh_hip.so not built")
+
+
+def test_binding_first_means_the_system_runtime_for_everyone():
+    """bench.py's order (the binding, then torch): exactly one libamdhip64 and one libhsa-runtime64, neither from the torch wheel."""
+    _need_lib()
+    rts = _probe("from immesh_amd import capi")
+    hip = [r for r in rts if "libamdhip64" in r]
+    hsa = [r for r in rts if "libhsa-runtime64" in r]
+    assert len(hip) == 1 and len(hsa) == 1, rts
+    assert "/torch/" not in hip[0] and "/torch/" not in hsa[0], rts
+
+
+def test_torch_first_is_still_one_runtime():
+    """A process that imported torch before the binding keeps torch's copy, and the library binds to it by soname: one runtime, never two."""
+    _need_lib()
+    rts = _probe("import torch")
+    assert len([r for r in rts if "libamdhip64" in r]) == 1, rts
+    assert len([r for r in rts if "libhsa-runtime64" in r]) == 1, rts
+
+
+@pytest.mark.gpu
+def test_this_process_runs_on_one_runtime(hip_lib):
+    """The GPU tier itself: conftest imports the binding before torch, so by now torch has initialised the device on the system runtime."""
+    import torch
+    from immesh_amd import capi
+    assert torch.cuda.is_available()
+    x = torch.arange(1 << 16, device="cuda", dtype=torch.float64)
+    assert float(x.sum()) == (1 << 16) * ((1 << 16) - 1) / 2
+    rts = capi.mapped_hip_runtimes()
+    hip = [r for r in rts if "libamdhip64" in r]
+    assert len(hip) == 1 and "/torch/" not in hip[0], rts
+    assert len([r for r in rts if "libhsa-runtime64" in r]) == 1, rts
