@@ -14,20 +14,33 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def one_hip_runtime():
-    """ONE HIP / HSA runtime in a test or bench process, and it is the one the product library is linked against (/opt/rocm).
+    """ONE HIP / HSA runtime in a test or bench process.
 
     The torch wheel bundles its own copies of libamdhip64 / libhsa-runtime64 and its libraries ask for them by the bare file names
-    ``libamdhip64.so`` / ``libhsa-runtime64.so``.  The loader reuses an object that is already mapped under the name asked for, so mapping the
-    system copies under exactly those names BEFORE torch is imported makes torch run on them too (measured on an MI355X box: device ops, a GEMM,
-    a world-1 RCCL all-reduce -- tools/r05_one_runtime.py).  In the reference's process there is no torch and therefore one runtime; the harness
-    now has the same shape.  When torch was imported first, its copy already is the process's runtime and the library binds to it by soname
-    (still one runtime, but torch's): nothing to do then.  Returns the runtime files mapped."""
+    ``libamdhip64.so`` / ``libhsa-runtime64.so``; the product library is linked against the system copies (/opt/rocm) by soname.  The loader reuses
+    an object that is already mapped under the name asked for, so WHO IS MAPPED FIRST decides, and this function fixes it:
+
+    * single-GPU processes (the GPU test tier, smoke, ``bench.py --gpus 1``): the SYSTEM copies are mapped under exactly the names torch asks for
+      BEFORE torch is imported, so torch runs on them too -- one runtime, and it is the one the reference's process would have (there is no torch
+      there), with torch as the guest (measured on an MI355X box: device ops, a GEMM, a world-1 RCCL all-reduce -- tools/r05_one_runtime.py);
+    * ranks of a multi-GPU job (WORLD_SIZE > 1): torch -- whose bundle of runtime + RCCL is the combination that is exercised together everywhere
+      -- is imported first, and the library binds to ITS copy by soname: still one runtime, no mix of an RCCL built for one runtime on another
+      where it cannot be tried beforehand (this container has no multi-GPU box);
+    * torch already imported by the caller: its copy is the process's runtime; nothing to do.
+
+    Returns the runtime files mapped."""
     if "torch" not in sys.modules:
-        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("IMMESH_SYSTEM_RUNTIME", "") != "1":
             try:
-                C.CDLL(name, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass                      # no ROCm in the loader's cache (a CPU-only box): the library load below fails loudly on its own
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        else:
+            for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+                try:
+                    C.CDLL(name, mode=C.RTLD_GLOBAL)
+                except OSError:
+                    pass                  # no ROCm in the loader's cache (a CPU-only box): the library load below fails loudly on its own
     return mapped_hip_runtimes()
 
 

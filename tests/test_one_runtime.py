@@ -22,8 +22,10 @@ print("RUNTIMES", "|".join(rts))
 """
 
 
-def _probe(first, second=""):
-    out = subprocess.run([sys.executable, "-c", _PROBE.format(root=ROOT, first=first, second=second)], capture_output=True, text=True, timeout=300)
+def _probe(first, second="", env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    e.update(env or {})
+    out = subprocess.run([sys.executable, "-c", _PROBE.format(root=ROOT, first=first, second=second)], capture_output=True, text=True, timeout=300, env=e)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("RUNTIMES")][-1]
     return [r for r in line.split(" ", 1)[1].split("|") if r]
@@ -51,6 +53,16 @@ def test_torch_first_is_still_one_runtime():
     rts = _probe("import torch")
     assert len([r for r in rts if "libamdhip64" in r]) == 1, rts
     assert len([r for r in rts if "libhsa-runtime64" in r]) == 1, rts
+
+
+def test_a_rank_of_a_multi_gpu_job_runs_on_torchs_bundle():
+    """WORLD_SIZE > 1: torch's runtime + RCCL bundle serves the rank and the library binds to it (capi.one_hip_runtime) -- one runtime there too."""
+    _need_lib()
+    rts = _probe("from immesh_amd import capi", env={"WORLD_SIZE": "8"})
+    hip = [r for r in rts if "libamdhip64" in r]
+    hsa = [r for r in rts if "libhsa-runtime64" in r]
+    assert len(hip) == 1 and len(hsa) == 1, rts
+    assert "/torch/" in hip[0] and "/torch/" in hsa[0], rts
 
 
 @pytest.mark.gpu
