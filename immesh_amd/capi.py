@@ -13,6 +13,9 @@ STATE_DOUBLES = 348
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+RUNTIME_CHOICE = None
+
+
 def one_hip_runtime():
     """ONE HIP / HSA runtime in a test or bench process.
 
@@ -29,13 +32,18 @@ def one_hip_runtime():
     * torch already imported by the caller: its copy is the process's runtime; nothing to do.
 
     Returns the runtime files mapped."""
-    if "torch" not in sys.modules:
+    global RUNTIME_CHOICE
+    if "torch" in sys.modules:
+        RUNTIME_CHOICE = "torch (imported before the binding)"
+    else:
         if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("IMMESH_SYSTEM_RUNTIME", "") != "1":
+            RUNTIME_CHOICE = "torch (rank of a multi-GPU job)"
             try:
                 import torch  # noqa: F401
             except ImportError:
                 pass
         else:
+            RUNTIME_CHOICE = "system"
             for name in ("libhsa-runtime64.so", "libamdhip64.so"):
                 try:
                     C.CDLL(name, mode=C.RTLD_GLOBAL)

@@ -100,8 +100,9 @@ def fetch_device(ptr, shape, dtype=np.float32):
     (capi.one_hip_runtime: the system copy the library is linked against, mapped before torch), so the soname resolves to it."""
     import ctypes
     rts = [r for r in capi.mapped_hip_runtimes() if "libamdhip64" in r]
-    assert len(rts) == 1, f"expected one HIP runtime in the process, found {rts}"
-    rt = ctypes.CDLL(rts[0])
+    assert rts, "no HIP runtime mapped"
+    # (tests/test_one_runtime.py is where "exactly one" is asserted; should a harness ever map a second one, the library's is the system copy)
+    rt = ctypes.CDLL(([r for r in rts if "/torch/" not in r] or rts)[0])
     rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     rt.hipMemcpy.restype = ctypes.c_int
     out = np.zeros(shape, dtype)

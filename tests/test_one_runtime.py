@@ -75,5 +75,7 @@ def test_this_process_runs_on_one_runtime(hip_lib):
     assert float(x.sum()) == (1 << 16) * ((1 << 16) - 1) / 2
     rts = capi.mapped_hip_runtimes()
     hip = [r for r in rts if "libamdhip64" in r]
-    assert len(hip) == 1 and "/torch/" not in hip[0], rts
+    assert len(hip) == 1, rts
     assert len([r for r in rts if "libhsa-runtime64" in r]) == 1, rts
+    # which one: the system copy unless something imported torch before the binding (then torch's own -- still one)
+    assert ("/torch/" not in hip[0]) == (capi.RUNTIME_CHOICE == "system"), (capi.RUNTIME_CHOICE, rts)
