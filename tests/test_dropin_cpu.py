@@ -34,3 +34,8 @@ def test_async_shim_with_the_reference_triangle_manager_against_the_oracle_build
     """the same shim with THE REFERENCE'S OWN Triangle_manager as the host mirror (drop_in/Makefile `refmirror`: triangle.hpp / triangle.cpp /
     tools_kd_hash.hpp compiled from where they lie), linked against the oracle: the real manager's live set and flips per frame equal the direct calls'"""
     run_drop_in_async(lambda cfg: make_oracle(oracle_lib, cfg), "_ref/libimmesh_dropin_async_refmirror_oracle.so", lockstep=True)
+
+
+def test_async_shim_without_a_mirror_thread_against_the_oracle_build(oracle_lib):
+    """queue depth 0: the service thread applies the lists itself (no mirror thread) -- the same frames, the same mirror states"""
+    run_drop_in_async(lambda cfg: make_oracle(oracle_lib, cfg), "libimmesh_dropin_async_oracle.so", lockstep=True, queue_depth=0)

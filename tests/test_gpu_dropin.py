@@ -155,12 +155,16 @@ def _apply(live, m):
             live[tri] = fl
 
 
-def run_drop_in_async(make_direct, libname, lockstep, shadow=None):
+def run_drop_in_async(make_direct, libname, lockstep, shadow=None, queue_depth=None):
     """Scans through the asynchronous shim (scan thread = this thread, service thread inside the driver) vs the SAME C-ABI calls issued directly:
     immesh_process_scan(IMMESH_MESH_ASYNC) + immesh_mesh_wait + immesh_mesh_fetch.  States, m_effct_feat_num and, per frame, the Global_map size and the
     live set of the Triangle_manager mirror (order-independent hash over (triplet, m_index_flip)) must be equal bit for bit."""
     import ctypes as C
     lib = _dropin_lib(libname)
+    depth = C.c_int.in_dll(lib, "g_immesh_mirror_queue_depth")   # frames between the service thread and the mirror thread (read when the service starts)
+    depth_default = depth.value
+    if queue_depth is not None:
+        depth.value = queue_depth
     cfg = capi.avia_config()
     extT = np.array(list(cfg.extT))
     n_scans = 7
@@ -195,6 +199,7 @@ def run_drop_in_async(make_direct, libname, lockstep, shadow=None):
         n_eff = lib.dropin_effect_features(d, ep.ctypes.data_as(C.c_void_p), en.ctypes.data_as(C.c_void_p), n_last)
     finally:
         lib.dropin_destroy(d, 1)
+        depth.value = depth_default
     h = make_direct(cfg)
     live, slive = {}, {}
     h.map_build(np.ascontiguousarray(scans[0][0][:, :3]), scans[0][2])
@@ -227,6 +232,14 @@ def test_async_drop_in_with_the_reference_triangle_manager_as_the_mirror(oracle_
     drop_in/Makefile `refmirror`): per frame the real manager's live set -- walked through its region buckets, m_triangle_set_vector -- and its flips hash
     to the direct calls' and the shadow oracle's.  This is the mirror bench.py's drop-in leg pays for."""
     run_drop_in_async(lambda cfg: make_hip(hip_lib, cfg), "_ref/libimmesh_dropin_async_refmirror.so", lockstep=False, shadow=make_oracle(oracle_lib, capi.avia_config()))
+
+
+@pytest.mark.parametrize("queue_depth", [1, 0])
+def test_async_drop_in_with_a_full_mirror_queue_and_without_a_mirror_thread(hip_lib, queue_depth):
+    """The host queue between the service thread and the mirror thread one frame deep (the service thread blocks on a full queue -- the scan thread is
+    not in lock-step here, so it does fill) and depth 0 (no mirror thread: the service thread applies the lists itself, round 4's arrangement): nothing
+    is dropped or reordered, every frame's mirror state equals the direct calls'."""
+    run_drop_in_async(lambda cfg: make_hip(hip_lib, cfg), "libimmesh_dropin_async.so", lockstep=False, queue_depth=queue_depth)
 
 
 def test_async_drop_in_stream_runner(hip_lib):
