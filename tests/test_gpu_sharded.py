@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _cfg(rank=0, world=0):
+def _cfg(rank=0, world=0, scheme=0):
     return capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 16, cap_triangles=1 << 18,
-                            shard_rank=rank, shard_world=world, shard_brick_log2=3)   # 8-voxel (4 m) bricks: many bricks in a 100 m scene
+                            shard_rank=rank, shard_world=world, shard_brick_log2=3, shard_scheme=scheme)   # 8-voxel (4 m) bricks: many bricks in a 100 m scene
 
 
 def _scans(n, npts=30000):
@@ -34,11 +34,12 @@ def _scans(n, npts=30000):
     return out
 
 
-def test_partial_sums_and_plane_tables_tile(hip_lib):
+@pytest.mark.parametrize("scheme", [0, 1])   # brick ownership: lattice colouring (the default) / hash of the brick (rounds 1-4), immesh_config::shard_scheme
+def test_partial_sums_and_plane_tables_tile(hip_lib, scheme):
     P = 2
     scans = _scans(3)
     ref = make_hip(hip_lib, _cfg())
-    shards = [make_hip(hip_lib, _cfg(r, P)) for r in range(P)]
+    shards = [make_hip(hip_lib, _cfg(r, P, scheme)) for r in range(P)]
     R0, t0, raw0, _ = scans[0]
     st0 = capi.make_state(R=R0, t=t0)
     p0 = np.ascontiguousarray(raw0[:, :3])
@@ -60,7 +61,7 @@ def test_partial_sums_and_plane_tables_tile(hip_lib):
     owned = []
     for r, h in enumerate(shards):
         d = h.dump_planes()
-        mine = np.array([capi.shard_owner(hip_lib, _cfg(r, P), k) == r for k in d["key"]])
+        mine = np.array([capi.shard_owner(hip_lib, _cfg(r, P, scheme), k) == r for k in d["key"]])
         assert mine.sum() > 100 and (~mine).sum() > 0                # has a halo
         owned.append(d[mine])
     tiled = np.concatenate(owned)
