@@ -61,6 +61,18 @@ static void fail(immesh_ctx* c, const char* what, int rc) {
     if (rc == IMMESH_E_HIP || rc == IMMESH_E_NODEV || !c) std::exit(1);
 }
 
+// ---- the lists of one frame, fetched, on their way to the host mirrors -------------------------------------------------------------------------
+struct MirrorJob {
+    int frame_idx = 0;
+    immesh_mesh_sizes_t z;
+    std::vector<float> vtx; std::vector<int32_t> add, rem, upd, sid; std::vector<uint8_t> fadd, fupd; std::vector<double> sxyz;
+};
+int g_immesh_mirror_queue_depth = 256;          // frames between the service thread and the mirror thread; 0 = apply on the service thread
+static std::mutex g_mirror_mu;
+static std::condition_variable g_mirror_cv;
+static std::deque<MirrorJob> g_mirror_queue;
+static bool g_mirror_producer_done = false;     // (under g_mirror_mu) the service thread has left its loop: nothing more will be pushed
+
 // ---- end of Voxel_mapping::init_ros_node() (src/voxel_mapping.cpp:1654), after read_ros_parameters() ----------------------------------
 void Voxel_mapping::immesh_shim_init() {
     if (!m_hip) {   // (a test harness may hand over a context that already holds a map: immesh_shim_adopt)
@@ -80,6 +92,7 @@ void Voxel_mapping::immesh_shim_init() {
         if (!m_hip) fail(nullptr, "immesh_create", IMMESH_E_NODEV);   // no CPU fallback
     }
     g_immesh_ctx = m_hip;
+    { std::lock_guard<std::mutex> lk(g_mirror_mu); g_mirror_queue.clear(); g_mirror_producer_done = false; }   // (statics: a second driver in one process starts from an empty queue)
     const int rc = immesh_mesh_collect_enable(m_hip, 1);
     if (rc) fail(m_hip, "immesh_mesh_collect_enable", rc);
 }
@@ -145,16 +158,6 @@ void Voxel_mapping::map_incremental_grow() {
     g_frame_idx++;
 }
 
-// ---- the lists of one frame, fetched, on their way to the host mirrors -------------------------------------------------------------------------
-struct MirrorJob {
-    int frame_idx = 0;
-    immesh_mesh_sizes_t z;
-    std::vector<float> vtx; std::vector<int32_t> add, rem, upd, sid; std::vector<uint8_t> fadd, fupd; std::vector<double> sxyz;
-};
-int g_immesh_mirror_queue_depth = 256;          // frames between the service thread and the mirror thread; 0 = apply on the service thread
-static std::mutex g_mirror_mu;
-static std::condition_variable g_mirror_cv;
-static std::deque<MirrorJob> g_mirror_queue;
 // Global_map::m_rgb_pts_vec (index == vertex id, pointcloud_rgbd.cpp:518-527) and the Triangle_manager: all removes, then all adds (ImMesh_mesh_reconstruction.cpp:228-244)
 static void apply_to_mirrors(const MirrorJob& j) {
     const long long t_c = now_ns();
@@ -175,10 +178,13 @@ static void apply_to_mirrors(const MirrorJob& j) {
     if (g_immesh_after_frame) g_immesh_after_frame(j.frame_idx);
     g_immesh_frames_meshed.fetch_add(1);
 }
-static void service_apply_mirrors() {   // the mirror thread: frames in order, until the service thread stops and the queue is empty
+// The mirror thread: frames in order, until the service thread HAS LEFT ITS LOOP and the queue is empty.  The exit condition is the producer's own
+// flag, set under the queue's mutex behind its last push -- not g_immesh_service_stop, which is raised while the service thread may still be fetching
+// a frame it pushes afterwards (that frame was lost and stayed in the static queue for the next driver).
+static void service_apply_mirrors() {
     for (;;) {
         std::unique_lock<std::mutex> lk(g_mirror_mu);
-        g_mirror_cv.wait(lk, [] { return !g_mirror_queue.empty() || g_immesh_service_stop.load(); });
+        g_mirror_cv.wait(lk, [] { return !g_mirror_queue.empty() || g_mirror_producer_done; });
         if (g_mirror_queue.empty()) return;
         MirrorJob j = std::move(g_mirror_queue.front());
         g_mirror_queue.pop_front();
@@ -226,7 +232,10 @@ void incremental_mesh_reconstruction(pcl::PointCloud<pcl::PointXYZI>::Ptr frame_
 // device, so the service thread itself collects the results, in order.
 void service_reconstruct_mesh() {
     std::thread mirror;
-    if (g_immesh_mirror_queue_depth > 0) mirror = std::thread(service_apply_mirrors);
+    if (g_immesh_mirror_queue_depth > 0) {
+        { std::lock_guard<std::mutex> lk(g_mirror_mu); g_mirror_producer_done = false; }
+        mirror = std::thread(service_apply_mirrors);
+    }
     while (!g_immesh_service_stop.load()) {
         g_mutex_data_package_lock.lock();
         if (g_rec_mesh_data_package_list.empty()) {
@@ -239,6 +248,7 @@ void service_reconstruct_mesh() {
         g_mutex_data_package_lock.unlock();
         incremental_mesh_reconstruction(pk.m_frame_pts, pk.m_pose_q, pk.m_pose_t, pk.m_frame_idx);
     }
+    { std::lock_guard<std::mutex> lk(g_mirror_mu); g_mirror_producer_done = true; }   // (under the mutex: the wake-up cannot fall between the mirror thread's test and its wait)
     g_mirror_cv.notify_all();
     if (mirror.joinable()) mirror.join();
 }

@@ -198,7 +198,8 @@ def shard_owner(lib, cfg, key3):
 
 
 def hip_library_path():
-    return os.path.join(_HERE, "csrc", "libimmesh_hip.so")
+    # IMMESH_HIP_LIBRARY: an A/B measurement against a library built from another commit (tools/r06_ab.sh); never set by tests or the default bench
+    return os.environ.get("IMMESH_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libimmesh_hip.so")
 
 
 def load_hip_library():

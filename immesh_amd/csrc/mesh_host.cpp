@@ -165,6 +165,7 @@ int mesh_alloc(immesh_ctx* c) {
             HIPCHK(c, hipStreamCreateWithPriority(&h.stream_b, hipStreamNonBlocking, prio_least));
         }
         HIPCHK(c, hipStreamCreateWithPriority(&h.stream_fetch, hipStreamNonBlocking, prio_least));
+        h.stream_q = h.stream_fetch;   // (no HSA queue of its own: an extra queue in the process costs every stream -- immesh_create; queries and fetches are both rare and short)
     }
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
@@ -189,6 +190,10 @@ void mesh_free(immesh_ctx* c) {
     if (h.stream_b) { (void)hipStreamSynchronize(h.stream_b); (void)hipStreamDestroy(h.stream_b); h.stream_b = nullptr; }
     if (h.stream_fetch) { (void)hipStreamSynchronize(h.stream_fetch); (void)hipStreamDestroy(h.stream_fetch); h.stream_fetch = nullptr; }
     if (h.h_fetch) { (void)hipHostFree(h.h_fetch); h.h_fetch = nullptr; h.h_fetch_bytes = 0; }
+    h.stream_q = nullptr;
+    if (h.q_host) { (void)hipHostFree(h.q_host); h.q_host = nullptr; h.q_host_bytes = 0; }
+    if (h.q_dev) { (void)hipFree(h.q_dev); h.q_dev = nullptr; h.q_dev_bytes = 0; }
+    if (h.q_exp) { (void)hipFree(h.q_exp); h.q_exp = nullptr; h.q_exp_bytes = 0; }
     if (h.exp_vtx) (void)hipFree(h.exp_vtx);
     if (h.exp_work) (void)hipFree(h.exp_work);
     if (h.exp_tmp) (void)hipFree(h.exp_tmp);
@@ -519,7 +524,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             std::memset(&f.r.sizes, 0, sizeof(f.r.sizes));
             h.err.clear();
             bool synced = false;
-            f.r.rc = mesh_scan_launch(c, job, synced);
+            { std::lock_guard<std::mutex> lq(h.launch_mu); f.r.rc = mesh_scan_launch(c, job, synced); }   // (a smooth_pts query runs between two jobs, never beside one)
             f.seq = h.seq; f.polls = 0;
             f.by_ticket = c->mesh.shard_world <= 1;   // (the sharded mesher runs on one stream and keeps its event)
             if (f.r.rc) f.r.err = h.err; else f.launched_ok = true;
@@ -854,6 +859,81 @@ static int grow(immesh_ctx* c, void** p, size_t* have, size_t need) {
     if (e != hipSuccess) { c->err = std::string("hipMalloc(export): ") + hipGetErrorString(e); return IMMESH_E_NOMEM; }
     *have = need;
     return 0;
+}
+
+// Global_map::smooth_pts (pointcloud_rgbd.cpp:932-958) for a batch of vertex ids, and the vertex positions the renderer puts into its GL buffer
+// (unparse_triangle_set_to_vector, mesh_rec_display.cpp:78-103: get_pos(1) after smoothing what is still unsmoothed).  Both may be called from a thread of
+// their own while scans are being meshed: the query holds launch_mu from "both mesher streams idle" until its results are on the host, so it reads the map
+// between two jobs.  The map is not modified (the reference's smooth_pts also stores its result in the point: the host mirror's business).
+static int mesh_query_smooth(immesh_ctx* c, const int32_t* ids, int32_t n, double smooth_factor, int32_t knn, double max_dis, int display, double* out_d, float* out_f) {
+    if (!c || n < 0 || (n > 0 && (!ids || (!out_d && !out_f)))) { if (c) c->err = "bad arguments"; return IMMESH_E_INVAL; }
+    if (knn != MV_KNN) { c->err = "smooth_pts: only knn = 20 (the reference's g_ply_smooth_k) is supported"; return IMMESH_E_INVAL; }
+    MeshHost& h = c->mesh_host;
+    const MeshDev& m = c->mesh;
+    if (max_dis <= 0) max_dis = m.voxel * 0.8;   // (pointcloud_rgbd.cpp:940-943)
+    if (max_dis > m.accept * 2.0) { c->err = "smooth_pts: maximum_smooth_dis above 2.5 x the mesh voxel (the search radius of the device's 20-NN pull)"; return IMMESH_E_INVAL; }
+    if (n == 0) return 0;
+    (void)hipSetDevice(c->cfg.device);
+    std::lock_guard<std::mutex> lq(h.launch_mu);
+    MHIPCHK(c, hipStreamSynchronize(h.stream));
+    MHIPCHK(c, hipStreamSynchronize(h.stream_b));
+    hipStream_t s = h.stream_q;
+    // device: ids | voxel of each id | voxel list;  host (pinned): the same + the results
+    const size_t bytes_dev = (size_t)n * 12 + (size_t)n * 24 + 64, bytes_host = bytes_dev;
+    if (h.q_dev_bytes < bytes_dev) {
+        if (h.q_dev) (void)hipFree(h.q_dev);
+        h.q_dev = nullptr; h.q_dev_bytes = 0;
+        if (hipMalloc(&h.q_dev, bytes_dev * 2) != hipSuccess) { c->err = "hipMalloc(smooth_pts)"; return IMMESH_E_NOMEM; }
+        h.q_dev_bytes = bytes_dev * 2;
+    }
+    if (h.q_host_bytes < bytes_host) {
+        if (h.q_host) (void)hipHostFree(h.q_host);
+        h.q_host = nullptr; h.q_host_bytes = 0;
+        if (hipHostMalloc((void**)&h.q_host, bytes_host * 2, hipHostMallocDefault) != hipSuccess) { c->err = "hipHostMalloc(smooth_pts)"; return IMMESH_E_NOMEM; }
+        h.q_host_bytes = bytes_host * 2;
+    }
+    int32_t pc[PC_COUNT];
+    MHIPCHK(c, hipMemcpyAsync(pc, m.pc, sizeof(pc), hipMemcpyDeviceToHost, s));
+    int32_t* d_ids = (int32_t*)h.q_dev; int32_t* d_vox = d_ids + n; int32_t* d_list = d_vox + n;
+    double* d_out = (double*)(((uintptr_t)(d_list + n) + 15) & ~(uintptr_t)15);
+    int32_t* h_ids = (int32_t*)h.q_host; int32_t* h_vox = h_ids + n; int32_t* h_list = h_vox + n;
+    double* h_out = (double*)(((uintptr_t)(h_list + n) + 15) & ~(uintptr_t)15);
+    std::memcpy(h_ids, ids, (size_t)n * 4);
+    MHIPCHK(c, hipMemcpyAsync(d_ids, h_ids, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    MHIPCHK(c, hipStreamSynchronize(s));
+    const int nv = pc[PC_VERTS];
+    launch_mesh_query_voxels(s, m, d_ids, n, nv, display, d_vox);
+    MHIPCHK(c, hipMemcpyAsync(h_vox, d_vox, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipStreamSynchronize(s));
+    int n_list = 0;
+    for (int i = 0; i < n; i++) {
+        if (h_vox[i] == -1) { c->err = "smooth_pts: vertex id out of range"; return IMMESH_E_INVAL; }
+        if (h_vox[i] >= 0) h_list[n_list++] = h_vox[i];
+    }
+    std::sort(h_list, h_list + n_list);
+    n_list = (int)(std::unique(h_list, h_list + n_list) - h_list);
+    if (n_list > 0) {
+        const size_t need = (size_t)std::max(nv, 1) * 24;
+        if (h.q_exp_bytes < need) {
+            if (h.q_exp) (void)hipFree(h.q_exp);
+            h.q_exp = nullptr; h.q_exp_bytes = 0;
+            if (hipMalloc(&h.q_exp, need + need / 4) != hipSuccess) { c->err = "hipMalloc(smooth_pts)"; return IMMESH_E_NOMEM; }
+            h.q_exp_bytes = need + need / 4;
+        }
+        MHIPCHK(c, hipMemcpyAsync(d_list, h_list, (size_t)n_list * 4, hipMemcpyHostToDevice, s));
+        launch_mesh_query_smooth(s, m, d_list, n_list, smooth_factor, max_dis, (double*)h.q_exp);
+    }
+    launch_mesh_query_gather(s, m, d_ids, d_vox, n, (const double*)h.q_exp, display, d_out, (float*)d_out);
+    MHIPCHK(c, hipMemcpyAsync(h_out, d_out, (size_t)n * (display ? 12 : 24), hipMemcpyDeviceToHost, s));
+    MHIPCHK(c, hipStreamSynchronize(s));
+    if (display) std::memcpy(out_f, h_out, (size_t)n * 12); else std::memcpy(out_d, h_out, (size_t)n * 24);
+    return 0;
+}
+int immesh_smooth_pts(immesh_ctx* c, const int32_t* ids, int32_t n, double smooth_factor, int32_t knn, double maximum_smooth_dis, double* out_xyz) {
+    return mesh_query_smooth(c, ids, n, smooth_factor, knn, maximum_smooth_dis, 0, out_xyz, nullptr);
+}
+int immesh_mesh_display_vertices(immesh_ctx* c, const int32_t* ids, int32_t n, double smooth_factor, int32_t knn, double maximum_smooth_dis, float* out_xyz) {
+    return mesh_query_smooth(c, ids, n, smooth_factor, knn, maximum_smooth_dis, 1, nullptr, out_xyz);
 }
 
 int immesh_mesh_export(immesh_ctx* c, double smooth_factor, int32_t knn, int64_t* n_vtx_out, int64_t* n_faces_out) {

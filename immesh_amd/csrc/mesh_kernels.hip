@@ -856,8 +856,11 @@ IMD double wave_max_d(double x) {
 // (mesh_rec_geometry.cpp:71-131, pointcloud_rgbd.cpp:932-958): the same 20-NN machinery run over all mesh voxels, output = the exported
 // vertex position pt*(1-f) + mean(neighbours 1..19 closer than accept)*f  (the nearest neighbour, the vertex itself, is skipped; no neighbour
 // -> 0/0 = NaN, as in the reference); nothing of the map is modified.
+// QUERY (round 6; EXPORT with a voxel list): Global_map::smooth_pts for the vertices of the listed mesh voxels only -- what the renderer asks for
+// (mesh_rec_display.cpp:78-103) -- as doubles into export_d (3 per vertex id), neighbours closer than `max_dis`; export_vtx is not written.
 template <bool EXPORT>
-__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __restrict__ export_vtx, double smooth_factor) {
+__global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __restrict__ export_vtx, double smooth_factor, const int32_t* __restrict__ vox_list, int n_list,
+                                                        double* __restrict__ export_d, double max_dis) {
     MESH_DYN(m_in);
     __shared__ float cx[KC], cy[KC], cz[KC];
     __shared__ int cid[KC];
@@ -876,12 +879,12 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (!EXPORT && blockIdx.x == 0)   // the admission's bucket fill counts: back to zero for the next scan (mesh_begin_scan_kernel counts, mesh_append_prepare_kernel reads)
         for (int k = tid; k <= MV_BIN_BUCKETS + 1; k += 256) m.bin_cnt[k] = 0;
-    const int n_active = EXPORT ? m.pc[PC_VOXELS] : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
+    const int n_active = EXPORT ? (vox_list ? n_list : m.pc[PC_VOXELS]) : min(m.sc[SC_ACTIVE], m.cap_active);   // launch size is fixed; the work list length lives on the device
     for (int r = blockIdx.x; r < n_active; r += gridDim.x) {
     unsigned long long tprev = m.dbg ? __builtin_readcyclecounter() : 0;
     const unsigned long long tvox0 = tprev;
 #define KDBG(k) do { if (m.dbg) { const unsigned long long _t = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&m.dbg[k], _t - tprev); tprev = _t; } } while (0)
-    const int vi = EXPORT ? r : m.act_vox_s[r];
+    const int vi = EXPORT ? (vox_list ? vox_list[r] : r) : m.act_vox_s[r];
     const int nq = min(m.vx_npts[vi], MV_VOX_CAP);
     if (EXPORT && nq == 0) continue;
     if (!EXPORT && m.shard_world > 1 && mesh_owner(m, m.vx_key[vi]) != m.shard_rank) {
@@ -1067,7 +1070,7 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
             if (lane < nb) {
                 const unsigned long long key = best[q][lane];
                 const int id = (int)(unsigned int)(key & 0xFFFFFFFFull);
-                use_l = lane >= 1 && (double)sqrtf(__uint_as_float((unsigned int)(key >> 32))) < m.accept;   // k = 1 .. size-1, sqrt(dis) < maximum_smooth_dis
+                use_l = lane >= 1 && (double)sqrtf(__uint_as_float((unsigned int)(key >> 32))) < (export_d ? max_dis : m.accept);   // k = 1 .. size-1, sqrt(dis) < maximum_smooth_dis
                 nxp = m.v_pos[(size_t)id * 3 + 0]; nyp = m.v_pos[(size_t)id * 3 + 1]; nzp = m.v_pos[(size_t)id * 3 + 2];
             }
             double sx = 0, sy = 0, sz = 0, valid = 0.0;
@@ -1079,9 +1082,10 @@ __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __re
             if (lane == 0) {
                 const int id = qid[q];
                 const double p0 = (double)qx[q], p1 = (double)qy[q], p2 = (double)qz[q];
-                export_vtx[(size_t)id * 3 + 0] = (float)(p0 * (1.0 - smooth_factor) + sx * smooth_factor / valid);
-                export_vtx[(size_t)id * 3 + 1] = (float)(p1 * (1.0 - smooth_factor) + sy * smooth_factor / valid);
-                export_vtx[(size_t)id * 3 + 2] = (float)(p2 * (1.0 - smooth_factor) + sz * smooth_factor / valid);
+                const double o0 = p0 * (1.0 - smooth_factor) + sx * smooth_factor / valid, o1 = p1 * (1.0 - smooth_factor) + sy * smooth_factor / valid,
+                             o2 = p2 * (1.0 - smooth_factor) + sz * smooth_factor / valid;
+                if (export_d) { export_d[(size_t)id * 3 + 0] = o0; export_d[(size_t)id * 3 + 1] = o1; export_d[(size_t)id * 3 + 2] = o2; }
+                else { export_vtx[(size_t)id * 3 + 0] = (float)o0; export_vtx[(size_t)id * 3 + 1] = (float)o1; export_vtx[(size_t)id * 3 + 2] = (float)o2; }
             }
         }
         __syncthreads();
@@ -2111,9 +2115,48 @@ void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand) { KL
 // IMMESH_MESH_GRID_DIV (experiments): divides the grids of the two big per-voxel kernels -- fewer resident mesher wavefronts per SIMD leave register
 // room for the registration chain's kernels
 static int mesh_grid_div() { static const int v = getenv("IMMESH_MESH_GRID_DIV") ? std::max(1, atoi(getenv("IMMESH_MESH_GRID_DIV"))) : 1; return v; }
-void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(512 / mesh_grid_div()), dim3(256), 0, s, m, (float*)nullptr, 1.0); }
+void launch_mesh_knn(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_knn_kernel<false>, dim3(512 / mesh_grid_div()), dim3(256), 0, s, m, (float*)nullptr, 1.0, (const int32_t*)nullptr, 0, (double*)nullptr, 0.0); }
 void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor) {
-    KLAUNCH(mesh_knn_kernel<true>, dim3(2048), dim3(256), 0, s, m, export_vtx, smooth_factor);
+    KLAUNCH(mesh_knn_kernel<true>, dim3(2048), dim3(256), 0, s, m, export_vtx, smooth_factor, (const int32_t*)nullptr, 0, (double*)nullptr, 0.0);
+}
+// ---- Global_map::smooth_pts on demand (the renderer's consumer of the map, mesh_rec_display.cpp:78-103) ---------------------------------------------
+// voxel of each requested vertex (-1: id out of range; display mode: also -1 for a vertex the mesher has smoothed -- its m_pos_aft_smooth is served as is)
+__global__ void mesh_query_voxels_kernel(MeshDev m, const int32_t* __restrict__ ids, int n, int n_vertices, int display, int32_t* __restrict__ vox_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int id = ids[i];
+    int v = -1;
+    if (id >= 0 && id < n_vertices) {
+        v = m.v_voxel[id];
+        if (display) {
+            const bool smoothed = m.v_smooth[(size_t)id * 3 + 0] != (double)m.v_pos[(size_t)id * 3 + 0] || m.v_smooth[(size_t)id * 3 + 1] != (double)m.v_pos[(size_t)id * 3 + 1] ||
+                                  m.v_smooth[(size_t)id * 3 + 2] != (double)m.v_pos[(size_t)id * 3 + 2];
+            if (smoothed) v = -2;
+        }
+    }
+    vox_out[i] = v;
+}
+// results in request order.  display == 0: smooth_pts' return value (doubles); display != 0: RGB_pts::get_pos(1) after the renderer's on-demand smoothing
+// (floats: m_pos_aft_smooth where the mesher has smoothed the vertex, smooth_pts' value elsewhere)
+__global__ void mesh_query_gather_kernel(MeshDev m, const int32_t* __restrict__ ids, const int32_t* __restrict__ vox, int n, const double* __restrict__ export_d, int display,
+                                         double* __restrict__ out_d, float* __restrict__ out_f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int id = ids[i];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double v = vox[i] == -2 ? m.v_smooth[(size_t)id * 3 + a] : (vox[i] >= 0 ? export_d[(size_t)id * 3 + a] : __longlong_as_double(0x7FF8000000000000ll));
+        if (display) out_f[(size_t)i * 3 + a] = (float)v; else out_d[(size_t)i * 3 + a] = v;
+    }
+}
+void launch_mesh_query_voxels(hipStream_t s, const MeshDev& m, const int32_t* ids, int n, int n_vertices, int display, int32_t* vox_out) {
+    KLAUNCH(mesh_query_voxels_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, ids, n, n_vertices, display, vox_out);
+}
+void launch_mesh_query_smooth(hipStream_t s, const MeshDev& m, const int32_t* vox_list, int n_list, double smooth_factor, double max_dis, double* export_d) {
+    KLAUNCH(mesh_knn_kernel<true>, dim3(std::min(std::max(n_list, 1), 2048)), dim3(256), 0, s, m, (float*)nullptr, smooth_factor, vox_list, n_list, export_d, max_dis);
+}
+void launch_mesh_query_gather(hipStream_t s, const MeshDev& m, const int32_t* ids, const int32_t* vox, int n, const double* export_d, int display, double* out_d, float* out_f) {
+    KLAUNCH(mesh_query_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, ids, vox, n, export_d, display, out_d, out_f);
 }
 // live triangles with the winding save_to_ply_file writes: m_index_flip != 0 -> (v0, v1, v2), else (v0, v2, v1)
 __global__ void mesh_export_faces_kernel(MeshDev m, int32_t* __restrict__ tri_idx, int32_t* __restrict__ count) {

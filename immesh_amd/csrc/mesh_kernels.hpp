@@ -180,6 +180,13 @@ struct MeshHost {
     size_t exp_vtx_bytes = 0, exp_work_bytes = 0, exp_tmp_bytes = 0;
     int32_t* exp_faces = nullptr;
     int64_t exp_nv = 0, exp_nf = 0;
+    // Global_map::smooth_pts on demand (immesh_smooth_pts / immesh_mesh_display_vertices): callable from a third thread (the renderer's) while scans are
+    // being meshed.  launch_mu is held by the worker while it ENQUEUES a job and by a query from "both mesher streams idle" to "results on the host": a
+    // query sees the map between two jobs, never one half appended
+    std::mutex launch_mu;
+    hipStream_t stream_q = nullptr;
+    void *q_dev = nullptr, *q_exp = nullptr; size_t q_dev_bytes = 0, q_exp_bytes = 0;
+    char* q_host = nullptr; size_t q_host_bytes = 0;
     // sharded mesher: all-gather callback + staging
     immesh_allgather_fn allgather = nullptr;
     void* allgather_user = nullptr;
@@ -207,6 +214,9 @@ void launch_mesh_select_active(hipStream_t s, const MeshDev& m, int n_cand);
 void launch_mesh_append_finish(hipStream_t s, const MeshDev& m, const float* pts);   // flags + scan + commit + select + active-voxel order in one launch (n_cand <= 16384)
 void launch_mesh_knn(hipStream_t s, const MeshDev& m);
 void launch_mesh_export_vertices(hipStream_t s, const MeshDev& m, float* export_vtx, double smooth_factor);
+void launch_mesh_query_voxels(hipStream_t s, const MeshDev& m, const int32_t* ids, int n, int n_vertices, int display, int32_t* vox_out);
+void launch_mesh_query_smooth(hipStream_t s, const MeshDev& m, const int32_t* vox_list, int n_list, double smooth_factor, double max_dis, double* export_d);
+void launch_mesh_query_gather(hipStream_t s, const MeshDev& m, const int32_t* ids, const int32_t* vox, int n, const double* export_d, int display, double* out_d, float* out_f);
 void launch_mesh_export_faces(hipStream_t s, const MeshDev& m, int32_t* tri_idx, int32_t* count);
 void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
