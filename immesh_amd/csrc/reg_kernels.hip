@@ -882,7 +882,12 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     for (int it = 0; it < a.max_iter; it++) {
         // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] block partials out [2] all partials in [3] update done
         unsigned long long* const tr = (sp.dbg && threadIdx.x == 0 && it < 8) ? sp.dbg + (64 + 16384 * 8) + ((size_t)it * 512 + blockIdx.x) * 8 : nullptr;
-        if (tr) { tr[0] = __builtin_amdgcn_s_memrealtime(); if (it == 0) tr[4] = t_entry; }
+        if (tr) {
+            tr[0] = __builtin_amdgcn_s_memrealtime();
+            if (it == 0) tr[4] = t_entry;
+            // (pass-1 record, spare words: WHERE the block runs -- HW_ID (CU / SE / wave slot) and XCC_ID -- for the "which workgroups are placed late" question)
+            if (it == 1) { tr[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); tr[5] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); }
+        }
         if (sp.dbg && threadIdx.x == 0) { atomicAdd(&sp.dbg[6], 1ull); if (blockIdx.x == 0) atomicAdd(&sp.dbg[7], 1ull); }   // (the RDBG phase sums are wavefront 0's)
         // the iterate of this pass: wave-uniform, through readfirstlane into scalar registers
         double Rm[9], tv[3], RextR[9];

@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   ( [ "$v" != "-" ] && export $v
     IMMESH_DEBUG=1 IMMESH_TRACE_FILE=/tmp/trace_x.bin timeout 200 python $R/bench.py --cpu-seconds 0 --extra-configs 0 --steps 12 --warmup 3 --profile-scans 0 --nu-scans 0 --async-mesh 1 2>/tmp/dbg_x.err > /dev/null
-    { echo "== $v"; grep -E '^\[(re|slow)' /tmp/dbg_x.err | tail -3; python $R/tools/trace_report.py /tmp/trace_x.bin; } >> $O/${T}_traces.txt )
+    { echo "== $v"; grep -E '^\[(re|slow)' /tmp/dbg_x.err | tail -3; python $R/tools/trace_report.py /tmp/trace_x.bin blocks; } >> $O/${T}_traces.txt )
 done
-grep -E "^==|kernel entry|pass 0|epilogue|replay_fused:|\[replay_list" $O/${T}_traces.txt
+grep -E "^==|kernel entry|per block|pass 0|epilogue|replay_fused:|\[replay_list" $O/${T}_traces.txt

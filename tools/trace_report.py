@@ -41,6 +41,11 @@ if (r[0, :, 0] > 0).any():
         ent = (b0[:, 4] - t0) * 0.01
         fin = (r[0, 0, 5] - t0) * 0.01
         print(f"  kernel entry (first wavefront of a block) min/max {ent.min():6.2f} {ent.max():6.2f}; block 0 finished (posterior out, ticket) {fin:6.2f}")
+        b1 = r[1][: len(b0)]
+        if len(sys.argv) > 2 and (b1[:, 5] >= 0).any():   # where each block ran: entry time, pass-0 partials out, XCC, SE, CU (HW_ID: cu_id bits 8-11, sh 12, se 13-15 on gfx9)
+            out0 = (b0[:, 1] - t0) * 0.01
+            print("  per block (entry us, pass-0 partials out us, xcc, se, cu): " + "  ".join(
+                f"[{ent[i]:.1f} {out0[i]:.1f} x{int(b1[i, 5]) & 15} s{(int(b1[i, 4]) >> 13) & 7} c{(int(b1[i, 4]) >> 8) & 15}]" for i in np.argsort(ent)))
         if (b0[:, 7] > 0).any():
             e5 = (b0[1:, 5] - t0) * 0.01; e6 = (b0[:, 6] - t0) * 0.01; e7 = (b0[:, 7] - t0) * 0.01
             print(f"  epilogue: start (blocks > 0) min/max {e5.min():6.2f} {e5.max():6.2f}; points prepared p50/max {np.percentile(e6, 50):6.2f} {e6.max():6.2f}; scan transformed p50/max {np.percentile(e7, 50):6.2f} {e7.max():6.2f}")
