@@ -436,7 +436,7 @@ def measure(args, torch, D, dist, hip, rank, world, local, dev, sharded, full):
                      "threads": "scan thread (immesh_process_scan per scan) / service thread (wait for the frame's job, fetch its lists, enqueue) / mirror thread (apply the lists; host queue 256 frames deep)",
                      "scans_per_s_until_last_pose": round(1e3 * args.steps / float(ms[0]), 1), "scans_per_s_until_mirrors_current": round(1e3 * args.steps / float(ms[1]), 1),
                      "ms_until_last_pose": round(float(ms[0]), 3), "ms_until_mirrors_current": round(float(ms[1]), 3), "mirror_vertices": int(nvm.value), "mirror_live_triangles": int(nlm.value),
-                     "host_ms_per_scan": {"scan_thread_pack_pcl_clouds": round(stage5[0] / args.steps, 4), "scan_thread_immesh_process_scan": round(stage5[1] / args.steps, 4),
+                     "host_ms_per_scan": {"scan_thread_before_the_call (round 5: packing the pcl clouds; round 6: consumed in place by immesh_process_scan_strided)": round(stage5[0] / args.steps, 4), "scan_thread_immesh_process_scan": round(stage5[1] / args.steps, 4),
                                           "service_thread_wait_for_job": round(stage5[2] / args.steps, 4), "service_thread_fetch": round(stage5[3] / args.steps, 4),
                                           "mirror_thread_update": round(stage5[4] / args.steps, 4)},
                      "mirror_equals_device": bool(nvm.value == cm["n_vertices"] and nlm.value == cm["n_triangles_live"])}
@@ -877,7 +877,7 @@ def main():
                        "registration_map": (f"built from the first {args.map_scans} scans of the stream (SURVEY 8(d) C4)" if (kitti and args.map_scans > 1) else "scan 0 only") if kitti else "dense survey (SURVEY 8(d) C2/C3)",
                        "mesh_mode": {0: "off", NOWAIT: "off (map update of scan k overlaps the host side of scan k+1)", 1: "serial", 2: "async (mesh of scan k overlaps registration of scan k+1; vertex admission + kNN of scan k+1 overlap triangulation of scan k)"}[mesh_mode],
                        "downsample": "device, inside the timed region (asynchronous: scan k+1's VoxelGrid on the pre-processing stream beside scan k's registration)" if args.device_downsample else "host (before the timed region; the hot path starts at lio_state_estimation)",
-                       "inputs": ("pcl-shaped host clouds through the drop-in shim (packed + staged over PCIe inside the timed region; result lists fetched, host mirrors applied)" if args.dropin_shim else
+                       "inputs": ("pcl-shaped host clouds through the drop-in shim, consumed in place by immesh_process_scan_strided (packed into pinned staging + copied over PCIe inside the timed region; result lists fetched, host mirrors applied)" if args.dropin_shim else
                                   "host buffers, staged over PCIe inside the timed region" if args.host_inputs else "resident in HBM before the timed region")},
             "stages_ms_serial": None,
             "counters_per_scan": {kk_: round(v / args.steps, 1) for kk_, v in cnt.items() if kk_ in COUNTER_KEYS},

@@ -181,6 +181,34 @@ int dropin_mirror_sizes(void* p, int64_t* nv, int64_t* nl) {
     *nv = (int64_t)g_map_rgb_pts_mesh.m_rgb_pts_vec.size(); *nl = immesh_mirror_live_count(g_triangles_manager);
     return 0;
 }
+// What the renderer does with a region's Triangle_set (unparse_triangle_set_to_vector, src/meshing/mesh_rec_display.cpp:78-103), here over EVERY live triangle
+// of the mirror: smooth what is still unsmoothed (Global_map::smooth_pts -- the shim's replaced body, one vertex per call, as the unchanged renderer would),
+// then three float positions (get_pos(1)) per triangle.  The same buffer is asked of the library in ONE call (immesh_mesh_display_vertices).
+// out[0] triangles, out[1] vertices smoothed by this pass, out[2] NaN coordinates in the buffer, out[3] coordinates that differ from the batched call's
+int dropin_render_pass(void* p, double smooth_factor, double knn, double max_dis, int64_t* out4, float* buffer, int64_t cap_floats) {
+    Driver* d = (Driver*)p;
+    std::vector<int32_t> ids;
+    immesh_mirror_for_each_live(g_triangles_manager, [&](const Triangle_ptr& t) { for (int k = 0; k < 3; k++) ids.push_back(t->m_tri_pts_id[k]); });
+    std::vector<float> batched(ids.size() * 3, 0.f);
+    // (the batched entry first: it reads the device's own smoothed positions, the per-vertex pass below then writes the mirror's)
+    if (!ids.empty() && immesh_mesh_display_vertices(d->vm.m_hip, ids.data(), (int32_t)ids.size(), smooth_factor, (int32_t)knn, max_dis, batched.data()) != 0) return -1;
+    int64_t n_now = 0, n_nan = 0, n_diff = 0;
+    std::vector<float> buf(ids.size() * 3);
+    for (size_t i = 0; i < ids.size(); i++) {
+        RGB_pt_ptr& pt = g_map_rgb_pts_mesh.m_rgb_pts_vec[ids[i]];
+        if (pt->m_smoothed == false) { g_map_rgb_pts_mesh.smooth_pts(pt, smooth_factor, knn, max_dis); n_now++; }
+        const vec_3 v = pt->get_pos(1);
+        for (int a = 0; a < 3; a++) {
+            const float f = (float)v(a);
+            buf[3 * i + a] = f;
+            if (f != f) n_nan++;
+            else if (f != batched[3 * i + a]) n_diff++;
+        }
+    }
+    out4[0] = (int64_t)ids.size() / 3; out4[1] = n_now; out4[2] = n_nan; out4[3] = n_diff;
+    if (buffer) std::memcpy(buffer, buf.data(), std::min<size_t>(buf.size(), (size_t)cap_floats) * 4);
+    return 0;
+}
 int dropin_wait_meshed(void* p, long n_frames, int timeout_ms) {
     (void)p;
     const auto t0 = std::chrono::steady_clock::now();

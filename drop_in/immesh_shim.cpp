@@ -152,6 +152,20 @@ void reconstruct_mesh_from_pointcloud(pcl::PointCloud<pcl::PointXYZI>::Ptr frame
     if (rc) fail(g_immesh_ctx, "immesh_reconstruct_mesh_from_pointcloud", rc);
 }
 
+// ---- vec_3 Global_map::smooth_pts( RGB_pt_ptr&, double smooth_factor, double knn, double maximum_smooth_dis )   src/meshing/r3live/pointcloud_rgbd.cpp:932-958 ----
+// The renderer calls it for every triangle vertex the mesher has not smoothed (unparse_triangle_set_to_vector, src/meshing/mesh_rec_display.cpp:86-90).  The
+// reference's body searches the HOST ikd-Tree (m_kdtree), which a drop-in never feeds -- zero neighbours, 0/0, a NaN vertex in the GL buffer; here the
+// search runs on the device's map.  The value is stored in the point like the reference does (set_smooth_pos -> m_smoothed: asked once per vertex).
+vec_3 Global_map::smooth_pts(RGB_pt_ptr& rgb_pt, double smooth_factor, double knn, double maximum_smooth_dis) {
+    const int32_t id = rgb_pt->m_pt_index;
+    double o[3] = {0, 0, 0};
+    const int rc = immesh_smooth_pts(g_immesh_ctx, &id, 1, smooth_factor, (int32_t)knn, maximum_smooth_dis, o);
+    if (rc) { fail(g_immesh_ctx, "immesh_smooth_pts", rc); return rgb_pt->get_pos(); }
+    const vec_3 v(o[0], o[1], o[2]);
+    rgb_pt->set_smooth_pos(v);
+    return v;
+}
+
 // ---- void save_to_ply_file(std::string, double smooth_factor, double knn)   src/meshing/mesh_rec_geometry.cpp:71-131 -----------------------
 void save_to_ply_file(std::string ply_file, double smooth_factor, double knn) {
     const int rc = immesh_save_ply(g_immesh_ctx, ply_file.c_str(), smooth_factor, (int32_t)knn);

@@ -60,8 +60,14 @@ class RGB_pts {
     bool m_smoothed = false;
     void set_pos(const vec_3& p) { for (int i = 0; i < 3; i++) m_pos[i] = p(i); }
     void set_smooth_pos(const vec_3& p) { for (int i = 0; i < 3; i++) m_pos_aft_smooth[i] = p(i); m_smoothed = true; }
+    vec_3 get_pos(bool get_smooth = false) { return (get_smooth && m_smoothed) ? vec_3(m_pos_aft_smooth[0], m_pos_aft_smooth[1], m_pos_aft_smooth[2]) : vec_3(m_pos[0], m_pos[1], m_pos[2]); }   // pointcloud_rgbd.cpp:70-80
 };
-class Global_map { public: std::vector<std::shared_ptr<RGB_pts>> m_rgb_pts_vec; };
+using RGB_pt_ptr = std::shared_ptr<RGB_pts>;
+class Global_map {   // pointcloud_rgbd.hpp:234-298
+  public:
+    std::vector<RGB_pt_ptr> m_rgb_pts_vec;
+    vec_3 smooth_pts(RGB_pt_ptr& rgb_pt, double smooth_factor, double knn = 20, double maximum_smooth_dis = 0);   // :287, pointcloud_rgbd.cpp:932-958 -- body replaced by the shim
+};
 class Triangle { public: int m_tri_pts_id[3] = {0, 0, 0}; int m_index_flip = 0; Triangle(int a, int b, int c) : m_tri_pts_id{a, b, c} { std::sort(m_tri_pts_id, m_tri_pts_id + 3); } };
 using Triangle_ptr = std::shared_ptr<Triangle>;
 using Triangle_set = std::set<Triangle_ptr>;

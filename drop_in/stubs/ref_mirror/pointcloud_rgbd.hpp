@@ -30,4 +30,9 @@ class RGB_pts {   // pointcloud_rgbd.hpp:77-163, pointcloud_rgbd.cpp:59-87
     void set_smooth_pos(const vec_3& p) { for (int i = 0; i < 3; i++) m_pos_aft_smooth[i] = p(i); m_smoothed = true; }
     vec_3 get_pos(bool get_smooth = false) { return get_smooth ? vec_3(m_pos_aft_smooth[0], m_pos_aft_smooth[1], m_pos_aft_smooth[2]) : vec_3(m_pos[0], m_pos[1], m_pos[2]); }
 };
-class Global_map { public: std::vector<std::shared_ptr<RGB_pts>> m_rgb_pts_vec; };   // pointcloud_rgbd.hpp:234-298
+using RGB_pt_ptr = std::shared_ptr<RGB_pts>;
+class Global_map {   // pointcloud_rgbd.hpp:234-298
+  public:
+    std::vector<RGB_pt_ptr> m_rgb_pts_vec;
+    vec_3 smooth_pts(RGB_pt_ptr& rgb_pt, double smooth_factor, double knn = 20, double maximum_smooth_dis = 0);   // :287, pointcloud_rgbd.cpp:932-958 -- body replaced by the shim
+};

@@ -354,9 +354,35 @@ class HotPath:
         self._check(g(self.ctx, _ptr(vtx), _ptr(faces)), "mesh_export_fetch")
         return vtx, faces
 
+    def smooth_pts(self, ids, smooth_factor=1.0, knn=20, maximum_smooth_dis=0.0):
+        """Global_map::smooth_pts for a batch of vertex ids -> (n, 3) float64"""
+        f = self._f("smooth_pts"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_void_p]; f.restype = C.c_int
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = np.zeros((len(ids), 3), np.float64)
+        self._check(f(self.ctx, _ptr(ids), len(ids), smooth_factor, knn, maximum_smooth_dis, _ptr(out)), "smooth_pts")
+        return out
+
+    def mesh_display_vertices(self, ids, smooth_factor=1.0, knn=20, maximum_smooth_dis=0.0):
+        """get_pos(1) after the renderer's on-demand smoothing, as floats -> (n, 3) float32"""
+        f = self._f("mesh_display_vertices"); f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_void_p]; f.restype = C.c_int
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = np.zeros((len(ids), 3), np.float32)
+        self._check(f(self.ctx, _ptr(ids), len(ids), smooth_factor, knn, maximum_smooth_dis, _ptr(out)), "mesh_display_vertices")
+        return out
+
     def save_ply(self, path, smooth_factor=1.0, knn=20):
         f = self._f("save_ply"); f.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.c_int32]; f.restype = C.c_int
         self._check(f(self.ctx, path.encode(), smooth_factor, knn), "save_ply")
+
+    def process_scan_strided(self, down_bytes, n_ds, down_stride, raw_bytes, n_raw, raw_stride, raw_int_off, state_prior, state, frame_idx=0, do_mesh=True):
+        """immesh_process_scan_strided: down_bytes / raw_bytes = numpy arrays (any dtype) or device pointers holding the pcl-shaped clouds"""
+        f = self._f("process_scan_strided"); f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        out = np.array(state, dtype=np.float64, copy=True)
+        n_iter, n_match = C.c_int32(0), C.c_int32(0)
+        self._check(f(self.ctx, _ptr(down_bytes), n_ds, down_stride, _ptr(raw_bytes), n_raw, raw_stride, raw_int_off, _ptr(np.ascontiguousarray(state_prior, dtype=np.float64)),
+                      _ptr(out), frame_idx, int(do_mesh), C.byref(n_iter), C.byref(n_match)), "process_scan_strided")
+        return out, {"n_iter": n_iter.value, "n_match": n_match.value}
 
     # -- whole scan -------------------------------------------------------------------------------------------
     def process_scan(self, pts_down, pts_raw_xyzi, state_prior, state, frame_idx=0, do_mesh=True, n_ds=None, n_raw=None):

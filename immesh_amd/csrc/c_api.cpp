@@ -185,6 +185,7 @@ void immesh_destroy(immesh_ctx* c) {
     if (c->h_reg_out) (void)hipHostFree(c->h_reg_out);
     if (c->h_epi_flag) (void)hipHostFree(c->h_epi_flag);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_pack) (void)hipHostFree(c->h_pack);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -696,6 +697,49 @@ int immesh_process_scan(immesh_ctx* c, const float* pts_down, int32_t n_ds, cons
     if (mesh_mode == IMMESH_MESH_SYNC && (rc = mesh_wait(c, job))) return rc;   // synchronous mode: results are current on return
     c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3];
     return 0;
+}
+
+// One cloud of immesh_process_scan_strided into the library's packed staging buffer on the registration stream.  Device memory: a gather kernel.  Host
+// memory: packed by this thread straight into PINNED staging (one pass over the cloud), then one asynchronous copy -- the pageable path costs a pass by
+// the caller (pcl -> packed floats) plus the runtime's own staging pass.
+static int stage_strided(immesh_ctx* c, const void* p, int n, int stride, int int_off, float* d_dst, size_t pack_off) {
+    hipPointerAttribute_t attr;
+    bool is_dev = false;
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess) is_dev = (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+    else (void)hipGetLastError();
+    if (is_dev) { launch_unpack_strided(c->stream, p, n, stride, int_off, d_dst); return 0; }
+    const int nf = int_off >= 0 ? 4 : 3;
+    float* dst = (float*)(c->h_pack + pack_off);
+    const unsigned char* src = (const unsigned char*)p;
+    if (nf == 4) for (int i = 0; i < n; i++) { const float* q = (const float*)(src + (size_t)i * stride); dst[4 * i] = q[0]; dst[4 * i + 1] = q[1]; dst[4 * i + 2] = q[2]; dst[4 * i + 3] = *(const float*)(src + (size_t)i * stride + int_off); }
+    else for (int i = 0; i < n; i++) { const float* q = (const float*)(src + (size_t)i * stride); dst[3 * i] = q[0]; dst[3 * i + 1] = q[1]; dst[3 * i + 2] = q[2]; }
+    HIPCHK(c, hipMemcpyAsync(d_dst, dst, (size_t)n * nf * 4, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+int immesh_process_scan_strided(immesh_ctx* c, const void* pts_down, int32_t n_ds, int32_t down_stride_bytes, const void* pts_raw, int32_t n_raw, int32_t raw_stride_bytes,
+                                int32_t raw_intensity_offset_bytes, const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out) {
+    if (!c || !pts_down || n_ds <= 0 || n_ds > c->cap_scan || down_stride_bytes < 12 || (down_stride_bytes & 3) || !state_prior || !state_inout ||
+        (do_mesh && (!pts_raw || n_raw <= 0 || n_raw > c->cap_scan || raw_stride_bytes < 16 || (raw_stride_bytes & 3) || raw_intensity_offset_bytes < 12 || (raw_intensity_offset_bytes & 3) ||
+                     raw_intensity_offset_bytes + 4 > raw_stride_bytes))) {
+        if (c) c->err = "bad arguments";
+        return IMMESH_E_INVAL;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    const size_t need = (size_t)n_ds * 12 + 64 + (do_mesh ? (size_t)n_raw * 16 : 0);
+    if (c->h_pack_bytes < need) {
+        // (the previous call's copies out of the old block have completed: a call returns with the pose, which the registration launch behind the copies produced)
+        if (c->h_pack) (void)hipHostFree(c->h_pack);
+        c->h_pack = nullptr; c->h_pack_bytes = 0;
+        const size_t want = std::max(need, (size_t)c->cap_scan * 28 + 64);
+        if (hipHostMalloc((void**)&c->h_pack, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc(strided staging)"; return IMMESH_E_NOMEM; }
+        c->h_pack_bytes = want;
+    }
+    int rc;
+    if ((rc = stage_strided(c, pts_down, n_ds, down_stride_bytes, -1, c->d_pts_down, 0))) return rc;
+    if (do_mesh && (rc = stage_strided(c, pts_raw, n_raw, raw_stride_bytes, raw_intensity_offset_bytes, c->d_pts_raw, ((size_t)n_ds * 12 + 63) & ~(size_t)63))) return rc;
+    // the caller's clouds are consumed here (host: packed; device: the gather is queued ahead of everything that reads the staging copy): the scan proper
+    // works on the library's own buffers
+    return immesh_process_scan(c, c->d_pts_down, n_ds, do_mesh ? c->d_pts_raw : nullptr, n_raw, state_prior, state_inout, frame_idx, do_mesh, n_iter_out, n_match_out);
 }
 
 // The stages before the path run on their own stream (they do not read the map) with their own scratch, so they overlap the previous scan's

@@ -54,6 +54,7 @@ struct immesh_ctx {
     float* d_pts_down = nullptr;     // staging for host inputs (n x 3)
     float* d_pts_raw = nullptr;      // staging (n x 4)
     float* d_ds_out = nullptr;       // immesh_downsample result (n x 3)
+    char* h_pack = nullptr; size_t h_pack_bytes = 0;   // immesh_process_scan_strided: pinned staging the host-side strided clouds are packed into (one pass: no second copy by the runtime)
     // immesh_downsample_begin / _end: two result buffers, the grid extents + leaf count of the running job in pinned memory, its parameters for the fallback
     struct DsAsync { bool ready = false; float* stage = nullptr; bool active = false; int par = 0, n = 0, stride = 0, used_bits = 64, pred_bits = 64; double leaf = 0; const void* d_in = nullptr; hipEvent_t ev = nullptr; int32_t ticket = 0; int32_t* h_info = nullptr; int32_t* h_info_dev = nullptr; float* out[2] = {nullptr, nullptr}; } dsa;
     double* d_partials = nullptr;    // residual block partials

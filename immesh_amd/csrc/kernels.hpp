@@ -93,6 +93,7 @@ void launch_replay(hipStream_t s, const RegMapDev& m, const uint32_t* sorted_slo
 void launch_dump_planes(hipStream_t s, const RegMapDev& m, PlaneRecDev* out, long long cap, unsigned long long* count);
 void launch_fill_u64(hipStream_t s, unsigned long long* p, unsigned long long v, size_t n);
 void launch_iota(hipStream_t s, int32_t* p, int n);
+void launch_unpack_strided(hipStream_t s, const void* src, int n, int stride_bytes, int intensity_off_bytes, float* out);   // intensity_off_bytes < 0: xyz only
 
 // VoxelGrid down-sampling (ds_kernels.hip)
 void launch_ds_minmax(hipStream_t s, const float* pts, int n, int stride, float inv, int* mm);

@@ -2198,6 +2198,28 @@ __global__ void iota_kernel(int32_t* p, int n) {
     if (i < n) p[i] = i;
 }
 
+// pcl-shaped clouds consumed in place (immesh_process_scan_strided): point i at src + i * stride bytes -- x, y, z first, the intensity (if asked for) at
+// int_off -- into the packed xyz / xyzI layout the kernels read.  One thread per point; rows of a 32- or 48-byte stride are read as whole 16-byte words.
+__global__ void unpack_strided_kernel(const unsigned char* __restrict__ src, int n, int stride, int int_off, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char* p = src + (size_t)i * stride;
+    float x, y, z, w = 0.f;
+    if ((stride & 15) == 0 && ((uintptr_t)src & 15) == 0) {
+        const float4 a = *(const float4*)p;
+        x = a.x; y = a.y; z = a.z;
+        if (int_off >= 0) w = *(const float*)(p + int_off);
+    } else {
+        x = *(const float*)p; y = *(const float*)(p + 4); z = *(const float*)(p + 8);
+        if (int_off >= 0) w = *(const float*)(p + int_off);
+    }
+    if (int_off >= 0) ((float4*)out)[i] = make_float4(x, y, z, w);
+    else { out[(size_t)i * 3] = x; out[(size_t)i * 3 + 1] = y; out[(size_t)i * 3 + 2] = z; }
+}
+void launch_unpack_strided(hipStream_t s, const void* src, int n, int stride_bytes, int intensity_off_bytes, float* out) {
+    KLAUNCH(unpack_strided_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned char*)src, n, stride_bytes, intensity_off_bytes, out);
+}
+
 // ---- launchers (called from the host layer) -------------------------------------------------------------------------
 void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
                      double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {

@@ -177,6 +177,23 @@ int immesh_mesh_export(immesh_ctx* ctx, double smooth_factor, int32_t knn, int64
 int immesh_mesh_export_fetch(immesh_ctx* ctx, float* vtx_xyz, int32_t* faces);
 int immesh_save_ply(immesh_ctx* ctx, const char* path, double smooth_factor, int32_t knn);
 
+/* ---- the renderer's consumer of the map (SURVEY 8(b) "service_refresh_and_synchronize_triangle ... Global_map::smooth_pts", 8(f) rank 3 "GL sync") ---- */
+/* vec_3 Global_map::smooth_pts( RGB_pt_ptr&, double smooth_factor, double knn, double maximum_smooth_dis )   src/meshing/r3live/pointcloud_rgbd.cpp:932-958
+ * as the renderer calls it for every triangle vertex with m_smoothed == false (src/meshing/mesh_rec_display.cpp:86-90; vertices of voxels that never
+ * reached 3 points are never smoothed by the mesher, src/ImMesh_mesh_reconstruction.cpp:147-151, but are pulled into their neighbours' triangulations).
+ * In the reference the function searches the HOST ikd-Tree, which a drop-in never feeds (zero neighbours -> 0/0 -> a NaN vertex in the GL buffer): the
+ * search runs here, on the device's map.  For each of the n vertex ids: the knn nearest vertices of the whole map, the nearest (the vertex itself)
+ * skipped, those closer than maximum_smooth_dis (<= 0: 0.8 x the mesh voxel; at most 2.5 x the mesh voxel, the reach of the device's 20-NN pull;
+ * the renderer passes g_kd_tree_accept_pt_dis = 1.25 x) averaged: out = pt (1 - f) + f mean; nobody close -> NaN as in the reference.  knn must be 20
+ * (g_ply_smooth_k).  The map is NOT modified (the reference also stores the value in the point -- RGB_pts::set_smooth_pos -- which is the host mirror's
+ * business: INTEGRATION.md).  Thread-safe against a running scan loop: may be called from a third thread (the renderer's) while immesh_process_scan /
+ * immesh_mesh_collect_* run on theirs; the query reads the map between two mesh jobs.  Ids must be vertices the caller has been handed (immesh_mesh_fetch). */
+int immesh_smooth_pts(immesh_ctx* ctx, const int32_t* vertex_ids, int32_t n, double smooth_factor, int32_t knn, double maximum_smooth_dis, double* out_xyz);
+/* The float vertex positions unparse_triangle_set_to_vector puts into the GL buffer (src/meshing/mesh_rec_display.cpp:78-103): RGB_pts::get_pos(1) AFTER the
+ * on-demand smoothing above -- m_pos_aft_smooth where the mesher has smoothed the vertex, smooth_pts' value where it has not -- cast to float, for a
+ * batch of ids (3 per triangle of a region's Triangle_set, in the caller's order): one call per refreshed region instead of one smooth_pts per vertex. */
+int immesh_mesh_display_vertices(immesh_ctx* ctx, const int32_t* vertex_ids, int32_t n, double smooth_factor, int32_t knn, double maximum_smooth_dis, float* out_xyz);
+
 /* ---- whole scan (what service_LiDAR_update does per scan, src/voxel_mapping.cpp:1959-1973) ---------------- */
 /* lio_state_estimation + map_incremental_grow (+ world transform of the full scan and incremental_mesh_reconstruction
  * when do_mesh != 0).  pts_raw_body_xyzi = m_feats_undistort (n_raw x 4).  Everything stays on the device between
@@ -192,6 +209,15 @@ int immesh_save_ply(immesh_ctx* ctx, const char* path, double smooth_factor, int
 int immesh_process_scan(immesh_ctx* ctx, const float* pts_down_body_xyz, int32_t n_ds, const float* pts_raw_body_xyzi, int32_t n_raw,
                         const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out,
                         int32_t* n_match_out);
+
+/* The same call on the clouds AS THE REFERENCE HOLDS THEM (src/voxel_mapping.cpp:1959-1973: m_feats_down_body, m_feats_undistort are pcl clouds of
+ * PointType = pcl::PointXYZINormal, 48 bytes a point: x y z at 0, intensity at 32; pcl::PointXYZI: 32 bytes, intensity at 16): point i of a cloud lies at
+ * base + i * stride_bytes, x y z first, the raw cloud's intensity at raw_intensity_offset_bytes.  Consumed in place -- host clouds are packed in ONE pass into
+ * the library's pinned staging and copied asynchronously, device clouds are gathered by a kernel -- so the caller keeps no packed copy and may reuse its
+ * clouds as soon as the call returns (no immesh_inputs_consumed needed).  Results identical to immesh_process_scan on the packed clouds, bit for bit. */
+int immesh_process_scan_strided(immesh_ctx* ctx, const void* pts_down_body, int32_t n_ds, int32_t down_stride_bytes, const void* pts_raw_body, int32_t n_raw,
+                                int32_t raw_stride_bytes, int32_t raw_intensity_offset_bytes, const double* state_prior, double* state_inout, int32_t frame_idx,
+                                int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out);
 
 /* ---- legacy registration path ------------------------------------------------------------------------------- */
 /* `voxel_map_en = false` -- dead in every shipped config, kept behind these separate entry points: the ikd-Tree of map points and the "Old map

@@ -325,6 +325,22 @@ int orc_mesh_export_fetch(void* p, float* vtx, int32_t* faces) {
     if (faces) std::memcpy(faces, o->exp_faces.data(), o->exp_faces.size() * 4);
     return 0;
 }
+int orc_smooth_pts(void* p, const int32_t* ids, int32_t n, double smooth_factor, int32_t knn, double max_dis, double* out_xyz) {
+    OrcCtx* o = (OrcCtx*)p;
+    for (int i = 0; i < n; i++) {
+        if (ids[i] < 0 || ids[i] >= (int)o->mesher.verts.size()) return IMMESH_E_INVAL;
+        o->mesher.smooth_pts(ids[i], smooth_factor, knn, max_dis, out_xyz + (size_t)i * 3);
+    }
+    return 0;
+}
+int orc_mesh_display_vertices(void* p, const int32_t* ids, int32_t n, double smooth_factor, int32_t knn, double max_dis, float* out_xyz) {
+    OrcCtx* o = (OrcCtx*)p;
+    for (int i = 0; i < n; i++) {
+        if (ids[i] < 0 || ids[i] >= (int)o->mesher.verts.size()) return IMMESH_E_INVAL;
+        o->mesher.display_vertex(ids[i], smooth_factor, knn, max_dis, out_xyz + (size_t)i * 3);
+    }
+    return 0;
+}
 int orc_save_ply(void*, const char*, double, int32_t) { return -1; }   // file output is a product feature; the checker compares the arrays  // the checker is synchronous
 int orc_mesh_sizes(void* p, immesh_mesh_sizes_t* s) {
     OrcCtx* o = (OrcCtx*)p;
@@ -387,6 +403,14 @@ int orc_process_scan(void* p, const float* pts_down, int32_t n_ds, const float* 
     g_timing[0] = ms(t0, t3); g_timing[1] = ms(t0, t1); g_timing[2] = ms(t1, t2); g_timing[3] = ms(t2, t3);
     (void)frame_idx;
     return 0;
+}
+// the strided form of the same call (pcl-shaped clouds consumed in place): the checker unpacks and calls the packed form
+int orc_process_scan_strided(void* p, const void* pts_down, int32_t n_ds, int32_t down_stride, const void* pts_raw, int32_t n_raw, int32_t raw_stride, int32_t raw_int_off,
+                             const double* state_prior, double* state_inout, int32_t frame_idx, int32_t do_mesh, int32_t* n_iter_out, int32_t* n_match_out) {
+    std::vector<float> down((size_t)n_ds * 3), raw(do_mesh ? (size_t)n_raw * 4 : 0);
+    for (int i = 0; i < n_ds; i++) std::memcpy(&down[(size_t)i * 3], (const char*)pts_down + (size_t)i * down_stride, 12);
+    if (do_mesh) for (int i = 0; i < n_raw; i++) { std::memcpy(&raw[(size_t)i * 4], (const char*)pts_raw + (size_t)i * raw_stride, 12); std::memcpy(&raw[(size_t)i * 4 + 3], (const char*)pts_raw + (size_t)i * raw_stride + raw_int_off, 4); }
+    return orc_process_scan(p, down.data(), n_ds, do_mesh ? raw.data() : nullptr, n_raw, state_prior, state_inout, frame_idx, do_mesh, n_iter_out, n_match_out);
 }
 int orc_last_timing(void* p, float ms[4]) { (void)p; for (int i = 0; i < 4; i++) ms[i] = g_timing[i]; return 0; }
 

@@ -340,6 +340,32 @@ struct Mesher {
         }
     }
 
+    // ---- Global_map::smooth_pts (pointcloud_rgbd.cpp:932-958) for ONE vertex, as the renderer calls it (mesh_rec_display.cpp:86-90: smooth_factor =
+    // g_ply_smooth_factor, knn = g_ply_smooth_k, maximum_smooth_dis = g_kd_tree_accept_pt_dis): the knn nearest vertices of the WHOLE map, the first one
+    // (the vertex itself) skipped, those closer than maximum_smooth_dis (<= 0: 0.8 x the mesh voxel, :940-943) averaged; nobody close -> 0/0 = NaN.
+    // The reference also stores the value in the point (set_smooth_pos); here the function is const -- the caller's mirror does that.
+    void smooth_pts(int id, double smooth_factor, int knn_k, double maximum_smooth_dis, double out[3]) const {
+        if (maximum_smooth_dis <= 0) maximum_smooth_dis = cfg.mesh_voxel * 0.8;
+        const double* p = verts[id].pos;
+        const float q[3] = {(float)p[0], (float)p[1], (float)p[2]};
+        std::vector<NN> nn;
+        knn(q, knn_k, cfg.mesh_voxel * 1.25 * 2, nn);   // (what lies beyond the search radius 2.5 x voxel is beyond every maximum_smooth_dis the entry accepts)
+        double s[3] = {0, 0, 0}, valid = 0.0;
+        for (size_t k = 1; k < nn.size(); k++)
+            if ((double)std::sqrt(nn[k].d2) < maximum_smooth_dis) { for (int a = 0; a < 3; a++) s[a] += verts[nn[k].id].pos[a]; valid += 1.0; }
+        for (int a = 0; a < 3; a++) out[a] = p[a] * (1.0 - smooth_factor) + s[a] * smooth_factor / valid;
+    }
+    // RGB_pts::get_pos(1) as unparse_triangle_set_to_vector reads it (mesh_rec_display.cpp:86-98): a vertex the mesher has smoothed serves its
+    // m_pos_aft_smooth, any other is smoothed on the spot
+    void display_vertex(int id, double smooth_factor, int knn_k, double maximum_smooth_dis, float out[3]) const {
+        const MeshVertex& v = verts[id];
+        const bool smoothed = v.smooth[0] != v.pos[0] || v.smooth[1] != v.pos[1] || v.smooth[2] != v.pos[2];
+        double o[3];
+        if (smoothed) { o[0] = v.smooth[0]; o[1] = v.smooth[1]; o[2] = v.smooth[2]; }
+        else smooth_pts(id, smooth_factor, knn_k, maximum_smooth_dis, o);
+        for (int a = 0; a < 3; a++) out[a] = (float)o[a];
+    }
+
     size_t live_triangle_count() const {
         size_t s = 0;
         for (const auto& kv : adj) s += kv.second.size();

@@ -197,6 +197,16 @@ def run_drop_in_async(make_direct, libname, lockstep, shadow=None, queue_depth=N
         n_last = len(scans[-1][1])
         ep, en = np.zeros((n_last, 3), np.float32), np.zeros((n_last, 4), np.float32)
         n_eff = lib.dropin_effect_features(d, ep.ctypes.data_as(C.c_void_p), en.ctypes.data_as(C.c_void_p), n_last)
+        # a simulated renderer pass over the mirror (unparse_triangle_set_to_vector, mesh_rec_display.cpp:78-103): every unsmoothed vertex of a live triangle
+        # through the shim's Global_map::smooth_pts (one vertex per call, as the unchanged renderer would) -- no NaN in the GL buffer (the reference's body would
+        # search a host ikd-Tree the drop-in never feeds), and the buffer equals what ONE immesh_mesh_display_vertices call returns
+        lib.dropin_render_pass.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64]
+        rp = np.zeros(4, np.int64)
+        assert lib.dropin_render_pass(d, 1.0, 20.0, 1.25 * cfg.mesh_voxel, rp.ctypes.data_as(C.c_void_p), None, 0) == 0
+        assert rp[0] > 3000 and rp[1] > 0 and rp[2] == 0 and rp[3] == 0, rp
+        rp2 = np.zeros(4, np.int64)   # a second pass finds every vertex smoothed (m_smoothed is set by the first, as in the reference) and the same buffer
+        assert lib.dropin_render_pass(d, 1.0, 20.0, 1.25 * cfg.mesh_voxel, rp2.ctypes.data_as(C.c_void_p), None, 0) == 0
+        assert rp2[0] == rp[0] and rp2[1] == 0 and rp2[2] == 0, rp2
     finally:
         lib.dropin_destroy(d, 1)
         depth.value = depth_default
