@@ -11,6 +11,9 @@
 //                                                          compute_angle / is_face_is_ok, triangle_compare, delaunay_triangulation (everything around
 //                                                          the CGAL call), retrieve_neighbor_pts_kdtree, remove_outlier_pts, correct_triangle_index
 //                                                                                                                                    (a19, a20, a22, a23)
+//   src/meshing/r3live/pointcloud_rgbd.cpp:932-958         Global_map::smooth_pts (round 6): the renderer's / the PLY export's smoothing, on the REAL ikd-Tree   (8(f) rank 3)
+//   src/meshing/mesh_rec_geometry.cpp:71-131               save_to_ply_file (round 6), whole: vertices through smooth_pts, every live triangle of every region with
+//                                                          its winding; pcl::io::savePLYFileBinary is a recorder (the file format is PCL's, not the reference's)
 //   src/ImMesh_mesh_reconstruction.cpp:92-267              incremental_mesh_reconstruction, whole: the append step, the voxel selection, the per-voxel
 //                                                          pull / triangulate / compare / orient, the commit (all removes, then all adds)   (a25)
 // The excerpts are cut out by line range into _ref/gm_src/ at BUILD time (sed; the directory is removed after the compile), whole files are symlinked:
@@ -91,6 +94,22 @@ void correct_triangle_index( Triangle_ptr &ptr, const vec_3 &camera_center, cons
     t.flips.push_back( ref_gm::FlipCall{ { ptr->m_tri_pts_id[ 0 ], ptr->m_tri_pts_id[ 1 ], ptr->m_tri_pts_id[ 2 ] }, ( int ) ptr->m_index_flip, t.rank } );
 }
 #include "mr_incremental_mesh_reconstruction.inc"   // ImMesh_mesh_reconstruction.cpp:92-267
+#include "rgbd_smooth_pts.inc"                      // pointcloud_rgbd.cpp:932-958
+// ---- what save_to_ply_file touches of PCL's mesh I/O: shapes + a recorder (the checker compares arrays, not PCL's file writer)
+// (g_kd_tree_accept_pt_dis: the reference's own global, mesh_rec_geometry.cpp:335 in mg_neighbor_pts.inc; retrieve_neighbor_pts_kdtree sets it to 1.25 x the mesh voxel, :343)
+namespace pcl {
+struct PCLPointCloud2 { std::vector< float > xyz; };
+struct Vertices { std::vector< int > vertices; };
+struct PolygonMesh { PCLPointCloud2 cloud; std::vector< Vertices > polygons; };
+inline void toPCLPointCloud2( const PointCloud< PointXYZ > &c, PCLPointCloud2 &out ) { out.xyz.resize( c.points.size() * 3 ); for ( size_t i = 0; i < c.points.size(); i++ ) { out.xyz[ i * 3 ] = c.points[ i ].x; out.xyz[ i * 3 + 1 ] = c.points[ i ].y; out.xyz[ i * 3 + 2 ] = c.points[ i ].z; } }
+namespace io {
+struct PlyTap { std::vector< float > xyz; std::vector< int > faces; };
+inline PlyTap &ply_tap() { static PlyTap t; return t; }
+inline int savePLYFileBinary( const std::string &, const PolygonMesh &m ) { PlyTap &t = ply_tap(); t.xyz = m.cloud.xyz; t.faces.clear(); for ( const Vertices &v : m.polygons ) t.faces.insert( t.faces.end(), v.vertices.begin(), v.vertices.end() ); return 0; }
+inline int savePCDFileBinary( const std::string &, const PointCloud< PointXYZ > & ) { return 0; }
+} // namespace io
+} // namespace pcl
+#include "mg_save_to_ply.inc"                       // mesh_rec_geometry.cpp:71-131
 
 extern "C" {
 // ImMesh_node.cpp:255-272: the mesher's set-up from the launch parameters
@@ -162,4 +181,26 @@ int64_t rg_recent_voxels( int64_t *keys3, int32_t *state3, int64_t cap )
     return n;
 }
 int64_t rg_n_voxels() { return ( int64_t ) g_map_rgb_pts_mesh.m_voxel_vec.size(); }
+// Global_map::smooth_pts for one vertex, with what it stores in the point put back (the function under test is the value; a stored smoothed position
+// would change what the following frames' correct_triangle_index reads)
+void rg_smooth_pts( int id, double smooth_factor, double knn, double maximum_smooth_dis, double *out3 )
+{
+    RGB_pt_ptr &p = g_map_rgb_pts_mesh.m_rgb_pts_vec[ id ];
+    const bool was = p->m_smoothed; const double keep[ 3 ] = { p->m_pos_aft_smooth[ 0 ], p->m_pos_aft_smooth[ 1 ], p->m_pos_aft_smooth[ 2 ] };
+    const vec_3 v = g_map_rgb_pts_mesh.smooth_pts( p, smooth_factor, knn, maximum_smooth_dis );
+    for ( int k = 0; k < 3; k++ ) { out3[ k ] = v( k ); p->m_pos_aft_smooth[ k ] = keep[ k ]; }
+    p->m_smoothed = was;
+}
+// save_to_ply_file, whole (call it LAST: smooth_pts leaves every vertex smoothed); returns the number of faces, the arrays through rg_ply_fetch
+int64_t rg_save_ply( double smooth_factor, double knn )
+{
+    save_to_ply_file( std::string( "/dev/null" ), smooth_factor, knn );
+    return ( int64_t ) pcl::io::ply_tap().faces.size() / 3;
+}
+void rg_ply_fetch( float *xyz, int32_t *faces )
+{
+    pcl::io::PlyTap &t = pcl::io::ply_tap();
+    if ( xyz ) std::memcpy( xyz, t.xyz.data(), t.xyz.size() * 4 );
+    if ( faces ) for ( size_t i = 0; i < t.faces.size(); i++ ) faces[ i ] = t.faces[ i ];
+}
 }  // extern "C"

@@ -46,6 +46,7 @@ struct Global_map
     void set_minimum_dis( double minimum_dis );
     void set_voxel_resolution( double minimum_dis );
     Global_map( int = 1 ) { m_mutex_m_box_recent_hitted = std::make_shared< std::mutex >(); }   /* pointcloud_rgbd.cpp:269-275 (the vectors' reserve( 1e9 ) is not copied) */
+    vec_3 smooth_pts( RGB_pt_ptr &rgb_pt, double smooth_factor, double knn = 20, double maximum_smooth_dis = 0 );   /* pointcloud_rgbd.hpp:287 */
     template < typename T >
     int append_points_to_global_map( pcl::PointCloud< T > &pc_in, double added_time, std::vector< RGB_pt_ptr > *pts_added_vec = nullptr, int step = 1, int disable_append = 0 );
 };

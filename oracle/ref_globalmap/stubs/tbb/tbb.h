@@ -16,4 +16,7 @@ template < typename It, typename F > void parallel_for_each( It b, It e, F f )
     } );
     for ( const V &x : v ) f( x );
 }
+// tbb::parallel_for over a blocked_range (save_to_ply_file, mesh_rec_geometry.cpp:81-98): one sequential pass over the whole range
+template < typename T > struct blocked_range { T b_, e_; blocked_range( T b, T e, T = 1 ) : b_( b ), e_( e ) {} T begin() const { return b_; } T end() const { return e_; } };
+template < typename R, typename F > void parallel_for( const R &r, F f ) { f( r ); }
 } // namespace tbb

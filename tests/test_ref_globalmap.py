@@ -141,3 +141,56 @@ def test_frames_through_the_reference_mesher_equal_the_oracle(oracle_lib, tmp_pa
     assert len(live_r) > 3000 and n_rem_total > 50
     assert len(tolerated) < 0.05 * len(live_r)                           # and the order-dependent ones are a sliver
     print(f"{kind}: {len(pos_r)} vertices, {len(live_r)} live triangles, {n_rem_total} removals, {n_multi} order-dependent flips")
+
+
+def test_smooth_pts_and_save_to_ply_file_of_the_reference_equal_the_oracle(oracle_lib, tmp_path):
+    """SURVEY 8(f) rank 3, pinned (round 6): Global_map::smooth_pts (pointcloud_rgbd.cpp:932-958, on the REAL ikd-Tree) and save_to_ply_file
+    (mesh_rec_geometry.cpp:71-131, whole; PCL's file writer is a recorder) against the oracle's smooth_pts / export_mesh after the same frames."""
+    cfg = capi.avia_config()
+    hp = make_oracle(oracle_lib, cfg)
+    lib = _load_fresh(tmp_path)
+    lib.rg_smooth_pts.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, VP]
+    lib.rg_save_ply.restype = C.c_int64; lib.rg_save_ply.argtypes = [C.c_double, C.c_double]
+    lib.rg_ply_fetch.argtypes = [VP, VP]
+    n_frames = 4
+    lib.rg_init(cfg.mesh_min_spacing, cfg.mesh_voxel, cfg.mesh_region, cfg.mesh_append_budget, n_frames)
+    for k in range(n_frames):
+        w, R, t = _scan_world("avia", k, 12000)      # a thin stream: plenty of frontier voxels with one or two vertices (never smoothed by the mesher)
+        hp.mesh_scan(w, t, frame_idx=k)
+        lib.rg_frame(_p(w), len(w), _p(np.ascontiguousarray(R)), _p(np.ascontiguousarray(t)), k)
+    nv = lib.rg_n_vertices()
+    assert nv == hp.counters()["n_vertices"] > 5000
+    accept = 1.25 * cfg.mesh_voxel
+    # -- smooth_pts: the renderer's parameters, a partial factor, the "<= 0 -> 0.8 x voxel" default, a wide radius; every vertex of the map
+    ids = np.arange(nv, dtype=np.int32)
+    for factor, max_dis in ((1.0, accept), (0.3, accept), (1.0, 0.0), (1.0, 2.0 * accept)):
+        so = hp.smooth_pts(ids, factor, 20, max_dis)
+        sr = np.zeros((nv, 3))
+        one = np.zeros(3)
+        for i in range(nv):
+            lib.rg_smooth_pts(i, factor, 20.0, max_dis, _p(one)); sr[i] = one
+        assert np.array_equal(np.isnan(so), np.isnan(sr))                  # nobody within reach -> 0/0 on both sides
+        assert np.isnan(sr).any(axis=1).sum() < nv // 2
+        np.testing.assert_allclose(np.nan_to_num(so), np.nan_to_num(sr), rtol=0, atol=1e-12)
+    # ... and the call left nothing behind (the wrapper puts the stored value back): the maps still agree
+    pos_r, sm_r = _ref_vertices(lib); pos_o, sm_o = _orc_vertices(oracle_lib, hp)
+    np.testing.assert_array_equal(pos_r, pos_o)
+    np.testing.assert_allclose(sm_r, sm_o, rtol=0, atol=1e-12)
+    # -- save_to_ply_file: vertices (float, smoothed with g_kd_tree_accept_pt_dis) and faces with their winding; the reference walks its region
+    #    buckets, the oracle orders by sorted triplet: compared as sets of rows
+    for factor in (0.0, 1.0):                                               # (1.0 last: the reference's smooth_pts stores its result in every point)
+        vo, fo = hp.mesh_export(factor, 20)
+        nf = lib.rg_save_ply(factor, 20.0)
+        vr, fr = np.zeros((nv, 3), np.float32), np.zeros((max(nf, 1), 3), np.int32)
+        lib.rg_ply_fetch(_p(vr), _p(fr))
+        assert nf == len(fo) > 5000
+        assert np.array_equal(np.isnan(vo), np.isnan(vr))
+        np.testing.assert_array_equal(np.nan_to_num(vo), np.nan_to_num(vr))  # the same doubles cast to float
+        # the same triangles; the winding of a face is its m_index_flip, equal except where the reference itself is order-dependent (a triangle two voxels
+        # add in one frame with different orientations -- the module docstring; test_frames_through_the_reference_mesher_equal_the_oracle checks those
+        # against the reference's own correct_triangle_index calls): a handful, never the rule
+        wr = {tuple(sorted(f)): tuple(f) for f in fr[:nf].tolist()}; wo = {tuple(sorted(f)): tuple(f) for f in fo.tolist()}
+        assert wr.keys() == wo.keys() and len(wr) == nf
+        even = lambda a, b: (a.index(b[0]) - 0) % 3 == 0 and a[(a.index(b[0]) + 1) % 3] == b[1]   # same cyclic order
+        n_other = sum(0 if even(wr[k], wo[k]) else 1 for k in wr)
+        assert n_other <= nf // 200, (n_other, nf)           # (61 of 28 124 on this stream)
