@@ -465,10 +465,19 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
 
 // Candidate i is accepted iff no ACCEPTED candidate j < i shares its cell or lies within min_spacing: exactly the sequential
 // loop's outcome.  Each lane re-evaluates until every lower-index conflicting candidate is decided (bounded; relaunched by the host).
+// Round 6: the FIRST evaluation of a candidate walks the 27 cells around it (three batches of nine lookups + the chains under them: tens of dependent
+// round trips) and keeps the conflicting lower-index candidates that were not decided yet in a per-thread list in LDS; every later evaluation only polls
+// those candidates' status words -- one round trip.  On fresh ground the "lowest scan index wins" chains are long (a survey lattice offered in row order:
+// every accepted point decides its neighbour, which decides the next -- hundreds of rounds), and every round used to repeat the whole walk: 1.2 ms
+// average over the bench's seeding packages, 4-6 ms at worst.  The candidate set under the cells does not change during a launch and a status only
+// moves from UNDECIDED to a final value, so the cached list decides exactly what the walk would.
+#define RC_MAX 14   /* cached undecided conflicts per candidate (more: the candidate keeps walking) */
 __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, const float* __restrict__ pts_arg, int max_iter) {
     MESH_DYN(m_in);
+    __shared__ int s_conf[RC_MAX][256];
     const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = threadIdx.x;
     const bool sharded = m.shard_world > 1;
     // Lanes of one wavefront may depend on each other, so the decision store must happen INSIDE the loop body and the loop must be left
     // by the whole wavefront together (__all): with a per-lane `return` the compiler may sink the store to the loop exit, which the
@@ -485,45 +494,68 @@ __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, 
         gx = rnd_cell(px, m.min_spacing); gy = rnd_cell(py, m.min_spacing); gz = rnd_cell(pz, m.min_spacing);
         own = m.cand_cell[i];
     }
+    int n_conf = -1;   // -1: not walked yet; >= 0: the cached list is complete; -2: more than RC_MAX undecided conflicts (keeps walking)
     for (int iter = 0; iter < max_iter; iter++) {
         if (my == ST_UNDECIDED) {
             bool rej = false, blocked = false, blocked_remote = false;
-            for (int dx = -1; dx <= 1 && !rej; dx++) {
-                unsigned long long key9[9], k9[9], h9[9];
-                int hd9[9];
+            if (n_conf >= 0) {
+                // ---- later rounds: poll the cached conflicts (all loads in flight together)
+                int sj[RC_MAX];
 #pragma unroll
-                for (int q = 0; q < 9; q++) {  // 9 independent cell lookups in flight
-                    key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
-                    h9[q] = hash64(key9[q]) & m.ch_mask;
-                    k9[q] = m.ch_keys[h9[q]];
-                    hd9[q] = m.ch_head[h9[q]];
-                }
+                for (int k = 0; k < RC_MAX; k++) sj[k] = k < n_conf ? ld_agent(&m.cand_status[s_conf[k][tid]]) : ST_REJECT;
 #pragma unroll
-                for (int q = 0; q < 9; q++) {
-                    int head = -1;
-                    if (k9[q] == key9[q]) head = hd9[q];
-                    else if (k9[q] != MKEY_EMPTY) { const long long s2 = h_find(m.ch_keys, m.ch_mask, key9[q]); if (s2 >= 0) head = m.ch_head[s2]; }
-                    for (int j = head; j >= 0 && !rej;) {
-                        const int nxt = m.cand_next[j];
-                        const int sj = ld_agent(&m.cand_status[j]);
-                        const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
-                        if (j < i && sj != ST_REJECT) {
-                            const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
-                            if (conflict) {
-                                if (sj == ST_ACCEPT) rej = true;
-                                else if (sj == ST_WAIT || (sharded && !(m.cand_flags[j] & CF_OWN))) blocked_remote = true;   // nothing in THIS launch will decide j
-                                else blocked = true;
-                            }
-                        }
-                        j = nxt;
+                for (int k = 0; k < RC_MAX; k++) {
+                    if (k < n_conf && sj[k] != ST_REJECT) {
+                        if (sj[k] == ST_ACCEPT) rej = true;
+                        else if (sj[k] == ST_WAIT || (sharded && !(m.cand_flags[s_conf[k][tid]] & CF_OWN))) blocked_remote = true;
+                        else blocked = true;
                     }
                 }
+            } else {
+                int nc = 0;
+                bool over = false;
+                for (int dx = -1; dx <= 1 && !rej; dx++) {
+                    unsigned long long key9[9], k9[9], h9[9];
+                    int hd9[9];
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {  // 9 independent cell lookups in flight
+                        key9[q] = mkey(gx + dx, gy + (q / 3 - 1), gz + (q % 3 - 1));
+                        h9[q] = hash64(key9[q]) & m.ch_mask;
+                        k9[q] = m.ch_keys[h9[q]];
+                        hd9[q] = m.ch_head[h9[q]];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; q++) {
+                        int head = -1;
+                        if (k9[q] == key9[q]) head = hd9[q];
+                        else if (k9[q] != MKEY_EMPTY) { const long long s2 = h_find(m.ch_keys, m.ch_mask, key9[q]); if (s2 >= 0) head = m.ch_head[s2]; }
+                        for (int j = head; j >= 0 && !rej;) {
+                            const int nxt = m.cand_next[j];
+                            const int sj = ld_agent(&m.cand_status[j]);
+                            const float4 qv = *(const float4*)(pts + 4 * (size_t)j * sp.step);
+                            if (j < i && sj != ST_REJECT) {
+                                const bool conflict = (key9[q] == own) || ((double)sqrtf(dist2f(px, py, pz, qv.x, qv.y, qv.z)) < m.min_spacing);
+                                if (conflict) {
+                                    if (sj == ST_ACCEPT) rej = true;
+                                    else {
+                                        if (sj == ST_WAIT || (sharded && !(m.cand_flags[j] & CF_OWN))) blocked_remote = true;   // nothing in THIS launch will decide j
+                                        else blocked = true;
+                                        if (nc < RC_MAX) s_conf[nc][tid] = j; else over = true;
+                                        nc++;
+                                    }
+                                }
+                            }
+                            j = nxt;
+                        }
+                    }
+                }
+                n_conf = over ? -2 : nc;   // (a walk cut short by a rejection leaves a partial list behind: the candidate is decided, nobody reads it)
             }
             if (rej) my = ST_REJECT; else if (!blocked && !blocked_remote) my = ST_ACCEPT; else if (!blocked) my = ST_WAIT;
             if (my != ST_UNDECIDED) st_agent(&m.cand_status[i], my);
         }
         if (__all(my != ST_UNDECIDED)) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
     }
     if (my == ST_UNDECIDED) atomicAdd(&m.sc[SC_UNDECIDED], 1);
 }

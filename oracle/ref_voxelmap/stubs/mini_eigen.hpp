@@ -54,6 +54,9 @@ template <typename T, int R, int C, int BR, int BC> struct BlockRef {   // writa
     }
     typename real_of<T>::type norm() const { return eval().norm(); }
     void setZero() { for (int i = 0; i < BR; i++) for (int j = 0; j < BC; j++) m(r0 + i, c0 + j) = T(0); }
+    // `.block< 3, 3 >( r, c ).diagonal() = v` (IMU_Processing.cpp:536-537, 857-860): a writable view of the block's diagonal
+    struct DiagRef { Matrix<T, R, C>& m; int r0, c0; template <int SR, int SC> DiagRef& operator=(const Matrix<T, SR, SC>& s) { static_assert(SR * SC == (BR < BC ? BR : BC), "diagonal assignment: size mismatch"); for (int i = 0; i < SR * SC; i++) m(r0 + i, c0 + i) = s.a[i]; return *this; } };
+    DiagRef diagonal() { return DiagRef{m, r0, c0}; }
     // (only inside the reference's `if ( 0 )` degeneracy print, voxel_mapping.cpp:1601-1607: has to compile, never runs)
     Matrix<std::complex<T>, BR, 1> eigenvalues() const { std::abort(); }
 };
@@ -109,6 +112,8 @@ template <typename T, int R, int C> struct Matrix {
         template <int BR, int BC> operator Matrix<T, BR, BC>() const { if (BR != nr || BC != nc) std::abort(); Matrix<T, BR, BC> o; for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) o(i, j) = m(r0 + i, c0 + j); return o; }
     };
     DynBlock block(int r0, int c0, int nr, int nc) { return DynBlock{*this, r0, c0, nr, nc}; }
+    // v.asDiagonal() (IMU_Processing.cpp:858): the dense diagonal matrix -- a product with it adds exact zeros to what Eigen's diagonal product computes
+    Matrix<T, R * C, R * C> asDiagonal() const { Matrix<T, R * C, R * C> o; for (int i = 0; i < R * C; i++) for (int j = 0; j < R * C; j++) o(i, j) = i == j ? a[i] : T(0); return o; }
     Matrix<T, (R < C ? R : C), 1> diagonal() const { Matrix<T, (R < C ? R : C), 1> o; for (int i = 0; i < R && i < C; i++) o.a[i] = (*this)(i, i); return o; }
     typename real_of<T>::type squaredNorm() const { typename real_of<T>::type s = 0; for (int i = 0; i < R * C; i++) s += std::norm(a[i]); return s; }
     typename real_of<T>::type norm() const { return std::sqrt(squaredNorm()); }

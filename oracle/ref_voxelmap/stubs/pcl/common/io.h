@@ -14,6 +14,10 @@ template <typename T> struct PointCloud {
     size_t size() const { return points.size(); }
     void clear() { points.clear(); }
     void push_back(const T& p) { points.push_back(p); }
+    void reserve(size_t n) { points.reserve(n); }
+    void resize(size_t n) { points.resize(n); }
+    T& operator[](size_t i) { return points[i]; }
+    const T& operator[](size_t i) const { return points[i]; }
     Ptr makeShared() const { return Ptr(new PointCloud<T>(*this)); }
 };
 }  // namespace pcl
