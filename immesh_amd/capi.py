@@ -31,12 +31,28 @@ def one_hip_runtime():
       where it cannot be tried beforehand (this container has no multi-GPU box);
     * torch already imported by the caller: its copy is the process's runtime; nothing to do.
 
+    IMMESH_RUNTIME = system | torch | none overrides the choice: ``none`` leaves the loader alone -- for an application that embeds this
+    binding next to its own torch and does not want the system ROCm mapped under torch's file names; ``torch`` / ``system`` force one of the two
+    arrangements above.  This is loader policy of the TEST / BENCH binding only: the product (libimmesh_hip.so behind include/immesh_c_api.h, loaded by a
+    C++ node) does none of it.
+
     Returns the runtime files mapped."""
     global RUNTIME_CHOICE
+    forced = os.environ.get("IMMESH_RUNTIME", "").strip().lower()
+    if forced == "none":
+        RUNTIME_CHOICE = "untouched (IMMESH_RUNTIME=none)"
+        return mapped_hip_runtimes()
+    if forced == "torch" and "torch" not in sys.modules:
+        RUNTIME_CHOICE = "torch (IMMESH_RUNTIME=torch)"
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        return mapped_hip_runtimes()
     if "torch" in sys.modules:
         RUNTIME_CHOICE = "torch (imported before the binding)"
     else:
-        if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("IMMESH_SYSTEM_RUNTIME", "") != "1":
+        if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 and os.environ.get("IMMESH_SYSTEM_RUNTIME", "") != "1" and forced != "system":
             RUNTIME_CHOICE = "torch (rank of a multi-GPU job)"
             try:
                 import torch  # noqa: F401
@@ -96,7 +112,7 @@ PLANE_DTYPE = np.dtype([("key", "<i8", 3), ("layer", "<i4"), ("path", "<i4"), ("
 assert PLANE_DTYPE.itemsize == C.sizeof(PlaneRec)
 
 COUNTER_FIELDS = ("n_ds", "n_iter", "n_match", "n_plane_tests", "n_extra_probe", "n_refits", "n_refit_pts", "n_app", "n_new", "v_act",
-                  "n_v", "n_u", "t_v", "t_add", "t_rem", "c1", "c20", "n_root_voxels", "n_nodes", "n_vertices", "n_triangles_live")
+                  "n_v", "n_u", "t_v", "t_add", "t_rem", "c1", "c20", "n_root_voxels", "n_nodes", "n_vertices", "n_triangles_live", "n_degenerate_skips")
 
 
 class KernelStat(C.Structure):

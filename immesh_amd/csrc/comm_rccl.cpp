@@ -5,6 +5,7 @@
 //   * sharded mesher: ncclAllGather of the exchange records (smoothed boundary-band vertices, triangle marks).
 // librccl.so is opened at immesh_rccl_init: a single-GPU process never loads it.  xGMI note: every message here is <= a few hundred KB, so
 // the collectives are latency-bound (one ring step per peer over point-to-point links), never link-bound.
+#include <algorithm>
 #include "host_ctx.hpp"
 #include <dlfcn.h>
 #include <cstdint>
@@ -123,33 +124,44 @@ int immesh_rccl_init(immesh_ctx* c, const uint8_t id_in[128]) {
 int immesh_broadcast_scan(immesh_ctx* c, const float* pts, int32_t n, int32_t stride, int32_t root, const float** dev_out, int32_t* n_out) {
     if (!c || !dev_out || !n_out) return IMMESH_E_INVAL;
     const int world = c->cfg.shard_world > 1 ? c->cfg.shard_world : 1, me = c->cfg.shard_world > 1 ? c->cfg.shard_rank : 0;
+    // (local argument errors every rank would see alike -- the same call on every rank -- may return before the collective)
     if (root < 0 || root >= world) { c->err = "immesh_broadcast_scan: root outside the job"; return IMMESH_E_INVAL; }
-    const bool am_root = me == root;
-    if (am_root && (!pts || n <= 0 || n > c->cap_scan || (stride != 3 && stride != 4))) { c->err = "immesh_broadcast_scan: the root's scan is empty, too large (cap_scan_points) or not 3 / 4 floats per point"; return IMMESH_E_INVAL; }
+    const bool stub = c->rccl_comm == RCCL_STUB;
+    // stubbed collectives (one process standing in for one rank of the job, bench.py's dry run): nobody sends, so EVERY rank must be handed the scan
+    const bool am_root = me == root || stub;
+    const bool use_rccl = c->rccl_comm && !stub;
+    if (world > 1 && !use_rccl && !stub && !c->mesh_host.allgather) { c->err = "immesh_broadcast_scan: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
     (void)hipSetDevice(c->cfg.device);
     hipStream_t s = c->stream;
-    for (int k = 0; k < 2; k++)
-        if (!c->d_bcast[k]) { const int arc = c->dalloc(&c->d_bcast[k], (size_t)c->cap_scan * (k ? 4 : 3)); if (arc) return arc; }
-    if (!c->d_bcast_hdr) { const int arc = c->dalloc(&c->d_bcast_hdr, 4); if (arc) return arc; }
-    int32_t hdr[4] = {am_root ? n : 0, am_root ? stride : 0, 0, 0};
-    const bool use_rccl = c->rccl_comm && c->rccl_comm != RCCL_STUB;
-    std::vector<char> gathered;
-    if (world > 1 && !use_rccl && c->rccl_comm != RCCL_STUB) {
-        if (!c->mesh_host.allgather) { c->err = "immesh_broadcast_scan: no collective registered (immesh_rccl_init or immesh_set_allgather)"; return IMMESH_E_INVAL; }
-        gathered.resize((size_t)world * 16);
-        if (c->mesh_host.allgather(hdr, 16, gathered.data(), c->mesh_host.allgather_user)) { c->err = "all-gather callback failed"; return IMMESH_E_INVAL; }
-        std::memcpy(hdr, gathered.data() + (size_t)root * 16, 16);
-    } else if (use_rccl) {
+    // two buffers per layout, used in turn: the buffer handed out by broadcast k is written again by broadcast k + 2 -- a mesh job that reads scan k
+    // asynchronously (immesh_mesh_scan / an asynchronous immesh_process_scan on it) has one whole scan of slack; the header says so
+    for (int k = 0; k < 4; k++)
+        if (!c->d_bcast[k]) { const int arc = c->dalloc(&c->d_bcast[k], (size_t)c->cap_scan * ((k & 1) ? 4 : 3)); if (arc) return arc; }
+    if (!c->d_bcast_hdr) { const int arc = c->dalloc(&c->d_bcast_hdr, 4 * 65); if (arc) return arc; }
+    // ---- header: an ALL-GATHER every rank takes part in whatever it was handed (a root that returned on a bad scan before the collective left
+    // the other ranks blocked in it; a rank too small for the scan returned while the root went on to the payload).  Each rank contributes
+    // {points (root: n, or -1 for an unusable scan; others 0), floats per point, its cap_scan_points, 0}; all ranks then take the SAME decision.
+    const bool root_ok = pts && n > 0 && n <= c->cap_scan && (stride == 3 || stride == 4);
+    int32_t hdr[4] = {me == root || stub ? (root_ok ? n : -1) : 0, me == root || stub ? stride : 0, (int32_t)std::min<int64_t>(c->cap_scan, 0x7fffffff), 0};
+    std::vector<int32_t> all((size_t)world * 4, 0);
+    if (world == 1 || stub) { for (int r = 0; r < world; r++) std::memcpy(&all[(size_t)r * 4], hdr, 16); }
+    else if (use_rccl) {
         HIPCHK(c, hipMemcpyAsync(c->d_bcast_hdr, hdr, 16, hipMemcpyHostToDevice, s));
-        const int rc = g_rccl.broadcast(c->d_bcast_hdr, c->d_bcast_hdr, 16, RCCL_INT8, root, c->rccl_comm, s);
-        if (rc) { c->err = "ncclBroadcast: " + rccl_why(rc); return IMMESH_E_HIP; }
-        c->rccl_calls++;
-        HIPCHK(c, hipMemcpyAsync(hdr, c->d_bcast_hdr, 16, hipMemcpyDeviceToHost, s));
+        std::string err;
+        const int rc = rccl_allgather_bytes(c, c->d_bcast_hdr, c->d_bcast_hdr + 4, 16, s, &err);
+        if (rc) { c->err = err; return rc; }
+        HIPCHK(c, hipMemcpyAsync(all.data(), c->d_bcast_hdr + 4, (size_t)world * 16, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
+    } else {
+        if (c->mesh_host.allgather(hdr, 16, all.data(), c->mesh_host.allgather_user)) { c->err = "all-gather callback failed"; return IMMESH_E_INVAL; }
     }
-    const int32_t np = hdr[0], st = hdr[1];
-    if (np <= 0 || np > c->cap_scan || (st != 3 && st != 4)) { c->err = "immesh_broadcast_scan: bad header from the root (its scan exceeds this rank's cap_scan_points?)"; return IMMESH_E_CAPACITY; }
-    float* buf = c->d_bcast[st == 4 ? 1 : 0];
+    const int32_t np = all[(size_t)root * 4], st = all[(size_t)root * 4 + 1];
+    if (np <= 0 || (st != 3 && st != 4)) { c->err = "immesh_broadcast_scan: the root's scan is empty, larger than its cap_scan_points or not 3 / 4 floats per point"; return IMMESH_E_INVAL; }
+    for (int r = 0; r < world; r++)
+        if (all[(size_t)r * 4 + 2] < np) { c->err = "immesh_broadcast_scan: the scan exceeds the cap_scan_points of rank " + std::to_string(r); return IMMESH_E_CAPACITY; }
+    // ---- payload
+    const int par = (c->bcast_parity ^= 1);
+    float* buf = c->d_bcast[2 * par + (st == 4 ? 1 : 0)];
     const size_t bytes = (size_t)np * st * sizeof(float);
     if (am_root) {
         hipPointerAttribute_t attr;
@@ -161,10 +173,9 @@ int immesh_broadcast_scan(immesh_ctx* c, const float* pts, int32_t n, int32_t st
         const int rc = g_rccl.broadcast(buf, buf, bytes, RCCL_INT8, root, c->rccl_comm, s);
         if (rc) { c->err = "ncclBroadcast: " + rccl_why(rc); return IMMESH_E_HIP; }
         c->rccl_calls++;
-    } else if (world > 1 && c->rccl_comm != RCCL_STUB) {
-        std::vector<char> send(bytes, 0);
+    } else if (world > 1 && !stub) {
+        std::vector<char> send(bytes, 0), gathered((size_t)world * bytes);
         if (am_root) { HIPCHK(c, hipMemcpyAsync(send.data(), buf, bytes, hipMemcpyDeviceToHost, s)); HIPCHK(c, hipStreamSynchronize(s)); }
-        gathered.resize((size_t)world * bytes);
         if (c->mesh_host.allgather(send.data(), (int64_t)bytes, gathered.data(), c->mesh_host.allgather_user)) { c->err = "all-gather callback failed"; return IMMESH_E_INVAL; }
         if (!am_root) { HIPCHK(c, hipMemcpyAsync(buf, gathered.data() + (size_t)root * bytes, bytes, hipMemcpyHostToDevice, s)); HIPCHK(c, hipStreamSynchronize(s)); }
     }

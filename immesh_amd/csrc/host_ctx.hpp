@@ -118,8 +118,9 @@ struct immesh_ctx {
 
     KProf prof;
     void* rccl_comm = nullptr;       // ncclComm_t of a sharded context after immesh_rccl_init (comm_rccl.cpp); null: host callbacks
-    float* d_bcast[2] = {nullptr, nullptr};   // immesh_broadcast_scan: the scan as every rank holds it ([0] stride 3, [1] stride 4; cap_scan points each, first use)
-    int32_t* d_bcast_hdr = nullptr;           // ... and its 16-byte header {points, stride}
+    float* d_bcast[4] = {nullptr, nullptr, nullptr, nullptr};   // immesh_broadcast_scan: the scan as every rank holds it ([2 parity + 0] stride 3, [2 parity + 1] stride 4; cap_scan points each, first use; two parities used in turn)
+    int bcast_parity = 0;
+    int32_t* d_bcast_hdr = nullptr;           // ... and its headers: this rank's 16 bytes {points, stride, cap_scan, -}, then every rank's (all-gather)
     std::atomic<int64_t> rccl_calls{0};   // (counted from the scan thread and from the mesher's worker thread)
 
     // cumulative counters (host side)

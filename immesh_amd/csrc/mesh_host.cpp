@@ -475,7 +475,7 @@ static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes
     h.cum[SC_ACCEPTED] += n_new; h.cum[SC_ACTIVE] += n_active; h.cum[SC_C1] += h.h_sc[SC_C1];
     h.cum[SC_RECENT] += n_cand;  // n_app: candidates offered
     h.cum[SC_ADD] += sizes.n_add; h.cum[SC_REM] += sizes.n_rem; h.cum[SC_C20] += h.h_sc[SC_C20]; h.cum[SC_NV] += h.h_sc[SC_NV];
-    h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV];
+    h.cum[SC_NU] += h.h_sc[SC_NU]; h.cum[SC_TV] += h.h_sc[SC_TV]; h.cum[SC_DEGEN] += h.h_sc[SC_DEGEN];
     h.n_live += sizes.n_add - sizes.n_rem;   // (sharded: the triangles this rank reports -- the ranks' counts add up to the serial one)
     h.cum[SC_MAXNU] = std::max<int64_t>(h.cum[SC_MAXNU], h.h_sc[SC_MAXNU]); h.cum[SC_PASS2] += h.h_sc[SC_PASS2];
     if (m.dbg) {
@@ -646,7 +646,7 @@ void mesh_counters(immesh_ctx* c, immesh_counters_t* out) {
     mesh_wait_all(c);
     const MeshHost& h = c->mesh_host;
     out->n_app = h.cum[SC_RECENT]; out->n_new = h.cum[SC_ACCEPTED]; out->v_act = h.cum[SC_ACTIVE]; out->n_v = h.cum[SC_NV]; out->n_u = h.cum[SC_NU];
-    out->t_v = h.cum[SC_TV]; out->t_add = h.cum[SC_ADD]; out->t_rem = h.cum[SC_REM]; out->c1 = h.cum[SC_C1]; out->c20 = h.cum[SC_C20];
+    out->t_v = h.cum[SC_TV]; out->t_add = h.cum[SC_ADD]; out->t_rem = h.cum[SC_REM]; out->c1 = h.cum[SC_C1]; out->c20 = h.cum[SC_C20]; out->n_degenerate_skips = h.cum[SC_DEGEN];
     out->n_vertices = h.n_vertices; out->n_triangles_live = h.n_live;
 }
 void mesh_counters_reset(immesh_ctx* c) { mesh_wait_all(c); std::memset(c->mesh_host.cum, 0, sizeof(c->mesh_host.cum)); }
@@ -830,15 +830,16 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
     size_t total = 0;
     for (const Part& q : parts) if (q.dst && q.bytes) total += (q.bytes + 63) & ~(size_t)63;
     if (total == 0) return 0;
-    {
-        std::lock_guard<std::mutex> lk(h.mu);   // (one fetch at a time uses the staging block: the service thread's)
-        if (total > h.h_fetch_bytes) {
-            if (h.h_fetch) (void)hipHostFree(h.h_fetch);
-            h.h_fetch = nullptr; h.h_fetch_bytes = 0;
-            const size_t want = total + total / 2 + (1 << 16);
-            if (hipHostMalloc((void**)&h.h_fetch, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc(fetch staging)"; return IMMESH_E_NOMEM; }
-            h.h_fetch_bytes = want;
-        }
+    // The staging block is shared: fetch_mu is held from its (re)allocation to the last memcpy out of it -- two fetches on one context (a scan thread and a
+    // service thread) take turns instead of overwriting each other's lists or freeing the block the other copies from.  Not h.mu: the
+    // mesher's worker needs that one, and a hipHostFree under it would stall the pipeline.
+    std::lock_guard<std::mutex> lf(h.fetch_mu);
+    if (total > h.h_fetch_bytes) {
+        if (h.h_fetch) (void)hipHostFree(h.h_fetch);
+        h.h_fetch = nullptr; h.h_fetch_bytes = 0;
+        const size_t want = total + total / 2 + (1 << 16);
+        if (hipHostMalloc((void**)&h.h_fetch, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc(fetch staging)"; return IMMESH_E_NOMEM; }
+        h.h_fetch_bytes = want;
     }
     size_t off = 0;
     for (const Part& q : parts)

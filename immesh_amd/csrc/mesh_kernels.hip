@@ -1397,6 +1397,7 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
             nt = 4;
             __syncthreads();
             bool fail = false;
+            int n_skip = 0;
 
             const unsigned long long* tri64 = (const unsigned long long*)tri;
             int pin = (int)(keys[0] & 0xFFFF);
@@ -1429,7 +1430,7 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
                     }
                     ncav += __popcll(mask);
                 }
-                if (ncav == 0) continue;  // duplicate / on every circle: not inserted
+                if (ncav == 0) { n_skip++; continue; }  // duplicate / on every circle: not inserted
                 if (ncav > DT_CAV_CAP) { fail = true; break; }
                 __syncthreads();
                 int ne = 3 * ncav;
@@ -1566,6 +1567,7 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
                 __syncthreads();
             }
             if (fail) { if (lane == 0) m.sc[SC_OVERFLOW] = 12; nt = 0; }
+            else if (n_skip && threadIdx.x == 0) atomicAdd(&m.sc[SC_DEGEN], n_skip);
         }
         DBG_T(3);
         // ---- finite faces that pass the skinny-face filter (is_face_is_ok: every interior angle * 57.3 <= 150) as sorted local triplets

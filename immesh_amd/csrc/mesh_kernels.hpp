@@ -35,6 +35,7 @@ enum {
     SC_ADD_OWN, SC_REM_OWN, SC_UPD_OWN,   /* sharded mesher: entries of the result lists this rank REPORTS (the lists it commits also hold its halo) */
     SC_SMOOTH_RX,    /* sharded mesher: smoothed positions received from other ranks this scan */
     SC_XBYTES,       /* sharded mesher: payload bytes this rank contributed to the scan's exchanges */
+    SC_DEGEN,        /* neighbourhood points the triangulations of this scan did not insert (no circumdisk contains them: immesh_counters_t::n_degenerate_skips) */
     SC_COUNT = 24
 };
 // persistent device counters (MeshDev::pc)
@@ -163,6 +164,7 @@ struct MeshHost {
     // overwrite the result buffers of a job not yet collected (id - 2) waits -- nothing is dropped
     bool collect_on = false;
     long collected = 0;
+    std::mutex fetch_mu;                     // immesh_mesh_fetch's staging block: one fetch at a time, from allocation to the last memcpy
     char* h_fetch = nullptr; size_t h_fetch_bytes = 0;   // immesh_mesh_fetch: pinned staging (the lists land here by DMA, all copies in flight together, then one memcpy each into the caller's pageable buffers)
     hipStream_t stream_fetch = nullptr;      // immesh_mesh_fetch's copies: a stream of their own, so that a service thread can fetch while the scan thread enqueues
     bool stop = false;

@@ -85,9 +85,11 @@ IMD int sym21_index(int r, int c) {  // r <= c, 6x6 upper triangle row-major
 
 // ---- sharding ---------------------------------------------------------------------------------------------------
 // owner of brick (bx, by, bz) -- ONE function for the registration map, the mesher and the host mirror (immesh_shard_owner): scheme 0 = lattice colouring
-// (bx + 3 by + 5 bz) mod P, scheme 1 = hash(brick) mod P (immesh_config::shard_scheme)
+// (bx + 3 by + 5 bz) mod P, scheme 1 = hash(brick) mod P (immesh_config::shard_scheme).  The colouring deals every axis out over ALL ranks only while 1, 3
+// and 5 are units mod P: for a world divisible by 3 or 5 one axis would drop out (P = 3: every brick along y the same owner), so such worlds use the hash
+// whatever the scheme says.
 IMD int brick_owner(int scheme, int world, int64_t bx, int64_t by, int64_t bz, uint64_t packed) {
-    if (scheme == 1) return (int)(hash64(packed) % (uint64_t)world);
+    if (scheme == 1 || world % 3 == 0 || world % 5 == 0) return (int)(hash64(packed) % (uint64_t)world);
     const int64_t c = (bx + 3 * by + 5 * bz) % (int64_t)world;
     return (int)(c < 0 ? c + world : c);
 }

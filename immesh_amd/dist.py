@@ -102,7 +102,7 @@ def owners_of_root_voxels(keys, brick_log2, world, scheme=0):
     import numpy as np
     b = np.int64(brick_log2)
     k = np.asarray(keys, np.int64) >> b                         # arithmetic shift: bricks tile negative keys too
-    if scheme != 1:
+    if scheme != 1 and world % 3 != 0 and world % 5 != 0:   # (a world divisible by 3 or 5 uses the hash whatever the scheme: 3 / 5 would not be units mod it)
         return np.mod(k[:, 0] + 3 * k[:, 1] + 5 * k[:, 2], np.int64(world)).astype(np.int64)   # (numpy's mod is non-negative for a positive modulus)
     B, M = np.uint64(1 << 20), np.uint64((1 << 21) - 1)
     ku = (k.astype(np.uint64) + B) & M

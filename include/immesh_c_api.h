@@ -68,7 +68,8 @@ typedef struct immesh_config {
     int32_t shard_mesh;        /* 1 = the mesher is sharded too (owner-computed admission / kNN / Delaunay per mesh-voxel brick, boundary band by all-gather, see immesh_set_allgather); 0 = every context meshes whatever it is handed */
     /* which rank owns brick (bx, by, bz): 0 = LATTICE COLOURING, owner = (bx + 3 by + 5 bz) mod shard_world -- along every axis consecutive bricks cycle
      * through all ranks (1, 3, 5 are units mod 2 / 4 / 8), so any axis-aligned surface patch a scan touches is dealt out evenly and neighbouring bricks never
-     * share an owner (round 5: the busiest of 8 ranks owns 0.137 of a configs[4] scan instead of 0.170, the idlest 0.117 instead of 0.083); 1 = hash(brick) mod shard_world (rounds 1-4) */
+     * share an owner (round 5: the busiest of 8 ranks owns 0.137 of a configs[4] scan instead of 0.170, the idlest 0.117 instead of 0.083); 1 = hash(brick) mod shard_world (rounds 1-4).  The colouring needs 3 and 5 to be units
+     * mod shard_world: a world divisible by 3 or 5 (3, 5, 6, 10, 12, 15 ...) uses the hash whatever this field says */
     int32_t shard_scheme;
     int32_t reserved_;
 } immesh_config;
@@ -326,9 +327,13 @@ int immesh_rccl_init(immesh_ctx* ctx, const uint8_t id[128]);
 const char* immesh_rccl_error(void);
 /* SURVEY 8(e) "Scan ... broadcast once per scan": the rank that holds the scan (root: pts = n points of `stride` = 3 or 4 floats, host or device) hands it
  * to every rank of the sharded job; the other ranks pass pts = NULL.  Collective -- every rank calls it, in the same order.  On return *dev_out points at the
- * scan in THIS context's device memory (one buffer per stride, valid until the next broadcast of that stride) and *n_out is its length: feed them to
- * immesh_process_scan / immesh_mesh_scan, which take device pointers as they are.  RCCL (immesh_rccl_init): ncclBroadcast on the registration stream;
- * otherwise through the all-gather callback (immesh_set_allgather).  Unsharded context: a plain copy into the buffer. */
+ * scan in THIS context's device memory (two buffers per stride used in turn: valid until the SECOND next broadcast of that stride, so a mesh job that still
+ * reads scan k asynchronously has a whole scan of slack -- wait for it, immesh_mesh_wait, before broadcasting scan k + 2) and *n_out is its length: feed them to
+ * immesh_process_scan / immesh_mesh_scan, which take device pointers as they are.  Every rank returns the SAME code: the header (points, floats per point,
+ * each rank's cap_scan_points) is all-gathered before anything is decided -- IMMESH_E_INVAL when the root's scan is unusable, IMMESH_E_CAPACITY when it
+ * exceeds some rank's cap_scan_points -- so no rank is left waiting in a collective.  RCCL (immesh_rccl_init): ncclAllGather of the headers + ncclBroadcast
+ * of the points on the registration stream; otherwise through the all-gather callback (immesh_set_allgather).  Stubbed collectives
+ * (immesh_stub_collectives): nobody sends, every rank must be handed the scan itself.  Unsharded context: a plain copy into the buffer. */
 int immesh_broadcast_scan(immesh_ctx* ctx, const float* pts, int32_t n, int32_t stride, int32_t root, const float** dev_out, int32_t* n_out);
 /* payload bytes this rank has contributed to the mesher's all-gathers, and the number of collective calls, since create */
 int immesh_shard_traffic(immesh_ctx* ctx, int64_t* bytes, int64_t* calls);
@@ -390,6 +395,8 @@ typedef struct immesh_counters_t {  /* cumulative since create / last reset; SUR
     int64_t n_ds, n_iter, n_match, n_plane_tests, n_extra_probe, n_refits, n_refit_pts;
     int64_t n_app, n_new, v_act, n_v, n_u, t_v, t_add, t_rem, c1, c20;
     int64_t n_root_voxels, n_nodes, n_vertices, n_triangles_live;
+    int64_t n_degenerate_skips;   /* neighbourhood points delaunay_triangulation did NOT insert: no live triangle's circumdisk contains them -- a duplicate in the 2-D projection or exact
+                                   * co-circularity (the deterministic rule of oracle/orc_delaunay.hpp, not CGAL's symbolic perturbation).  0 on noisy scans; lattices produce some */
 } immesh_counters_t;
 int immesh_counters(immesh_ctx* ctx, immesh_counters_t* out, int32_t reset);
 

@@ -443,7 +443,7 @@ int orc_counters(void* p, immesh_counters_t* c, int32_t reset) {
     const Counters& k = o->vm.cnt;
     c->n_ds = k.n_ds; c->n_iter = k.n_iter; c->n_match = k.n_match; c->n_plane_tests = k.n_plane_tests; c->n_extra_probe = k.n_extra_probe;
     c->n_refits = k.n_refits; c->n_refit_pts = k.n_refit_pts; c->n_app = k.n_app; c->n_new = k.n_new; c->v_act = k.v_act; c->n_v = k.n_v;
-    c->n_u = k.n_u; c->t_v = k.t_v; c->t_add = k.t_add; c->t_rem = k.t_rem; c->c1 = k.c1; c->c20 = k.c20;
+    c->n_u = k.n_u; c->t_v = k.t_v; c->t_add = k.t_add; c->t_rem = k.t_rem; c->c1 = k.c1; c->c20 = k.c20; c->n_degenerate_skips = k.n_degenerate_skips;
     c->n_root_voxels = (int64_t)o->vm.map.size(); c->n_nodes = 0; c->n_vertices = (int64_t)o->mesher.verts.size();
     c->n_triangles_live = (int64_t)o->mesher.live_triangle_count();
     if (reset) o->vm.cnt = Counters();

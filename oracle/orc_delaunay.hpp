@@ -49,6 +49,7 @@ struct Delaunay2D {
     std::vector<T> tris;
     std::vector<int> free_list;
     int last = 0;
+    long n_skipped = 0;             // points of this run that were not inserted (no triangle's disk contains them: a duplicate in the projection / exact co-circularity)
     bool force_link_free = false;   // tests: every insertion by the link-free rule (what the HIP path does throughout) -- the result must not depend on it
 
     const double* P(int i) const { return xy + 2 * i; }
@@ -130,7 +131,7 @@ struct Delaunay2D {
 
     // triangulate n points; out = finite faces as local index triples (ccw)
     void run(const double* xy_, int n, std::vector<int>& out) {
-        xy = xy_; out.clear(); tris.clear(); free_list.clear();
+        xy = xy_; out.clear(); tris.clear(); free_list.clear(); n_skipped = 0;
         if (n < 3) return;
         // insertion order: Hilbert-like (Morton) order over the bounding box, ties by index
         double mn[2] = {xy[0], xy[1]}, mx[2] = {xy[0], xy[1]};
@@ -247,7 +248,7 @@ struct Delaunay2D {
             // ---- link-free insertion on the set of live triangles
             std::vector<int> G;
             for (int i = 0; i < (int)tris.size(); i++) if (tris[i].alive && in_disk(tris[i], p)) G.push_back(i);
-            if (G.empty()) continue;                       // duplicate of a vertex / on every circle: not inserted
+            if (G.empty()) { n_skipped++; continue; }      // duplicate of a vertex / on every circle: not inserted (counted: immesh_counters_t::n_degenerate_skips)
             auto boundary_of = [&](const std::vector<int>& S, std::vector<std::pair<int, int>>& bd) {
                 std::vector<unsigned long long> ek;
                 for (int t : S) for (int i = 0; i < 3; i++) ek.push_back(edge_key(tris[t].v[(i + 1) % 3], tris[t].v[(i + 2) % 3]));

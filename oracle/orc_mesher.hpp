@@ -132,7 +132,7 @@ struct Mesher {
 
     // ---- a20: delaunay_triangulation, mesh_rec_geometry.cpp:174-295 -----------------------------------------
     // ids ascending; returns accepted faces as vertex-id triples (unsorted within a face)
-    void delaunay_triangulation(const std::vector<int>& ids, double short_axis[3], std::vector<int>& tri_ids) {
+    void delaunay_triangulation(const std::vector<int>& ids, double short_axis[3], std::vector<int>& tri_ids, long* n_skipped = nullptr) {
         tri_ids.clear();
         const int n = (int)ids.size();
         if (n < 3) return;
@@ -167,6 +167,7 @@ struct Mesher {
         Delaunay2D dt;
         std::vector<int> faces;
         dt.run(xy.data(), n, faces);
+        if (n_skipped) *n_skipped += dt.n_skipped;
         // skinny-face filter: is_face_is_ok always uses 150 (:31-57)
         auto angle = [&](int a, int b, int cc) {  // compute_angle :24-29, at a
             const double abx = xy[2 * b] - xy[2 * a], aby = xy[2 * b + 1] - xy[2 * a + 1];
@@ -213,7 +214,7 @@ struct Mesher {
         // The per-voxel work splits into a part that reads only raw vertex positions (20-NN pull, smoothed means, 2-D Delaunay) and a part that
         // depends on the order of the voxels (smoothed positions seen so far, the live triangle set, which voxel's flip wins).  The first runs
         // voxel-parallel (the reference's TBB pool), the second strictly in ascending voxel order: same results for any thread count.
-        struct VoxWork { int vi; std::vector<int> ids; std::vector<std::pair<int, std::array<double, 3>>> sm; std::vector<int> tri_ids; long c20 = 0; };
+        struct VoxWork { int vi; std::vector<int> ids; std::vector<std::pair<int, std::array<double, 3>>> sm; std::vector<int> tri_ids; long c20 = 0, n_skip = 0; };
         std::vector<VoxWork> work;
         for (int vi : recent) {
             MeshVoxel& vox = voxels[vi];
@@ -247,7 +248,7 @@ struct Mesher {
                 w.sm.push_back({id, {sv[0], sv[1], sv[2]}});
             }
             w.ids.assign(rel.begin(), rel.end());
-            delaunay_triangulation(w.ids, vox.short_axis, w.tri_ids);
+            delaunay_triangulation(w.ids, vox.short_axis, w.tri_ids, &w.n_skip);
         }
         for (VoxWork& w : work) {
             MeshVoxel& vox = voxels[w.vi];
@@ -259,7 +260,7 @@ struct Mesher {
             const std::vector<int>& tri_ids = w.tri_ids;
             const std::set<long> rel(ids.begin(), ids.end());
             out.n_u_list.push_back((int)ids.size());
-            if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); }
+            if (cnt) { cnt->c20 += w.c20; cnt->n_u += (long)ids.size(); cnt->n_degenerate_skips += w.n_skip; }
             // a21 find_relative_triangulation_combination, triangle.hpp:223-246
             std::set<Tri> old;
             for (int id : ids) {

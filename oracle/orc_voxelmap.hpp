@@ -33,7 +33,7 @@ struct State {  // StatesGroup, include/common_lib.h:199-288
 struct Counters {  // per-scan counters feeding the roofline denominator
     long n_ds = 0, n_iter = 0, n_match = 0, n_plane_tests = 0, n_extra_probe = 0;
     long n_refits = 0, n_refit_pts = 0;
-    long n_app = 0, n_new = 0, v_act = 0, n_v = 0, n_u = 0, t_v = 0, t_add = 0, t_rem = 0, c1 = 0, c20 = 0;
+    long n_app = 0, n_new = 0, v_act = 0, n_v = 0, n_u = 0, t_v = 0, t_add = 0, t_rem = 0, c1 = 0, c20 = 0, n_degenerate_skips = 0;
 };
 
 // ---- a1: key quantisation, voxel_mapping.cpp:118-127 / 172-181 / 328-337 -------------------------------

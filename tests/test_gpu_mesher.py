@@ -237,6 +237,7 @@ def test_async_pipeline_matches_serial(hip_lib):
         np.testing.assert_array_equal(m1[key], m2[key], err_msg=key)
     for key in ("n_new", "v_act", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
         assert c1[key] == c2[key], key
+    assert c1["n_degenerate_skips"] == 0 == c2["n_degenerate_skips"]      # a noisy scan never meets the degenerate-admission rule
 
 
 def test_mesh_volumetric_cloud(oracle_lib, hip_lib):
@@ -492,6 +493,11 @@ def test_exact_ties_lattice_cloud(oracle_lib, hip_lib, spacing):
         np.testing.assert_array_equal(h.mesh_neighbourhood_sizes(), nu)
         n_u_max = max(n_u_max, int(nu.max()) if len(nu) else 0)
     assert (n_u_max <= 64) if spacing >= 0.25 else (n_u_max > 64), n_u_max
+    # how often the degenerate-admission rule fired ("no circumdisk contains the point: not inserted", oracle/orc_delaunay.hpp:11-27): the same count on both
+    # sides, reported by immesh_counters_t::n_degenerate_skips (0 on every noisy stream of this suite)
+    ds_o, ds_h = o.counters()["n_degenerate_skips"], h.counters()["n_degenerate_skips"]
+    assert ds_h == ds_o, (ds_h, ds_o)
+    print(f"lattice {spacing}: n_degenerate_skips = {ds_h}")
     co, ch = o.counters(), h.counters()
     for key in ("n_app", "n_new", "v_act", "n_v", "n_u", "t_v", "t_add", "t_rem", "n_vertices", "n_triangles_live"):
         assert ch[key] == co[key], key
