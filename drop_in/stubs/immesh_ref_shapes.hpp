@@ -16,8 +16,26 @@
 #include <vector>
 
 namespace Eigen {   // element access only: the shim marshals through operator() and never relies on the storage order
-struct Vector3d { double v[3] = {0, 0, 0}; double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
-struct Matrix3d { double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; double& operator()(int r, int c) { return m[c * 3 + r]; } double operator()(int r, int c) const { return m[c * 3 + r]; } };
+// (constructors, Identity / Zero, the float twins, Matrix< T, 3, 1 > and the two products below: what the member initialisers and the inline member templates of
+//  the reference's class Voxel_mapping use, for the `realclass` compile check -- stubs/real_class)
+template <typename T, int R, int C> struct Matrix;
+template <typename T> struct Matrix<T, 3, 1> {
+    T v[3] = {0, 0, 0};
+    Matrix() {}
+    Matrix(T x, T y, T z) : v{x, y, z} {}
+    T& operator()(int i) { return v[i]; } T operator()(int i) const { return v[i]; }
+    T& operator[](int i) { return v[i]; } T operator[](int i) const { return v[i]; }
+    static Matrix Zero() { return Matrix(); }
+    Matrix operator+(const Matrix& o) const { return Matrix(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+};
+template <typename T> struct Matrix<T, 3, 3> {
+    T m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    T& operator()(int r, int c) { return m[c * 3 + r]; } T operator()(int r, int c) const { return m[c * 3 + r]; }
+    static Matrix Identity() { return Matrix(); }
+    Matrix<T, 3, 1> operator*(const Matrix<T, 3, 1>& x) const { Matrix<T, 3, 1> o; for (int r = 0; r < 3; r++) o.v[r] = (*this)(r, 0) * x.v[0] + (*this)(r, 1) * x.v[1] + (*this)(r, 2) * x.v[2]; return o; }
+};
+typedef Matrix<double, 3, 1> Vector3d; typedef Matrix<float, 3, 1> Vector3f;
+typedef Matrix<double, 3, 3> Matrix3d; typedef Matrix<float, 3, 3> Matrix3f;
 struct Quaterniond { double w = 1, x = 0, y = 0, z = 0; };
 template <int N> struct MatrixNd { std::vector<double> m = std::vector<double>(N * N, 0.0); double& operator()(int r, int c) { return m[c * N + r]; } double operator()(int r, int c) const { return m[c * N + r]; } };
 }  // namespace Eigen
@@ -33,6 +51,9 @@ template <typename T> struct PointCloud {
     size_t size() const { return points.size(); }
     void resize(size_t n) { points.resize(n); }
     void clear() { points.clear(); }
+    PointCloud() {}
+    PointCloud(unsigned w, unsigned h) : points((size_t)w * h) {}
+    Ptr makeShared() const { return std::make_shared<PointCloud<T>>(*this); }
 };
 }  // namespace pcl
 typedef pcl::PointXYZINormal PointType;               // include/common_lib.h:58
@@ -92,9 +113,21 @@ inline void immesh_mirror_reset(Triangle_manager& m, Global_map*, double) { m = 
 extern Global_map g_map_rgb_pts_mesh;           // src/ImMesh_mesh_reconstruction.cpp:40
 extern Triangle_manager g_triangles_manager;    // :41
 
+struct immesh_ctx;
+#ifdef IMMESH_SHIM_REF_CLASS
+// `make -C drop_in realclass`: class Voxel_mapping IS THE REFERENCE'S -- src/voxel_mapping.hpp:132-414 cut out by line range at build time (vm_class_body.inc,
+// removed after the compile; nothing is copied) -- closed below with the members INTEGRATION.md ("One context per scan thread") has the maintainer add
+#include "real_class/ref_class_prelude.hpp"
+#include "vm_class_body.inc"
+    immesh_ctx* m_hip = nullptr;
+    std::vector<float> m_immesh_xyz, m_immesh_xyzi;
+    bool m_immesh_scan_queued = false;
+    void immesh_shim_init();
+    void immesh_fetch_effect_features();
+};
+#else
 struct Preprocess_shape { int calib_laser = 0; };   // src/preprocess.h:170
 
-struct immesh_ctx;
 class Voxel_mapping {   // src/voxel_mapping.hpp:132-420 -- only what the replaced bodies read or write
   public:
     V3D m_extT; M3D m_extR;                                   // :149-150
@@ -122,6 +155,7 @@ class Voxel_mapping {   // src/voxel_mapping.hpp:132-420 -- only what the replac
     bool voxel_map_init();                                    // :409  (src/voxel_mapping.cpp:1243)
     void lio_state_estimation(StatesGroup& state_propagat);   // :412  (src/voxel_mapping.cpp:1284)
 };
+#endif
 struct Rec_mesh_data_package {   // src/ImMesh_mesh_reconstruction.cpp:63-76
     pcl::PointCloud<pcl::PointXYZI>::Ptr m_frame_pts;
     Eigen::Quaterniond m_pose_q;
