@@ -10,6 +10,7 @@
 //                        64-lane butterfly reductions for the moment sums and the 21-entry plane covariance.
 // Bound: HBM/latency (dependent gathers through hash -> node -> plane); no GEMM-shaped work, MFMA is not used.
 #include <algorithm>
+#include <cstdlib>
 #include "regmap.hpp"
 #include "kernels.hpp"
 #include "prof.hpp"
@@ -1987,6 +1988,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
 }
 
 __device__ bool replay_split_root(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w);
+__device__ bool replay_split_leaves(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w, int* s_key, int* s_first);
 // updateVoxelMap without any global sort: one wavefront per root voxel of the work list gathers that voxel's points of this scan from its
 // list, orders them as std::sort(pv_list, var_contrast) would (ascending covariance norm, ties by scan index) and replays them through the
 // general state machine.  The grid is FIXED and strides over the list (a few dozen voxels per scan on a settled map, every touched voxel while
@@ -2054,7 +2056,9 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // settled planar roots take the register-resident fast path; whatever it does not consume goes through the general state machine
-        if (replay_split_root(m, root, order[wv], cnt, pt_data, w)) continue;   // (a subdivided root of a deep octree: its octants go to replay_sub_kernel)
+        // (a subdivided root of a deep octree: its points go to replay_sub_kernel -- grouped by the LEAF each one descends to (round 6), long lists by octant)
+        if (replay_split_leaves(m, root, order[wv], cnt, pt_data, w, (int*)skey[wv], sidx[wv])) continue;
+        if (replay_split_root(m, root, order[wv], cnt, pt_data, w)) continue;
         const unsigned long long tdbg1 = dbg ? __builtin_readcyclecounter() : 0;
         int jf = wave_replay_planar_root(m, root, order[wv], cnt, pt_data, w);
         if (jf == 0) jf = wave_replay_planar_node(m, root, order[wv], cnt, pt_data, w);   // (planar roots that do not fit the register path: deep-octree configurations)
@@ -2075,6 +2079,76 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
 // 263-288), so the eight octants are independent state machines and only the order of the points WITHIN an octant matters.  replay_list_kernel
 // therefore cuts such a root's ordered list into its octants' lists (replay_split_root) and replay_sub_kernel replays each with a wavefront of its own.
 // What the octants share is the root's flat list of planar descendants: edited under the root's lock (node_set_flags, shared).
+// Round 6: the same cut, all the way down.  An octant of a subdivided 3 m root still holds ~30 of a scan's points, and replay_sub_kernel replayed them ONE BY
+// ONE through three more levels of dependent header reads (wave_update_point: ~8 us a point -- the launch was the densest octant's chain, 0.11 ms per scan).
+// Every point's destination is known before anything is written: the node its descent through the tree AS IT STANDS stops at -- a plane, a node still
+// filling up, a last-layer node, a former plane that still holds its points, or the parent of a child that does not exist yet.  Destinations are disjoint
+// subtrees, so they are independent state machines exactly like the octants, and whatever a destination's batch changes (a leaf that fills up and is cut, a
+// plane that turns non-planar) happens below it.  Each lane descends for its own point (read-only, in parallel), the points are grouped by destination in
+// the voxel's replay order, and every group becomes a work item for replay_sub_kernel: a planar leaf takes its batch in one go (wave_replay_planar_node),
+// anything else replays from ITS node instead of from the octant.  Lists of up to RL_CAP points (the LDS tables of the caller); longer ones take the octant cut.
+#define SPLIT_MISSING 0x40000000   /* group key of "child `oct` of `node` does not exist": node | oct << 26 | this bit (node ids stay below 2^26 on deep-octree maps, checked) */
+__device__ __noinline__ bool replay_split_leaves(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w, int* s_key, int* s_first) {
+    const NodeRec& nr = m.nodes[root];
+    const int flags = nr.flags;
+    if (!m.split_general || cnt < 2 || cnt > RL_CAP || !(flags & NF_INIT) || (flags & NF_PLANE) || nr.layer >= m.max_layer || m.cap_nodes >= (1 << 26)) return false;
+    if (w.lane == 0 && nr.npts != 0) node_free_points(m, root);   // what UpdateOctoTree does on its first visit after the cut (voxel_loc.cpp:263-266)
+    const int lane = w.lane;
+    // ---- descent: lane j < cnt follows point order[j] down the tree as it stands
+    int key = -1;
+    if (lane < cnt) {
+        const double* q = pt_data + (size_t)order[lane] * IM_PT_DOUBLES;
+        const double qx = q[0], qy = q[1], qz = q[2];
+        int nd = root;
+        for (int depth = 0; depth < 8; depth++) {
+            const NodeRec& r = m.nodes[nd];
+            const int f = r.flags, layer = r.layer, npts = r.npts;
+            // a routing node: initialised, not a plane, below the last layer, its buffer already dropped (everything else is a destination)
+            if (!((f & NF_INIT) && !(f & NF_PLANE) && layer < m.max_layer && (npts == 0 || nd == root))) { key = nd; break; }
+            const int oct = 4 * (qx > r.center[0] ? 1 : 0) + 2 * (qy > r.center[1] ? 1 : 0) + (qz > r.center[2] ? 1 : 0);   // octant_of
+            const int child = r.child[oct];
+            if (child < 0) { key = nd | (oct << 26) | SPLIT_MISSING; break; }
+            nd = child;
+        }
+        if (key < 0) key = nd;   // (deeper than any octree of the library: treat as a destination)
+    }
+    if (lane < cnt) s_key[lane] = key;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // ---- grouping in replay order: first = lowest position with my key, rank = earlier positions with my key, size = positions with my key
+    int first = lane, rank = 0, size = 0;
+    if (lane < cnt) {
+        first = -1;
+        for (int f = 0; f < cnt; f++) {
+            const bool same = s_key[f] == key;
+            if (same && first < 0) first = f;
+            if (same && f < lane) rank++;
+            if (same) size++;
+        }
+        s_first[lane] = first;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int before = 0;   // points whose group starts before mine
+    if (lane < cnt) for (int f = 0; f < cnt; f++) before += s_first[f] < first ? 1 : 0;
+    const bool leader = lane < cnt && first == lane;
+    const unsigned long long lm = __ballot(leader);
+    const int n_items = (int)__popcll(lm);
+    int seg = 0, item0 = 0;
+    if (lane == 0) { seg = atomicAdd(&m.counters[11], cnt); item0 = atomicAdd(&m.counters[12], n_items); }
+    seg = __shfl(seg, 0, 64); item0 = __shfl(item0, 0, 64);
+    if (lane < cnt) m.sub_order[seg + before + rank] = order[lane];
+    if (leader) {
+        const int it = item0 + (int)__popcll(lm & ((1ull << lane) - 1ull));
+        // item: start node (for a missing child: its parent -- the general state machine creates the child with the first point and routes the rest), root
+        const int start = (key & SPLIT_MISSING) ? (key & ((1 << 26) - 1)) : key;
+        m.sub_items[2 * (size_t)it] = (unsigned long long)(unsigned int)start | ((unsigned long long)(unsigned int)root << 32);
+        m.sub_items[2 * (size_t)it + 1] = (unsigned long long)(unsigned int)(seg + before) | ((unsigned long long)(unsigned int)size << 32);
+    }
+    return true;
+}
 __device__ bool replay_split_root(const RegMapDev& m, const int root, const int* order, const int cnt, const double* __restrict__ pt_data, const WaveCtx& w) {
     const NodeRec& nr = m.nodes[root];
     const int flags = nr.flags;
@@ -2256,10 +2330,16 @@ void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_ne
                          unsigned long long* flag_dev, unsigned long long* flag_host, unsigned long long flag_seq) {
     KLAUNCH(replay_fused_kernel, dim3(std::min((n + 3) / 4, 768)), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg, flag_dev, flag_host, flag_seq);
     // the work list's length is only known on the device: a fixed grid strides over it (sized for the map-building case, where every touched voxel is on it)
-    const int nb_list = std::min(std::max((n + 127) / 128, 32), 4096);
+    // points per workgroup of the list kernel's grid.  Two-layer maps (avia.yaml): 128 -- its ~1 100 general voxels are bound by the slowest voxel's chain, more
+    // workgroups only get in the mesher's way (sweep 64 / 32 / 16 / 8: 5 700-5 930 scans/s against 5 920-5 930, round 6).  Deep octrees (velodyne.yaml: every
+    // touched root is on the list and most are split here): 32 -- the launch was 252 wavefronts working through 960 roots, 0.124 -> 0.094 ms per scan.
+    static const int list_div_env = [] { const char* e = getenv("IMMESH_LIST_DIV"); const int v = e ? atoi(e) : 0; return v >= 4 ? v : 0; }();   // (measurement knob, tools/r06_c4div.sh)
+    const int list_div = list_div_env ? list_div_env : (m.split_general ? 32 : 128);
+    const int nb_list = std::min(std::max((n + list_div - 1) / list_div, 32), 4096);
     KLAUNCH(replay_list_kernel, dim3(nb_list), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, big_idx, big_order, dbg, (const uint32_t*)general_list,
             (const int32_t*)(m.counters + 10));
-    if (m.split_general) KLAUNCH(replay_sub_kernel, dim3(std::min(std::max((n + 63) / 64, 32), 2048)), dim3(256), 0, s, m, pt_data, stats);
+    // (items are leaf groups since round 6 -- a few points each, thousands per scan: one wavefront per ~4 points instead of per 16)
+    if (m.split_general) KLAUNCH(replay_sub_kernel, dim3(std::min(std::max((n + 15) / 16, 32), 2048)), dim3(256), 0, s, m, pt_data, stats);
     if (with_tail) KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters);
 }
 void launch_map_update_tail(hipStream_t s, const RegMapDev& m, int32_t* host_counters) { KLAUNCH(merge_free_tail_kernel, dim3(1), dim3(256), 0, s, m, host_counters); }
