@@ -320,6 +320,8 @@ static int register_enqueue_fused(immesh_ctx* c, const float* d_pts, int n_ds, c
         // ONE launch for the scan: a resident grid runs every pass and the 18-state update (residual_persistent_kernel); a.mat = the prior covariance
         a.mode = REG_MODE_FUSED; a.it = 0;
         if (c->rp_force_abort) a.pad |= 2;   // (IMMESH_RP_FORCE_ABORT: the test hook of the bounded gather)
+        static const bool match_seq = getenv("IMMESH_MATCH_SEQ") != nullptr;   // A/B: the lane-by-lane leaf walk of rounds 1-5 instead of the wave-cooperative one
+        if (match_seq) a.pad |= 4;
         std::memcpy(a.mat, st.cov, sizeof(a.mat));
         const int par = (c->rp_parity ^= 1);   // this scan's slot buffer; the launch re-arms the other one for the next scan
         RpEpilogue none{};

@@ -113,6 +113,151 @@ IMD void match_tree(const RegMapDev& m, int root, const double* pw, const double
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the leaf lists of a wavefront's points, matched by the WHOLE wavefront.  match_tree above walks a non-planar root's flat leaf list in the lane
+// of its point -- one dependent gather per leaf, one leaf after the other -- while the lanes whose root voxel is a plane (97 % on the avia map) have long
+// finished: a lane with twenty leaves held its wavefront, and through the pass's all-gather every wavefront of the grid, for twenty gathers (velodyne.yaml,
+// every root subdivided: 45 k of a pass's 60 k cycles).  Here the (point, leaf) PAIRS of the wavefront are enumerated into an LDS work list -- each "tree
+// lane" contributes one 15-id chunk line of its list per step -- and taken 64 at a time, one pair per lane: the leaf gathers of a step are in flight
+// together.  A pair's lane evaluates build_single_residual's test with the owner's point (fetched by lane shuffles) in the SAME expressions as
+// test_plane; the owner's best is the maximum probability (ties: the smaller depth-first key -- the plane the reference's recursion reaches first), found
+// by LDS atomics on the probability's bit pattern, which is monotone for the positive values that can win (`this_prob > best.prob`, best.prob >= 0).
+// The accept set, the winner and every value derived from it are the sequential walk's; only who computes what has changed.
+// wl: COOP_WORDS words of LDS of this wavefront.  Node ids must fit 26 bits (the caller checks).
+// ---------------------------------------------------------------------------------------------------------------------
+#define COOP_LIST 960                                  /* 64 lanes x 15 leaves of one enumeration step */
+#define COOP_STAGE (64 * 12 * 2)                       /* words: every lane's world point (3 doubles) + its covariance (9): what a pair's lane needs of the owner */
+#define COOP_WORDS (COOP_STAGE + COOP_LIST + 64 * 2 + 64 * 3)   /* + per owner: best probability (64-bit), winner, any-accepted flag, finalists of the round.  13.4 KB:
+                                                          lives in the wavefront's reduction transpose buffer (16.6 KB), which is idle while points are matched */
+IMD void coop_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+IMD double shfl_d(const double x, const int src) {
+    const int lo = __shfl(__double2loint(x), src, 64), hi = __shfl(__double2hiint(x), src, 64);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void match_trees_coop(const RegMapDev& m, const bool is_tree, const int head, const double* pw, const double* var, const double sigma_num, BestMatch& best,
+                                                 int& n_tests, const int lane, unsigned int* __restrict__ wl) {
+    double* const stage = (double*)wl;                 // [64][12]: pw, var of every lane (read by the lanes that take its pairs)
+    unsigned int* const list = wl + COOP_STAGE;
+    unsigned long long* const bestp = (unsigned long long*)(list + COOP_LIST);
+    int* const bestn = (int*)(list + COOP_LIST + 128);
+    int* const okf = (int*)(list + COOP_LIST + 192);
+    unsigned int* const nfin = list + COOP_LIST + 256;
+    bestp[lane] = 0ull; bestn[lane] = -1; okf[lane] = 0;
+    if (is_tree) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) stage[lane * 12 + k] = pw[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) stage[lane * 12 + 3 + k] = var[k];
+    }
+    int ch = is_tree ? head : -1;
+    while (__any(ch >= 0)) {
+        // ---- enumeration step: every tree lane's next chunk line (15 node ids + next) goes onto the work list
+        int e[16];
+        int cnt = 0;
+        if (ch >= 0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) e[k] = m.leaf_chunks[(size_t)ch * 16 + k];
+#pragma unroll
+            for (int k = 0; k < IM_LEAF_SLOTS; k++) cnt += e[k] >= 0 ? 1 : 0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off, 64); if (lane >= off) incl += y; }
+        const int total = __shfl(incl, 63, 64);
+        if (ch >= 0) {
+            int k2 = incl - cnt;
+#pragma unroll
+            for (int k = 0; k < IM_LEAF_SLOTS; k++) if (e[k] >= 0) list[k2++] = ((unsigned int)lane << 26) | (unsigned int)e[k];
+            n_tests += cnt;
+            ch = e[15];
+        }
+        coop_sync();
+        // ---- the pairs, 64 at a time
+        for (int base = 0; base < total; base += 64) {
+            const int idx = base + lane;
+            const bool live = idx < total;
+            const unsigned int ent = live ? list[idx] : ((unsigned int)lane << 26);
+            const int owner = (int)(ent >> 26), node = (int)(ent & 0x3FFFFFFu);
+            bool cand = false;
+            double prob = 0.0;
+            if (live) {
+                const NodeRec& lr = m.nodes[node];
+                PlaneRegs P;
+                load_plane_geometry(lr, P);
+                const double opw[3] = {stage[owner * 12 + 0], stage[owner * 12 + 1], stage[owner * 12 + 2]};
+                float dp, rd;
+                plane_gates(P, opw, dp, rd);
+                if ((double)rd <= 3.0 * (double)P.radius) {
+                    load_plane_var(lr, P);
+                    double ovar[9];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) ovar[k] = stage[owner * 12 + 3 + k];
+                    // test_plane<true>, its comparison against the running best replaced by the reduction below
+                    const double nx = P.n[0], ny = P.n[1], nz = P.n[2];
+                    const double J[6] = {opw[0] - P.c[0], opw[1] - P.c[1], opw[2] - P.c[2], -nx, -ny, -nz};
+                    double sigma_l = plane_sigma(P.pv, J);
+                    const double nrm[3] = {nx, ny, nz};
+                    double vn[3];
+                    m3t_vec(ovar, nrm, vn);
+                    sigma_l += vn[0] * nx + vn[1] * ny + vn[2] * nz;
+                    if ((double)dp < sigma_num * sqrt(sigma_l)) {
+                        atomicOr(&okf[owner], 1);
+                        prob = 1.0 / (sqrt(sigma_l)) * exp(-0.5 * (double)dp * (double)dp / sigma_l);
+                        cand = prob > 0.0;
+                    }
+                }
+            }
+            if (!__any(cand)) continue;   // (wave-uniform)
+            // ---- the owners' maxima.  Exact ties (two planes, one probability to the last bit) go to the smaller depth-first key: the rare path below
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(prob);
+            nfin[lane] = 0u;
+            const unsigned long long before = cand ? bestp[owner] : 0ull;
+            coop_sync();
+            if (cand) atomicMax(&bestp[owner], bits);
+            coop_sync();
+            const unsigned long long after = cand ? bestp[owner] : 0ull;
+            const bool fin = cand && bits == after;
+            const int prevn = fin ? bestn[owner] : -1;
+            if (fin) atomicAdd(&nfin[owner], 1u);
+            coop_sync();
+            const bool tie = fin && (nfin[owner] > 1u || (after == before && prevn >= 0));
+            if (fin && !tie) bestn[owner] = node;
+            if (__any(tie)) {
+                // all of an owner's finalists (and the winner of an earlier step that holds the same probability) compete with their depth-first keys
+                unsigned int* const bestk = nfin;   // (the counts have been read)
+                coop_sync();
+                if (tie) bestk[owner] = 0xFFFFFFFFu;
+                coop_sync();
+                const unsigned int dk = tie ? dfs_key(m, node) : 0xFFFFFFFFu;
+                if (tie && after == before && prevn >= 0) atomicMin(&bestk[owner], dfs_key(m, prevn));
+                if (tie) atomicMin(&bestk[owner], dk);
+                coop_sync();
+                if (tie && bestk[owner] == dk) bestn[owner] = node;
+            }
+            coop_sync();
+        }
+        coop_sync();   // (the work list is rewritten by the next step)
+    }
+    coop_sync();
+    if (is_tree) {
+        if (okf[lane]) best.ok = true;
+        const int nd = bestn[lane];
+        const double p = __longlong_as_double((long long)bestp[lane]);
+        if (nd >= 0 && p > best.prob) {
+            best.node = nd; best.layer = 1; best.prob = p;
+            const NodeRec& lr = m.nodes[nd];
+            load_plane_geometry(lr, best.P);
+            load_plane_var(lr, best.P);
+        }
+    }
+    coop_sync();
+}
+
 // =====================================================================================================================
 // the 18-state iterated-EKF update on one wavefront (imh::EkfLoop::step, ekf_host.hpp -- the same operations in the same order:
 // Gauss-Jordan with partial pivoting on [H^T R^-1 H + P^-1 | e_0..e_5], G = K1 H^T R^-1 H, solution, boxplus, stop rule, (I - G) P)
@@ -403,8 +548,13 @@ IMD void residual_prep(const ScanParams& sp, const float* __restrict__ pts, cons
     q.key = PREP_NO_KEY; q.root = -1;
 }
 // sp: the per-scan constants (kernel arguments: scalar loads); Rm / tv / RextR: the iterate of this pass (wave-uniform)
+template <bool coop>
 IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* Rm, const double* tv, const double* RextR, PointPrep& q, const int i, double* acc, unsigned long long& tprev,
-                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal) {
+                       int8_t* __restrict__ o_match, int32_t* __restrict__ o_node, float* __restrict__ o_dis, double* __restrict__ o_rinv, double* __restrict__ o_normal,
+                       const bool active, unsigned int* __restrict__ wl) {
+        // EVERY lane of the wavefront calls this (active = the lane holds a point): the leaf lists of non-planar roots are matched by the whole wavefront
+        // (match_trees_coop).  coop == false (node ids beyond 26 bits, or IMMESH_MATCH_SEQ): the lane-by-lane walk of rounds 1-5 (match_tree).
+        const int lane = (int)(threadIdx.x & 63);
         // --- transformLidar (:1344): f64 compute, f32 store
         double pwd[3];
         m3_vec(Rm, q.pimu, pwd);
@@ -425,7 +575,7 @@ IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* R
 #pragma unroll
         for (int j = 0; j < 3; j++) { loc[j] = loc_axis(pw[j] / m.voxel_size_d); kx[j] = (int64_t)loc[j]; }
         // sharded map: a point is matched by the rank that owns its root voxel (every rank sees the whole scan; the 48 sums are all-reduced)
-        const bool mine = m.shard_world <= 1 || shard_owner(m, kx[0], kx[1], kx[2]) == m.shard_rank;
+        const bool mine = active && (m.shard_world <= 1 || shard_owner(m, kx[0], kx[1], kx[2]) == m.shard_rank);
         const uint64_t key = pack_key(kx[0], kx[1], kx[2]);
         int root = -1;
         if (mine) {
@@ -438,23 +588,50 @@ IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* R
         }
         BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
         int n_tests = 0, n_extra = 0;
-        if (root != -2 && mine) {
-            if (root >= 0) match_tree(m, root, pw, var, sp.sigma_num, best, n_tests);
-            RDBG(1);
-            if (root >= 0 && !best.ok) {  // near-voxel retry with the literal unit mismatch
-                int64_t nk[3] = {kx[0], kx[1], kx[2]};
-                const float ql = m.nodes[root].quarter;
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    const double c = m.nodes[root].center[j];
-                    if ((double)loc[j] > (c + (double)ql)) nk[j] = nk[j] + 1;
-                    else if ((double)loc[j] < (c - (double)ql)) nk[j] = nk[j] - 1;
+        // two rounds: the point's own root voxel, then -- no plane accepted -- the neighbour of the near-voxel retry (the literal unit mismatch)
+        int cur_root = (mine && root >= 0) ? root : -1;
+        for (int round = 0; round < 2; round++) {
+            bool is_tree = false;
+            int tree_head = -1;
+            if (cur_root >= 0) {
+                if (!coop) match_tree(m, cur_root, pw, var, sp.sigma_num, best, n_tests);
+                else {
+                    // (the root's plane record is gathered together with its flags: one dependent access for the common case of a planar root voxel)
+                    const NodeRec& nr = m.nodes[cur_root];
+                    const int flags = nr.flags, leaf_head = nr.leaf_head;
+                    PlaneRegs P;
+                    load_plane_geometry(nr, P);
+                    load_plane_var(nr, P);
+                    if (flags & NF_PLANE) {
+                        n_tests++;
+                        float dp, rd;
+                        plane_gates(P, pw, dp, rd);
+                        test_plane<false>(m, P, cur_root, 0, pw, var, sp.sigma_num, dp, rd, best);
+                    } else if (m.max_layer > 0) { is_tree = true; tree_head = leaf_head; }
                 }
-                n_extra = 1;
-                const int64_t s2 = hash_find(m, pack_key(nk[0], nk[1], nk[2]));
-                if (s2 >= 0 && m.htab[s2].root >= 0) match_tree(m, m.htab[s2].root, pw, var, sp.sigma_num, best, n_tests);
+            }
+            if (coop && __any(is_tree)) match_trees_coop(m, is_tree, tree_head, pw, var, sp.sigma_num, best, n_tests, lane, wl);
+            if (round == 0) {
+                RDBG(1);
+                const bool retry = mine && root >= 0 && !best.ok;
+                cur_root = -1;
+                if (retry) {
+                    int64_t nk[3] = {kx[0], kx[1], kx[2]};
+                    const float ql = m.nodes[root].quarter;
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const double c = m.nodes[root].center[j];
+                        if ((double)loc[j] > (c + (double)ql)) nk[j] = nk[j] + 1;
+                        else if ((double)loc[j] < (c - (double)ql)) nk[j] = nk[j] - 1;
+                    }
+                    n_extra = 1;
+                    const int64_t s2 = hash_find(m, pack_key(nk[0], nk[1], nk[2]));
+                    if (s2 >= 0 && m.htab[s2].root >= 0) cur_root = m.htab[s2].root;
+                }
+                if (!__any(cur_root >= 0)) break;
             }
         }
+        if (!active) return;
         RDBG(2);
         acc[29] += (double)n_tests; acc[30] += (double)n_extra;
         // is_success with prob still 0 (sigma_l = inf / NaN after a diverged covariance): the reference pushes an uninitialised ptpl there;
@@ -503,6 +680,7 @@ IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* R
 // One wavefront per block (n/64 blocks: a down-sampled scan is only ~8k points, so small blocks are what spreads it over the CUs).
 // Block sums go through an LDS transpose (lane k adds column k in lane order: fixed order, deterministic); the last block to
 // finish adds the per-block partials in block order and writes the 48-double result straight into pinned host memory.
+template <bool COOP>   // COOP: the leaf lists of non-planar roots are matched by the whole wavefront (match_trees_coop); false: the lane-by-lane walk (node ids beyond 26 bits, IMMESH_MATCH_SEQ)
 __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
                                                        double* __restrict__ partials, unsigned int* __restrict__ done_counter, double* __restrict__ out48,
                                                        double* __restrict__ reg_out, double ticket,
@@ -524,9 +702,16 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
     double acc[RES_NR];
 #pragma unroll
     for (int k = 0; k < RES_NR; k++) acc[k] = 0;
-    if (i < n) { PointPrep q; residual_prep(sp, pts, i, q); residual_pass(m, sp, sp.R, sp.t, sp.RextR, q, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal); }
-    RDBG(3);
     __shared__ double red[RES_NR][65];
+    unsigned int* const coop_wl = (unsigned int*)&red[0][0];   // (the transpose buffer is idle until the points are done)
+    {
+        PointPrep q = {};
+        q.key = PREP_NO_KEY; q.root = -1;
+        if (i < n) residual_prep(sp, pts, i, q);
+        residual_pass<COOP>(m, sp, sp.R, sp.t, sp.RextR, q, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal, i < n, coop_wl);
+    }
+    RDBG(3);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     __shared__ int s_last;
     const int lane = threadIdx.x;
 #pragma unroll
@@ -604,6 +789,7 @@ __global__ __launch_bounds__(64) void residual_kernel(RegMapDev m, RegIterArgs a
 #define RP_MAX_BLOCKS 128
 #define RP_SPIN_TICKS 100000000ull   /* 1 s */
 #define RP_SENTINEL 0x7FF8DEADBEEF0001ull
+static_assert(COOP_WORDS * 4 <= RES_NR * 65 * 8, "the cooperative matcher's scratch lives in a wavefront's reduction transpose buffer");
 struct RpShared {
     double red[4][RES_NR][65];   // per-wavefront transposes
     double wsum[4][RES_NR];
@@ -800,6 +986,7 @@ __device__ __forceinline__ void rp_finish(RpShared& S, const RegIterArgs& a, Reg
     if (tid == 0) __hip_atomic_store(&reg_out[REG_OUT_DOUBLES - 1], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+template <bool COOP>   // (see residual_kernel)
 __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, RegIterArgs a, RegState* rs, const float* __restrict__ pts, int n,
                                                                    double* __restrict__ slots, double* __restrict__ slots_next, int n_slots_next,
                                                                    int32_t* __restrict__ host_counters,
@@ -878,7 +1065,7 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
     __syncthreads();
     const int ntiles = (n + 63) / 64;
     const bool one_tile = ntiles <= G * 4;
-    PointPrep prep;
+    PointPrep prep = {};
     prep.key = PREP_NO_KEY; prep.root = -1;
     for (int it = 0; it < a.max_iter; it++) {
         // IMMESH_DEBUG trace (s_memrealtime, 100 MHz) per (pass, block): [0] pass start [1] block partials out [2] all partials in [3] update done
@@ -908,10 +1095,8 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
         for (int k = 0; k < RES_NR; k++) acc[k] = 0;
         for (int tile = blockIdx.x * 4 + wv; tile < ntiles; tile += G * 4) {
             const int i = tile * 64 + lane;
-            if (i < n) {
-                if (!(one_tile && it > 0)) residual_prep(sp, pts, i, prep);   // one tile per wavefront (any down-sampled scan): the pass-independent part is computed once
-                residual_pass(m, sp, Rm, tv, RextR, prep, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal);
-            }
+            if (i < n && !(one_tile && it > 0)) residual_prep(sp, pts, i, prep);   // one tile per wavefront (any down-sampled scan): the pass-independent part is computed once
+            residual_pass<COOP>(m, sp, Rm, tv, RextR, prep, i, acc, tprev, o_match, o_node, o_dis, o_rinv, o_normal, i < n, (unsigned int*)&S.red[wv][0][0]);   // (every lane: the leaf lists are matched by the whole wavefront)
         }
         RDBG(3);
         // ---- per-wavefront sums (LDS transpose: lane k adds column k in lane order -- a fixed order), combined in wave order
@@ -2298,7 +2483,8 @@ void launch_unpack_strided(hipStream_t s, const void* src, int n, int stride_byt
 void launch_residual(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* partials, unsigned int* done_counter,
                      double* out48, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal) {
     const int nb = (n + 63) / 64;
-    KLAUNCH(residual_kernel, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+    if (!(a.pad & 4) && m.cap_nodes < (1 << 26)) KLAUNCH(residual_kernel<true>, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
+    else KLAUNCH(residual_kernel<false>, dim3(nb), dim3(64), 0, s, m, a, rs, pts, n, partials, done_counter, out48, reg_out, ticket, o_match, o_node, o_dis, o_rinv, o_normal);
 }
 void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIterArgs& a, RegState* rs, const float* pts, int n, double* slots, double* slots_next,
                                 int32_t* host_counters, double* reg_out, double ticket, int8_t* o_match, int32_t* o_node, float* o_dis, double* o_rinv, double* o_normal,
@@ -2306,13 +2492,15 @@ void launch_residual_persistent(hipStream_t s, const RegMapDev& m, const RegIter
     // resident grid: at most max_blocks (<= RP_MAX_BLOCKS) four-wavefront blocks + the tail's -- half of what the device holds resident, so that two
     // contexts registering at the same time can never wait for each other's CUs
     const int nb = std::max(1, std::min((n + 255) / 256, std::min(max_blocks, RP_MAX_BLOCKS)));
-    KLAUNCH(residual_persistent_kernel, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
+    if (!(a.pad & 4) && m.cap_nodes < (1 << 26)) KLAUNCH(residual_persistent_kernel<true>, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
+            o_dis, o_rinv, o_normal, ep);
+    else KLAUNCH(residual_persistent_kernel<false>, dim3(nb + 1), dim3(256), 0, s, m, a, rs, pts, n, slots, slots_next, a.max_iter * RP_MAX_BLOCKS * RES_NR, host_counters, reg_out, ticket, o_match, o_node,
             o_dis, o_rinv, o_normal, ep);
 }
 // workgroups of residual_persistent_kernel the device holds resident at once (registers + LDS decide: one per CU on an MI355X)
 int residual_persistent_resident_blocks(int device) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, residual_persistent_kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, residual_persistent_kernel<true>, 256, 0) != hipSuccess) { (void)hipGetLastError(); per_cu = 1; }
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); cus = 0; }
     return std::max(1, per_cu) * cus;
 }
