@@ -59,6 +59,7 @@ int mesh_alloc(immesh_ctx* c) {
     A(m.act_key, cap_active_p2); A(m.act_vox, cap_active_p2); A(m.act_key_s, cap_active); A(m.act_vox_s, cap_active);
     A(m.rel_ids, cap_active * MV_REL_CAP); A(m.rel_n, cap_active); A(m.rel_nq, cap_active);
     A(m.vox_tris, cap_active * 2 * MV_REL_CAP); A(m.vox_ntris, cap_active);
+    A(m.tri_fh, cap_active * 256); A(m.tri_nf, cap_active); A(m.tri_axis, cap_active * 3);
     A(m.list_add, cap_list); A(m.list_rem, cap_list); A(m.list_upd, cap_list); A(m.list_smooth, cap_list);
     const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
     if (shard_mesh && g.shard_brick_log2 > 0 && g.shard_brick_log2 < 2) { c->err = "sharded mesher: bricks below 4 voxels per axis are not supported (the boundary band reaches 2 voxels)"; return IMMESH_E_INVAL; }
@@ -70,8 +71,8 @@ int mesh_alloc(immesh_ctx* c) {
         if (shard_mesh) { A(o.own_add, cap_list); A(o.own_rem, cap_list); A(o.own_upd, cap_list); } else o.own_add = o.own_rem = o.own_upd = nullptr;
     }
     for (int k = 0; k < MESH_WORLD_BUFS; k++) A(h.d_world[k], cap_cand * 4);
-    A(m.tick0, 4);   // (one 64-bit word per job parity)
-    HIPCHK(c, hipMemsetAsync(m.tick0, 0, 32, c->stream));
+    A(m.tick0, 32);   // (16 64-bit words per job parity: [0] the job's start, [1..] the phase marks)
+    HIPCHK(c, hipMemsetAsync(m.tick0, 0, 256, c->stream));
     A(m.dv_scratch, (size_t)32 * 128 * 1024);   // (MV_GEN_BLOCKS x MV_GEN_SCRATCH of mesh_kernels.hip)
     A(h.p_a, cap_list);
     h.sort_temp_bytes = exclusive_sum_temp_bytes((int)cap_cand) + 256;
@@ -85,6 +86,7 @@ int mesh_alloc(immesh_ctx* c) {
     A(m1.sc, SC_COUNT);
     A(m1.act_key, cap_active_p2); A(m1.act_vox, cap_active_p2); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
     A(m1.rel_ids, cap_active * MV_REL_CAP); A(m1.rel_n, cap_active); A(m1.rel_nq, cap_active);
+    A(m1.tri_fh, cap_active * 256); A(m1.tri_nf, cap_active); A(m1.tri_axis, cap_active * 3);
 #undef A
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
@@ -128,8 +130,9 @@ int mesh_alloc(immesh_ctx* c) {
         v.v_smooth_new = m1.v_smooth_new; v.vx_rank = m1.vx_rank; v.vx_rank_seq = m1.vx_rank_seq; v.vx_rank_seq_alt = m.vx_rank_seq;
         v.sc = m1.sc; v.act_key = m1.act_key; v.act_vox = m1.act_vox; v.act_key_s = m1.act_key_s; v.act_vox_s = m1.act_vox_s;
         v.rel_ids = m1.rel_ids; v.rel_n = m1.rel_n; v.rel_nq = m1.rel_nq;
+        v.tri_fh = m1.tri_fh; v.tri_nf = m1.tri_nf; v.tri_axis = m1.tri_axis;
         v.dyn = h.d_dyn[1];
-        v.tick0 = m.tick0 + 1;
+        v.tick0 = m.tick0 + 16;
         for (int k = 0; k < 2; k++) {
             const MeshOutSet& o = h.outs[k];
             MeshDev& w = h.mpar[k];
@@ -139,6 +142,7 @@ int mesh_alloc(immesh_ctx* c) {
         }
     }
     h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
+    h.split_tri = getenv("IMMESH_NO_SPLIT") == nullptr;   // (measurement knob: the round-5 arrangement, triangulation at the head of phase B)
     h.pipeline = getenv("IMMESH_NO_PIPELINE") == nullptr;
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_pc, 0, PC_COUNT * 4);
@@ -170,6 +174,7 @@ int mesh_alloc(immesh_ctx* c) {
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&h.ev_c[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&h.ev_b[k]));   // (doubles as the end time of the job: every record is a barrier packet on the phase-B chain)
     }
     std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
@@ -179,7 +184,30 @@ int mesh_alloc(immesh_ctx* c) {
     return 0;
 }
 
+static void mesh_print_marks(const MeshHost& h) {
+    // the last 64 jobs (minus the newest 4: the wind-down): mean kernel-entry times relative to the job's start, the job period and the scan thread's wait
+    if (h.mark_n < 24 || h.wait_calls < 24) return;
+    const long long hi = h.mark_n - 4, lo = std::max<long long>(hi - 56, 1);
+    double rel[MESH_N_MARKS] = {}, period = 0, bgap = 0;
+    long long n = 0;
+    for (long long j = lo; j < hi; j++, n++) {
+        const unsigned long long* mk = h.mark_ring[j & 63];
+        const unsigned long long* pv = h.mark_ring[(j - 1) & 63];
+        for (int k = 1; k < MESH_N_MARKS; k++) rel[k] += 0.01 * (double)(long long)(mk[k] - mk[0]);
+        period += 0.01 * (double)(long long)(mk[MESH_N_MARKS - 1] - pv[MESH_N_MARKS - 1]);
+        bgap += 0.01 * (double)(long long)((mk[12] > mk[0] ? mk[12] : mk[5]) - pv[MESH_N_MARKS - 1]);
+    }
+    double w = 0; long long nw = 0;
+    for (long long j = std::max<long long>(h.wait_calls - 60, 0); j < h.wait_calls - 4; j++, nw++) w += 1e-3 * (double)h.wait_ring[j & 63];
+    static const char* nm[MESH_N_MARKS] = {"begin", "prepare", "resolve", "finish", "knn", "tri64", "general", "finalize", "chunk_sort", "merge_emit", "commit_add", "publish", "diff64", "end"};
+    fprintf(stderr, "[mesh marks] last %lld jobs, us after the job's start:", n);
+    for (int k = 1; k < MESH_N_MARKS; k++) fprintf(stderr, " %s %.1f", nm[k], rel[k] / (double)n);
+    fprintf(stderr, " | end-to-end %.1f us, previous job's end -> phase B's first kernel %.1f us | scan thread's wait for a world buffer %.1f us (last %lld scans)\n", period / (double)n, bgap / (double)n, nw ? w / (double)nw : 0.0, nw);
+}
 void mesh_free(immesh_ctx* c) {
+    if (getenv("IMMESH_DEBUG_WAITS")) mesh_print_marks(c->mesh_host);
+    if (getenv("IMMESH_DEBUG_WAITS") && c->mesh_host.wait_calls) fprintf(stderr, "[mesh] scan thread waited for a world buffer: %.1f us per scan over %lld scans\n", 1e-3 * (double)c->mesh_host.wait_ns / (double)c->mesh_host.wait_calls, c->mesh_host.wait_calls);
+    if (getenv("IMMESH_DEBUG_WAITS") && c->mesh_host.job_ms_n) fprintf(stderr, "[mesh] device time per job (begin_scan's poll answered -> publish): %.1f us over %lld jobs\n", 1e3 * c->mesh_host.job_ms_sum / (double)c->mesh_host.job_ms_n, c->mesh_host.job_ms_n);
     MeshHost& h = c->mesh_host;
     if (h.worker.joinable()) {
         { std::lock_guard<std::mutex> lk(h.mu); h.stop = true; }
@@ -204,6 +232,7 @@ void mesh_free(immesh_ctx* c) {
     for (int k = 0; k < 2; k++) {
         if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
         if (h.ev_a[k]) (void)hipEventDestroy(h.ev_a[k]);
+        if (h.ev_c[k]) (void)hipEventDestroy(h.ev_c[k]);
         if (h.ev_b[k]) (void)hipEventDestroy(h.ev_b[k]);
         if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
         if (h.graph_exec_b[k]) { (void)hipGraphExecDestroy(h.graph_exec_b[k]); h.graph_exec_b[k] = nullptr; }
@@ -256,9 +285,9 @@ static int mesh_enqueue_a(immesh_ctx* c, const MeshDev& m, int par, hipStream_t 
 }
 // Phase B: a20-a24 (triangulation, diff against the live set, commit: all removes, then all adds -- ImMesh_mesh_reconstruction.cpp:228-244;
 // result lists sorted by triplet), then the counters go to the host.
-static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s, int part = 0) {   // part 1: triangulation only, 2: the rest
-    MeshHost& h = c->mesh_host;
-    if (part != 2) launch_mesh_delaunay(s, m);                // a20-a23
+static int mesh_enqueue_b(immesh_ctx* c, const MeshDev& m, int par, hipStream_t s, int part = 0, bool split = false) {   // part 1: triangulation only, 2: the rest
+    MeshHost& h = c->mesh_host;                                // split: the triangulations ran on the third stream (mesh_tri64_kernel): only the diff is left
+    if (part != 2) { if (split) launch_mesh_diff64(s, m); else launch_mesh_delaunay(s, m); }   // a20-a23
     if (part == 1) return 0;
     launch_mesh_finalize(s, m);                               // (+ the removals: Triangle_manager::remove_triangle_list)
     launch_mesh_sort_emit(s, m, 1, h.d_sort_recs, h.p_a);
@@ -443,11 +472,22 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     // (an event between the phases -- a poll at the head of phase B would hold LDS phase A's single-workgroup launch needs: measured deadlock --
     //  but none behind phase B: mesh_publish_kernel's ticket in pinned memory / the worker's poll)
     MHIPCHK(c, hipEventRecord(h.ev_a[par], sa));
-    MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
+    // Round 6: the triangulations of the job (80 % of what used to be phase B's first launch) need phase A's results and nothing of the previous job's
+    // phase B: they run on a third stream (the fetch / query stream -- no HSA queue of its own, see mesh_alloc) and only the diff against the live
+    // triangle set waits for the previous commit.  Phase B + its queue gap WAS the pipeline's period (profiles/r06_marks_*.txt).
+    const bool split = h.split_tri && sp.n_cand <= 65536;
+    if (split) {
+        static const int which = [] { const char* e = getenv("IMMESH_TRI_STREAM"); return e ? atoi(e) : 0; }();   // (measurement knob: 0 fetch stream, 1 pre-processing stream, 2 null stream)
+        hipStream_t st = which == 1 ? c->stream_pre : (which == 2 ? (hipStream_t)nullptr : h.stream_fetch);
+        MHIPCHK(c, hipStreamWaitEvent(st, h.ev_a[par], 0));
+        launch_mesh_tri64(st, m);
+        MHIPCHK(c, hipEventRecord(h.ev_c[par], st));
+        MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_c[par], 0));
+    } else MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
     if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && is_world) {
-        if ((rc = mesh_graph_run(c, h.graph_exec_b[par], sb, [&] { return mesh_enqueue_b(c, m, par, sb); }))) return rc;
+        if ((rc = mesh_graph_run(c, h.graph_exec_b[par], sb, [&] { return mesh_enqueue_b(c, m, par, sb, 0, split); }))) return rc;
     } else {
-        if ((rc = mesh_enqueue_b(c, m, par, sb))) return rc;
+        if ((rc = mesh_enqueue_b(c, m, par, sb, 0, split))) return rc;
     }
     return 0;
 }
@@ -555,6 +595,9 @@ static void mesh_worker_main(immesh_ctx* c) {
             if (q != hipSuccess) { f.r.rc = IMMESH_E_HIP; f.r.err = std::string("mesh job: ") + hipGetErrorString(q); }
             else {
                 f.r.ms = (float)((double)*(volatile unsigned long long*)(h.h_sc2[par] + MESH_PUB_TICKS) * 1e-5);   // (100 MHz ticks of the device's real-time counter)
+                h.job_ms_sum += f.r.ms; h.job_ms_n++;
+                for (int k = 0; k < MESH_N_MARKS; k++) h.mark_ring[h.mark_n & 63][k] = *(volatile unsigned long long*)(h.h_sc2[par] + MESH_PUB_MARKS + 2 * k);
+                h.mark_n++;
                 f.r.rc = mesh_scan_finish(c, f.job, f.r.sizes);
                 f.r.st_add = h.fin_state[0]; f.r.st_rem = h.fin_state[1]; f.r.st_upd = h.fin_state[2];
                 if (f.r.rc) f.r.err = h.err;
@@ -614,7 +657,11 @@ float* mesh_next_world_buffer(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     std::unique_lock<std::mutex> lk(h.mu);
     const long next = h.submitted + 1;
+    // IMMESH_DEBUG_WAITS: how long the scan thread stands here = how far the mesher is behind the pose chain (printed by mesh_free)
+    static const bool dbg_waits = getenv("IMMESH_DEBUG_WAITS") != nullptr;
+    const auto t0 = dbg_waits ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     h.cv_done.wait(lk, [&] { return h.completed >= next - MESH_WORLD_BUFS && (!h.collect_on || h.collected >= next - 2); });   // (result lists: two sets, job parity)
+    if (dbg_waits) { const long long w = (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); h.wait_ns += w; h.wait_ring[h.wait_calls & 63] = w; h.wait_calls++; }
     return h.d_world[next % MESH_WORLD_BUFS];
 }
 // wait for job `id` (0 = the newest submitted) and make it the one immesh_mesh_sizes / fetch / last_timing report

@@ -176,6 +176,8 @@ IMD float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
 
 // Per-scan parameters live in device memory (MeshDev::dyn, refreshed by a copy at the head of every scan) so that the kernel arguments
 // are identical from scan to scan and the whole launch sequence can be replayed as a hipGraph.
+// phase marks (IMMESH_DEBUG_WAITS): thread 0 of block 0 leaves the device's real-time counter at kernel entry; mesh_publish_kernel hands the marks to the host
+#define MESH_MARK(arg, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) (arg).tick0[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define MESH_DYN(arg)                                  \
     MeshDev m = (arg);                                 \
     const MeshScanParams sp = (arg).dyn->sp;           \
@@ -280,8 +282,13 @@ __global__ void mesh_publish_kernel(MeshDev m_in, int32_t* __restrict__ host_sc)
     const int k = threadIdx.x;
     if (k < SC_COUNT) __hip_atomic_store(&host_sc[k], m_in.sc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (k == 0) {
-        const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - *m_in.tick0;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long ticks = now - *m_in.tick0;
         __hip_atomic_store((unsigned long long*)&host_sc[MESH_PUB_TICKS], ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (k < MESH_N_MARKS) {   // phase marks: [0] = the job's first kernel past its poll, [1..10] kernel entries, [11] = now (absolute ticks: the host takes differences)
+        const unsigned long long v = k == MESH_N_MARKS - 1 ? __builtin_amdgcn_s_memrealtime() : m_in.tick0[k];
+        __hip_atomic_store((unsigned long long*)&host_sc[MESH_PUB_MARKS + 2 * k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -417,6 +424,7 @@ IMD int mesh_admit_candidate(const MeshDev& m, bool live, int i, float px, float
     return probes;
 }
 __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
+    MESH_MARK(m_in, 1);
     // (everything a thread needs to find its candidate is requested before anything is waited for: the slot's fill count, the slot, the scan's parameters)
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(256) void mesh_append_prepare_kernel(MeshDev m_in, 
 // moves from UNDECIDED to a final value, so the cached list decides exactly what the walk would.
 #define RC_MAX 14   /* cached undecided conflicts per candidate (more: the candidate keeps walking) */
 __global__ __launch_bounds__(256) void mesh_append_resolve_kernel(MeshDev m_in, const float* __restrict__ pts_arg, int max_iter) {
+    MESH_MARK(m_in, 2);
     MESH_DYN(m_in);
     __shared__ int s_conf[RC_MAX][256];
     const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
@@ -715,6 +724,7 @@ IMD int next_pow2_i(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 #define MV_FIN_ACT 8192        /* visited voxels whose selection + ordering run in LDS; more than that (sparse far-field scans) take the global arrays */
 // (~100 KB of static LDS for one workgroup: the 160 KB of a gfx950 CU -- the only target of this library, see the Makefile -- is assumed)
 __global__ __launch_bounds__(1024) void mesh_append_finish_kernel(MeshDev m_in, const float* __restrict__ pts_arg) {
+    MESH_MARK(m_in, 3);
     MESH_DYN(m_in);
     const float* __restrict__ pts = pts_arg ? pts_arg : dyn_pts;
     __shared__ unsigned long long skey[MV_FIN_ACT];
@@ -893,6 +903,7 @@ IMD double wave_max_d(double x) {
 template <bool EXPORT>
 __global__ __launch_bounds__(256) void mesh_knn_kernel(MeshDev m_in, float* __restrict__ export_vtx, double smooth_factor, const int32_t* __restrict__ vox_list, int n_list,
                                                         double* __restrict__ export_d, double max_dis) {
+    if (!EXPORT) MESH_MARK(m_in, 4);
     MESH_DYN(m_in);
     __shared__ float cx[KC], cy[KC], cz[KC];
     __shared__ int cid[KC];
@@ -1710,6 +1721,7 @@ __device__ __forceinline__ void mesh_delaunay_voxel(const MeshDev& m, const Mesh
 // nothing to do, so what counts is how quickly its blocks are placed and gone): neighbourhoods of 65..256 vertices and the voxels the fast path
 // handed over from LDS tables, neighbourhoods above 256 vertices (space-filling clouds) from tables in global scratch.
 __global__ __launch_bounds__(64) void mesh_delaunay_general_kernel(MeshDev m_in) {
+    MESH_MARK(m_in, 6);
     MESH_DYN(m_in);
     const int n_active = min(m.sc[SC_ACTIVE], m.cap_active);
     for (int r = (int)blockIdx.x; r < n_active; r += (int)gridDim.x) {
@@ -1738,6 +1750,7 @@ IMD void mesh_commit_rem_slice(const MeshDev& m, const int32_t* __restrict__ tri
     }
 }
 __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
+    MESH_MARK(m_in, 7);
     __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     mesh_commit_rem_slice(m, m.list_rem, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);   // Triangle_manager::remove_triangle_list rides along (independent data)
@@ -1977,6 +1990,7 @@ IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
     pl.blk_base[LS_JOBS] = blk; pl.eblk_base[LS_JOBS] = eblk;
 }
 __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int which, SortRec* __restrict__ recs_out) {
+    if (which == 1) MESH_MARK(m_in, 8);
     __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     __shared__ SortRec recs[LS_CHUNK];
@@ -2016,6 +2030,7 @@ IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& k
     return lo;
 }
 __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
+    if (which == 1) MESH_MARK(m_in, 9);
     __builtin_amdgcn_s_setprio(2);
     MESH_DYN(m_in);
     LSortPlan pl;
@@ -2092,6 +2107,7 @@ __global__ void mesh_commit_rem_kernel(MeshDev m_in, const int32_t* __restrict__
 // Triangle_manager::insert_triangle (triangle.hpp:330-395).  The list is sorted by triplet, so triangles sharing their smallest
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
 __global__ void mesh_commit_add_kernel(MeshDev m_in, const int32_t* __restrict__ tris) {
+    MESH_MARK(m_in, 10);
     __builtin_amdgcn_s_setprio(2);
     MESH_DYN(m_in);
     const int n = min(m.sc[SC_ADD], m.cap_list);
@@ -2220,8 +2236,14 @@ void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tri
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces) { KLAUNCH(mesh_export_wind_kernel, g1(n), dim3(256), 0, s, m, tri_sorted, n, faces); }
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m) {
     // (grids: the dispatcher places ~130 workgroups per us, so a launch of 2048 workgroups lasts >= 16 us however little they do; the kernels stride)
-    KLAUNCH(mesh_delaunay64_kernel, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m);           // n_u <= 64: register fast path
+    KLAUNCH(mesh_delaunay64_kernel<0>, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m);           // n_u <= 64: register fast path
     KLAUNCH(mesh_delaunay_general_kernel, dim3(MV_GEN_BLOCKS), dim3(64), 0, s, m);     // 64 < n_u and what the fast path handed over
+}
+// the same in two launches on two streams (mesh_delaunay64.inc): the triangulations behind phase A, the diff against the live set at the head of phase B
+void launch_mesh_tri64(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_tri64_kernel, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m); }
+void launch_mesh_diff64(hipStream_t s, const MeshDev& m) {
+    KLAUNCH(mesh_diff64_kernel, dim3(768 / mesh_grid_div()), dim3(64), 0, s, m);
+    KLAUNCH(mesh_delaunay_general_kernel, dim3(MV_GEN_BLOCKS), dim3(64), 0, s, m);
 }
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m) { KLAUNCH(mesh_finalize_kernel, dim3(128), dim3(64), 0, s, m); }
 void launch_mesh_commit_rem(hipStream_t s, const MeshDev& m, const int32_t* tris) { KLAUNCH(mesh_commit_rem_kernel, dim3(128), dim3(256), 0, s, m, tris); }

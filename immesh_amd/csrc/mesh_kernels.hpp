@@ -87,6 +87,7 @@ struct MeshDev {
     int32_t* recent;                                                       // voxel indices visited this scan
     unsigned long long* act_key; int32_t* act_vox; unsigned long long* act_key_s; int32_t* act_vox_s;
     int32_t* rel_ids; int32_t* rel_n; int32_t* rel_nq;                     // [n_active][MV_REL_CAP], [n_active], [n_active] (vertices the voxel held when it was searched)
+    unsigned int* tri_fh; int32_t* tri_nf; double* tri_axis;                // per job parity: mesh_tri64_kernel -> mesh_diff64_kernel ([n_active][256] fresh-face hash set, face count / -1, short axis)
     int32_t* vox_tris; int32_t* vox_ntris;                                 // [n_active][2*MV_REL_CAP] triangle ids touched (bit 31 = add)
     int32_t* list_add; int32_t* list_rem; int32_t* list_upd; int32_t* list_smooth;   // unsorted unique lists
     int32_t* list_smooth_rx;                                               // sharded mesher: vertices whose smoothed positions arrived from other ranks
@@ -122,7 +123,9 @@ struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 #define MESH_WORLD_BUFS 4
 #define MESH_PUB_SEQ (SC_COUNT + 0)     /* job sequence number: the completion ticket the worker polls */
 #define MESH_PUB_TICKS (SC_COUNT + 2)   /* 64-bit: device time of the job, 100 MHz ticks */
-#define MESH_PUB_WORDS (SC_COUNT + 8)
+#define MESH_N_MARKS 14
+#define MESH_PUB_MARKS (SC_COUNT + 8)  /* MESH_N_MARKS x 64-bit: absolute real-time-counter values at the entries of the job's kernels (MESH_MARK) */
+#define MESH_PUB_WORDS (SC_COUNT + 8 + 2 * MESH_N_MARKS)
 struct MeshJob { const float* d_pts; int n_raw; double cam[3]; int frame_idx; long id; hipEvent_t ready; const unsigned long long* wait_flag = nullptr; unsigned long long wait_seq = 0; };
 struct MeshOutSet { int32_t* tri_add; uint8_t* flip_add; int32_t* tri_rem; int32_t* tri_upd; uint8_t* flip_upd; int32_t* smooth_ids; double* smooth_xyz;
                     uint8_t* own_add; uint8_t* own_rem; uint8_t* own_upd; };
@@ -149,6 +152,7 @@ struct MeshHost {
     hipStream_t stream = nullptr;            // the mesher's own streams: phase A ...
     hipStream_t stream_b = nullptr;          // ... and phase B
     hipEvent_t ev_ready[2] = {nullptr, nullptr};   // (a job's device time comes from mesh_publish_kernel, not from events)
+    hipEvent_t ev_c[2] = {nullptr, nullptr};   // the job's triangulations (third stream) finished
     hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};   // phase A / B of the job of that parity finished
     // world-frame full scans.  The mesher pipelines two jobs (phase A of one over phase B of the other) and takes ~2.4 scan periods per job, so the scan
     // thread writes up to MESH_WORLD_BUFS scans ahead of the oldest running job (buffer = job id mod MESH_WORLD_BUFS) before it has to wait
@@ -163,6 +167,10 @@ struct MeshHost {
     // service-thread collection (immesh_mesh_collect_*): jobs are handed to the collector strictly in order; with it enabled a submission that would
     // overwrite the result buffers of a job not yet collected (id - 2) waits -- nothing is dropped
     bool collect_on = false;
+    double job_ms_sum = 0; long long job_ms_n = 0;
+    unsigned long long mark_ring[64][MESH_N_MARKS] = {}; long long mark_n = 0;   // IMMESH_DEBUG_WAITS: phase marks of the last 64 jobs
+    long long wait_ring[64] = {}; 
+    long long wait_ns = 0, wait_calls = 0;   // IMMESH_DEBUG_WAITS (mesh_next_world_buffer)
     long collected = 0;
     std::mutex fetch_mu;                     // immesh_mesh_fetch's staging block: one fetch at a time, from allocation to the last memcpy
     char* h_fetch = nullptr; size_t h_fetch_bytes = 0;   // immesh_mesh_fetch: pinned staging (the lists land here by DMA, all copies in flight together, then one memcpy each into the caller's pageable buffers)
@@ -176,6 +184,7 @@ struct MeshHost {
     hipGraphExec_t graph_exec_b[2] = {nullptr, nullptr}; // phase B
     int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
     bool use_graph = true;
+    bool split_tri = true;   // triangulation on the third stream, the diff at the head of phase B (IMMESH_NO_SPLIT: one launch at the head of phase B)
     bool pipeline = true;                    // phase A of scan k+1 may overlap phase B of scan k (IMMESH_NO_PIPELINE turns it off)
     // mesh export scratch (grow-only)
     void *exp_vtx = nullptr, *exp_work = nullptr, *exp_tmp = nullptr;
@@ -223,6 +232,8 @@ void launch_mesh_export_faces(hipStream_t s, const MeshDev& m, int32_t* tri_idx,
 void launch_mesh_export_keys(hipStream_t s, const MeshDev& m, const int32_t* tris, int n, int which, uint32_t* k32, unsigned long long* k64);
 void launch_mesh_export_wind(hipStream_t s, const MeshDev& m, const int32_t* tri_sorted, int n, int32_t* faces);
 void launch_mesh_delaunay(hipStream_t s, const MeshDev& m);
+void launch_mesh_tri64(hipStream_t s, const MeshDev& m);
+void launch_mesh_diff64(hipStream_t s, const MeshDev& m);
 void launch_mesh_finalize(hipStream_t s, const MeshDev& m);
 // exchange blocks of the sharded mesher: every rank contributes ONE fixed-size block per exchange -- 16-byte header {records, aux, -, -} + records -- so an
 // exchange is a single all-gather, and the unpack kernels read the counts on the device (cap_rec = records a block holds)

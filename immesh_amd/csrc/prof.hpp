@@ -15,7 +15,10 @@ struct KProf {
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
 
-    int id_of(const char* n) {
+    int id_of(const char* n0) {
+        std::string n(n0);   // (instantiations of one kernel template report under the template's name: residual_persistent_kernel<true> / <false>)
+        const size_t lt = n.find('<');
+        if (lt != std::string::npos) n.resize(lt);
         for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i;
         names.emplace_back(n); ms.push_back(0.0); cnt.push_back(0);
         return (int)names.size() - 1;

@@ -2516,7 +2516,8 @@ void launch_point_var(hipStream_t s, const RegMapDev& m, const ScanParams& sp, c
 void launch_replay_lists(hipStream_t s, const RegMapDev& m, const int32_t* pt_next, const unsigned long long* sort_key, const double* pt_data, int n,
                          int64_t* stats, int32_t* host_counters, int32_t* big_idx, int32_t* big_order, uint32_t* general_list, unsigned long long* dbg, bool with_tail,
                          unsigned long long* flag_dev, unsigned long long* flag_host, unsigned long long flag_seq) {
-    KLAUNCH(replay_fused_kernel, dim3(std::min((n + 3) / 4, 768)), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg, flag_dev, flag_host, flag_seq);
+    static const int fused_wgs = [] { const char* e = getenv("IMMESH_FUSED_WGS"); const int v = e ? atoi(e) : 0; return v >= 32 ? v : 768; }();   // (measurement knob, tools/r06_fused.sh)
+    KLAUNCH(replay_fused_kernel, dim3(std::min((n + 3) / 4, fused_wgs)), dim3(256), 0, s, m, pt_next, sort_key, pt_data, stats, general_list, dbg, flag_dev, flag_host, flag_seq);
     // the work list's length is only known on the device: a fixed grid strides over it (sized for the map-building case, where every touched voxel is on it)
     // points per workgroup of the list kernel's grid.  Two-layer maps (avia.yaml): 128 -- its ~1 100 general voxels are bound by the slowest voxel's chain, more
     // workgroups only get in the mesher's way (sweep 64 / 32 / 16 / 8: 5 700-5 930 scans/s against 5 920-5 930, round 6).  Deep octrees (velodyne.yaml: every
