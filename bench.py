@@ -211,7 +211,7 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
         return n_ds * 96 + (c["n_refit_pts"] * 96 + c["n_refits"] * 229) / n_scans
     if kname == "mesh_knn_kernel":      # per scan: C20 inspected vertices x 12 B + query 12 B + 20 ids out
         return (c["c20"] * 12 + c["n_v"] * (12 + 80 + 24)) / n_scans
-    if kname in ("mesh_delaunay_kernel", "mesh_delaunay64_kernel"):  # per scan: n_u x (12 B pos + 6 x 12 B incident triangles) + T_v x 12 B
+    if kname in ("mesh_delaunay_kernel", "mesh_delaunay64_kernel", "mesh_tri64_kernel"):  # per scan: n_u x (12 B pos + 6 x 12 B incident triangles) + T_v x 12 B
         return (c["n_u"] * 84 + c["t_v"] * 12) / n_scans
     if kname == "mesh_transform_kernel":
         return n_raw * 32

@@ -147,7 +147,19 @@ immesh_ctx* immesh_create(const immesh_config* cfg) {
         g_create_error = "hipSetDevice/hipStreamCreate failed"; delete c; return nullptr;
     }
     for (auto& ev : c->ev) (void)hipEventCreate(&ev);
-    if (hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) != hipSuccess ||
+    // IMMESH_MESH_CUS=n (measurement knob, see mesh_alloc): the mesher's streams -- and this one, which carries the mesher's triangulations -- are confined to n CUs
+    hipError_t pre_rc = hipErrorUnknown;
+    {
+        int ncu = 0;
+        if (const char* e = getenv("IMMESH_MESH_CUS")) ncu = atoi(e);
+        if (ncu >= 8 && ncu < 1024) {
+            uint32_t mask[32];
+            std::memset(mask, 0, sizeof(mask));
+            for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
+            pre_rc = hipExtStreamCreateWithCUMask(&c->stream_pre, 32, mask);
+        } else pre_rc = hipStreamCreateWithFlags(&c->stream_pre, hipStreamNonBlocking);
+    }
+    if (pre_rc != hipSuccess || hipEventCreateWithFlags(&c->ev_inputs_free, hipEventDisableTiming) != hipSuccess ||
         hipEventRecord(c->ev_inputs_free, c->stream) != hipSuccess || !(c->ev_inputs_cur = c->ev_inputs_free)) {
         g_create_error = "hipStreamCreate/hipEventCreate failed"; immesh_destroy(c); return nullptr;
     }

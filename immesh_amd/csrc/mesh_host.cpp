@@ -64,29 +64,32 @@ int mesh_alloc(immesh_ctx* c) {
     const bool shard_mesh = g.shard_world > 1 && g.shard_mesh != 0;
     if (shard_mesh && g.shard_brick_log2 > 0 && g.shard_brick_log2 < 2) { c->err = "sharded mesher: bricks below 4 voxels per axis are not supported (the boundary band reaches 2 voxels)"; return IMMESH_E_INVAL; }
     if (shard_mesh) A(m.list_smooth_rx, cap_list);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < MESH_NPAR; k++) {
         MeshOutSet& o = h.outs[k];
         A(o.tri_add, cap_list * 3); A(o.flip_add, cap_list); A(o.tri_rem, cap_list * 3); A(o.tri_upd, cap_list * 3); A(o.flip_upd, cap_list);
         A(o.smooth_ids, cap_list); A(o.smooth_xyz, cap_list * 3);
         if (shard_mesh) { A(o.own_add, cap_list); A(o.own_rem, cap_list); A(o.own_upd, cap_list); } else o.own_add = o.own_rem = o.own_upd = nullptr;
     }
     for (int k = 0; k < MESH_WORLD_BUFS; k++) A(h.d_world[k], cap_cand * 4);
-    A(m.tick0, 32);   // (16 64-bit words per job parity: [0] the job's start, [1..] the phase marks)
-    HIPCHK(c, hipMemsetAsync(m.tick0, 0, 256, c->stream));
+    A(m.tick0, 16 * MESH_NPAR);   // (16 64-bit words per set: [0] the job's start, [1..] the phase marks)
+    HIPCHK(c, hipMemsetAsync(m.tick0, 0, 128 * MESH_NPAR, c->stream));
     A(m.dv_scratch, (size_t)32 * 128 * 1024);   // (MV_GEN_BLOCKS x MV_GEN_SCRATCH of mesh_kernels.hip)
     A(h.p_a, cap_list);
     h.sort_temp_bytes = exclusive_sum_temp_bytes((int)cap_cand) + 256;
     { char* t; A(t, h.sort_temp_bytes); h.d_sort_temp = t; }
     { unsigned long long* t; A(t, (size_t)(4 * cap_list + cap_active + 5 * 1024) * 2); h.d_sort_recs = t; }
     { unsigned long long* t; A(t, (size_t)(cap_active + 5 * 1024) * 2); h.d_sort_recs_a = t; }
-    // parity 1 copies of everything phase A of scan k+1 writes while phase B of scan k still reads it (parity 0 = the arrays above)
-    MeshDev m1;
-    std::memset(&m1, 0, sizeof(m1));
-    A(m1.v_smooth_new, cap_verts * 3); A(m1.vx_rank, cap_voxels); A(m1.vx_rank_seq, cap_voxels);
-    A(m1.sc, SC_COUNT);
-    A(m1.act_key, cap_active_p2); A(m1.act_vox, cap_active_p2); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
-    A(m1.rel_ids, cap_active * MV_REL_CAP); A(m1.rel_n, cap_active); A(m1.rel_nq, cap_active);
-    A(m1.tri_fh, cap_active * 256); A(m1.tri_nf, cap_active); A(m1.tri_axis, cap_active * 3);
+    // further sets of everything a job's phases hand to each other while other jobs are in flight (set 0 = the arrays above)
+    MeshDev mx[MESH_NPAR];
+    for (int p = 1; p < MESH_NPAR; p++) {
+        MeshDev& m1 = mx[p];
+        std::memset(&m1, 0, sizeof(m1));
+        A(m1.v_smooth_new, cap_verts * 3); A(m1.vx_rank, cap_voxels); A(m1.vx_rank_seq, cap_voxels);
+        A(m1.sc, SC_COUNT);
+        A(m1.act_key, cap_active_p2); A(m1.act_vox, cap_active_p2); A(m1.act_key_s, cap_active); A(m1.act_vox_s, cap_active);
+        A(m1.rel_ids, cap_active * MV_REL_CAP); A(m1.rel_n, cap_active); A(m1.rel_nq, cap_active);
+        A(m1.tri_fh, cap_active * 256); A(m1.tri_nf, cap_active); A(m1.tri_axis, cap_active * 3);
+    }
 #undef A
     m.cap_verts = (int32_t)cap_verts; m.cap_voxels = (int32_t)cap_voxels; m.cap_tris = (int32_t)cap_tris; m.cap_adj_chunks = (int32_t)cap_adj;
     m.cap_cand = (int32_t)cap_cand; m.cap_active = (int32_t)cap_active; m.cap_list = (int32_t)cap_list;
@@ -108,10 +111,12 @@ int mesh_alloc(immesh_ctx* c) {
         { char* t; if ((rc = c->dalloc(&t, h.xcap_bytes))) return rc; h.d_xsend = t; }
         { char* t; if ((rc = c->dalloc(&t, h.xall_bytes))) return rc; h.d_xall = t; }
     }
-    HIPCHK(c, hipMemsetAsync(m1.sc, 0, SC_COUNT * 4, s));
     HIPCHK(c, hipMemsetAsync(m.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
-    HIPCHK(c, hipMemsetAsync(m1.vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
-    for (int k = 0; k < 2; k++) {
+    for (int p = 1; p < MESH_NPAR; p++) {
+        HIPCHK(c, hipMemsetAsync(mx[p].sc, 0, SC_COUNT * 4, s));
+        HIPCHK(c, hipMemsetAsync(mx[p].vx_rank_seq, 0, (size_t)cap_voxels * 4, s));
+    }
+    for (int k = 0; k < MESH_NPAR; k++) {
         MeshDyn* t; if ((rc = c->dalloc(&t, 1))) return rc; h.d_dyn[k] = t;
         HIPCHK(c, hipHostMalloc((void**)&h.h_dyn[k], sizeof(MeshDyn), hipHostMallocMapped));
         HIPCHK(c, hipHostGetDevicePointer((void**)&h.h_dyn_dev[k], h.h_dyn[k], 0));
@@ -122,18 +127,23 @@ int mesh_alloc(immesh_ctx* c) {
     }
     h.h_sc = h.h_sc2[0];
     m.dyn = h.d_dyn[0];
-    m.vx_rank_seq_alt = m1.vx_rank_seq;
-    {   // the two parity views
+    static_assert(MESH_NPAR == 3, "the views below name the two other sets' stamps");
+    m.vx_rank_seq_alt = mx[1].vx_rank_seq; m.vx_rank_seq_alt2 = mx[2].vx_rank_seq;
+    {   // the views, one per set
         h.mpar[0] = m;
-        MeshDev& v = h.mpar[1];
-        v = m;
-        v.v_smooth_new = m1.v_smooth_new; v.vx_rank = m1.vx_rank; v.vx_rank_seq = m1.vx_rank_seq; v.vx_rank_seq_alt = m.vx_rank_seq;
-        v.sc = m1.sc; v.act_key = m1.act_key; v.act_vox = m1.act_vox; v.act_key_s = m1.act_key_s; v.act_vox_s = m1.act_vox_s;
-        v.rel_ids = m1.rel_ids; v.rel_n = m1.rel_n; v.rel_nq = m1.rel_nq;
-        v.tri_fh = m1.tri_fh; v.tri_nf = m1.tri_nf; v.tri_axis = m1.tri_axis;
-        v.dyn = h.d_dyn[1];
-        v.tick0 = m.tick0 + 16;
-        for (int k = 0; k < 2; k++) {
+        for (int p = 1; p < MESH_NPAR; p++) {
+            MeshDev& v = h.mpar[p];
+            const MeshDev& m1 = mx[p];
+            v = m;
+            v.v_smooth_new = m1.v_smooth_new; v.vx_rank = m1.vx_rank; v.vx_rank_seq = m1.vx_rank_seq;
+            v.vx_rank_seq_alt = p == 1 ? m.vx_rank_seq : mx[1].vx_rank_seq; v.vx_rank_seq_alt2 = p == 2 ? m.vx_rank_seq : mx[2].vx_rank_seq;
+            v.sc = m1.sc; v.act_key = m1.act_key; v.act_vox = m1.act_vox; v.act_key_s = m1.act_key_s; v.act_vox_s = m1.act_vox_s;
+            v.rel_ids = m1.rel_ids; v.rel_n = m1.rel_n; v.rel_nq = m1.rel_nq;
+            v.tri_fh = m1.tri_fh; v.tri_nf = m1.tri_nf; v.tri_axis = m1.tri_axis;
+            v.dyn = h.d_dyn[p];
+            v.tick0 = m.tick0 + 16 * p;
+        }
+        for (int k = 0; k < MESH_NPAR; k++) {
             const MeshOutSet& o = h.outs[k];
             MeshDev& w = h.mpar[k];
             w.out_tri_add = o.tri_add; w.out_flip_add = o.flip_add; w.out_tri_rem = o.tri_rem; w.out_tri_upd = o.tri_upd; w.out_flip_upd = o.flip_upd;
@@ -142,7 +152,8 @@ int mesh_alloc(immesh_ctx* c) {
         }
     }
     h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
-    h.split_tri = getenv("IMMESH_NO_SPLIT") == nullptr;   // (measurement knob: the round-5 arrangement, triangulation at the head of phase B)
+    h.split_tri = getenv("IMMESH_NO_SPLIT") == nullptr;
+    if (const char* e = getenv("IMMESH_MESH_ROOM")) h.room = std::min(std::max(atoi(e), 1), MESH_NPAR);   // (measurement knob: jobs in flight; 2 = rounds 1-5)   // (measurement knob: the round-5 arrangement, triangulation at the head of phase B)
     h.pipeline = getenv("IMMESH_NO_PIPELINE") == nullptr;
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_pc, 0, PC_COUNT * 4);
@@ -171,13 +182,13 @@ int mesh_alloc(immesh_ctx* c) {
         HIPCHK(c, hipStreamCreateWithPriority(&h.stream_fetch, hipStreamNonBlocking, prio_least));
         h.stream_q = h.stream_fetch;   // (no HSA queue of its own: an extra queue in the process costs every stream -- immesh_create; queries and fetches are both rare and short)
     }
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
+    for (int k = 0; k < MESH_WORLD_BUFS; k++) HIPCHK(c, hipEventCreateWithFlags(&h.ev_ready[k], hipEventDisableTiming));
+    for (int k = 0; k < MESH_NPAR; k++) {
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_a[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&h.ev_c[k], hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&h.ev_b[k]));   // (doubles as the end time of the job: every record is a barrier packet on the phase-B chain)
     }
-    std::memset(&h.res[0].sizes, 0, sizeof(immesh_mesh_sizes_t)); std::memset(&h.res[1].sizes, 0, sizeof(immesh_mesh_sizes_t));
+    for (int k = 0; k < MESH_NPAR; k++) std::memset(&h.res[k].sizes, 0, sizeof(immesh_mesh_sizes_t));
     h.stop = false;
     h.worker = std::thread(mesh_worker_main, c);
     h.ready = true;
@@ -229,8 +240,8 @@ void mesh_free(immesh_ctx* c) {
     if (h.d_xbig) (void)hipFree(h.d_xbig);
     h.d_xbig = nullptr; h.xbig_bytes = 0;
     h.exp_vtx = h.exp_work = h.exp_tmp = nullptr;
-    for (int k = 0; k < 2; k++) {
-        if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
+    for (int k = 0; k < MESH_WORLD_BUFS; k++) if (h.ev_ready[k]) (void)hipEventDestroy(h.ev_ready[k]);
+    for (int k = 0; k < MESH_NPAR; k++) {
         if (h.ev_a[k]) (void)hipEventDestroy(h.ev_a[k]);
         if (h.ev_c[k]) (void)hipEventDestroy(h.ev_c[k]);
         if (h.ev_b[k]) (void)hipEventDestroy(h.ev_b[k]);
@@ -391,7 +402,7 @@ static int mesh_graph_run(immesh_ctx* c, hipGraphExec_t& exec, hipStream_t s, co
 // offline-sized.  `synced` tells the caller that both streams are already drained.
 static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     MeshHost& h = c->mesh_host;
-    const int par = (int)(job.id & 1);
+    const int par = (int)(job.id % MESH_NPAR);
     const MeshDev& m = h.mpar[par];
     hipStream_t sa = h.stream, sb = h.stream_b;
     const float* d_pts = job.d_pts;
@@ -477,7 +488,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     // triangle set waits for the previous commit.  Phase B + its queue gap WAS the pipeline's period (profiles/r06_marks_*.txt).
     const bool split = h.split_tri && sp.n_cand <= 65536;
     if (split) {
-        static const int which = [] { const char* e = getenv("IMMESH_TRI_STREAM"); return e ? atoi(e) : 0; }();   // (measurement knob: 0 fetch stream, 1 pre-processing stream, 2 null stream)
+        static const int which = [] { const char* e = getenv("IMMESH_TRI_STREAM"); return e ? atoi(e) : 1; }();   // (measurement knob: 0 fetch stream, 1 pre-processing stream (default), 2 null stream)
         hipStream_t st = which == 1 ? c->stream_pre : (which == 2 ? (hipStream_t)nullptr : h.stream_fetch);
         MHIPCHK(c, hipStreamWaitEvent(st, h.ev_a[par], 0));
         launch_mesh_tri64(st, m);
@@ -495,7 +506,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
 // Worker thread, after ev_b of the job's parity has completed: sizes, cumulative counters, capacity / hang checks.
 static int mesh_scan_finish(immesh_ctx* c, const MeshJob& job, immesh_mesh_sizes_t& sizes) {
     MeshHost& h = c->mesh_host;
-    const int par = (int)(job.id & 1);
+    const int par = (int)(job.id % MESH_NPAR);
     const MeshDev& m = h.mpar[par];
     h.h_sc = h.h_sc2[par];
     int rc = mesh_overflow(c);
@@ -554,7 +565,7 @@ static void mesh_worker_main(immesh_ctx* c) {
         {
             std::unique_lock<std::mutex> lk(h.mu);
             if (fl.empty()) h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
-            const size_t room = (h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? 2 : 1;
+            const size_t room = (h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (size_t)h.room : 1;
             if (!h.q.empty() && fl.size() < room) { job = h.q.front(); h.q.pop_front(); have = true; }
             else if (fl.empty() && h.q.empty()) break;   // stop requested and nothing left to do
         }
@@ -573,7 +584,7 @@ static void mesh_worker_main(immesh_ctx* c) {
         }
         // ---- finish the oldest scan in flight once its phase B is done; meanwhile keep an eye on the queue
         Flight& f = fl.front();
-        const int par = (int)(f.job.id & 1);
+        const int par = (int)(f.job.id % MESH_NPAR);
         if (f.launched_ok) {
             hipError_t q;
             if (f.by_ticket) {
@@ -587,7 +598,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             } else q = hipEventQuery(h.ev_b[par]);
             if (q == hipErrorNotReady) {
                 bool more;
-                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? 2u : 1u); }
+                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (size_t)h.room : (size_t)1); }
                 if (!more) std::this_thread::yield();
                 continue;
             }
@@ -614,7 +625,7 @@ static void mesh_worker_main(immesh_ctx* c) {
         }
         {
             std::lock_guard<std::mutex> lk(h.mu);
-            h.res[f.job.id & 1] = f.r;
+            h.res[f.job.id % MESH_NPAR] = f.r;
             h.completed = f.job.id;
         }
         h.cv_done.notify_all();
@@ -629,8 +640,8 @@ hipEvent_t mesh_record_ready(immesh_ctx* c) {
     MeshHost& h = c->mesh_host;
     long next;
     { std::unique_lock<std::mutex> lk(h.mu); next = h.submitted + 1; }
-    (void)hipEventRecord(h.ev_ready[next & 1], c->stream);
-    return h.ev_ready[next & 1];
+    (void)hipEventRecord(h.ev_ready[next % MESH_WORLD_BUFS], c->stream);
+    return h.ev_ready[next % MESH_WORLD_BUFS];
 }
 long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sensor_pos, int frame_idx, bool ready_recorded, const unsigned long long* wait_flag, unsigned long long wait_seq) {
     MeshHost& h = c->mesh_host;
@@ -641,7 +652,7 @@ long mesh_submit(immesh_ctx* c, const float* d_pts, int n_raw, const double* sen
     }
     job.d_pts = d_pts; job.n_raw = n_raw; job.frame_idx = frame_idx;
     job.cam[0] = sensor_pos[0]; job.cam[1] = sensor_pos[1]; job.cam[2] = sensor_pos[2];
-    job.ready = h.ev_ready[job.id & 1];
+    job.ready = h.ev_ready[job.id % MESH_WORLD_BUFS];
     job.wait_flag = wait_flag; job.wait_seq = wait_seq;
     if (!ready_recorded && !wait_flag) (void)hipEventRecord(job.ready, c->stream);
     {
@@ -673,7 +684,7 @@ int mesh_wait(immesh_ctx* c, long id) {
     if (id < h.submitted - 1) { c->err = "mesh job results already overwritten (only the two newest jobs are kept)"; return IMMESH_E_INVAL; }
     h.cv_done.wait(lk, [&] { return h.completed >= id; });
     h.current = id;
-    const MeshResult& r = h.res[id & 1];
+    const MeshResult& r = h.res[id % MESH_NPAR];
     c->timing[3] = r.ms;
     if (r.rc) c->err = r.err;
     return r.rc;
@@ -752,7 +763,7 @@ int immesh_mesh_collect_begin(immesh_ctx* c, int32_t timeout_ms, int64_t* job_or
     if (!h.cv_done.wait_for(lk, std::chrono::milliseconds(timeout_ms < 0 ? 0 : timeout_ms), [&] { return h.completed >= id; })) return IMMESH_NOT_READY;
     h.current = id;
     if (job_ordinal) *job_ordinal = id;
-    return h.res[id & 1].rc;
+    return h.res[id % MESH_NPAR].rc;
 }
 int immesh_mesh_collect_end(immesh_ctx* c) {
     if (!c) return IMMESH_E_INVAL;
@@ -771,7 +782,7 @@ int immesh_mesh_sizes(immesh_ctx* c, immesh_mesh_sizes_t* sizes) {
     MeshHost& h = c->mesh_host;
     std::lock_guard<std::mutex> lk(h.mu);
     if (h.current <= 0) { std::memset(sizes, 0, sizeof(*sizes)); return 0; }
-    *sizes = h.res[h.current & 1].sizes;
+    *sizes = h.res[h.current % MESH_NPAR].sizes;
     return 0;
 }
 
@@ -785,7 +796,7 @@ int immesh_mesh_neighbourhood_sizes(immesh_ctx* c, int32_t* out, int32_t cap, in
         std::lock_guard<std::mutex> lk(h.mu);
         if (h.current <= 0) { *n_out = 0; return 0; }
         if (h.current < h.submitted) { c->err = "a newer mesh job is in flight (immesh_mesh_wait first)"; return IMMESH_E_INVAL; }
-        par = (int)(h.current & 1);
+        par = (int)(h.current % MESH_NPAR);
         n = h.res[par].sizes.n_voxels_meshed;
     }
     *n_out = n;
@@ -806,7 +817,7 @@ int immesh_mesh_world_scan(immesh_ctx* c, float* out_xyzi, int32_t cap_pts, int3
         std::lock_guard<std::mutex> lk(h.mu);
         if (h.current <= 0) { *n_out = 0; return 0; }
         if (h.current < h.submitted - (MESH_WORLD_BUFS - 2)) { c->err = "the job's world buffer has been handed to a newer scan"; return IMMESH_E_INVAL; }
-        d_pts = h.res[h.current & 1].d_pts; n = h.res[h.current & 1].n_raw;
+        d_pts = h.res[h.current % MESH_NPAR].d_pts; n = h.res[h.current % MESH_NPAR].n_raw;
     }
     *n_out = n;
     if (out_xyzi && n > 0) {
@@ -827,8 +838,8 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
         std::lock_guard<std::mutex> lk(h.mu);
         if (h.current <= 0) return 0;
         if (h.current < h.submitted - 1) { c->err = "mesh job results already overwritten (only the two newest jobs are kept)"; return IMMESH_E_INVAL; }
-        z = h.res[h.current & 1].sizes;
-        o = h.outs[h.current & 1];
+        z = h.res[h.current % MESH_NPAR].sizes;
+        o = h.outs[h.current % MESH_NPAR];
     }
     const MeshDev& m = c->mesh;
     hipStream_t s = h.stream_fetch;   // (the job has finished: nothing to order against; the scan thread may be enqueueing on its own streams meanwhile)
@@ -836,7 +847,7 @@ int immesh_mesh_fetch(immesh_ctx* c, float* new_vtx_xyz, int32_t* tri_add, uint8
         // sharded mesher: the device lists are what this rank COMMITTED (own bricks + halo), flagged entry by entry; the caller gets the entries
         // this rank reports -- the union of the ranks' lists is the serial list
         int st[3];
-        { std::lock_guard<std::mutex> lk(h.mu); const MeshResult& r = h.res[h.current & 1]; st[0] = r.st_add; st[1] = r.st_rem; st[2] = r.st_upd; }
+        { std::lock_guard<std::mutex> lk(h.mu); const MeshResult& r = h.res[h.current % MESH_NPAR]; st[0] = r.st_add; st[1] = r.st_rem; st[2] = r.st_upd; }
         const int32_t* d_tri[3] = {o.tri_add, o.tri_rem, o.tri_upd};
         const uint8_t* d_flip[3] = {o.flip_add, nullptr, o.flip_upd};
         const uint8_t* d_own[3] = {o.own_add, o.own_rem, o.own_upd};

@@ -330,7 +330,7 @@ IMD int mesh_admit_candidate(const MeshDev& m, bool live, int i, float px, float
             vi = atomicAdd(&m.pc[PC_VOXELS], 1);
             if (vi >= m.cap_voxels) { m.sc[SC_OVERFLOW] = 2; vi = -1; }
             else {
-                m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_stamp[vi] = m.seq;
+                m.vx_key[vi] = vkey; m.vx_npts[vi] = 0; m.vx_meshing_times[vi] = 0; m.vx_new_added[vi] = 0; m.vx_rank_seq[vi] = 0; m.vx_rank_seq_alt[vi] = 0; m.vx_rank_seq_alt2[vi] = 0; m.vx_stamp[vi] = m.seq;
                 m.vx_short_axis[(size_t)vi * 3 + 0] = 0; m.vx_short_axis[(size_t)vi * 3 + 1] = 0; m.vx_short_axis[(size_t)vi * 3 + 2] = 0;
                 *visit_new = vi;
                 __threadfence();

@@ -71,7 +71,7 @@ struct MeshDev {
     // mesh voxels
     MeshVoxEnt* x_ent; uint64_t x_mask;                        // 16-byte entries {key, voxel index}: one round trip per lookup
     unsigned long long* vx_key; int32_t* vx_npts; int32_t* vx_pts; int32_t* vx_meshing_times; int32_t* vx_new_added; int32_t* vx_stamp;
-    int32_t* vx_rank; int32_t* vx_rank_seq; int32_t* vx_rank_seq_alt; double* vx_short_axis;   // (rank, stamp): per job parity; _alt = the other parity's stamps
+    int32_t* vx_rank; int32_t* vx_rank_seq; int32_t* vx_rank_seq_alt; int32_t* vx_rank_seq_alt2; double* vx_short_axis;   // (rank, stamp): per job parity; _alt = the other parity's stamps
     // triangles
     int32_t* t_v; unsigned long long* t_word; int32_t* t_live; int32_t* t_rem_seq; int8_t* t_flip;
     int32_t* th_slots; uint64_t th_mask;
@@ -121,6 +121,7 @@ struct MeshCdRec { int32_t i, status; };          // sharded admission: candidat
 struct MeshSmRec { int32_t id, pad; double x, y, z; };
 struct MeshMkRec { int32_t a, b, c, rk; unsigned long long word; };
 #define MESH_WORLD_BUFS 4
+#define MESH_NPAR 3   /* jobs in flight = sets of everything a job's phases hand to each other (round 6: three -- phase A of job k+2 beside the triangulations of k+1 and phase B of k) */
 #define MESH_PUB_SEQ (SC_COUNT + 0)     /* job sequence number: the completion ticket the worker polls */
 #define MESH_PUB_TICKS (SC_COUNT + 2)   /* 64-bit: device time of the job, 100 MHz ticks */
 #define MESH_N_MARKS 14
@@ -137,28 +138,28 @@ struct MeshHost {
     int64_t cum[SC_COUNT];
     int32_t* p_a = nullptr;    // add list as sorted triangle indices (input of the adjacency commit)
     int32_t* h_sc = nullptr;   // pinned copy of the per-scan counters of the job being finished (points into h_sc2)
-    int32_t* h_sc2[2] = {nullptr, nullptr};      // pinned + mapped: [0, SC_COUNT) the job's counters, then MESH_PUB_* words written by mesh_publish_kernel
-    int32_t* h_sc2_dev[2] = {nullptr, nullptr};
+    int32_t* h_sc2[MESH_NPAR] = {};      // pinned + mapped: [0, SC_COUNT) the job's counters, then MESH_PUB_* words written by mesh_publish_kernel
+    int32_t* h_sc2_dev[MESH_NPAR] = {};
     int32_t* h_pc = nullptr;
     void* d_sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     void* d_sort_recs = nullptr;   // 16-byte sort records of the chunk sort (phase B: result lists)
     void* d_sort_recs_a = nullptr; // same, phase A (active-voxel list)
-    MeshDev mpar[2];               // per-parity views
+    MeshDev mpar[MESH_NPAR];               // per-parity views
     int32_t n_vertices = 0;
     int64_t n_live = 0;
     bool ready = false;
     // asynchronous execution
     hipStream_t stream = nullptr;            // the mesher's own streams: phase A ...
     hipStream_t stream_b = nullptr;          // ... and phase B
-    hipEvent_t ev_ready[2] = {nullptr, nullptr};   // (a job's device time comes from mesh_publish_kernel, not from events)
-    hipEvent_t ev_c[2] = {nullptr, nullptr};   // the job's triangulations (third stream) finished
-    hipEvent_t ev_a[2] = {nullptr, nullptr}, ev_b[2] = {nullptr, nullptr};   // phase A / B of the job of that parity finished
+    hipEvent_t ev_ready[MESH_WORLD_BUFS] = {};   // (a job's device time comes from mesh_publish_kernel, not from events)
+    hipEvent_t ev_c[MESH_NPAR] = {};   // the job's triangulations (third stream) finished
+    hipEvent_t ev_a[MESH_NPAR] = {}, ev_b[MESH_NPAR] = {};   // phase A / B of the job of that parity finished
     // world-frame full scans.  The mesher pipelines two jobs (phase A of one over phase B of the other) and takes ~2.4 scan periods per job, so the scan
     // thread writes up to MESH_WORLD_BUFS scans ahead of the oldest running job (buffer = job id mod MESH_WORLD_BUFS) before it has to wait
     float* d_world[MESH_WORLD_BUFS] = {};
-    MeshOutSet outs[2];                      // result lists, double-buffered (job id parity)
-    MeshResult res[2];
+    MeshOutSet outs[MESH_NPAR];                      // result lists, double-buffered (job id parity)
+    MeshResult res[MESH_NPAR];
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
@@ -177,13 +178,14 @@ struct MeshHost {
     hipStream_t stream_fetch = nullptr;      // immesh_mesh_fetch's copies: a stream of their own, so that a service thread can fetch while the scan thread enqueues
     bool stop = false;
     // per-scan parameters + graph replay
-    MeshDyn* d_dyn[2] = {nullptr, nullptr};  // device copies read by the kernels (job parity)
-    MeshDyn* h_dyn[2] = {nullptr, nullptr};  // pinned, device-mapped host copies (read by the first kernel of a scan)
-    MeshDyn* h_dyn_dev[2] = {nullptr, nullptr};   // their device-side addresses
-    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // phase A, one per job parity (world buffer / result set pointers differ)
-    hipGraphExec_t graph_exec_b[2] = {nullptr, nullptr}; // phase B
-    int graph_ncand[2] = {-1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
+    MeshDyn* d_dyn[MESH_NPAR] = {};  // device copies read by the kernels (job parity)
+    MeshDyn* h_dyn[MESH_NPAR] = {};  // pinned, device-mapped host copies (read by the first kernel of a scan)
+    MeshDyn* h_dyn_dev[MESH_NPAR] = {};   // their device-side addresses
+    hipGraphExec_t graph_exec[MESH_NPAR] = {};   // phase A, one per job parity (world buffer / result set pointers differ)
+    hipGraphExec_t graph_exec_b[MESH_NPAR] = {}; // phase B
+    int graph_ncand[MESH_NPAR] = {-1, -1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
     bool use_graph = true;
+    int room = MESH_NPAR;    // jobs the worker keeps in flight
     bool split_tri = true;   // triangulation on the third stream, the diff at the head of phase B (IMMESH_NO_SPLIT: one launch at the head of phase B)
     bool pipeline = true;                    // phase A of scan k+1 may overlap phase B of scan k (IMMESH_NO_PIPELINE turns it off)
     // mesh export scratch (grow-only)

@@ -519,8 +519,12 @@ struct PointPrep {
     double b[9];        // (-[p_imu]x) Srot (-[p_imu]x)^T with the z == 0 -> 1e-3 quirk
     double bv[9];       // calcBodyVar of the IMU-frame point (H build, :1509-1517)
     unsigned long long key; int root;   // root voxel the previous pass found the point in (PREP_NO_KEY: none yet)
+    unsigned int slot;                  // ... and its hash slot (valid with root >= 0): the map update's preparation starts from it (RpEpilogue)
 };
 #define PREP_NO_KEY 0xFFFFFFFFFFFFFFFEull
+#ifndef IMMESH_EPI_HINT
+#define IMMESH_EPI_HINT 1   /* (0: A/B builds without the epilogue's slot hint) */
+#endif
 IMD void residual_prep(const ScanParams& sp, const float* __restrict__ pts, const int i, PointPrep& q) {
     const double p[3] = {(double)pts[(size_t)i * 3 + 0], (double)pts[(size_t)i * 3 + 1], (double)pts[(size_t)i * 3 + 2]};
     double pz[3] = {p[0], p[1], p[2]};
@@ -545,7 +549,7 @@ IMD void residual_prep(const ScanParams& sp, const float* __restrict__ pts, cons
     }
     double pthis[3] = {q.pimu[0], q.pimu[1], q.pimu[2]};
     calc_body_var(pthis, sp.dept_err, sp.calib_laser ? sp.dvar_calib : sp.dvar_beam, q.bv);
-    q.key = PREP_NO_KEY; q.root = -1;
+    q.key = PREP_NO_KEY; q.root = -1; q.slot = 0;
 }
 // sp: the per-scan constants (kernel arguments: scalar loads); Rm / tv / RextR: the iterate of this pass (wave-uniform)
 template <bool coop>
@@ -583,7 +587,7 @@ IMD void residual_pass(const RegMapDev& m, const ScanParams& sp, const double* R
             else {
                 const int64_t slot = hash_find(m, key);
                 root = slot >= 0 ? m.htab[slot].root : -2;   // -2: no such voxel
-                q.key = key; q.root = root;
+                q.key = key; q.root = root; q.slot = (unsigned int)slot;
             }
         }
         BestMatch best; best.node = -1; best.layer = 0; best.prob = 0; best.ok = false;
@@ -922,7 +926,8 @@ __device__ __forceinline__ void rp_update(RpShared& S, const RegIterArgs& a, con
 
 IMD float4 transform_value(const double* extR, const double* extT, const double* R, const double* t, const float4 v);
 IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, const int stride, const int mode,
-                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next);
+                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next,
+                         const unsigned long long hint_key = PREP_NO_KEY, const unsigned int hint_slot = 0, const int hint_root = -1);
 
 // The pass that stops the loop, all 256 threads: the posterior covariance is P - K1 (H^T H P[0:6,:]); M = H^T H P6 and XM = X M (rows 0..5 of the
 // correction; rows 6..17 = T XM) are left in LDS.  Every block does this when the map update's preparation runs as the epilogue (it propagates
@@ -1222,7 +1227,11 @@ __global__ __launch_bounds__(256) void residual_persistent_kernel(RegMapDev m, R
 #pragma unroll
                     for (int u = 0; u < TB; u++) { const int i = t0i + u * tstride; if (i < ep.n_raw) rv[u] = raw4[i]; }
                 }
-                for (int i = t0i; i < n; i += tstride) point_var_point(m, q, pts, i, 3, 0, ep.pt_data, ep.sort_key, ep.slot_out, ep.pt_next);
+                // (one tile per wavefront: this thread's point of the passes is the first point of this loop, and `prep` still names its root voxel)
+                for (int i = t0i; i < n; i += tstride) {
+                    const bool own = IMMESH_EPI_HINT && one_tile && i == t0i && m.shard_world <= 1;
+                    point_var_point(m, q, pts, i, 3, 0, ep.pt_data, ep.sort_key, ep.slot_out, ep.pt_next, own ? prep.key : PREP_NO_KEY, prep.slot, own ? prep.root : -1);
+                }
                 if (tre) tre[6] = __builtin_amdgcn_s_memrealtime();
                 if (raw4) {
 #pragma unroll
@@ -1283,8 +1292,12 @@ IMD void transform_point(const double* extR, const double* extT, const double* R
 }
 // one point of the map update's preparation (sp = the pose / covariance blocks to propagate with): world point, covariance, sort key, root voxel
 // (found or created), push on the voxel's list of this update.  Shared by point_var_kernel and the epilogue of residual_persistent_kernel.
+// hint_key / hint_slot / hint_root (residual_persistent_kernel's epilogue): the root voxel the LAST matcher pass found the point in.  The posterior moves a
+// point by a fraction of a millimetre against that pass's iterate, so the key is almost always the same -- then the voxel exists and its slot and root
+// node are known: no hash probe and no read of the entry in front of the list push (two dependent round trips less on the pose chain's tail).
 IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* __restrict__ pts, const int i, const int stride, const int mode,
-                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next) {
+                         double* __restrict__ pt_data, unsigned long long* __restrict__ sort_key, uint32_t* __restrict__ slot_out, int32_t* __restrict__ pt_next,
+                         const unsigned long long hint_key, const unsigned int hint_slot, const int hint_root) {
     const double p[3] = {(double)pts[(size_t)i * stride + 0], (double)pts[(size_t)i * stride + 1], (double)pts[(size_t)i * stride + 2]};
     double pimu[3], pwd[3];
     m3_vec(sp.extR, p, pimu);
@@ -1327,8 +1340,9 @@ IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* 
     for (int j = 0; j < 3; j++) kx[j] = key_axis(pw[j] / (double)m.voxel_size_f);
     const uint64_t pk = pack_key(kx[0], kx[1], kx[2]);
     if (m.shard_world > 1 && !shard_keeps(m, kx[0], kx[1], kx[2])) { slot_out[i] = 0xFFFFFFFFu; return; }   // another rank's voxel (outside our halo)
-    bool created;
-    const int64_t slot = hash_find_or_insert(m, pk, &created);
+    bool created = false;
+    const bool hinted = hint_root >= 0 && pk == hint_key;
+    const int64_t slot = hinted ? (int64_t)hint_slot : hash_find_or_insert(m, pk, &created);
     if (slot < 0) { m.counters[5] = 5; slot_out[i] = 0xFFFFFFFFu; return; }
     if (created) {
         const float vs = m.voxel_size_f;
@@ -1354,7 +1368,7 @@ IMD void point_var_point(const RegMapDev& m, const ScanParams& sp, const float* 
             const int k = base + (int)__popcll(fm & ((1ull << lane) - 1ull));
             // (slot, root node): the replay kernel starts from the node without a second trip through the hash; a root another lane of this launch
             // is still creating reads as -1 here and is looked up there
-            m.touched[2 * (size_t)k] = (uint32_t)slot; m.touched[2 * (size_t)k + 1] = (uint32_t)m.htab[slot].root;
+            m.touched[2 * (size_t)k] = (uint32_t)slot; m.touched[2 * (size_t)k + 1] = hinted ? (uint32_t)hint_root : (uint32_t)m.htab[slot].root;
         }
         else pt_next[i] = (int)(unsigned int)(old & 0xFFFFFFFFull);
     }

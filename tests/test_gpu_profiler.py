@@ -37,5 +37,8 @@ def test_profiled_scans_with_mesher(hip_lib, mode):
         assert info["n_match"] > 1000
     ks = h.profile_read()
     h.profile_enable(False)
-    assert ks["residual_persistent_kernel"]["launches"] == 5 and ks["mesh_delaunay64_kernel"]["launches"] == 5   # one resident launch per scan for all EKF passes
-    assert 0.005 < ks["mesh_delaunay64_kernel"]["total_ms"] / 5 < 5.0
+    # one resident launch per scan for all EKF passes; the triangulations (mesh_tri64_kernel, third stream) and the diff against the live set
+    # (mesh_diff64_kernel, head of phase B) are the two launches mesh_delaunay64_kernel was cut into in round 6
+    assert ks["residual_persistent_kernel"]["launches"] == 5 and ks["mesh_tri64_kernel"]["launches"] == 5 and ks["mesh_diff64_kernel"]["launches"] == 5
+    assert "mesh_delaunay64_kernel" not in ks
+    assert 0.005 < ks["mesh_tri64_kernel"]["total_ms"] / 5 < 5.0

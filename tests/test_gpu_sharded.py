@@ -276,6 +276,8 @@ def test_bench_gpus_flag_spawns_two_ranks_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--map-voxels", "150000",
                         "--pts", "30000", "--profile-scans", "0", "--cpu-seconds", "0", "--extra-configs", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        print(r.stderr[-8000:])   # (pytest shows captured output in full; its assertion repr truncates)
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     d = json.loads(lines[0])
     # N > 1: the headline is the sharded job (ONE stream, voxel bricks over the ranks, strong scaling); the replica leg is reported beside it

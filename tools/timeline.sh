@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 N=$1; shift
 rm -rf /tmp/tl
-timeout 120 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $GRAFT_REPO_ROOT/bench.py --cpu-seconds 0 --steps 40 --warmup 5 --profile-scans 0 --extra-configs 0 "$@" > /tmp/tl.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python $GRAFT_REPO_ROOT/bench.py --cpu-seconds 0 --steps 40 --warmup 5 --profile-scans 0 --extra-configs 0 "$@" > /tmp/tl.log 2>&1
 grep '^{' /tmp/tl.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['scan_thread_ms'])"
 f=$(find /tmp/tl -name '*kernel_trace.csv' | head -1)
 python - "$f" "$N" <<'PY'
