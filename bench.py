@@ -973,12 +973,17 @@ def main():
                              ("configs[4] dry run: every rank of 8 in turn, alone, 500k-pt scans, 50 M-voxel survey, collectives stubbed (the job waits for the slowest)", ["--dry-run-rank", "-2", "--pts", "500000", "--map-voxels", "50e6", "--steps", "10", "--warmup", "3"])):
             cmd = [sys.executable, os.path.abspath(sys.argv[0]), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--profile-scans", "0", "--extra-configs", "0"] + flags   # (later flags win)
             try:
-                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
+                # (IMMESH_DEBUG_WAITS: the library prints, when the context is destroyed, the kernel-entry times of the mesher's last jobs, the job-to-job period
+                #  and how long the scan thread stood waiting for a world buffer -- who paces the pipeline; two getenv calls and one clock read per scan)
+                r = subprocess.run(cmd, env=dict(env, IMMESH_DEBUG_WAITS="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.profile_timeout, text=True)
                 lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 if r.returncode == 0 and lines:
                     d = json.loads(lines[-1])
                     extra[label] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "metric": d["metric"], "n_ds_mean": d["config"]["n_ds_mean"],
                                     "map_root_voxels": d["config"]["map_root_voxels"], "scan_thread_ms": d.get("scan_thread_ms")}
+                    marks = [ln for ln in (r.stderr or "").splitlines() if ln.startswith("[mesh marks]")]
+                    if marks and "steady state" in label:
+                        extra[label]["mesher_pipeline"] = marks[-1][len("[mesh marks] "):]
                     if d.get("cpu_baseline"):
                         cb = d["cpu_baseline"]
                         extra[label]["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "ms_per_scan": cb["ms_per_scan"],

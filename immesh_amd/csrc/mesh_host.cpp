@@ -204,7 +204,7 @@ static void mesh_print_marks(const MeshHost& h) {
     for (long long j = lo; j < hi; j++, n++) {
         const unsigned long long* mk = h.mark_ring[j & 63];
         const unsigned long long* pv = h.mark_ring[(j - 1) & 63];
-        for (int k = 1; k < MESH_N_MARKS; k++) rel[k] += 0.01 * (double)(long long)(mk[k] - mk[0]);
+        for (int k = 1; k < MESH_N_MARKS; k++) rel[k] += (mk[k] >= mk[0] && mk[k] - mk[0] < 100000000ull) ? 0.01 * (double)(long long)(mk[k] - mk[0]) : -1e9;   // (a mark of another arrangement's kernel: stale)
         period += 0.01 * (double)(long long)(mk[MESH_N_MARKS - 1] - pv[MESH_N_MARKS - 1]);
         bgap += 0.01 * (double)(long long)((mk[12] > mk[0] ? mk[12] : mk[5]) - pv[MESH_N_MARKS - 1]);
     }
@@ -212,7 +212,7 @@ static void mesh_print_marks(const MeshHost& h) {
     for (long long j = std::max<long long>(h.wait_calls - 60, 0); j < h.wait_calls - 4; j++, nw++) w += 1e-3 * (double)h.wait_ring[j & 63];
     static const char* nm[MESH_N_MARKS] = {"begin", "prepare", "resolve", "finish", "knn", "tri64", "general", "finalize", "chunk_sort", "merge_emit", "commit_add", "publish", "diff64", "end"};
     fprintf(stderr, "[mesh marks] last %lld jobs, us after the job's start:", n);
-    for (int k = 1; k < MESH_N_MARKS; k++) fprintf(stderr, " %s %.1f", nm[k], rel[k] / (double)n);
+    for (int k = 1; k < MESH_N_MARKS; k++) if (rel[k] >= 0) fprintf(stderr, " %s %.1f", nm[k], rel[k] / (double)n);
     fprintf(stderr, " | end-to-end %.1f us, previous job's end -> phase B's first kernel %.1f us | scan thread's wait for a world buffer %.1f us (last %lld scans)\n", period / (double)n, bgap / (double)n, nw ? w / (double)nw : 0.0, nw);
 }
 void mesh_free(immesh_ctx* c) {

@@ -176,6 +176,9 @@ IMD float dist2f(float ax, float ay, float az, float bx, float by, float bz) {
 
 // Per-scan parameters live in device memory (MeshDev::dyn, refreshed by a copy at the head of every scan) so that the kernel arguments
 // are identical from scan to scan and the whole launch sequence can be replayed as a hipGraph.
+#ifndef MESH_B_PRIO
+#define MESH_B_PRIO 2   /* wave priority of the mesher's phase B + triangulation kernels (s_setprio; the registration runs at 3, the map update at REG_UPD_PRIO) */
+#endif
 // phase marks (IMMESH_DEBUG_WAITS): thread 0 of block 0 leaves the device's real-time counter at kernel entry; mesh_publish_kernel hands the marks to the host
 #define MESH_MARK(arg, k) do { if (blockIdx.x == 0 && threadIdx.x == 0) (arg).tick0[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define MESH_DYN(arg)                                  \
@@ -287,7 +290,7 @@ __global__ void mesh_publish_kernel(MeshDev m_in, int32_t* __restrict__ host_sc)
         __hip_atomic_store((unsigned long long*)&host_sc[MESH_PUB_TICKS], ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (k < MESH_N_MARKS) {   // phase marks: [0] = the job's first kernel past its poll, [1..10] kernel entries, [11] = now (absolute ticks: the host takes differences)
-        const unsigned long long v = k == MESH_N_MARKS - 1 ? __builtin_amdgcn_s_memrealtime() : m_in.tick0[k];
+        const unsigned long long v = (k == MESH_N_MARKS - 1 || k == 11) ? __builtin_amdgcn_s_memrealtime() : m_in.tick0[k];   // ([11]: this kernel's own entry)
         __hip_atomic_store((unsigned long long*)&host_sc[MESH_PUB_MARKS + 2 * k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1751,7 +1754,7 @@ IMD void mesh_commit_rem_slice(const MeshDev& m, const int32_t* __restrict__ tri
 }
 __global__ __launch_bounds__(64) void mesh_finalize_kernel(MeshDev m_in) {
     MESH_MARK(m_in, 7);
-    __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
+    __builtin_amdgcn_s_setprio(MESH_B_PRIO);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     mesh_commit_rem_slice(m, m.list_rem, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);   // Triangle_manager::remove_triangle_list rides along (independent data)
     const int lane = threadIdx.x;
@@ -1991,7 +1994,7 @@ IMD void lsort_plan_dev(const MeshDev& m, int which, LSortPlan& pl) {
 }
 __global__ __launch_bounds__(256) void mesh_chunk_sort_kernel(MeshDev m_in, int which, SortRec* __restrict__ recs_out) {
     if (which == 1) MESH_MARK(m_in, 8);
-    __builtin_amdgcn_s_setprio(2);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
+    __builtin_amdgcn_s_setprio(MESH_B_PRIO);   // phase B is the mesher's longest chain: issue ahead of the map update's waves (1), behind the registration's (3)
     MESH_DYN(m_in);
     __shared__ SortRec recs[LS_CHUNK];
     LSortPlan pl;
@@ -2031,7 +2034,7 @@ IMD int lsort_lower_bound(const SortRec* __restrict__ a, int n, const SortRec& k
 }
 __global__ __launch_bounds__(256) void mesh_merge_emit_kernel(MeshDev m_in, int which, const SortRec* __restrict__ recs, int32_t* __restrict__ add_sorted) {
     if (which == 1) MESH_MARK(m_in, 9);
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(MESH_B_PRIO);
     MESH_DYN(m_in);
     LSortPlan pl;
     lsort_plan_dev(m, which, pl);
@@ -2108,7 +2111,7 @@ __global__ void mesh_commit_rem_kernel(MeshDev m_in, const int32_t* __restrict__
 // vertex are contiguous: the lane at the head of such a run inserts the whole run -- no two lanes touch the same vertex list.
 __global__ void mesh_commit_add_kernel(MeshDev m_in, const int32_t* __restrict__ tris) {
     MESH_MARK(m_in, 10);
-    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_setprio(MESH_B_PRIO);
     MESH_DYN(m_in);
     const int n = min(m.sc[SC_ADD], m.cap_list);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

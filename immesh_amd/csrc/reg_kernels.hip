@@ -521,6 +521,9 @@ struct PointPrep {
     unsigned long long key; int root;   // root voxel the previous pass found the point in (PREP_NO_KEY: none yet)
     unsigned int slot;                  // ... and its hash slot (valid with root >= 0): the map update's preparation starts from it (RpEpilogue)
 };
+#ifndef REG_UPD_PRIO
+#define REG_UPD_PRIO 1   /* wave priority of the map update's kernels */
+#endif
 #define PREP_NO_KEY 0xFFFFFFFFFFFFFFFEull
 #ifndef IMMESH_EPI_HINT
 #define IMMESH_EPI_HINT 1   /* (0: A/B builds without the epilogue's slot hint) */
@@ -2028,7 +2031,7 @@ __global__ __launch_bounds__(256, 3) void replay_fused_kernel(RegMapDev m, const
     __shared__ unsigned long long skey[4][RL_CAP];
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(REG_UPD_PRIO);
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // A resident grid strides over the touched voxels (four wavefronts per workgroup: one-wavefront workgroups were measured dispatch-bound, ~130
     // workgroups per us; one workgroup per four down-sampled POINTS -- the count of touched voxels is only known on the device -- kept the
@@ -2199,7 +2202,7 @@ __global__ __launch_bounds__(256) void replay_list_kernel(RegMapDev m, const int
     __shared__ int sidx[4][RL_CAP];
     __shared__ int order[4][RL_CAP];
     __shared__ int stacks[4][48];
-    __builtin_amdgcn_s_setprio(1);   // map growth is on the pose chain too (the next scan's registration waits for it)
+    __builtin_amdgcn_s_setprio(REG_UPD_PRIO);   // map growth is on the pose chain too (the next scan's registration waits for it)
     const int wv = threadIdx.x >> 6;
     const int nw = *n_work;
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats;
@@ -2414,7 +2417,7 @@ __device__ bool replay_split_root(const RegMapDev& m, const int root, const int*
 }
 __global__ __launch_bounds__(256) void replay_sub_kernel(RegMapDev m, const double* __restrict__ pt_data, int64_t* stats) {
     __shared__ int stacks[4][48];
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(REG_UPD_PRIO);
     const int wv = threadIdx.x >> 6;
     const int n_items = m.counters[12];
     WaveCtx w; w.lane = threadIdx.x & 63; w.stats = stats; w.shared = true;
