@@ -152,8 +152,10 @@ int mesh_alloc(immesh_ctx* c) {
         }
     }
     h.use_graph = getenv("IMMESH_NO_GRAPH") == nullptr;
-    h.split_tri = getenv("IMMESH_NO_SPLIT") == nullptr;
-    if (const char* e = getenv("IMMESH_MESH_ROOM")) h.room = std::min(std::max(atoi(e), 1), MESH_NPAR);   // (measurement knob: jobs in flight; 2 = rounds 1-5)   // (measurement knob: the round-5 arrangement, triangulation at the head of phase B)
+    h.split_mode = getenv("IMMESH_NO_SPLIT") ? 0 : 2;
+    if (const char* e = getenv("IMMESH_SPLIT")) h.split_mode = atoi(e) == 0 ? 0 : 1;
+    h.room = 0;   // 0: the worker decides (two jobs in flight; three, with the triangulations on the third stream, while the mesher is behind)
+    if (const char* e = getenv("IMMESH_MESH_ROOM")) h.room = std::min(std::max(atoi(e), 1), MESH_NPAR);   // (measurement knob: a fixed number of jobs in flight; 2 = rounds 1-5)
     h.pipeline = getenv("IMMESH_NO_PIPELINE") == nullptr;
     HIPCHK(c, hipHostMalloc((void**)&h.h_pc, PC_COUNT * 4));
     std::memset(h.h_pc, 0, PC_COUNT * 4);
@@ -246,7 +248,7 @@ void mesh_free(immesh_ctx* c) {
         if (h.ev_c[k]) (void)hipEventDestroy(h.ev_c[k]);
         if (h.ev_b[k]) (void)hipEventDestroy(h.ev_b[k]);
         if (h.graph_exec[k]) { (void)hipGraphExecDestroy(h.graph_exec[k]); h.graph_exec[k] = nullptr; }
-        if (h.graph_exec_b[k]) { (void)hipGraphExecDestroy(h.graph_exec_b[k]); h.graph_exec_b[k] = nullptr; }
+        for (int q = 0; q < 2; q++) if (h.graph_exec_b[k][q]) { (void)hipGraphExecDestroy(h.graph_exec_b[k][q]); h.graph_exec_b[k][q] = nullptr; }
         if (h.h_dyn[k]) (void)hipHostFree(h.h_dyn[k]);
         if (h.h_sc2[k]) (void)hipHostFree(h.h_sc2[k]);
         h.h_dyn[k] = nullptr; h.h_sc2[k] = nullptr;
@@ -383,7 +385,7 @@ static int mesh_exchange(immesh_ctx* c, hipStream_t s, size_t rec, int cap_small
     return 0;
 }
 
-static int mesh_graph_run(immesh_ctx* c, hipGraphExec_t& exec, hipStream_t s, const std::function<int()>& enqueue) {
+static int mesh_graph_run(immesh_ctx* c, hipGraphExec_t& exec, hipStream_t s, const std::function<int()>& enqueue, bool launch = true) {
     if (exec == nullptr) {
         hipGraph_t g = nullptr;
         MHIPCHK(c, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
@@ -394,13 +396,13 @@ static int mesh_graph_run(immesh_ctx* c, hipGraphExec_t& exec, hipStream_t s, co
         (void)hipGraphDestroy(g);
         if (ie != hipSuccess) { exec = nullptr; c->mesh_host.err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return IMMESH_E_HIP; }
     }
-    MHIPCHK(c, hipGraphLaunch(exec, s));
+    if (launch) MHIPCHK(c, hipGraphLaunch(exec, s));   // (launch == false: capture + instantiate only -- the other variant of phase B, ahead of its first use)
     return 0;
 }
 
 // Worker thread: enqueue one scan (phase A on h.stream, phase B on h.stream_b behind it).  Returns without waiting unless the scan is
 // offline-sized.  `synced` tells the caller that both streams are already drained.
-static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
+static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, bool deep) {
     MeshHost& h = c->mesh_host;
     const int par = (int)(job.id % MESH_NPAR);
     const MeshDev& m = h.mpar[par];
@@ -472,7 +474,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     } else if (h.use_graph && !h.prof.on && is_world) {
         // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
         if (h.graph_ncand[par] != sp.n_cand) {
-            for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
+            for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par][0], &h.graph_exec_b[par][1]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
             h.graph_ncand[par] = sp.n_cand;
         }
         // (captured with a null scan pointer: the kernels take it from MeshDyn, so one graph serves every world buffer)
@@ -486,7 +488,11 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
     // Round 6: the triangulations of the job (80 % of what used to be phase B's first launch) need phase A's results and nothing of the previous job's
     // phase B: they run on a third stream (the fetch / query stream -- no HSA queue of its own, see mesh_alloc) and only the diff against the live
     // triangle set waits for the previous commit.  Phase B + its queue gap WAS the pipeline's period (profiles/r06_marks_*.txt).
-    const bool split = h.split_tri && sp.n_cand <= 65536;
+    // WHEN: the third stream (and a third job in flight) buy throughput -- phase B's head shrinks from ~100 to ~20 us -- at the price of company for the pose
+    // chain (~3 us per scan) and ~15 us of job latency (two cross-stream events).  That pays while the mesher is what the pipeline waits for and costs
+    // 1.7 % where it is not (the driver's 20-scan run on a young map: the pose chain is slower than even the one-launch phase B).  The worker therefore
+    // switches: `deep` = a job found another one queued behind it within the last 64 jobs (mesh_worker_main).  IMMESH_SPLIT = 1 / 0: always / never.
+    const bool split = sp.n_cand <= 65536 && (h.split_mode == 1 || (h.split_mode == 2 && deep));
     if (split) {
         static const int which = [] { const char* e = getenv("IMMESH_TRI_STREAM"); return e ? atoi(e) : 1; }();   // (measurement knob: 0 fetch stream, 1 pre-processing stream (default), 2 null stream)
         hipStream_t st = which == 1 ? c->stream_pre : (which == 2 ? (hipStream_t)nullptr : h.stream_fetch);
@@ -496,7 +502,11 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced) {
         MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_c[par], 0));
     } else MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
     if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && is_world) {
-        if ((rc = mesh_graph_run(c, h.graph_exec_b[par], sb, [&] { return mesh_enqueue_b(c, m, par, sb, 0, split); }))) return rc;
+        // (both variants of phase B are captured when the first of them is needed: instantiating a graph takes a millisecond, and the switch to the other
+        //  arrangement must not pay it in the middle of a stream)
+        if (h.graph_exec_b[par][split ? 0 : 1] == nullptr && h.split_mode == 2 &&
+            (rc = mesh_graph_run(c, h.graph_exec_b[par][split ? 0 : 1], sb, [&] { return mesh_enqueue_b(c, m, par, sb, 0, !split); }, false))) return rc;
+        if ((rc = mesh_graph_run(c, h.graph_exec_b[par][split ? 1 : 0], sb, [&] { return mesh_enqueue_b(c, m, par, sb, 0, split); }))) return rc;
     } else {
         if ((rc = mesh_enqueue_b(c, m, par, sb, 0, split))) return rc;
     }
@@ -558,6 +568,9 @@ static void mesh_worker_main(immesh_ctx* c) {
     g_kprof = &h.prof;
     struct Flight { MeshJob job; MeshResult r; bool launched_ok; int seq; bool by_ticket; unsigned polls; };
     std::deque<Flight> fl;
+    long deep_until = 0;   // (job id) the deep arrangement stays on for jobs below it
+    bool deep = false;
+    int backlog_streak = 0;
     for (;;) {
         // ---- take a new job when one is queued and the pipeline has room
         bool have = false;
@@ -565,8 +578,16 @@ static void mesh_worker_main(immesh_ctx* c) {
         {
             std::unique_lock<std::mutex> lk(h.mu);
             if (fl.empty()) h.cv_job.wait(lk, [&] { return h.stop || !h.q.empty(); });
-            const size_t room = (h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (size_t)h.room : 1;
-            if (!h.q.empty() && fl.size() < room) { job = h.q.front(); h.q.pop_front(); have = true; }
+            const bool deep_now = h.split_mode == 1 || (h.split_mode == 2 && !h.q.empty() && h.q.front().id < deep_until);
+            const size_t room = (h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (h.room ? (size_t)h.room : (deep_now ? (size_t)MESH_NPAR : (size_t)2)) : 1;
+            if (!h.q.empty() && fl.size() < room) {
+                job = h.q.front(); h.q.pop_front(); have = true;
+                // the mesher is behind when a job leaves the queue and the next one is already waiting: go deep (three jobs in flight, triangulations on
+                // the third stream) for the next 64 jobs -- long enough not to flutter, short enough to fall back when the stream slows down
+                backlog_streak = h.q.empty() ? 0 : backlog_streak + 1;
+                if (backlog_streak >= 3) deep_until = job.id + 64;   // (three jobs in a row: a lag, not the hiccup of a graph capture or a first touch)
+                deep = h.split_mode == 1 || (h.split_mode == 2 && job.id < deep_until);
+            }
             else if (fl.empty() && h.q.empty()) break;   // stop requested and nothing left to do
         }
         if (have) {
@@ -575,7 +596,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             std::memset(&f.r.sizes, 0, sizeof(f.r.sizes));
             h.err.clear();
             bool synced = false;
-            { std::lock_guard<std::mutex> lq(h.launch_mu); f.r.rc = mesh_scan_launch(c, job, synced); }   // (a smooth_pts query runs between two jobs, never beside one)
+            { std::lock_guard<std::mutex> lq(h.launch_mu); f.r.rc = mesh_scan_launch(c, job, synced, deep); }   // (a smooth_pts query runs between two jobs, never beside one)
             f.seq = h.seq; f.polls = 0;
             f.by_ticket = c->mesh.shard_world <= 1;   // (the sharded mesher runs on one stream and keeps its event)
             if (f.r.rc) f.r.err = h.err; else f.launched_ok = true;
@@ -598,7 +619,7 @@ static void mesh_worker_main(immesh_ctx* c) {
             } else q = hipEventQuery(h.ev_b[par]);
             if (q == hipErrorNotReady) {
                 bool more;
-                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (size_t)h.room : (size_t)1); }
+                { std::lock_guard<std::mutex> lk(h.mu); more = !h.q.empty() && fl.size() < ((h.pipeline && !h.prof.on && c->mesh.shard_world <= 1) ? (h.room ? (size_t)h.room : ((h.split_mode == 1 || h.q.front().id < deep_until) ? (size_t)MESH_NPAR : (size_t)2)) : (size_t)1); }
                 if (!more) std::this_thread::yield();
                 continue;
             }

@@ -182,11 +182,11 @@ struct MeshHost {
     MeshDyn* h_dyn[MESH_NPAR] = {};  // pinned, device-mapped host copies (read by the first kernel of a scan)
     MeshDyn* h_dyn_dev[MESH_NPAR] = {};   // their device-side addresses
     hipGraphExec_t graph_exec[MESH_NPAR] = {};   // phase A, one per job parity (world buffer / result set pointers differ)
-    hipGraphExec_t graph_exec_b[MESH_NPAR] = {}; // phase B
+    hipGraphExec_t graph_exec_b[MESH_NPAR][2] = {}; // phase B ([1]: without the triangulations)
     int graph_ncand[MESH_NPAR] = {-1, -1, -1};           // candidate count the graph was captured for (grid sizes, clear sizes)
     bool use_graph = true;
-    int room = MESH_NPAR;    // jobs the worker keeps in flight
-    bool split_tri = true;   // triangulation on the third stream, the diff at the head of phase B (IMMESH_NO_SPLIT: one launch at the head of phase B)
+    int room = 0;            // jobs the worker keeps in flight: 0 = two, three while the mesher is behind (mesh_worker_main); IMMESH_MESH_ROOM fixes it
+    int split_mode = 2;      // the triangulations on the third stream, the diff at the head of phase B: 0 never (IMMESH_NO_SPLIT / IMMESH_SPLIT=0), 1 always (IMMESH_SPLIT=1), 2 while the mesher is behind (with the third job in flight)
     bool pipeline = true;                    // phase A of scan k+1 may overlap phase B of scan k (IMMESH_NO_PIPELINE turns it off)
     // mesh export scratch (grow-only)
     void *exp_vtx = nullptr, *exp_work = nullptr, *exp_tmp = nullptr;

@@ -34,8 +34,12 @@ def _compare_scan(mo, mh, tag=""):
     np.testing.assert_allclose(mh["smooth_xyz"], mo["smooth_xyz"], rtol=0, atol=1e-9, err_msg=f"{tag} smooth xyz")
 
 
-def test_mesh_stream_parity(oracle_lib, hip_lib):
-    """8 overlapping scans: append (ids), 20-NN union, Delaunay, diff, flips -- every result list must be identical."""
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_mesh_stream_parity(oracle_lib, hip_lib, split, monkeypatch):
+    """8 overlapping scans: append (ids), 20-NN union, Delaunay, diff, flips -- every result list must be identical.  split 1: the triangulations as a launch
+    of their own on the third stream (mesh_tri64_kernel) and the diff against the live set at the head of phase B (mesh_diff64_kernel) -- what the
+    worker switches to when two jobs are in flight -- forced for every job; 0: the one-launch form."""
+    monkeypatch.setenv("IMMESH_SPLIT", split)   # (read when a context is created)
     cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
     o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
     tot_add = tot_rem = 0
@@ -200,9 +204,16 @@ def test_process_scan_strided_equals_packed(hip_lib, where):
         assert results["packed"][1][key] == results["strided"][1][key], key
 
 
-def test_async_pipeline_matches_serial(hip_lib):
-    """Queueing mesh jobs (depth 2) while later scans register must give the same mesh as the strictly serial order."""
+@pytest.mark.parametrize("split", ["adaptive", "always", "never"])
+def test_async_pipeline_matches_serial(hip_lib, split, monkeypatch):
+    """Queueing mesh jobs (up to three in flight) while later scans register must give the same mesh as the strictly serial order -- with the triangulations
+    on the third stream for every job (IMMESH_SPLIT=1: mesh_tri64_kernel + mesh_diff64_kernel), for none (0: the one-launch mesh_delaunay64_kernel),
+    and decided per job by the jobs in flight (the default)."""
     torch = pytest.importorskip("torch")
+    if split != "adaptive":
+        monkeypatch.setenv("IMMESH_SPLIT", "1" if split == "always" else "0")   # (read when a context is created)
+    else:
+        monkeypatch.delenv("IMMESH_SPLIT", raising=False)
     cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
     extT = np.array(list(cfg.extT))
     scans = []
@@ -460,12 +471,14 @@ def test_more_active_voxels_than_the_lds_stage_holds(oracle_lib, hip_lib):
 
 
 @pytest.mark.parametrize("spacing", [0.25, 0.125])
-def test_exact_ties_lattice_cloud(oracle_lib, hip_lib, spacing):
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_exact_ties_lattice_cloud(oracle_lib, hip_lib, spacing, split, monkeypatch):
     """exact ties, not avoided.  A REGULAR lattice on exactly representable coordinates (binary fractions): every 20-NN query
     has equal distances at the cut (shells of 4 / 4 / 4 / 8 neighbours: the 20th falls inside the shell of eight), every lattice square is a cocircular
     quadruple (in-circle determinant exactly zero), the PCA of a neighbourhood has a repeated eigenvalue.  The checker's rules (ties by ascending id in
     the kNN, insertion order in the triangulation) must be the HIP path's, bit for bit -- spacing 0.25 m keeps the neighbourhoods on the
     register-resident triangulation (n_u <= 64), 0.125 m puts them on the general kernel (65..256)."""
+    monkeypatch.setenv("IMMESH_SPLIT", split)   # (the hand-over to the general path -- tri_nf = -1 -- crosses two launches when split)
     cfg = capi.avia_config(cap_root_voxels=1 << 12, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
     o, h = make_oracle(oracle_lib, cfg), make_hip(hip_lib, cfg)
     nx = int(6.0 / spacing)

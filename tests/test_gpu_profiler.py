@@ -37,8 +37,9 @@ def test_profiled_scans_with_mesher(hip_lib, mode):
         assert info["n_match"] > 1000
     ks = h.profile_read()
     h.profile_enable(False)
-    # one resident launch per scan for all EKF passes; the triangulations (mesh_tri64_kernel, third stream) and the diff against the live set
-    # (mesh_diff64_kernel, head of phase B) are the two launches mesh_delaunay64_kernel was cut into in round 6
-    assert ks["residual_persistent_kernel"]["launches"] == 5 and ks["mesh_tri64_kernel"]["launches"] == 5 and ks["mesh_diff64_kernel"]["launches"] == 5
-    assert "mesh_delaunay64_kernel" not in ks
-    assert 0.005 < ks["mesh_tri64_kernel"]["total_ms"] / 5 < 5.0
+    # one resident launch per scan for all EKF passes.  The triangulations: the one-launch mesh_delaunay64_kernel, or -- when the asynchronous scans before
+    # the profiled ones left the worker in its three-jobs arrangement (mode 2) -- mesh_tri64_kernel + mesh_diff64_kernel; five scans either way
+    assert ks["residual_persistent_kernel"]["launches"] == 5
+    tri = {k_: ks.get(k_, {"launches": 0, "total_ms": 0.0}) for k_ in ("mesh_delaunay64_kernel", "mesh_tri64_kernel", "mesh_diff64_kernel")}
+    assert tri["mesh_delaunay64_kernel"]["launches"] + tri["mesh_tri64_kernel"]["launches"] == 5 and tri["mesh_tri64_kernel"]["launches"] == tri["mesh_diff64_kernel"]["launches"]
+    assert 0.005 < (tri["mesh_delaunay64_kernel"]["total_ms"] + tri["mesh_tri64_kernel"]["total_ms"]) / 5 < 5.0
