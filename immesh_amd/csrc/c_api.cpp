@@ -933,10 +933,13 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     ProfBind _pb(c);
     if (const int s_rc = settle(c)) return s_rc;
     int64_t stats[STATS_WORDS];
+    // (copies on the context's stream, never through the legacy stream: this is called in the middle of a scan loop -- bench.py resets the counters behind
+    //  its warm-up -- and a legacy-stream operation fails while the mesher's worker thread has a graph capture open: "operation would make the legacy
+    //  stream depend on a capturing blocking stream".  Seen in the GPU tier once the mesher captured three graphs per job set instead of two.)
+    HIPCHK(c, hipMemcpyAsync(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(stats), hipMemcpyDeviceToHost));
     for (int k = 0; k < 64; k++) { stats[0] += stats[16 + k * 16]; stats[1] += stats[16 + k * 16 + 1]; }   // the fused replay kernel's shards
-    HIPCHK(c, hipMemcpy(c->h_counters, c->map.counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
     *out = c->cnt;
     out->n_refits = stats[0]; out->n_refit_pts = stats[1];
     out->n_root_voxels = c->h_counters[6]; out->n_nodes = c->h_counters[0];
@@ -959,7 +962,8 @@ int immesh_counters(immesh_ctx* c, immesh_counters_t* out, int32_t reset) {
     if (reset) {
         mesh_counters_reset(c);
         std::memset(&c->cnt, 0, sizeof(c->cnt));
-        HIPCHK(c, hipMemset(c->d_stats, 0, sizeof(stats)));
+        HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(stats), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return 0;
 }
