@@ -418,7 +418,13 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, boo
     sp.n_cand = (n_raw + sp.step - 1) / sp.step;
     sp.vtx_base = 0;   // filled in on the device (mesh_begin_scan_kernel)
     if (sp.n_cand > m.cap_cand) { h.err = "scan larger than cap_scan_points"; return IMMESH_E_CAPACITY; }
-    const int64_t ccap = np2((int64_t)sp.n_cand * 4);
+    // Everything the HOST sizes by the candidate count -- grids, the candidate hash's capacity, which admission tail runs, the graphs' key -- takes the count
+    // rounded up to 2048 (the kernels take the real count from MeshDyn and bound themselves by it; a larger grid or hash costs idle workgroups / a few more
+    // cleared entries).  A real sensor's scans differ in size from one to the next (rays without a return): keyed by the exact count, the phase graphs of a
+    // job set were captured and instantiated again for EVERY job -- milliseconds of host time each -- on anything but a constant-size synthetic stream
+    // (configs[3]: 1 450 scans/s with three graphs per set, 2 200 with round 5's two).  16 384 and 65 536, where the paths change, are multiples of 2048.
+    const int n_key = (int)std::min<int64_t>(((int64_t)sp.n_cand + 2047) / 2048 * 2048, (int64_t)m.cap_cand);
+    const int64_t ccap = np2((int64_t)n_key * 4);
     h.h_dyn[par]->sp = sp; h.h_dyn[par]->seq = h.seq; h.h_dyn[par]->ch_mask = (uint64_t)ccap - 1;
     h.h_dyn[par]->wait_flag = job.wait_flag; h.h_dyn[par]->wait_seq = job.wait_seq;
     h.h_dyn[par]->pts = d_pts;
@@ -459,7 +465,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, boo
         MHIPCHK(c, hipEventRecord(h.ev_b[par], sa));
         return 0;
     }
-    if (sp.n_cand > 65536) {
+    if (n_key > 65536) {
         // offline-sized clouds: the admission kernel's blocks are no longer all resident -> bounded rounds with a host check in between
         launch_mesh_begin_scan(sa, m, h.h_dyn_dev[par], (unsigned long long)ccap);
         launch_mesh_append_prepare(sa, m, sp.n_cand, d_pts);
@@ -473,14 +479,14 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, boo
         if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, false))) return rc;
     } else if (h.use_graph && !h.prof.on && is_world) {
         // steady state: the launches of a phase are captured once per (parity, candidate count) and replayed as one hipGraph
-        if (h.graph_ncand[par] != sp.n_cand) {
+        if (h.graph_ncand[par] != n_key) {
             for (hipGraphExec_t* e : {&h.graph_exec[par], &h.graph_exec_b[par][0], &h.graph_exec_b[par][1]}) if (*e) { (void)hipGraphExecDestroy(*e); *e = nullptr; }
-            h.graph_ncand[par] = sp.n_cand;
+            h.graph_ncand[par] = n_key;
         }
         // (captured with a null scan pointer: the kernels take it from MeshDyn, so one graph serves every world buffer)
-        if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, nullptr, sp.n_cand, ccap, true); }))) return rc;
+        if ((rc = mesh_graph_run(c, h.graph_exec[par], sa, [&] { return mesh_enqueue_a(c, m, par, sa, nullptr, n_key, ccap, true); }))) return rc;
     } else {
-        if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, sp.n_cand, ccap, true))) return rc;
+        if ((rc = mesh_enqueue_a(c, m, par, sa, d_pts, n_key, ccap, true))) return rc;
     }
     // (an event between the phases -- a poll at the head of phase B would hold LDS phase A's single-workgroup launch needs: measured deadlock --
     //  but none behind phase B: mesh_publish_kernel's ticket in pinned memory / the worker's poll)
@@ -492,7 +498,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, boo
     // chain (~3 us per scan) and ~15 us of job latency (two cross-stream events).  That pays while the mesher is what the pipeline waits for and costs
     // 1.7 % where it is not (the driver's 20-scan run on a young map: the pose chain is slower than even the one-launch phase B).  The worker therefore
     // switches: `deep` = a job found another one queued behind it within the last 64 jobs (mesh_worker_main).  IMMESH_SPLIT = 1 / 0: always / never.
-    const bool split = sp.n_cand <= 65536 && (h.split_mode == 1 || (h.split_mode == 2 && deep));
+    const bool split = n_key <= 65536 && (h.split_mode == 1 || (h.split_mode == 2 && deep));
     if (split) {
         static const int which = [] { const char* e = getenv("IMMESH_TRI_STREAM"); return e ? atoi(e) : 1; }();   // (measurement knob: 0 fetch stream, 1 pre-processing stream (default), 2 null stream)
         hipStream_t st = which == 1 ? c->stream_pre : (which == 2 ? (hipStream_t)nullptr : h.stream_fetch);
@@ -501,7 +507,7 @@ static int mesh_scan_launch(immesh_ctx* c, const MeshJob& job, bool& synced, boo
         MHIPCHK(c, hipEventRecord(h.ev_c[par], st));
         MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_c[par], 0));
     } else MHIPCHK(c, hipStreamWaitEvent(sb, h.ev_a[par], 0));
-    if (h.use_graph && !h.prof.on && sp.n_cand <= 65536 && is_world) {
+    if (h.use_graph && !h.prof.on && n_key <= 65536 && is_world) {
         // (both variants of phase B are captured when the first of them is needed: instantiating a graph takes a millisecond, and the switch to the other
         //  arrangement must not pay it in the middle of a stream)
         if (h.graph_exec_b[par][split ? 0 : 1] == nullptr && h.split_mode == 2 &&
