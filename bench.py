@@ -218,8 +218,8 @@ def algorithmic_bytes(kname, c, n_scans, n_raw):
     return None
 
 
-COMMITTED_STATS = "r05_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
-COMMITTED_TRAFFIC = "traffic_r05.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
+COMMITTED_STATS = "r06_full_kernel_stats.csv"   # profiles/: rocprofv3 --kernel-trace --stats of the default command on HEAD
+COMMITTED_TRAFFIC = "traffic_r06.json"          # profiles/: PMC-derived HBM bytes per launch (tools/pmc_traffic.py), same command
 
 
 def kernel_sources_sha():
@@ -865,6 +865,8 @@ def main():
                                             f"{kernel_sources_sha()}: stale, not reported (tools/refresh_profiles.sh regenerates it)")
                 else:
                     rec = tj.get(rf["kernel"])
+                    if rec is None:   # (rocprofv3 names template instantiations -- residual_persistent_kernel<true> --, the in-library profiler the template)
+                        rec = next((v_ for k_, v_ in tj.items() if k_ != "_meta" and k_.split("<")[0] == rf["kernel"].split("<")[0]), None)
                     rf["traffic"] = rec.get("hbm_bytes_per_launch") if isinstance(rec, dict) else None   # bytes per launch, like `algorithmic_bytes_per_launch`
                     rf["traffic_unit"] = "bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024, the guide's gfx950 correction"
                     rf["traffic_detail"] = rec
