@@ -702,6 +702,7 @@ def dry_run_leg(args, torch, hip, dev, local):
     side = float(np.sqrt(args.map_voxels / 8.8)) + 40.0
     d_down = [torch.from_numpy(dn).to(dev) for dn in downs_h]
     per_rank = []
+    by_calls = {}     # exchanges a scan needed (>= 2 admission rounds + the two bands) -> that scan's time, over all ranks
     for r in ranks:
         cfg = mk(r)
         cfg.shard_scheme = args.shard_scheme
@@ -724,15 +725,19 @@ def dry_run_leg(args, torch, hip, dev, local):
         torch.cuda.synchronize()
         tb = time.perf_counter()
         marks = [tb]
+        xc = [h.shard_traffic()["calls"]]
         for _ in range(args.steps):
             prior = capi.forward_without_imu_native(hip, st)
             st, info = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
             h.last_timing()                 # (serial per scan in this leg: the scan's map update has finished)
             marks.append(time.perf_counter())
+            xc.append(h.shard_traffic()["calls"])   # (a host counter: which scans needed a third admission round is what makes the scan times bimodal)
         torch.cuda.synchronize()
         el = time.perf_counter() - tb
         cnt = h.counters()
         per = np.diff(marks) * 1e3
+        for ms_, nx_ in zip(per, np.diff(xc)):
+            by_calls.setdefault(int(nx_), []).append(float(ms_))
         # the median scan, not the mean: a rank's ten scans follow the allocation of its 90 GB context, and one stalled call (a 6 ms hiccup seen on one rank
         # of one run) would otherwise decide which rank "the job waits for"
         per_rank.append({"rank": r, "ms_per_scan": round(float(np.median(per)), 4), "ms_per_scan_mean": round(1e3 * el / args.steps, 4), "ms_per_scan_max": round(float(per.max()), 4), "root_voxels_kept": int(n_map), "device_bytes_allocated": int(h.device_bytes()), "map_build_seconds": round(t_map, 1),
@@ -743,6 +748,37 @@ def dry_run_leg(args, torch, hip, dev, local):
         del h
         import gc as _gc
         _gc.collect()
+    # the SAME scans through ONE unsharded GPU (VERDICT r05 next #3d): what a rank of the sharded job has to beat.  The metric's 10 M-voxel map (50 M root
+    # voxels do not fit one GPU: that is what the job is sharded for), serial per scan exactly like the ranks above, then asynchronous as the headline runs
+    single = None
+    if len(ranks) > 1 and args.mesh:
+        try:
+            cfg1 = capi.avia_config(device=local, cap_root_voxels=int(10e6 * 1.3) + (1 << 16), cap_scan_points=2_500_000, cap_vertices=1 << 24, cap_triangles=1 << 25)
+            h = capi.HotPath(hip, cfg1, "immesh_")
+            n_map1 = build_big_map(h, cfg1, torch, dev, 10e6, float(np.sqrt(10e6 / 8.8)) + 40.0)
+            single = {"map_root_voxels": int(n_map1)}
+            for mode_, label_ in ((1, "ms_per_scan_serial"), (2, "ms_per_scan_async")):
+                R0, t0_ = synth.trajectory_pose(0)
+                st = capi.make_state(R=R0, t=t0_)
+                st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+                k = 1
+                for _ in range(args.warmup):
+                    prior = capi.forward_without_imu_native(hip, st)
+                    st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode_, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+                h.mesh_wait(); h.counters(reset=True)
+                tb = time.perf_counter(); marks = [tb]
+                for _ in range(args.steps):
+                    prior = capi.forward_without_imu_native(hip, st)
+                    st, _ = h.process_scan(d_down[k].data_ptr(), d_raw[k].data_ptr(), prior, prior, frame_idx=k, do_mesh=mode_, n_ds=n_ds[k], n_raw=d_raw[k].shape[0]); k += 1
+                    if mode_ == 1:
+                        h.last_timing()
+                    marks.append(time.perf_counter())
+                h.mesh_wait(); h.counters()
+                single[label_] = round(float(np.median(np.diff(marks))) * 1e3, 4) if mode_ == 1 else round(1e3 * (time.perf_counter() - tb) / args.steps, 4)
+            h.close()
+            del h
+        except Exception as e:   # noqa: BLE001
+            single = {"error": str(e)[:160]}
     slow = max(per_rank, key=lambda q_: q_["ms_per_scan"])
     el_ms = slow["ms_per_scan"]
     who = f"rank {slow['rank']} of {W}, the slowest of {'all ' + str(W) + ' ranks run in turn' if len(ranks) > 1 else 'the one rank run'}"
@@ -755,7 +791,9 @@ def dry_run_leg(args, torch, hip, dev, local):
            "load_balance_point_share_per_brick_size": balance,
            "share": {"per_rank": per_rank, "slowest_rank": slow["rank"], "fastest_ms_per_scan": min(q_["ms_per_scan"] for q_ in per_rank),
                      "root_voxels_kept_by_this_rank": int(slow["root_voxels_kept"]), "of_total_surveyed": int(args.map_voxels), "device_bytes_allocated": int(slow["device_bytes_allocated"]),
-                     "busiest_point_share_mean": bal_now[int(bv)]["max_share_mean"], "fair_share": round(1.0 / W, 4)},
+                     "busiest_point_share_mean": bal_now[int(bv)]["max_share_mean"], "fair_share": round(1.0 / W, 4),
+                     "ms_per_scan_by_exchanges_of_the_scan": {str(k_): {"scans": len(v_), "median_ms": round(float(np.median(v_)), 4)} for k_, v_ in sorted(by_calls.items())},
+                     "one_unsharded_gpu_on_the_same_scans": single},
            "pose_err_m": slow["pose_err_m"]}
     print(json.dumps(out), flush=True)
 

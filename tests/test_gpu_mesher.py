@@ -251,6 +251,48 @@ def test_async_pipeline_matches_serial(hip_lib, split, monkeypatch):
     assert c1["n_degenerate_skips"] == 0 == c2["n_degenerate_skips"]      # a noisy scan never meets the degenerate-admission rule
 
 
+def test_long_async_stream_under_all_arrangements(hip_lib, monkeypatch):
+    """24 asynchronous scans in a row without ever waiting for the mesher: up to three jobs in flight, the worker free to switch between its two
+    arrangements in the middle of the stream (a backlog builds while the scan thread runs ahead).  Always deep (IMMESH_SPLIT=1), never (0) and the
+    worker's own choice must leave the same map: every pose, the lists of the last job, the vertex / live-triangle / refit totals."""
+    torch = pytest.importorskip("torch")
+    cfg = capi.avia_config(cap_root_voxels=1 << 16, cap_scan_points=200000, cap_vertices=1 << 18, cap_triangles=1 << 20)
+    extT = np.array(list(cfg.extT))
+    scans = []
+    for k in range(25):
+        Rk, tk = synth.trajectory_pose(k)
+        raw = synth.livox_scan(k, Rk, tk, n_pts=20000, extT=extT)
+        scans.append((torch.from_numpy(synth.voxel_grid_downsample(raw, 0.4)).cuda(), torch.from_numpy(raw).cuda(), Rk, tk))
+    torch.cuda.current_stream().synchronize()
+    results = {}
+    for split in ("0", "1", None):
+        if split is None:
+            monkeypatch.delenv("IMMESH_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("IMMESH_SPLIT", split)
+        h = make_hip(hip_lib, cfg)
+        st = capi.make_state(R=scans[0][2], t=scans[0][3])
+        h.map_build(np.ascontiguousarray(scans[0][1].cpu().numpy()[:, :3]), st)
+        st[12:15] = [1.0, 0, 0]; st[15:18] = [0, 0, np.deg2rad(2.0)]
+        poses = []
+        for k in range(1, 25):
+            prior = synth.forward_without_imu(st)
+            st, _ = h.process_scan(scans[k][0].data_ptr(), scans[k][1].data_ptr(), prior, prior, frame_idx=k, do_mesh=2, n_ds=scans[k][0].shape[0], n_raw=scans[k][1].shape[0])
+            poses.append(st[:12].copy())
+        h.mesh_wait()
+        results[split] = (np.array(poses), h.mesh_fetch(), h.counters())
+        h.close()
+    p0, m0, c0 = results["0"]
+    for split in ("1", None):
+        p1, m1, c1 = results[split]
+        np.testing.assert_array_equal(p0, p1)
+        for key in ("new_vtx", "tri_add", "tri_rem", "tri_upd", "flip_add", "flip_upd", "smooth_ids"):
+            np.testing.assert_array_equal(m0[key], m1[key], err_msg=f"IMMESH_SPLIT={split} {key}")
+        for key in ("n_new", "v_act", "t_add", "t_rem", "n_u", "t_v", "n_vertices", "n_triangles_live", "n_refits", "n_degenerate_skips"):
+            assert c0[key] == c1[key], (split, key)
+    assert c0["n_triangles_live"] > 1000 and c0["t_rem"] > 0
+
+
 def test_mesh_volumetric_cloud(oracle_lib, hip_lib):
     """A space-filling cloud (vegetation-like): up to ~45 vertices per mesh voxel, thousands of candidates around a voxel (the kNN kernel
     stages them in several LDS batches), neighbourhoods above 256 vertices (the large-neighbourhood Delaunay instantiation)."""
